@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+def pe_cases(ok_only=True):
+    import json
+
+    base = os.path.join(GOLDEN, "pe")
+    out = []
+    for name in sorted(os.listdir(base)):
+        d = os.path.join(base, name)
+        if not os.path.isdir(d):
+            continue
+        with open(os.path.join(d, "meta.json")) as fh:
+            meta = json.load(fh)
+        if ok_only and meta["returncode"] != 0:
+            continue
+        out.append((name, d, meta))
+    return out
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN

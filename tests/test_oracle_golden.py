@@ -1,0 +1,39 @@
+"""The Python oracle vs. the outputs of the real reference script (tests/golden/pe)."""
+import json
+import os
+
+import pytest
+
+from conftest import pe_cases
+from oracle import pe_oracle
+
+
+def _read(path):
+    with open(path, "r", newline="") as fh:
+        return fh.read()
+
+
+@pytest.mark.parametrize("name,d,meta", pe_cases(), ids=[c[0] for c in pe_cases()])
+def test_python_oracle_matches_reference_files(name, d, meta):
+    pe, st, stats = pe_oracle.run_files(
+        os.path.join(d, "graph.gfa"), os.path.join(d, "fwd.fq"), os.path.join(d, "rve.fq"), meta["k"])
+    assert pe == _read(os.path.join(d, "pe_info"))
+    assert st == _read(os.path.join(d, "st_info"))
+
+
+@pytest.mark.parametrize("name,d,meta", pe_cases(), ids=[c[0] for c in pe_cases()])
+def test_integer_acceptance_test_equals_float_form(name, d, meta):
+    ids, seqs = pe_oracle.read_gfa_segments(os.path.join(d, "graph.gfa"))
+    f = pe_oracle.fastq_sequences(os.path.join(d, "fwd.fq"))
+    r = pe_oracle.fastq_sequences(os.path.join(d, "rve.fq"))
+    a = pe_oracle.pe_matrices(seqs, f, r, meta["k"], mapper=pe_oracle.map_read_end)
+    b = pe_oracle.pe_matrices(seqs, f, r, meta["k"], mapper=pe_oracle.map_read_end_int)
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[2] == b[2]
+
+
+def test_lowercase_node_raises_like_reference():
+    (case,) = [c for c in pe_cases(ok_only=False) if c[2]["returncode"] != 0]
+    name, d, meta = case
+    with pytest.raises(KeyError) as ei:
+        pe_oracle.run_files(os.path.join(d, "graph.gfa"), os.path.join(d, "fwd.fq"), os.path.join(d, "rve.fq"), meta["k"])
+    assert "KeyError: %r" % ei.value.args[0] == meta["stderr_last"]
