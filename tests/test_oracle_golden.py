@@ -37,3 +37,35 @@ def test_lowercase_node_raises_like_reference():
     with pytest.raises(KeyError) as ei:
         pe_oracle.run_files(os.path.join(d, "graph.gfa"), os.path.join(d, "fwd.fq"), os.path.join(d, "rve.fq"), meta["k"])
     assert "KeyError: %r" % ei.value.args[0] == meta["stderr_last"]
+
+
+@pytest.mark.parametrize("name,d,meta", pe_cases(), ids=[c[0] for c in pe_cases()])
+def test_c_oracle_matches_reference_files(name, d, meta):
+    from oracle import pe_oracle_c
+
+    ids, seqs = pe_oracle.read_gfa_segments(os.path.join(d, "graph.gfa"))
+    f = pe_oracle.fastq_sequences(os.path.join(d, "fwd.fq"))
+    r = pe_oracle.fastq_sequences(os.path.join(d, "rve.fq"))
+    orc = pe_oracle_c.Oracle(seqs, meta["k"])
+    node_mat, short_mat, stats = orc.count_pairs(f, r)
+    assert pe_oracle.matrix_text(ids, node_mat) == _read(os.path.join(d, "pe_info"))
+    assert pe_oracle.matrix_text(ids, short_mat) == _read(os.path.join(d, "st_info"))
+    ref = pe_oracle.pe_matrices(seqs, f, r, meta["k"])
+    assert tuple(int(x) for x in stats) == ref[2]
+    # per-end lists too
+    tab = pe_oracle.build_table(seqs, meta["k"] + 1)
+    lens = [len(s) for s in seqs]
+    for s in (f + r)[:200]:
+        if len(s) >= meta["k"] + 1:
+            assert orc.map_end(s) == pe_oracle.map_read_end(s, tab, lens, meta["k"] + 1)
+
+
+def test_c_oracle_lowercase_node_keyerror():
+    from oracle import pe_oracle_c
+
+    (case,) = [c for c in pe_cases(ok_only=False) if c[2]["returncode"] != 0]
+    name, d, meta = case
+    ids, seqs = pe_oracle.read_gfa_segments(os.path.join(d, "graph.gfa"))
+    with pytest.raises(KeyError) as ei:
+        pe_oracle_c.Oracle(seqs, meta["k"])
+    assert "KeyError: %r" % ei.value.args[0] == meta["stderr_last"]
