@@ -1,0 +1,121 @@
+/*
+ * vstrains_hip.h -- C ABI of libvstrains_hip.so, the MI355X (gfx950) implementation of the
+ * VStrains hot path.  extern "C", plain pointers and sizes only; no C++ or torch types cross
+ * this line.  Host code (Python via ctypes, or any C caller) binds exactly these symbols.
+ *
+ * Every entry returns 0 on success and a negative VS_E_* code on failure; the message is
+ * available from vs_last_error(ctx) (or vs_last_error(NULL) for vs_ctx_create failures).
+ * A context belongs to one device and one host thread at a time.  Nothing here falls back
+ * to the CPU: without a usable HIP device the calls fail with VS_E_HIP.
+ *
+ * "Replaces" cites the reference lines (under /root/reference/) each entry stands in for.
+ */
+#ifndef VSTRAINS_HIP_H
+#define VSTRAINS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VS_ABI_VERSION 1
+
+enum {
+    VS_OK = 0,
+    VS_E_ARG = -1,       /* bad argument */
+    VS_E_HIP = -2,       /* HIP runtime error (no device, launch failure, ...) */
+    VS_E_OOM = -3,       /* device or host allocation failed */
+    VS_E_NODE_BASE = -4, /* a node of length >= k+1 holds a byte outside ACGT: the reference
+                            dies with KeyError in reverse_seq (PE_Inference.py:12-13,122) */
+    VS_E_STATE = -5,     /* call order (e.g. counting before an index exists) */
+    VS_E_RANGE = -6      /* a size exceeds what this build supports */
+};
+
+typedef struct vs_ctx vs_ctx;     /* one per device */
+typedef struct vs_reads vs_reads; /* a device-resident block of packed read pairs */
+
+/* ---- context ------------------------------------------------------------------------------ */
+int vs_abi_version(void);
+int vs_device_count(void);
+int vs_ctx_create(int device, vs_ctx **out);
+void vs_ctx_destroy(vs_ctx *ctx);
+const char *vs_last_error(const vs_ctx *ctx);
+/* Work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream). */
+int vs_ctx_set_stream(vs_ctx *ctx, void *stream);
+int vs_ctx_sync(vs_ctx *ctx);
+
+/* ---- K1: node index -------------------------------------------------------------------------
+ * Replaces utils/VStrains_PE_Inference.py:114-135 (split_len = k+1; the dict of every
+ * (k+1)-mer window of every node, forward and reverse-complemented).
+ * node_ascii: the N node sequences concatenated (host memory); node_off[N+1]: byte offsets.
+ * On VS_E_NODE_BASE, bad_node / bad_char (may be NULL) receive the node index and the byte the
+ * reference's KeyError would name.  Rebuilding replaces the previous index. */
+int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint64_t *node_off,
+                   uint32_t n_nodes, uint32_t ksize, uint32_t *bad_node, uint8_t *bad_char);
+
+/* Index facts for reporting: info[0]=seed length w, [1]=probe stride s, [2]=seed positions
+ * indexed, [3]=hash slots, [4]=distinct seeds, [5]=bytes of device memory held by the index. */
+int vs_index_info(const vs_ctx *ctx, uint64_t info[6]);
+
+/* ---- read blocks ----------------------------------------------------------------------------
+ * Replaces the FASTQ record slicing of PE_Inference.py:146-159 from the point where the two
+ * sequence strings of a pair are known.  Ends are interleaved: end 2r = forward read of pair
+ * r, end 2r+1 = its reverse read.  ascii/off are host memory: off[n_ends+1] byte offsets into
+ * ascii.  Bytes are taken verbatim: 'N' marks the pair as an N-pair (:160); any other byte
+ * outside ACGT makes every window covering it miss, as a dict lookup would (:25-26). */
+int vs_reads_pack(vs_ctx *ctx, const uint8_t *ascii, const uint64_t *off, uint64_t n_ends,
+                  vs_reads **out);
+void vs_reads_free(vs_ctx *ctx, vs_reads *reads);
+/* info[0]=ends, [1]=packed words, [2]=max read length, [3]=ends holding bytes outside ACGTN,
+ * [4]=device bytes held. */
+int vs_reads_info(const vs_reads *reads, uint64_t info[5]);
+/* Unpack back to ASCII (ACGT only; testing aid).  out must hold off[n_ends] bytes where off is
+ * the cumulative read length; lens[n_ends] and flags[n_ends] (bit0: has N, bit1: has other
+ * non-ACGT) may be NULL. */
+int vs_reads_unpack(vs_ctx *ctx, const vs_reads *reads, uint8_t *out, uint32_t *lens,
+                    uint8_t *flags);
+
+/* Synthetic pairs generated on the device from a seed (bench workload; the CPU twin is
+ * oracle/pe_oracle.c:peo_synth_pairs).  genomes: concatenated ACGT ASCII (host), goff
+ * [n_strains+1]; cum[s]: inclusive upper bound of strain s in a uniform u32 draw (last =
+ * 0xFFFFFFFF).  sub_thresh / n_thresh: u32 thresholds (rate * 2^32) for per-base
+ * substitutions and for pairs that get one 'N'.  Pairs first_pair .. first_pair+n_pairs-1 of
+ * the stream are produced, so ranks can take disjoint slices of one stream. */
+int vs_synth_pairs(vs_ctx *ctx, const uint8_t *genomes, const uint64_t *goff,
+                   const uint32_t *cum, uint32_t n_strains, uint64_t seed, uint64_t first_pair,
+                   uint64_t n_pairs, uint32_t read_len, uint32_t sub_thresh, uint32_t n_thresh,
+                   vs_reads **out);
+
+/* ---- K2-K4: PE-link counting ----------------------------------------------------------------
+ * Replaces PE_Inference.py:155-188 (pair filters, single_end_read_mapping on both ends,
+ * short_mat / node_mat updates) for all pairs of `reads`.
+ * d_node_mat, d_short_mat: DEVICE pointers to N*N row-major uint32 counters, d_stats: DEVICE
+ * pointer to 3 uint64 {n_reads, short_reads, used_reads}.  Counts are ADDED (atomically), so
+ * several blocks / ranks can accumulate and the caller all-reduces (RCCL) as it likes.
+ * uint32 is exact while pairs counted into one buffer stay below 2^31. */
+int vs_pe_count(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, uint32_t *d_short_mat,
+                uint64_t *d_stats);
+
+/* Per-end result of single_end_read_mapping (PE_Inference.py:16-48) for testing: for each end
+ * e, counts[e] = number of accepted nodes (0 for ends of pairs the filters drop), and up to
+ * `cap` of them, ascending, in lists[e*cap ...].  Host pointers. */
+int vs_pe_map_ends(vs_ctx *ctx, const vs_reads *reads, uint32_t cap, uint32_t *lists,
+                   uint32_t *counts);
+
+/* Timing of the most recent vs_pe_count on this ctx, measured with HIP events on the ctx
+ * stream: ms[0] = main kernel, ms[1] = overflow (slow-path) kernel, ms[2] = pairs sent to the
+ * slow path.  Synchronises the stream. */
+int vs_pe_last_timing(vs_ctx *ctx, double ms[3]);
+
+/* ---- device memory helpers for C callers without another allocator ----------------------- */
+int vs_dev_alloc(vs_ctx *ctx, size_t bytes, void **out); /* zero-filled */
+int vs_dev_free(vs_ctx *ctx, void *ptr);
+int vs_dev_zero(vs_ctx *ctx, void *ptr, size_t bytes);
+int vs_dev_to_host(vs_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSTRAINS_HIP_H */

@@ -1,0 +1,81 @@
+"""String-level model of the device algorithm (seed at stride s, canonical w-mer table, exact
+extension, first-seed-owns-the-match rule).  It exists to pin the *algorithm* of
+vstrains_amd/csrc/vs_pe.hip against the oracle on the CPU, where no GPU is available; the HIP
+kernels themselves are checked against the oracle in the -m gpu tests."""
+from typing import Dict, List, Sequence, Tuple
+
+_C = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+
+def rc(s: str) -> str:
+    return "".join(_C[c] for c in reversed(s))
+
+
+def geometry(K: int) -> Tuple[int, int]:
+    w = min(K, 31)
+    if w % 2 == 0:
+        w -= 1
+    return w, K - w + 1
+
+
+def build(seqs: Sequence[str], K: int):
+    w, s = geometry(K)
+    table: Dict[str, List[Tuple[int, int, int]]] = {}
+    for i, seq in enumerate(seqs):
+        if len(seq) < K:
+            continue
+        for p in range(len(seq) - w + 1):
+            f = seq[p : p + w]
+            r = rc(f)
+            key, strand = (f, 0) if f < r else (r, 1)
+            table.setdefault(key, []).append((i, p, strand))
+    return table, w, s
+
+
+def valid(ch: str) -> bool:
+    return ch in _C
+
+
+def map_end(read: str, seqs: Sequence[str], rcs: Sequence[str], table, w: int, s: int, K: int) -> List[int]:
+    rlen = len(read)
+    agg: Dict[int, List[int]] = {}
+    j = 0
+    while j + w <= rlen:
+        f = read[j : j + w]
+        if all(valid(c) for c in f):
+            r = rc(f)
+            key, sr = (f, 0) if f < r else (r, 1)
+            for node, p, sn in table.get(key, ()):
+                opp = sn ^ sr
+                text = rcs[node] if opp else seqs[node]
+                tlen = len(text)
+                q = tlen - p - w if opp else p
+                c = min(s, j, q)
+                left = 0
+                while left < c and read[j - 1 - left] == text[q - 1 - left]:
+                    left += 1
+                if left >= s:
+                    continue
+                ext = 0
+                while j + w + ext < rlen and q + w + ext < tlen and read[j + w + ext] == text[q + w + ext]:
+                    ext += 1
+                ln = left + w + ext
+                if ln < K:
+                    continue
+                a = j - left
+                qa = q - left
+                minp = tlen - qa - ln if opp else qa
+                rec = agg.setdefault(node, [0, minp, a])
+                rec[0] += ln - K + 1
+                rec[1] = min(rec[1], minp)
+                rec[2] = min(rec[2], a)
+        j += s
+    keep = []
+    for node in sorted(agg):
+        v, c, ki = agg[node]
+        nlen = len(seqs[node])
+        right = min(c + nlen - 1, c - ki + rlen - 1)
+        saturate = right - c - K + 2
+        if v >= saturate or v * rlen >= (min(rlen, nlen) - K + 1) * (rlen - K):
+            keep.append(node)
+    return keep

@@ -1,0 +1,231 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and with the reference's own
+outputs.  Integer work: the bar is bit-exact."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, pe_cases
+from oracle import pe_oracle, pe_oracle_c
+
+pytestmark = pytest.mark.gpu
+
+
+def _read(path):
+    with open(path, "r", newline="") as fh:
+        return fh.read()
+
+
+@pytest.fixture(scope="module")
+def host():
+    from vstrains_amd import pe as host
+
+    return host
+
+
+@pytest.fixture(scope="module")
+def ctx(host):
+    c = host.Context(0)
+    yield c
+    c.close()
+
+
+def _gpu_matrices(host, ctx, seqs, fwd, rve, k):
+    ctx.build_index(seqs, k)
+    counter = host.PeCounter(ctx)
+    block = ctx.pack_pairs(fwd, rve)
+    counter.add(block)
+    res = counter.result()
+    return res, block
+
+
+@pytest.mark.parametrize("name,d,meta", pe_cases(), ids=[c[0] for c in pe_cases()])
+def test_golden_files_bit_exact(host, ctx, name, d, meta):
+    ids, seqs = host.read_gfa_segments(os.path.join(d, "graph.gfa"))
+    fq_f = host.FastqSeqs(os.path.join(d, "fwd.fq"))
+    fq_r = host.FastqSeqs(os.path.join(d, "rve.fq"))
+    total = min(len(fq_f), len(fq_r))
+    ctx.build_index(seqs, meta["k"])
+    counter = host.PeCounter(ctx)
+    data, off = host.interleave_pairs(fq_f, fq_r, 0, total)
+    block = ctx.pack(data, off)
+    counter.add(block)
+    node_mat, short_mat, stats = counter.result()
+    assert pe_oracle.matrix_text(ids, node_mat) == _read(os.path.join(d, "pe_info"))
+    assert pe_oracle.matrix_text(ids, short_mat) == _read(os.path.join(d, "st_info"))
+    f = pe_oracle.fastq_sequences(os.path.join(d, "fwd.fq"))
+    r = pe_oracle.fastq_sequences(os.path.join(d, "rve.fq"))
+    assert stats == pe_oracle.pe_matrices(seqs, f, r, meta["k"])[2]
+
+
+@pytest.mark.parametrize("name,d,meta", pe_cases(), ids=[c[0] for c in pe_cases()])
+def test_per_end_lists_match_oracle(host, ctx, name, d, meta):
+    K = meta["k"] + 1
+    ids, seqs = host.read_gfa_segments(os.path.join(d, "graph.gfa"))
+    f = pe_oracle.fastq_sequences(os.path.join(d, "fwd.fq"))
+    r = pe_oracle.fastq_sequences(os.path.join(d, "rve.fq"))
+    n = min(len(f), len(r))
+    if n == 0:
+        pytest.skip("no pairs")
+    ctx.build_index(seqs, meta["k"])
+    block = ctx.pack_pairs(f[:n], r[:n])
+    lists = ctx.map_ends(block, cap=max(len(seqs), 1))
+    tab = pe_oracle.build_table(seqs, K)
+    lens = [len(s) for s in seqs]
+    for p in range(n):
+        used = not (f[p].count("N") or r[p].count("N")) and len(f[p]) >= K and len(r[p]) >= K
+        want_f = pe_oracle.map_read_end(f[p], tab, lens, K) if used else []
+        want_r = pe_oracle.map_read_end(r[p], tab, lens, K) if used else []
+        assert lists[2 * p] == want_f, (p, f[p])
+        assert lists[2 * p + 1] == want_r, (p, r[p])
+
+
+def test_lowercase_node_raises_keyerror(host, ctx):
+    (case,) = [c for c in pe_cases(ok_only=False) if c[2]["returncode"] != 0]
+    name, d, meta = case
+    ids, seqs = host.read_gfa_segments(os.path.join(d, "graph.gfa"))
+    with pytest.raises(KeyError) as ei:
+        ctx.build_index(seqs, meta["k"])
+    assert "KeyError: %r" % ei.value.args[0] == meta["stderr_last"]
+
+
+def test_cli_drop_in_writes_identical_files(tmp_path):
+    name, d, meta = [c for c in pe_cases() if c[0] == "errors_k21"][0]
+    out = tmp_path / "aln"
+    proc = subprocess.run(
+        [sys.executable, "-m", "vstrains_amd.pe_inference", "-g", os.path.join(d, "graph.gfa"), "-o", str(out) + "/",
+         "-f", os.path.join(d, "fwd.fq"), "-r", os.path.join(d, "rve.fq"), "-k", str(meta["k"])],
+        cwd=ROOT, capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stderr
+    assert _read(out / "pe_info") == _read(os.path.join(d, "pe_info"))
+    assert _read(out / "st_info") == _read(os.path.join(d, "st_info"))
+    lines = proc.stdout.splitlines()
+    assert lines[0] == "----------------------Paired-End Information Alignment----------------------"
+    assert lines[1] == "Start aligning reads to gfa nodes"
+    assert [l for l in lines if l.startswith("Number of processed reads")] == meta["progress_lines"]
+    assert lines[-2].startswith("Global time elapsed:  ")
+    assert lines[-1] == "result stored in:  %s/pe_info" % out
+
+
+def test_cli_drop_in_fails_like_reference_on_bad_node(tmp_path):
+    (case,) = [c for c in pe_cases(ok_only=False) if c[2]["returncode"] != 0]
+    name, d, meta = case
+    proc = subprocess.run(
+        [sys.executable, "-m", "vstrains_amd.pe_inference", "-g", os.path.join(d, "graph.gfa"), "-o", str(tmp_path / "aln"),
+         "-f", os.path.join(d, "fwd.fq"), "-r", os.path.join(d, "rve.fq"), "-k", str(meta["k"])],
+        cwd=ROOT, capture_output=True, text=True)
+    assert proc.returncode != 0
+    assert proc.stderr.strip().splitlines()[-1] == meta["stderr_last"]
+
+
+def _dense_case(k, n_pairs, read_len, seed, snp, n_strains=6, glen=1500, sub=0.01, nrate=0.02):
+    from vstrains_amd import synth
+
+    st = synth.make_strains(n_strains, glen, snp, seed=seed)
+    g = synth.compact_dbg(st, k)
+    f, r = synth.sample_pairs(st, n_pairs, read_len, seed=seed + 1, sub_rate=sub, n_rate=nrate)
+    return g, f, r
+
+
+def test_overflow_pairs_take_slow_path_and_stay_exact(host, ctx):
+    # dense variation at k=21: an 80-base read crosses far more than 8 short nodes
+    g, f, r = _dense_case(21, 1500, 80, seed=301, snp=0.09)
+    (node_mat, short_mat, stats), block = _gpu_matrices(host, ctx, g.seqs, f, r, 21)
+    t = ctx.last_timing()
+    assert t["slow_pairs"] > 0, "case does not exercise the overflow path"
+    orc = pe_oracle_c.Oracle(g.seqs, 21)
+    ref_node, ref_short, ref_stats = orc.count_pairs(f, r)
+    assert np.array_equal(node_mat, ref_node)
+    assert np.array_equal(short_mat, ref_short)
+    assert stats == tuple(int(x) for x in ref_stats)
+    lists = ctx.map_ends(block, cap=len(g.seqs))
+    for p in range(0, len(f), 37):
+        if "N" in f[p] or "N" in r[p]:
+            continue
+        assert lists[2 * p] == orc.map_end(f[p])
+        assert lists[2 * p + 1] == orc.map_end(r[p])
+
+
+@pytest.mark.parametrize("k,read_len,n_pairs,snp", [(55, 150, 20000, 0.03), (127, 250, 6000, 0.02), (31, 100, 8000, 0.05), (32, 100, 8000, 0.05)])
+def test_random_graphs_against_c_oracle(host, ctx, k, read_len, n_pairs, snp):
+    g, f, r = _dense_case(k, n_pairs, read_len, seed=400 + k, snp=snp, glen=4000)
+    (node_mat, short_mat, stats), _ = _gpu_matrices(host, ctx, g.seqs, f, r, k)
+    orc = pe_oracle_c.Oracle(g.seqs, k)
+    ref_node, ref_short, ref_stats = orc.count_pairs(f, r)
+    assert np.array_equal(node_mat, ref_node)
+    assert np.array_equal(short_mat, ref_short)
+    assert stats == tuple(int(x) for x in ref_stats)
+    assert int(ref_node.sum()) > 0
+
+
+def test_variable_lengths_and_empty_block(host, ctx):
+    g, f, r = _dense_case(21, 3000, 90, seed=501, snp=0.03)
+    rng = np.random.default_rng(5)
+    f = [s[: int(rng.integers(0, 91))] for s in f]
+    r = [s[: int(rng.integers(15, 91))] for s in r]
+    (node_mat, short_mat, stats), _ = _gpu_matrices(host, ctx, g.seqs, f, r, 21)
+    orc = pe_oracle_c.Oracle(g.seqs, 21)
+    ref_node, ref_short, ref_stats = orc.count_pairs(f, r)
+    assert np.array_equal(node_mat, ref_node) and np.array_equal(short_mat, ref_short)
+    assert stats == tuple(int(x) for x in ref_stats)
+    # an empty block adds nothing
+    counter = host.PeCounter(ctx)
+    counter.add(ctx.pack_pairs([], []))
+    a, b, s = counter.result()
+    assert a.sum() == 0 and b.sum() == 0 and s == (0, 0, 0)
+
+
+def test_blocks_add_up_and_swapping_ends_transposes(host, ctx):
+    g, f, r = _dense_case(55, 12000, 150, seed=601, snp=0.03, glen=5000)
+    ctx.build_index(g.seqs, 55)
+    whole = host.PeCounter(ctx)
+    whole.add(ctx.pack_pairs(f, r))
+    parts = host.PeCounter(ctx)
+    for lo in range(0, len(f), 5000):
+        parts.add(ctx.pack_pairs(f[lo:lo + 5000], r[lo:lo + 5000]))
+    a, b = whole.result(), parts.result()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    swapped = host.PeCounter(ctx)
+    swapped.add(ctx.pack_pairs(r, f))
+    c = swapped.result()
+    assert np.array_equal(c[0], a[0].T) and np.array_equal(c[1], a[1])
+
+
+def test_device_read_generator_equals_cpu_twin(host, ctx):
+    from vstrains_amd import synth
+
+    st = synth.make_strains(5, 2000, 0.02, seed=71)
+    ab = np.array(st.abundance)
+    cum = np.minimum(np.floor(np.cumsum(ab) / ab.sum() * 2 ** 32), 2 ** 32 - 1).astype(np.uint32)
+    cum[-1] = 0xFFFFFFFF
+    sub = int(0.01 * 2 ** 32)
+    nth = int(0.02 * 2 ** 32)
+    block = ctx.synth_pairs(st.genomes, cum, seed=99, first_pair=1000, n_pairs=3000, read_len=150, sub_thresh=sub, n_thresh=nth)
+    text, lens, flags = block.unpack()
+    fw, rv = pe_oracle_c.synth_pairs(st.genomes, cum, 99, 1000, 3000, 150, sub, nth)
+    assert (lens == 150).all()
+    got = text.reshape(3000, 2, 150)
+    has_n_f = (fw == ord("N")).any(axis=1)
+    has_n_r = (rv == ord("N")).any(axis=1)
+    assert np.array_equal((flags[0::2] & 1).astype(bool), has_n_f)
+    assert np.array_equal((flags[1::2] & 1).astype(bool), has_n_r)
+    ok_f = ~has_n_f
+    ok_r = ~has_n_r
+    assert np.array_equal(got[ok_f, 0, :], fw[ok_f])
+    assert np.array_equal(got[ok_r, 1, :], rv[ok_r])
+    assert has_n_f.sum() + has_n_r.sum() > 10
+    # and the counts over that stream agree with the oracle run on the twin's text
+    g = synth.compact_dbg(st, 55)
+    ctx.build_index(g.seqs, 55)
+    counter = host.PeCounter(ctx)
+    counter.add(block)
+    node_mat, short_mat, stats = counter.result()
+    orc = pe_oracle_c.Oracle(g.seqs, 55)
+    f = [bytes(x).decode() for x in fw]
+    r = [bytes(x).decode() for x in rv]
+    ref_node, ref_short, ref_stats = orc.count_pairs(f, r)
+    assert np.array_equal(node_mat, ref_node) and np.array_equal(short_mat, ref_short)
+    assert stats == tuple(int(x) for x in ref_stats)

@@ -1,0 +1,160 @@
+// Internal structures and device helpers shared by the HIP translation units.
+// gfx950 only: wave = 64 lanes, no other target is considered.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/vstrains_hip.h"
+
+#define VS_WAVE 64
+
+// ---- packed text ---------------------------------------------------------------------------
+// 2 bits per base (A=0 C=1 G=2 T=3), 16 bases per uint32 word, base i of a sequence sits in
+// word i/16 at bits 2*(i%16) (LSB first).  Every sequence starts on a word boundary and every
+// buffer carries two zero pad words so that a 3-word window read never leaves the allocation.
+
+struct VsNodeMeta {
+    uint32_t woff;  // first word of the node in fwd_words / rc_words
+    uint32_t len;   // bases
+};
+
+// One open-address slot of the seed table (16 B, read with one dwordx4 load).
+//  key  : canonical w-mer (2w <= 62 bits); bit 62 set = several postings; all ones = empty
+//  a, b : single -> a = node, b = pos | (node_strand << 31)
+//         multi  -> a = first posting index, b = number of postings
+struct VsSlot {
+    uint64_t key;
+    uint32_t a;
+    uint32_t b;
+};
+#define VS_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+#define VS_MULTI_BIT (1ull << 62)
+
+struct VsIndexDev {
+    uint32_t n_nodes;
+    uint32_t K;  // split_len = ksize + 1
+    uint32_t w;  // seed length (odd, <= 31, <= K)
+    uint32_t s;  // probe stride on the read = K - w + 1
+    uint32_t table_bits;
+    const VsNodeMeta *meta;     // [n_nodes]
+    const uint32_t *fwd_words;  // packed node texts
+    const uint32_t *rc_words;   // packed reverse complements, same offsets
+    const VsSlot *table;        // [1 << table_bits]
+    const uint2 *postings;      // (node, pos | strand << 31)
+};
+
+struct VsReadsDev {
+    uint64_t n_ends;
+    const uint32_t *woff;   // [n_ends + 1] word offsets into words
+    const uint32_t *meta;   // [n_ends] length (bits 0..23) | flags << 24
+    const uint32_t *words;  // packed bases
+    const uint32_t *mask;   // same layout, 0b11 at bytes outside ACGT; NULL when no end has any
+};
+#define VS_FLAG_N 1u        // read holds an upper-case 'N'
+#define VS_FLAG_INVALID 2u  // read holds some other byte outside ACGT
+#define VS_LEN_MASK 0x00FFFFFFu
+
+// ---- host-side objects -----------------------------------------------------------------------
+struct vs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool has_index = false;
+    VsIndexDev idx{};
+    // owned device allocations of the index
+    void *d_meta = nullptr, *d_fwd = nullptr, *d_rc = nullptr, *d_table = nullptr, *d_post = nullptr;
+    uint64_t n_seed_pos = 0, n_slots = 0, n_distinct = 0, index_bytes = 0;
+    // scratch for vs_pe_count
+    void *d_slow_list = nullptr;   // pair indices sent to the slow path
+    uint64_t slow_cap = 0;
+    void *d_slow_count = nullptr;  // uint32 counter
+    void *d_dense = nullptr;       // dense per-workgroup state for the slow path
+    uint64_t dense_bytes = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    double last_ms[3] = {0, 0, 0};
+    int n_cu = 256;
+};
+
+struct vs_reads {
+    uint64_t n_ends = 0, n_words = 0, max_len = 0, n_invalid = 0, bytes = 0;
+    void *d_woff = nullptr, *d_meta = nullptr, *d_words = nullptr, *d_mask = nullptr;
+    VsReadsDev dev() const {
+        VsReadsDev r;
+        r.n_ends = n_ends;
+        r.woff = (const uint32_t *)d_woff;
+        r.meta = (const uint32_t *)d_meta;
+        r.words = (const uint32_t *)d_words;
+        r.mask = (const uint32_t *)d_mask;
+        return r;
+    }
+};
+
+int vs_fail(vs_ctx *ctx, int code, const char *fmt, ...);
+extern "C" void vs_ctx_free_index(vs_ctx *ctx);
+#define VS_HIP(ctx, call)                                                                  \
+    do {                                                                                   \
+        hipError_t e__ = (call);                                                           \
+        if (e__ != hipSuccess)                                                             \
+            return vs_fail(ctx, e__ == hipErrorOutOfMemory ? VS_E_OOM : VS_E_HIP,          \
+                           "%s failed: %s", #call, hipGetErrorString(e__));                \
+    } while (0)
+
+// Exclusive scan of n uint32 values on the ctx stream (in -> out, may alias); total (uint64) is
+// written to d_total if not NULL.  tmp must hold ceil(n/2048)+1 uint64.
+int vs_scan_u32(vs_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t n, uint64_t *d_tmp,
+                uint64_t *d_total);
+
+// ---- device helpers ----------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+__device__ __forceinline__ uint32_t vs_code(uint8_t c) {
+    // A C G T -> 0 1 2 3, anything else -> 4
+    return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+}
+
+// 32 bases (64 bits) starting at base offset `base` of a packed word array.
+__device__ __forceinline__ uint64_t vs_win64(const uint32_t *w, uint64_t base) {
+    uint64_t i = base >> 4;
+    uint32_t sh = (uint32_t)(base & 15u) * 2u;
+    uint64_t lo = (uint64_t)w[i] | ((uint64_t)w[i + 1] << 32);
+    uint64_t hi = (uint64_t)w[i + 2];
+    return sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
+}
+
+__device__ __forceinline__ uint64_t vs_lowmask(uint32_t bits) {  // bits in 0..64
+    return bits >= 64u ? ~0ull : ((1ull << bits) - 1ull);
+}
+
+// Reverse complement of a w-mer held LSB-first in the low 2w bits.
+__device__ __forceinline__ uint64_t vs_rc(uint64_t x, uint32_t w) {
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    x = __builtin_bswap64(x);
+    return (~x) >> (64u - 2u * w);
+}
+
+__device__ __forceinline__ uint32_t vs_slot_of(uint64_t key, uint32_t bits) {
+    return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64u - bits));
+}
+
+__device__ __forceinline__ uint64_t vs_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// index of the last element <= x in a sorted array a[0..n) with a[0] <= x
+template <typename T>
+__device__ __forceinline__ uint32_t vs_upper_idx(const T *a, uint32_t n, T x) {
+    uint32_t lo = 0, hi = n;  // invariant: a[lo] <= x, a[hi] > x (virtually)
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,576 @@
+// K2-K4 fused: seed probe -> load-balanced hit expansion + exact extension -> per-end
+// aggregation in LDS -> acceptance test -> PE-link counters.
+//
+// What it computes is single_end_read_mapping + the pair loop of the reference
+// (utils/VStrains_PE_Inference.py:16-48 and :155-188), bit for bit:
+//   for a read end and a node, the reference's three numbers are
+//     v        = number of (read window, table entry) coincidences for that node   (:29)
+//     coords   = smallest forward node offset among them                           (:30)
+//     kindices = smallest read offset among them                                   (:31)
+//   Windows that coincide lie on diagonals; on one diagonal they form maximal runs, and a run
+//   is exactly a maximal exact match (MEM) of length l >= K between the read and one strand of
+//   the node: it contributes l-K+1 to v, its first node offset to coords (mapped back to the
+//   forward strand for reverse matches: the reference stores the forward offset under the
+//   reverse-complemented window, :132) and its first read offset to kindices.  Palindromic
+//   windows are held twice by the reference (:125,:132) and are found here once per strand.
+//   Every MEM holds a seed at a read offset divisible by s; the MEM is credited by the first
+//   such seed only (left extension < s), so nothing is counted twice.
+//
+// Work split per 256-thread workgroup and tile of `ept` read ends (ept/2 pairs):
+//   P0  tile header + packed reads -> LDS (coalesced dword loads)
+//   P1  one thread per (end, probe): seed, canonical form, open-address table probe (one 16-B
+//       load per slot visited); posting count per probe -> LDS
+//   P2  workgroup inclusive scan of the posting counts
+//   P3  one thread per posting (binary search of the scan = CSR-style frontier expansion, so a
+//       repeat seed's many postings spread over lanes): left/right extension on 64-bit windows
+//       (XOR + clz/ctz), LDS atomics into an 8-slot per-end table keyed by node
+//   P4  acceptance test per occupied slot (integer form, see oracle/pe_oracle.py)
+//   P5  per-end compaction, then node_mat / short_mat global atomics
+// Ends that touch more than 8 nodes overflow the LDS table; their pairs go to a list that a
+// second, fully general kernel (dense per-workgroup node state in HBM) works through.
+#include "vs_internal.h"
+
+#define TPB 256
+#define SL 8u  // node slots per read end in LDS
+#define EMPTY_NODE 0xFFFFFFFFu
+
+struct PeParams {
+    VsIndexDev idx;
+    VsReadsDev rd;
+    uint32_t *node_mat, *short_mat;
+    unsigned long long *stats;
+    uint32_t ept, pmax, words_cap;
+    uint64_t n_tiles;
+    uint32_t *slow_list, *slow_count;
+    uint32_t *dbg_lists, *dbg_counts;
+    uint32_t dbg_cap;
+    uint32_t accumulate;
+};
+
+struct Mem {  // one credited maximal exact match
+    uint32_t cnt, minp, minj;
+};
+
+// Extension of a seed hit.  rw/rbase: packed read (LDS or global) and its first base; tw/tbase:
+// packed node strand.  mk/mbase: validity mask of the read or NULL.  Returns false when the
+// match is owned by an earlier probe or is shorter than K.
+template <typename RW>
+__device__ __forceinline__ bool vs_extend(const RW *rw, uint64_t rbase, uint32_t rlen, const uint32_t *tw,
+                                          uint64_t tbase, uint32_t tlen, uint32_t j, uint32_t q, uint32_t w,
+                                          uint32_t s, uint32_t K, const uint32_t *mk, uint64_t mbase,
+                                          uint32_t *a_out, uint32_t *qa_out, uint32_t *len_out) {
+    uint32_t c = s < j ? s : j;
+    c = c < q ? c : q;
+    uint32_t left = 0;
+    if (c) {
+        uint64_t x = vs_win64(rw, rbase + j - c) ^ vs_win64(tw, tbase + q - c);
+        if (mk) x |= vs_win64(mk, mbase + j - c);
+        x &= vs_lowmask(2u * c);
+        left = x ? c - 1u - (uint32_t)((63 - __clzll((long long)x)) >> 1) : c;
+        if (left >= s) return false;
+    }
+    uint32_t rj = j + w, rq = q + w;
+    uint32_t rem = rlen - rj;
+    uint32_t rem2 = tlen - rq;
+    rem = rem < rem2 ? rem : rem2;
+    uint32_t ext = 0;
+    while (rem) {
+        uint64_t x = vs_win64(rw, rbase + rj + ext) ^ vs_win64(tw, tbase + rq + ext);
+        if (mk) x |= vs_win64(mk, mbase + rj + ext);
+        if (x) {
+            uint32_t m = (uint32_t)(__ffsll((long long)x) - 1) >> 1;
+            ext += m < rem ? m : rem;
+            break;
+        }
+        uint32_t adv = rem < 32u ? rem : 32u;
+        ext += adv;
+        rem -= adv;
+    }
+    uint32_t len = left + w + ext;
+    if (len < K) return false;
+    *a_out = j - left;
+    *qa_out = q - left;
+    *len_out = len;
+    return true;
+}
+
+__device__ __forceinline__ bool vs_accept(uint32_t v, uint32_t coord, uint32_t kidx, uint32_t nlen, uint32_t rlen, uint32_t K) {
+    long long c = coord, ki = kidx, nl = nlen, rl = rlen, k = K;
+    long long right = c + nl - 1;
+    long long alt = c - ki + rl - 1;
+    if (alt < right) right = alt;
+    long long saturate = right - c - k + 2;
+    long long span = (rl < nl ? rl : nl) - k + 1;
+    return ((long long)v >= saturate) || ((long long)v * rl >= span * (rl - k));
+}
+
+// Probe the table for the seed at read offset j.  Returns posting count (0 = miss) and payload.
+__device__ __forceinline__ uint32_t vs_probe(const VsIndexDev &idx, uint64_t f, uint32_t *pa, uint32_t *pb) {
+    uint64_t r = vs_rc(f, idx.w);
+    uint32_t sr = r < f ? 1u : 0u;
+    uint64_t key = sr ? r : f;
+    uint32_t mask = (1u << idx.table_bits) - 1u;
+    uint32_t sl = vs_slot_of(key, idx.table_bits);
+    const uint4 *tab = (const uint4 *)idx.table;
+    for (;;) {
+        uint4 raw = tab[sl];
+        uint64_t k = (uint64_t)raw.x | ((uint64_t)raw.y << 32);
+        if (k == VS_EMPTY_KEY) return 0u;
+        if ((k & ~VS_MULTI_BIT) == key) {
+            if (k & VS_MULTI_BIT) {
+                *pa = raw.z;
+                *pb = raw.w | (sr << 31);
+                return raw.w;
+            }
+            *pa = raw.z;
+            *pb = raw.w ^ (sr << 31);
+            return 1u;
+        }
+        sl = (sl + 1u) & mask;
+    }
+}
+
+extern __shared__ __attribute__((aligned(16))) uint32_t vs_lds[];
+
+__global__ void __launch_bounds__(TPB)
+k_pe_tiles(PeParams P) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t ept = P.ept, pmax = P.pmax;
+    const uint32_t NI = ept * pmax;
+    const uint32_t w = P.idx.w, s = P.idx.s, K = P.idx.K;
+    // LDS carve
+    uint32_t *s_woff = vs_lds;                       // ept + 1 (+ pad to even)
+    uint32_t *s_meta = s_woff + ((ept + 2u) & ~1u);   // ept
+    uint32_t *s_words = s_meta + ept;                 // words_cap + 4
+    uint32_t *s_pcnt = s_words + P.words_cap + 4u;    // NI  (counts, then inclusive scan)
+    uint32_t *s_pa = s_pcnt + NI;                     // NI
+    uint32_t *s_pb = s_pa + NI;                       // NI
+    uint32_t *s_hnode = s_pb + NI;                    // ept * SL
+    uint32_t *s_hcnt = s_hnode + ept * SL;
+    uint32_t *s_hminp = s_hcnt + ept * SL;
+    uint32_t *s_hminj = s_hminp + ept * SL;
+    uint32_t *s_ns = s_hminj + ept * SL;              // ept   survivors per end
+    uint32_t *s_state = s_ns + ept;                   // ept   bit0: end belongs to a used pair, bit1: overflow
+    uint32_t *s_misc = s_state + ept;                 // 16
+
+    if (tid < 3) s_misc[8 + tid] = 0;  // workgroup-local stats
+
+    for (uint64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+        const uint64_t e0 = tile * ept;
+        const uint32_t ne = (uint32_t)((P.rd.n_ends - e0) < ept ? (P.rd.n_ends - e0) : ept);
+        __syncthreads();  // previous tile fully consumed
+        // ---- P0: header
+        for (uint32_t i = tid; i <= ne; i += TPB) s_woff[i] = P.rd.woff[e0 + i];
+        for (uint32_t i = tid; i < ne; i += TPB) s_meta[i] = P.rd.meta[e0 + i];
+        for (uint32_t i = tid; i < ept * SL; i += TPB) {
+            s_hnode[i] = EMPTY_NODE;
+            s_hcnt[i] = 0;
+            s_hminp[i] = 0xFFFFFFFFu;
+            s_hminj[i] = 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        const uint32_t w0 = s_woff[0];
+        const uint32_t nw = s_woff[ne] - w0;
+        for (uint32_t i = tid; i < nw + 3u; i += TPB) s_words[i] = i < nw ? P.rd.words[w0 + i] : 0u;
+        // pair classification (PE_Inference.py:160-165): one thread per pair
+        if (tid < ne / 2u) {
+            uint32_t mf = s_meta[2 * tid], mr = s_meta[2 * tid + 1];
+            uint32_t cls;
+            if (((mf | mr) >> 24) & VS_FLAG_N) cls = 0;
+            else if ((mf & VS_LEN_MASK) < K || (mr & VS_LEN_MASK) < K) cls = 1;
+            else cls = 2;
+            atomicAdd(&s_misc[8 + cls], 1u);
+            s_state[2 * tid] = s_state[2 * tid + 1] = (cls == 2) ? 1u : 0u;
+            s_ns[2 * tid] = s_ns[2 * tid + 1] = 0;
+        }
+        __syncthreads();
+        // ---- P1: probes
+        for (uint32_t it = tid; it < NI; it += TPB) {
+            uint32_t e = it / pmax, pi = it - e * pmax;
+            uint32_t cnt = 0, pa = 0, pb = 0;
+            if (e < ne && (s_state[e] & 1u)) {
+                uint32_t meta = s_meta[e];
+                uint32_t rlen = meta & VS_LEN_MASK;
+                uint32_t j = pi * s;
+                if (j + w <= rlen) {
+                    uint64_t rb = (uint64_t)(s_woff[e] - w0) * 16u + j;
+                    uint64_t f = vs_win64(s_words, rb) & vs_lowmask(2u * w);
+                    bool ok = true;
+                    if ((meta >> 24) & VS_FLAG_INVALID)
+                        ok = (vs_win64(P.rd.mask, (uint64_t)s_woff[e] * 16u + j) & vs_lowmask(2u * w)) == 0ull;
+                    if (ok) cnt = vs_probe(P.idx, f, &pa, &pb);
+                }
+            }
+            s_pcnt[it] = cnt;
+            s_pa[it] = pa;
+            s_pb[it] = pb;
+        }
+        __syncthreads();
+        // ---- P2: inclusive scan of s_pcnt[0..NI)
+        {
+            const uint32_t chunk = (NI + TPB - 1u) / TPB;
+            const uint32_t b = tid * chunk;
+            uint32_t local = 0;
+            for (uint32_t i = 0; i < chunk; i++)
+                if (b + i < NI) local += s_pcnt[b + i];
+            uint32_t incl = local;
+            const uint32_t lane = tid & 63u;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t t = __shfl_up(incl, d, 64);
+                if (lane >= (uint32_t)d) incl += t;
+            }
+            if (lane == 63u) s_misc[tid >> 6] = incl;
+            __syncthreads();
+            uint32_t off = incl - local;
+            for (uint32_t wv = 0; wv < (tid >> 6); wv++) off += s_misc[wv];
+            for (uint32_t i = 0; i < chunk; i++)
+                if (b + i < NI) {
+                    off += s_pcnt[b + i];
+                    s_pcnt[b + i] = off;
+                }
+        }
+        __syncthreads();
+        const uint32_t total = s_pcnt[NI - 1u];
+        // ---- P3: one thread per posting
+        for (uint32_t t = tid; t < total; t += TPB) {
+            uint32_t lo = 0, hi = NI - 1u;
+            while (lo < hi) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (s_pcnt[mid] > t) hi = mid; else lo = mid + 1u;
+            }
+            const uint32_t it = lo;
+            const uint32_t excl = it ? s_pcnt[it - 1u] : 0u;
+            const uint32_t cnt = s_pcnt[it] - excl;
+            uint32_t pa = s_pa[it], pb = s_pb[it];
+            uint32_t node, pos, opp;
+            if (cnt == 1u) {
+                node = pa; pos = pb & 0x7FFFFFFFu; opp = pb >> 31;
+            } else {
+                uint2 po = P.idx.postings[pa + (t - excl)];
+                node = po.x; pos = po.y & 0x7FFFFFFFu; opp = (po.y >> 31) ^ (pb >> 31);
+            }
+            const uint32_t e = it / pmax, j = (it - e * pmax) * s;
+            const uint32_t meta = s_meta[e];
+            const uint32_t rlen = meta & VS_LEN_MASK;
+            const VsNodeMeta nm = P.idx.meta[node];
+            const uint32_t *tw = opp ? P.idx.rc_words : P.idx.fwd_words;
+            const uint32_t q = opp ? nm.len - pos - w : pos;
+            const uint32_t *mk = ((meta >> 24) & VS_FLAG_INVALID) ? P.rd.mask : nullptr;
+            uint32_t a, qa, len;
+            if (!vs_extend(s_words, (uint64_t)(s_woff[e] - w0) * 16u, rlen, tw, (uint64_t)nm.woff * 16u, nm.len, j, q, w, s, K,
+                           mk, (uint64_t)s_woff[e] * 16u, &a, &qa, &len))
+                continue;
+            const uint32_t add = len - K + 1u;
+            const uint32_t minp = opp ? nm.len - qa - len : qa;
+            // LDS table of the end
+            uint32_t h = (node * 0x9E3779B1u) >> 29;
+            bool placed = false;
+            for (uint32_t pr = 0; pr < SL; pr++) {
+                uint32_t at = e * SL + ((h + pr) & (SL - 1u));
+                uint32_t old = atomicCAS(&s_hnode[at], EMPTY_NODE, node);
+                if (old == EMPTY_NODE || old == node) {
+                    atomicAdd(&s_hcnt[at], add);
+                    atomicMin(&s_hminp[at], minp);
+                    atomicMin(&s_hminj[at], a);
+                    placed = true;
+                    break;
+                }
+            }
+            if (!placed) atomicOr(&s_state[e], 2u);
+        }
+        __syncthreads();
+        // ---- P4: acceptance test per slot
+        for (uint32_t i = tid; i < ne * SL; i += TPB) {
+            uint32_t node = s_hnode[i];
+            if (node != EMPTY_NODE) {
+                uint32_t e = i / SL;
+                uint32_t rlen = s_meta[e] & VS_LEN_MASK;
+                uint32_t nlen = P.idx.meta[node].len;
+                if (!vs_accept(s_hcnt[i], s_hminp[i], s_hminj[i], nlen, rlen, K)) s_hnode[i] = EMPTY_NODE;
+            }
+        }
+        __syncthreads();
+        // ---- P5a: compaction (one thread per end), in place at the front of the end's slots
+        if (tid < ne) {
+            uint32_t n = 0;
+            uint32_t keep[SL];
+#pragma unroll
+            for (uint32_t k2 = 0; k2 < SL; k2++) {
+                uint32_t v = s_hnode[tid * SL + k2];
+                keep[k2] = v;
+            }
+#pragma unroll
+            for (uint32_t k2 = 0; k2 < SL; k2++)
+                if (keep[k2] != EMPTY_NODE) s_hnode[tid * SL + n++] = keep[k2];
+            s_ns[tid] = n;
+        }
+        __syncthreads();
+        // pairs with an overflowed end go to the slow list
+        if (tid < ne / 2u) {
+            uint32_t st = s_state[2 * tid] | s_state[2 * tid + 1];
+            if ((st & 1u) && (st & 2u)) {
+                uint32_t at = atomicAdd(P.slow_count, 1u);
+                P.slow_list[at] = (uint32_t)(e0 / 2u) + tid;
+                s_state[2 * tid] |= 2u;
+                s_state[2 * tid + 1] |= 2u;
+            }
+        }
+        __syncthreads();
+        // ---- P5b: counters
+        const uint32_t N = P.idx.n_nodes;
+        if (P.accumulate) {
+            const uint32_t combos = (ne / 2u) * SL * SL;
+            for (uint32_t i = tid; i < combos; i += TPB) {
+                uint32_t pr = i / (SL * SL), ab = i - pr * (SL * SL);
+                uint32_t a = ab / SL, b = ab - a * SL;
+                uint32_t ef = 2u * pr, er = ef + 1u;
+                if ((s_state[ef] & 3u) != 1u) continue;
+                uint32_t nl = s_ns[ef], nr = s_ns[er];
+                if (a < nl && b < nr) atomicAdd(&P.node_mat[(uint64_t)s_hnode[ef * SL + a] * N + s_hnode[er * SL + b]], 1u);
+                if (a < nl && b < nl) {
+                    uint32_t x = s_hnode[ef * SL + a], y = s_hnode[ef * SL + b];
+                    if (x < y || a == b) atomicAdd(&P.short_mat[(uint64_t)x * N + y], 1u);
+                }
+                if (a < nr && b < nr) {
+                    uint32_t x = s_hnode[er * SL + a], y = s_hnode[er * SL + b];
+                    if (x < y || a == b) atomicAdd(&P.short_mat[(uint64_t)x * N + y], 1u);
+                }
+            }
+        }
+        if (P.dbg_counts) {
+            for (uint32_t i = tid; i < ne; i += TPB) {
+                if (s_state[i] & 2u) continue;  // the slow kernel reports these
+                uint32_t n = s_ns[i];
+                P.dbg_counts[e0 + i] = n;
+                for (uint32_t k2 = 0; k2 < n && k2 < P.dbg_cap; k2++) P.dbg_lists[(e0 + i) * P.dbg_cap + k2] = s_hnode[i * SL + k2];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 3 && P.stats && s_misc[8 + tid]) atomicAdd(&P.stats[tid], (unsigned long long)s_misc[8 + tid]);
+}
+
+// ---- slow path: any number of nodes per end ------------------------------------------------------
+// One workgroup per listed pair.  Node state is dense in HBM (three uint32 per node, the
+// reference's own layout, PE_Inference.py:19-21), updated with global atomics, swept and reset
+// after each end.  dense layout per workgroup: cnt[N] minp[N] minj[N] surv0[N] surv1[N].
+__global__ void __launch_bounds__(TPB)
+k_pe_slow(PeParams P, uint32_t *dense, uint32_t n_slow_cap) {
+    __shared__ uint32_t s_n[2];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t N = P.idx.n_nodes, w = P.idx.w, s = P.idx.s, K = P.idx.K;
+    uint32_t n_slow = *P.slow_count;
+    if (n_slow > n_slow_cap) n_slow = n_slow_cap;
+    uint32_t *cnt = dense + (uint64_t)blockIdx.x * 5u * N;
+    uint32_t *minp = cnt + N, *minj = minp + N, *surv0 = minj + N, *surv1 = surv0 + N;
+    for (uint32_t li = blockIdx.x; li < n_slow; li += gridDim.x) {
+        const uint32_t pair = P.slow_list[li];
+        if (tid < 2) s_n[tid] = 0;
+        __syncthreads();
+        for (uint32_t side = 0; side < 2; side++) {
+            const uint64_t e = 2ull * pair + side;
+            const uint32_t meta = P.rd.meta[e];
+            const uint32_t rlen = meta & VS_LEN_MASK;
+            const uint64_t rbase = (uint64_t)P.rd.woff[e] * 16u;
+            const uint32_t *mk = ((meta >> 24) & VS_FLAG_INVALID) ? P.rd.mask : nullptr;
+            uint32_t *surv = side ? surv1 : surv0;
+            const uint32_t nprobe = rlen >= w ? (rlen - w) / s + 1u : 0u;
+            for (uint32_t pi = tid; pi < nprobe; pi += TPB) {
+                uint32_t j = pi * s;
+                uint64_t f = vs_win64(P.rd.words, rbase + j) & vs_lowmask(2u * w);
+                if (mk && (vs_win64(mk, rbase + j) & vs_lowmask(2u * w))) continue;
+                uint32_t pa, pb;
+                uint32_t c = vs_probe(P.idx, f, &pa, &pb);
+                for (uint32_t k2 = 0; k2 < c; k2++) {
+                    uint32_t node, pos, opp;
+                    if (c == 1u) { node = pa; pos = pb & 0x7FFFFFFFu; opp = pb >> 31; }
+                    else {
+                        uint2 po = P.idx.postings[pa + k2];
+                        node = po.x; pos = po.y & 0x7FFFFFFFu; opp = (po.y >> 31) ^ (pb >> 31);
+                    }
+                    const VsNodeMeta nm = P.idx.meta[node];
+                    const uint32_t *tw = opp ? P.idx.rc_words : P.idx.fwd_words;
+                    const uint32_t q = opp ? nm.len - pos - w : pos;
+                    uint32_t a, qa, len;
+                    if (!vs_extend(P.rd.words, rbase, rlen, tw, (uint64_t)nm.woff * 16u, nm.len, j, q, w, s, K, mk, rbase, &a, &qa, &len))
+                        continue;
+                    atomicAdd(&cnt[node], len - K + 1u);
+                    atomicMin(&minp[node], opp ? nm.len - qa - len : qa);
+                    atomicMin(&minj[node], a);
+                }
+            }
+            __threadfence();
+            __syncthreads();
+            for (uint32_t nd = tid; nd < N; nd += TPB) {
+                uint32_t v = __hip_atomic_load(&cnt[nd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v) {
+                    uint32_t c = __hip_atomic_load(&minp[nd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    uint32_t ki = __hip_atomic_load(&minj[nd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (vs_accept(v, c, ki, P.idx.meta[nd].len, rlen, K)) surv[atomicAdd(&s_n[side], 1u)] = nd;
+                    __hip_atomic_store(&cnt[nd], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&minp[nd], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&minj[nd], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __threadfence();
+            __syncthreads();
+        }
+        const uint32_t nl = s_n[0], nr = s_n[1];
+        if (P.accumulate) {
+            for (uint64_t i = tid; i < (uint64_t)nl * nr; i += TPB) {
+                uint32_t a = (uint32_t)(i / nr), b = (uint32_t)(i - (uint64_t)a * nr);
+                atomicAdd(&P.node_mat[(uint64_t)__hip_atomic_load(&surv0[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * N +
+                                      __hip_atomic_load(&surv1[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)], 1u);
+            }
+            for (uint32_t side = 0; side < 2; side++) {
+                const uint32_t *sv = side ? surv1 : surv0;
+                const uint32_t n = side ? nr : nl;
+                for (uint64_t i = tid; i < (uint64_t)n * n; i += TPB) {
+                    uint32_t a = (uint32_t)(i / n), b = (uint32_t)(i - (uint64_t)a * n);
+                    uint32_t x = __hip_atomic_load(&sv[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    uint32_t y = __hip_atomic_load(&sv[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (x < y || a == b) atomicAdd(&P.short_mat[(uint64_t)x * N + y], 1u);
+                }
+            }
+        }
+        if (P.dbg_counts) {
+            for (uint32_t side = 0; side < 2; side++) {
+                const uint32_t *sv = side ? surv1 : surv0;
+                const uint32_t n = side ? nr : nl;
+                const uint64_t e = 2ull * pair + side;
+                if (tid == 0) P.dbg_counts[e] = n;
+                for (uint32_t i = tid; i < n && i < P.dbg_cap; i += TPB)
+                    P.dbg_lists[e * P.dbg_cap + i] = __hip_atomic_load(&sv[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(TPB) k_dense_zero_cnt(uint32_t *dense, uint64_t N, uint64_t groups) {
+    uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i < N * groups) dense[(i / N) * 5ull * N + (i % N)] = 0u;
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+#define LDS_BUDGET_BYTES (48u * 1024u)
+#define NI_CAP 4096u
+#define SLOW_GRID 256u
+
+static size_t lds_bytes(uint32_t ept, uint32_t pmax, uint32_t words_cap) {
+    size_t u = ((ept + 2u) & ~1u) + ept + (words_cap + 4u) + 3ull * ept * pmax + 4ull * ept * SL + ept + ept + 16u;
+    return u * sizeof(uint32_t);
+}
+
+static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, uint32_t *d_short_mat, uint64_t *d_stats,
+                     uint32_t *d_dbg_lists, uint32_t *d_dbg_counts, uint32_t dbg_cap) {
+    if (!ctx->has_index) return vs_fail(ctx, VS_E_STATE, "vs_pe_count: build an index first (vs_index_build)");
+    VS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const VsIndexDev &idx = ctx->idx;
+    const uint64_t n_ends = reads->n_ends, n_pairs = n_ends / 2;
+    ctx->last_ms[0] = ctx->last_ms[1] = ctx->last_ms[2] = 0;
+    if (n_ends == 0) return VS_OK;
+    const uint32_t maxlen = (uint32_t)reads->max_len;
+    const uint32_t pmax = maxlen >= idx.w ? (maxlen - idx.w) / idx.s + 1u : 1u;
+    const uint32_t wpe = (maxlen + 15u) / 16u;
+    uint32_t ept = 128;
+    while (ept > 2 && (ept * pmax > NI_CAP || lds_bytes(ept, pmax, ept * wpe) > LDS_BUDGET_BYTES)) ept -= 2;
+    size_t lds = lds_bytes(ept, pmax, ept * wpe);
+    if (lds > 160u * 1024u)
+        return vs_fail(ctx, VS_E_RANGE, "reads of %u bases with k+1=%u need %zu B of LDS per pair (limit 160 KiB)", maxlen, idx.K, lds);
+
+    // scratch: slow list (one slot per pair), counter, dense state
+    if (ctx->slow_cap < n_pairs) {
+        if (ctx->d_slow_list) VS_HIP(ctx, hipFree(ctx->d_slow_list));
+        ctx->d_slow_list = nullptr;
+        VS_HIP(ctx, hipMalloc(&ctx->d_slow_list, sizeof(uint32_t) * n_pairs));
+        ctx->slow_cap = n_pairs;
+    }
+    if (!ctx->d_slow_count) VS_HIP(ctx, hipMalloc(&ctx->d_slow_count, 16));
+    uint64_t need_dense = sizeof(uint32_t) * 5ull * (idx.n_nodes ? idx.n_nodes : 1) * SLOW_GRID;
+    if (ctx->dense_bytes < need_dense) {
+        if (ctx->d_dense) VS_HIP(ctx, hipFree(ctx->d_dense));
+        ctx->d_dense = nullptr;
+        ctx->dense_bytes = 0;
+        VS_HIP(ctx, hipMalloc(&ctx->d_dense, need_dense));
+        ctx->dense_bytes = need_dense;
+        // cnt = 0, minp/minj = ~0 once; k_pe_slow restores this state after every end it sweeps
+        uint64_t N = idx.n_nodes ? idx.n_nodes : 1;
+        VS_HIP(ctx, hipMemsetAsync(ctx->d_dense, 0xFF, need_dense, st));
+        hipLaunchKernelGGL(k_dense_zero_cnt, dim3((unsigned)((N * SLOW_GRID + TPB - 1) / TPB)), dim3(TPB), 0, st,
+                           (uint32_t *)ctx->d_dense, N, (uint64_t)SLOW_GRID);
+    }
+    VS_HIP(ctx, hipMemsetAsync(ctx->d_slow_count, 0, 16, st));
+
+    PeParams P;
+    P.idx = idx;
+    P.rd = reads->dev();
+    P.node_mat = d_node_mat;
+    P.short_mat = d_short_mat;
+    P.stats = (unsigned long long *)d_stats;
+    P.ept = ept;
+    P.pmax = pmax;
+    P.words_cap = ept * wpe;
+    P.n_tiles = (n_ends + ept - 1) / ept;
+    P.slow_list = (uint32_t *)ctx->d_slow_list;
+    P.slow_count = (uint32_t *)ctx->d_slow_count;
+    P.dbg_lists = d_dbg_lists;
+    P.dbg_counts = d_dbg_counts;
+    P.dbg_cap = dbg_cap;
+    P.accumulate = d_node_mat ? 1u : 0u;
+
+    if (lds > 64u * 1024u)
+        VS_HIP(ctx, hipFuncSetAttribute((const void *)k_pe_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    uint64_t grid = P.n_tiles;
+    uint64_t max_grid = (uint64_t)ctx->n_cu * 8u;
+    if (grid > max_grid) grid = max_grid;
+    VS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+    hipLaunchKernelGGL(k_pe_tiles, dim3((unsigned)grid), dim3(TPB), lds, st, P);
+    VS_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+    hipLaunchKernelGGL(k_pe_slow, dim3(SLOW_GRID), dim3(TPB), 0, st, P, (uint32_t *)ctx->d_dense, (uint32_t)n_pairs);
+    VS_HIP(ctx, hipEventRecord(ctx->ev[2], st));
+    VS_HIP(ctx, hipGetLastError());
+    return VS_OK;
+}
+
+extern "C" int vs_pe_count(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, uint32_t *d_short_mat, uint64_t *d_stats) {
+    if (!ctx || !reads || !d_node_mat || !d_short_mat || !d_stats) return VS_E_ARG;
+    return pe_launch(ctx, reads, d_node_mat, d_short_mat, d_stats, nullptr, nullptr, 0);
+}
+
+extern "C" int vs_pe_last_timing(vs_ctx *ctx, double ms[3]) {
+    if (!ctx || !ms) return VS_E_ARG;
+    VS_HIP(ctx, hipSetDevice(ctx->device));
+    VS_HIP(ctx, hipEventSynchronize(ctx->ev[2]));
+    float a = 0, b = 0;
+    VS_HIP(ctx, hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
+    VS_HIP(ctx, hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
+    uint32_t n_slow = 0;
+    VS_HIP(ctx, hipMemcpy(&n_slow, ctx->d_slow_count, sizeof n_slow, hipMemcpyDeviceToHost));
+    ms[0] = a; ms[1] = b; ms[2] = (double)n_slow;
+    ctx->last_ms[0] = a; ctx->last_ms[1] = b; ctx->last_ms[2] = n_slow;
+    return VS_OK;
+}
+
+extern "C" int vs_pe_map_ends(vs_ctx *ctx, const vs_reads *reads, uint32_t cap, uint32_t *lists, uint32_t *counts) {
+    if (!ctx || !reads || !lists || !counts || !cap) return VS_E_ARG;
+    VS_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t n = reads->n_ends;
+    if (!n) return VS_OK;
+    uint32_t *d_lists = nullptr, *d_counts = nullptr;
+    VS_HIP(ctx, hipMalloc((void **)&d_lists, sizeof(uint32_t) * n * cap));
+    hipError_t e1 = hipMalloc((void **)&d_counts, sizeof(uint32_t) * n);
+    int rc = VS_OK;
+    if (e1 == hipSuccess) e1 = hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * n, ctx->stream);
+    if (e1 == hipSuccess) e1 = hipMemsetAsync(d_lists, 0xFF, sizeof(uint32_t) * n * cap, ctx->stream);
+    if (e1 == hipSuccess) rc = pe_launch(ctx, reads, nullptr, nullptr, nullptr, d_lists, d_counts, cap);
+    if (e1 == hipSuccess && rc == VS_OK) e1 = hipMemcpyAsync(lists, d_lists, sizeof(uint32_t) * n * cap, hipMemcpyDeviceToHost, ctx->stream);
+    if (e1 == hipSuccess && rc == VS_OK) e1 = hipMemcpyAsync(counts, d_counts, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e1 == hipSuccess && rc == VS_OK) e1 = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_lists);
+    if (d_counts) (void)hipFree(d_counts);
+    if (e1 != hipSuccess) return vs_fail(ctx, VS_E_HIP, "vs_pe_map_ends: %s", hipGetErrorString(e1));
+    return rc;
+}

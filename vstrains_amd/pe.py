@@ -1,0 +1,289 @@
+"""Host side of PE-link inference: the Python mirror of the reference's
+``utils/VStrains_PE_Inference.py`` (file:line citations are into /root/reference) on top of the
+HIP library.  Torch is used for device buffers, the stream and torch.distributed only."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native as nat
+
+
+# ---- text inputs ---------------------------------------------------------------------------------
+def _universal_newlines(raw: bytes) -> bytes:
+    # open(path, "r") translates \r\n and lone \r to \n (PE_Inference.py:105,147-150 use text mode)
+    if b"\r" in raw:
+        raw = raw.replace(b"\r\n", b"\n").replace(b"\r", b"\n")
+    return raw
+
+
+def read_gfa_segments(path: str) -> Tuple[List[str], List[str]]:
+    """``S`` records in file order -> (ids, sequences).  Every line loses its last character
+    before the tab split, whatever that character is (PE_Inference.py:105-112)."""
+    with open(path, "rb") as fh:
+        raw = _universal_newlines(fh.read())
+    ids: List[str] = []
+    seqs: List[str] = []
+    pieces = raw.split(b"\n")
+    last_has_nl = raw.endswith(b"\n")
+    if last_has_nl:
+        pieces = pieces[:-1]
+    for i, piece in enumerate(pieces):
+        if i == len(pieces) - 1 and not last_has_nl:
+            piece = piece[:-1]  # no newline to drop: a real character goes instead
+        cols = piece.split(b"\t")
+        if cols[0] == b"S":
+            ids.append(cols[1].decode("latin-1"))
+            seqs.append(cols[2].decode("latin-1"))
+    return ids, seqs
+
+
+class FastqSeqs:
+    """Sequence lines of a FASTQ file as (buffer, starts, lengths) without Python strings.
+    Record r is lines 4r..4r+3 of ``readlines()``; the sequence is line 4r+1 minus its last
+    character (PE_Inference.py:149-159)."""
+
+    def __init__(self, path: str):
+        with open(path, "rb") as fh:
+            raw = _universal_newlines(fh.read())
+        if raw and max(raw) >= 0x80:
+            raise ValueError("%s holds non-ASCII bytes; text-mode decoding of the reference is not reproduced" % path)
+        buf = np.frombuffer(raw, dtype=np.uint8)
+        nl = np.flatnonzero(buf == 10)
+        n_lines = nl.size + (1 if (buf.size and (nl.size == 0 or nl[-1] != buf.size - 1)) else 0)
+        starts = np.empty(n_lines, dtype=np.int64)
+        ends = np.empty(n_lines, dtype=np.int64)  # exclusive end after dropping the last character
+        if n_lines:
+            starts[0] = 0
+            starts[1:] = nl[: n_lines - 1] + 1
+            ends[: nl.size] = nl  # the dropped character is the newline itself
+            if n_lines > nl.size:
+                ends[-1] = max(buf.size - 1, starts[-1])  # last line without newline: chop a real char
+        self.buf = buf
+        self.n_records = n_lines // 4
+        self.starts = starts[1::4][: self.n_records].copy()
+        self.lens = (ends[1::4][: self.n_records] - self.starts).astype(np.int64)
+
+    def __len__(self):
+        return self.n_records
+
+
+def interleave_pairs(fwd: FastqSeqs, rve: FastqSeqs, lo: int, hi: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Ends 2r / 2r+1 = forward / reverse sequence of pair r, lo <= r < hi, as one byte array
+    plus offsets (the layout vs_reads_pack takes)."""
+    n = hi - lo
+    lens = np.empty(2 * n, dtype=np.int64)
+    lens[0::2] = fwd.lens[lo:hi]
+    lens[1::2] = rve.lens[lo:hi]
+    off = np.zeros(2 * n + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:].view(np.int64))
+    total = int(off[-1])
+    out = np.empty(max(total, 1), dtype=np.uint8)
+    if total:
+        src = np.empty(2 * n, dtype=np.int64)
+        src[0::2] = fwd.starts[lo:hi]
+        src[1::2] = rve.starts[lo:hi] + fwd.buf.size  # index into the concatenation below
+        both = np.concatenate([fwd.buf, rve.buf])
+        # gather: position t of the output comes from src[e] + (t - off[e])
+        e_of_t = np.repeat(np.arange(2 * n, dtype=np.int64), lens)
+        idx = src[e_of_t] + (np.arange(total, dtype=np.int64) - off[:-1].astype(np.int64)[e_of_t])
+        out[:total] = both[idx]
+    return out, off
+
+
+def encode_seqs(seqs: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    if len(seqs):
+        off[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+    data = np.frombuffer("".join(seqs).encode("latin-1"), dtype=np.uint8)
+    if data.size == 0:
+        data = np.zeros(1, dtype=np.uint8)
+    return np.ascontiguousarray(data), off
+
+
+# ---- device objects ------------------------------------------------------------------------------
+class ReadBlock:
+    def __init__(self, ctx: "Context", handle):
+        self._ctx = ctx
+        self._h = handle
+
+    @property
+    def info(self):
+        a = (C.c_uint64 * 5)()
+        nat.check(self._ctx._h, nat.lib().vs_reads_info(self._h, a))
+        return dict(ends=a[0], words=a[1], max_len=a[2], invalid_ends=a[3], device_bytes=a[4])
+
+    def unpack(self):
+        inf = self.info
+        n = inf["ends"]
+        lens = np.zeros(max(n, 1), dtype=np.uint32)
+        flags = np.zeros(max(n, 1), dtype=np.uint8)
+        # two passes: lengths first (cheap), then text
+        out = np.zeros(max(int(inf["words"]) * 16, 1), dtype=np.uint8)
+        nat.check(self._ctx._h, nat.lib().vs_reads_unpack(self._ctx._h, self._h, out.ctypes.data,
+                                                          lens.ctypes.data, flags.ctypes.data))
+        total = int(lens[:n].sum())
+        return out[:total], lens[:n], flags[:n]
+
+    def free(self):
+        if self._h:
+            nat.lib().vs_reads_free(self._ctx._h, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One HIP context (= one device).  ``device`` is the HIP ordinal."""
+
+    def __init__(self, device: int = 0):
+        L = nat.lib()
+        h = C.c_void_p()
+        rc = L.vs_ctx_create(device, C.byref(h))
+        if rc != nat.VS_OK:
+            nat.check(None, rc)
+        self._h = h
+        self.device = device
+        self.n_nodes = 0
+        self.ksize = 0
+
+    def close(self):
+        if self._h:
+            nat.lib().vs_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr: int):
+        nat.check(self._h, nat.lib().vs_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def sync(self):
+        nat.check(self._h, nat.lib().vs_ctx_sync(self._h))
+
+    def build_index(self, seqs: Sequence[str], ksize: int):
+        """KeyError(char) if a node of length >= ksize+1 holds a byte outside ACGT, as the
+        reference's reverse_seq raises (PE_Inference.py:12-13)."""
+        data, off = encode_seqs(seqs)
+        bad_node = C.c_uint32(0)
+        bad_char = C.c_uint8(0)
+        rc = nat.lib().vs_index_build(self._h, data.ctypes.data, off.ctypes.data, len(seqs), ksize,
+                                      C.byref(bad_node), C.byref(bad_char))
+        if rc == nat.VS_E_NODE_BASE:
+            raise KeyError(chr(bad_char.value))
+        nat.check(self._h, rc)
+        self.n_nodes = len(seqs)
+        self.ksize = ksize
+
+    @property
+    def index_info(self):
+        a = (C.c_uint64 * 6)()
+        nat.check(self._h, nat.lib().vs_index_info(self._h, a))
+        return dict(seed_len=a[0], stride=a[1], seed_positions=a[2], slots=a[3], distinct_seeds=a[4], device_bytes=a[5])
+
+    def pack(self, ascii_bytes: np.ndarray, off: np.ndarray) -> ReadBlock:
+        ascii_bytes = np.ascontiguousarray(ascii_bytes, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        h = C.c_void_p()
+        nat.check(self._h, nat.lib().vs_reads_pack(self._h, ascii_bytes.ctypes.data, off.ctypes.data,
+                                                   off.size - 1, C.byref(h)))
+        return ReadBlock(self, h)
+
+    def pack_pairs(self, fwd: Sequence[str], rve: Sequence[str]) -> ReadBlock:
+        n = min(len(fwd), len(rve))
+        seqs: List[str] = []
+        for r in range(n):
+            seqs.append(fwd[r])
+            seqs.append(rve[r])
+        data, off = encode_seqs(seqs)
+        return self.pack(data, off)
+
+    def synth_pairs(self, genomes: Sequence[str], cum: np.ndarray, seed: int, first_pair: int, n_pairs: int,
+                    read_len: int, sub_thresh: int = 0, n_thresh: int = 0) -> ReadBlock:
+        gd, go = encode_seqs(genomes)
+        cum = np.ascontiguousarray(cum, dtype=np.uint32)
+        h = C.c_void_p()
+        nat.check(self._h, nat.lib().vs_synth_pairs(self._h, gd.ctypes.data, go.ctypes.data, cum.ctypes.data,
+                                                    len(genomes), seed, first_pair, n_pairs, read_len,
+                                                    sub_thresh, n_thresh, C.byref(h)))
+        return ReadBlock(self, h)
+
+    def pe_count(self, reads: ReadBlock, node_mat_ptr: int, short_mat_ptr: int, stats_ptr: int):
+        nat.check(self._h, nat.lib().vs_pe_count(self._h, reads._h, C.c_void_p(node_mat_ptr),
+                                                 C.c_void_p(short_mat_ptr), C.c_void_p(stats_ptr)))
+
+    def last_timing(self):
+        a = (C.c_double * 3)()
+        nat.check(self._h, nat.lib().vs_pe_last_timing(self._h, a))
+        return dict(main_ms=a[0], slow_ms=a[1], slow_pairs=int(a[2]))
+
+    def map_ends(self, reads: ReadBlock, cap: int = 64) -> List[List[int]]:
+        n = reads.info["ends"]
+        lists = np.zeros((max(n, 1), cap), dtype=np.uint32)
+        counts = np.zeros(max(n, 1), dtype=np.uint32)
+        nat.check(self._h, nat.lib().vs_pe_map_ends(self._h, reads._h, cap, lists.ctypes.data, counts.ctypes.data))
+        out = []
+        for e in range(n):
+            c = int(counts[e])
+            if c > cap:
+                raise ValueError("end %d has %d nodes, cap %d" % (e, c, cap))
+            out.append(sorted(int(x) for x in lists[e, :c]))
+        return out
+
+
+class PeCounter:
+    """node_mat / short_mat accumulation on one device (PE_Inference.py:137-188), counters held
+    in torch tensors so that torch.distributed (RCCL) can all-reduce them in place."""
+
+    def __init__(self, ctx: Context, device: Optional[str] = None):
+        import torch
+
+        self.torch = torch
+        self.ctx = ctx
+        self.device = torch.device(device or ("cuda:%d" % ctx.device))
+        n = ctx.n_nodes
+        self.n = n
+        self.mats = torch.zeros((2, max(n, 1), max(n, 1)), dtype=torch.int32, device=self.device)
+        self.stats = torch.zeros(3, dtype=torch.int64, device=self.device)
+        self.pairs_seen = 0
+
+    def add(self, reads: ReadBlock):
+        torch = self.torch
+        self.pairs_seen += reads.info["ends"] // 2
+        if self.pairs_seen >= 2 ** 31:
+            raise OverflowError("uint32 PE counters hold < 2^31 pairs per buffer; all-reduce and fold earlier")
+        with torch.cuda.device(self.device):
+            self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            self.ctx.pe_count(reads, self.mats[0].data_ptr(), self.mats[1].data_ptr(), self.stats.data_ptr())
+
+    def all_reduce(self):
+        from .dist import all_reduce_counts
+
+        all_reduce_counts(self.mats, self.stats)
+
+    def result(self):
+        """-> (node_mat int64 [N,N], short_mat int64 [N,N], (n_reads, short_reads, used_reads))"""
+        m = self.mats.cpu().numpy().astype(np.int64)
+        s = self.stats.cpu().numpy()
+        n = self.n
+        return m[0, :n, :n], m[1, :n, :n], (int(s[0]), int(s[1]), int(s[2]))
+
+
+# ---- outputs -------------------------------------------------------------------------------------
+def write_matrix_text(path: str, ids: Sequence[str], mat: np.ndarray):
+    """``{id_i}:{id_j}:{count}`` for all i, j in row-major order, zeros included
+    (PE_Inference.py:194-205)."""
+    tails = [":%s:" % j for j in ids]
+    with open(path, "w") as fh:
+        for i, idi in enumerate(ids):
+            row = mat[i].tolist()
+            fh.write("".join([idi + t + str(v) + "\n" for t, v in zip(tails, row)]))
