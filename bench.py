@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- PE-link inference throughput on MI355X (BASELINE.json metric, configs[2]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs R]
+
+Workload (configs[2]): 15 synthetic strains of a 10.8 kb genome, compacted de Bruijn graph at
+k = 55 (~4.5k nodes), R = 10M pairs of 2x150 bp per GPU sampled ON THE DEVICE from the strains
+(0.5 % substitutions, 0.1 % N-pairs).  One step = one pass of the hot path over that block with
+everything resident in HBM: zero the counters, vs_pe_count over all pairs (seed probe, extension,
+acceptance test, node_mat/short_mat atomics) and, for N > 1, the RCCL all-reduce of the counters.
+Weak scaling: every rank works on its own R pairs (disjoint slices of one seeded stream).
+
+Prints ONE JSON line (rank 0).  `roofline` uses the algorithmic bytes per pair of SURVEY.md 8(d)
+(2*ceil(L/4) + 2*(L-k)*8 + 16 = 1612 B at L=150,k=55) over the main kernel's HIP-event time;
+`cpu_baseline` times the C restatement of the reference algorithm (oracle/, 1 thread) on a
+prefix of the same read stream and checks that the GPU gives the same counters on that prefix.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def workload(k=55, n_strains=15, genome_len=10800, snp_rate=0.09, seed=1003):
+    from vstrains_amd import synth
+
+    st = synth.make_strains(n_strains, genome_len, snp_rate, seed=seed)
+    g = synth.compact_dbg(st, k)
+    ab = np.array(st.abundance)
+    cum = np.minimum(np.floor(np.cumsum(ab) / ab.sum() * 2 ** 32), 2 ** 32 - 1).astype(np.uint32)
+    cum[-1] = 0xFFFFFFFF
+    return st, g, cum
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per GPU")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--k", type=int, default=55)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from vstrains_amd import pe as host
+
+    L, k, R = args.read_len, args.k, args.pairs
+    seed = 20250001
+    sub_thresh = int(0.005 * 2 ** 32)
+    n_thresh = int(0.001 * 2 ** 32)
+    st, g, cum = workload(k=k)
+    ctx = host.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    t0 = time.time()
+    ctx.build_index(g.seqs, k)
+    ctx.sync()
+    index_s = time.time() - t0
+    reads = ctx.synth_pairs(st.genomes, cum, seed, rank * R, R, L, sub_thresh, n_thresh)
+    counter = host.PeCounter(ctx)
+
+    def step():
+        counter.mats.zero_()
+        counter.stats.zero_()
+        counter.pairs_seen = 0
+        counter.add(reads)
+        counter.all_reduce()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ms = []
+    slow_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # HIP events recorded by the library around the kernels on the stream they ran on; reading
+        # them synchronises that stream, which the next step would do anyway (it reuses the buffers)
+        t = ctx.last_timing()
+        kernel_ms.append(t["main_ms"])
+        slow_ms.append(t["slow_ms"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    node_mat, short_mat, stats = counter.result()
+
+    if rank == 0:
+        b_alg = 2 * ((L + 3) // 4) + 2 * (L - k) * 8 + 16
+        ms_step = elapsed / args.steps * 1e3
+        value = world * R * args.steps / elapsed
+        avg_kernel_ms = float(np.mean(kernel_ms))
+        achieved = R * b_alg / (avg_kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "PE read pairs/sec through PE-link inference (GFA index + packed reads in HBM -> node_mat/short_mat)",
+            "value": value,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[2]: 15-strain synthetic (10.8 kb genome), %d x 2x%d bp pairs per GPU, %d-node GFA, k=%d"
+                            % (R, L, len(g.seqs), k),
+                "pairs_per_gpu": R, "read_len": L, "k": k, "nodes": len(g.seqs),
+                "node_bases": int(sum(len(s) for s in g.seqs)),
+                "parallelism": "read-block sharding x%d + all-reduce of [2,N,N] counters" % world,
+                "index": ctx.index_info, "index_build_s": index_s,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "k_pe_tiles", "kernel_ms_avg": avg_kernel_ms, "slow_kernel_ms_avg": float(np.mean(slow_ms)),
+                "algorithmic_bytes_per_pair": b_alg,
+            },
+            "pe_stats": {"n_reads": stats[0], "short_reads": stats[1], "used_reads": stats[2],
+                         "node_mat_sum": int(node_mat.sum()), "short_mat_sum": int(short_mat.sum()),
+                         "slow_pairs_per_step": ctx.last_timing()["slow_pairs"]},
+            "strain_extract_s": None,
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(ctx, host, st, g, cum, seed, L, k, sub_thresh, n_thresh, R, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ctx, host, st, g, cum, seed, L, k, sub_thresh, n_thresh, R, target_s):
+    """oracle/pe_oracle.c (1 thread) on the first M pairs of rank 0's stream; M sized from a
+    short calibration so the whole leg stays near target_s.  Also the checker: the GPU counters
+    for the same M pairs must be identical."""
+    from oracle import pe_oracle_c
+
+    t0 = time.perf_counter()
+    orc = pe_oracle_c.Oracle(g.seqs, k)
+    build_s = time.perf_counter() - t0
+
+    def run(first, n):
+        fw, rv = pe_oracle_c.synth_pairs(st.genomes, cum, seed, first, n, L, sub_thresh, n_thresh)
+        off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
+        t = time.perf_counter()
+        res = orc.count_pairs_raw(fw.reshape(-1), off, rv.reshape(-1), off, n)
+        return res, time.perf_counter() - t
+
+    _, cal = run(0, 20000)
+    rate = 20000 / max(cal, 1e-6)
+    M = int(min(R, max(20000, rate * target_s)))
+    (ref_node, ref_short, ref_stats), secs = run(0, M)
+    block = ctx.synth_pairs(st.genomes, cum, seed, 0, M, L, sub_thresh, n_thresh)
+    chk = host.PeCounter(ctx)
+    chk.add(block)
+    node_mat, short_mat, stats = chk.result()
+    same = bool(np.array_equal(node_mat, ref_node) and np.array_equal(short_mat, ref_short)
+                and stats == tuple(int(x) for x in ref_stats))
+    return {
+        "value": M / secs, "unit": "pairs/s", "cores": 1, "kind": "port",
+        "sample": "first %d pairs of the same seeded stream (%.1f s; table build %.2f s not included)" % (M, secs, build_s),
+        "gpu_matches_on_sample": same,
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -131,12 +131,13 @@ def _dense_case(k, n_pairs, read_len, seed, snp, n_strains=6, glen=1500, sub=0.0
 
 
 def test_overflow_pairs_take_slow_path_and_stay_exact(host, ctx):
-    # dense variation at k=21: an 80-base read crosses far more than 8 short nodes
-    g, f, r = _dense_case(21, 1500, 80, seed=301, snp=0.09)
-    (node_mat, short_mat, stats), block = _gpu_matrices(host, ctx, g.seqs, f, r, 21)
+    # dense variation at k=11: a 100-base read is accepted by more than 16 short nodes in ~30 % of
+    # the ends, which overflows the per-end list kept in LDS
+    g, f, r = _dense_case(11, 1500, 100, seed=301, snp=0.2)
+    (node_mat, short_mat, stats), block = _gpu_matrices(host, ctx, g.seqs, f, r, 11)
     t = ctx.last_timing()
     assert t["slow_pairs"] > 0, "case does not exercise the overflow path"
-    orc = pe_oracle_c.Oracle(g.seqs, 21)
+    orc = pe_oracle_c.Oracle(g.seqs, 11)
     ref_node, ref_short, ref_stats = orc.count_pairs(f, r)
     assert np.array_equal(node_mat, ref_node)
     assert np.array_equal(short_mat, ref_short)

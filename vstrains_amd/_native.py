@@ -58,6 +58,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 "%s is missing: the HIP library is not built and there is no fallback path" % LIB_PATH)
+        # torch ships its own libamdhip64.so.7; two HIP runtimes in one process cannot both own
+        # the GPU.  Importing torch first makes the loader bind our NEEDED libamdhip64.so.7 to
+        # the copy that is already mapped, so the library and torch share one runtime.
+        import torch  # noqa: F401
+
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol

@@ -72,6 +72,7 @@ struct vs_ctx {
     void *d_slow_count = nullptr;  // uint32 counter
     void *d_dense = nullptr;       // dense per-workgroup state for the slow path
     uint64_t dense_bytes = 0;
+    uint32_t dense_nodes = 0xFFFFFFFFu;  // node count the dense layout was initialised for
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     double last_ms[3] = {0, 0, 0};
     int n_cu = 256;

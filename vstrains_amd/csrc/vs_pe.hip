@@ -28,10 +28,12 @@
 //   P5  per-end compaction, then node_mat / short_mat global atomics
 // Ends that touch more than 8 nodes overflow the LDS table; their pairs go to a list that a
 // second, fully general kernel (dense per-workgroup node state in HBM) works through.
+#include <stdlib.h>
+
 #include "vs_internal.h"
 
 #define TPB 256
-#define SL 8u  // node slots per read end in LDS
+#define LC 16u  // accepted nodes kept per read end in LDS (more -> slow path)
 #define EMPTY_NODE 0xFFFFFFFFu
 
 struct PeParams {
@@ -39,7 +41,7 @@ struct PeParams {
     VsReadsDev rd;
     uint32_t *node_mat, *short_mat;
     unsigned long long *stats;
-    uint32_t ept, pmax, words_cap;
+    uint32_t ept, pmax, words_cap, pool, pool_bits, debug_stop;
     uint64_t n_tiles;
     uint32_t *slow_list, *slow_count;
     uint32_t *dbg_lists, *dbg_counts;
@@ -62,13 +64,18 @@ __device__ __forceinline__ bool vs_extend(const RW *rw, uint64_t rbase, uint32_t
     uint32_t c = s < j ? s : j;
     c = c < q ? c : q;
     uint32_t left = 0;
-    if (c) {
-        uint64_t x = vs_win64(rw, rbase + j - c) ^ vs_win64(tw, tbase + q - c);
-        if (mk) x |= vs_win64(mk, mbase + j - c);
-        x &= vs_lowmask(2u * c);
-        left = x ? c - 1u - (uint32_t)((63 - __clzll((long long)x)) >> 1) : c;
-        if (left >= s) return false;
+    while (left < c) {  // backwards, 32 bases at a time
+        uint32_t n = c - left < 32u ? c - left : 32u;
+        uint64_t x = vs_win64(rw, rbase + j - left - n) ^ vs_win64(tw, tbase + q - left - n);
+        if (mk) x |= vs_win64(mk, mbase + j - left - n);
+        x &= vs_lowmask(2u * n);
+        if (x) {
+            left += n - 1u - (uint32_t)((63 - __clzll((long long)x)) >> 1);
+            break;
+        }
+        left += n;
     }
+    if (left >= s) return false;  // an earlier probe lies inside this match and owns it
     uint32_t rj = j + w, rq = q + w;
     uint32_t rem = rlen - rj;
     uint32_t rem2 = tlen - rq;
@@ -132,26 +139,54 @@ __device__ __forceinline__ uint32_t vs_probe(const VsIndexDev &idx, uint64_t f, 
 
 extern __shared__ __attribute__((aligned(16))) uint32_t vs_lds[];
 
+// LDS carve shared by the kernel and the host-side size computation
+struct TileLayout {
+    uint32_t woff, meta, words, pcnt, pa, pb, hkey, hcnt, hminp, hminj, ns, state, list, misc, total;
+};
+__host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, uint32_t words_cap, uint32_t pool) {
+    TileLayout t;
+    uint32_t o = 0;
+    const uint32_t NI = ept * pmax;
+    t.woff = o;  o += (ept + 2u) & ~1u;
+    t.meta = o;  o += ept;
+    t.words = o; o += words_cap + 4u;
+    t.pcnt = o;  o += NI;
+    t.pa = o;    o += NI;
+    t.pb = o;    o += NI;
+    t.hkey = o;  o += pool;
+    t.hcnt = o;  o += pool;
+    t.hminp = o; o += pool;
+    t.hminj = o; o += pool;
+    t.ns = o;    o += ept;
+    t.state = o; o += ept;
+    t.list = o;  o += ept * LC;
+    t.misc = o;  o += 16u;
+    t.total = o;
+    return t;
+}
+
 __global__ void __launch_bounds__(TPB)
 k_pe_tiles(PeParams P) {
     const uint32_t tid = threadIdx.x;
     const uint32_t ept = P.ept, pmax = P.pmax;
     const uint32_t NI = ept * pmax;
     const uint32_t w = P.idx.w, s = P.idx.s, K = P.idx.K;
-    // LDS carve
-    uint32_t *s_woff = vs_lds;                       // ept + 1 (+ pad to even)
-    uint32_t *s_meta = s_woff + ((ept + 2u) & ~1u);   // ept
-    uint32_t *s_words = s_meta + ept;                 // words_cap + 4
-    uint32_t *s_pcnt = s_words + P.words_cap + 4u;    // NI  (counts, then inclusive scan)
-    uint32_t *s_pa = s_pcnt + NI;                     // NI
-    uint32_t *s_pb = s_pa + NI;                       // NI
-    uint32_t *s_hnode = s_pb + NI;                    // ept * SL
-    uint32_t *s_hcnt = s_hnode + ept * SL;
-    uint32_t *s_hminp = s_hcnt + ept * SL;
-    uint32_t *s_hminj = s_hminp + ept * SL;
-    uint32_t *s_ns = s_hminj + ept * SL;              // ept   survivors per end
-    uint32_t *s_state = s_ns + ept;                   // ept   bit0: end belongs to a used pair, bit1: overflow
-    uint32_t *s_misc = s_state + ept;                 // 16
+    const uint32_t pool = P.pool, pool_shift = 32u - P.pool_bits;
+    const TileLayout T = tile_layout(ept, pmax, P.words_cap, pool);
+    uint32_t *s_woff = vs_lds + T.woff;
+    uint32_t *s_meta = vs_lds + T.meta;
+    uint32_t *s_words = vs_lds + T.words;
+    uint32_t *s_pcnt = vs_lds + T.pcnt;    // posting counts per probe, then their inclusive scan
+    uint32_t *s_pa = vs_lds + T.pa;
+    uint32_t *s_pb = vs_lds + T.pb;
+    uint32_t *s_hkey = vs_lds + T.hkey;    // tile-wide (end, node) table: key = end << 25 | node
+    uint32_t *s_hcnt = vs_lds + T.hcnt;
+    uint32_t *s_hminp = vs_lds + T.hminp;
+    uint32_t *s_hminj = vs_lds + T.hminj;
+    uint32_t *s_ns = vs_lds + T.ns;        // accepted nodes per end
+    uint32_t *s_state = vs_lds + T.state;  // bit0: end belongs to a used pair, bit1: overflow
+    uint32_t *s_list = vs_lds + T.list;    // accepted node ids, LC per end
+    uint32_t *s_misc = vs_lds + T.misc;
 
     if (tid < 3) s_misc[8 + tid] = 0;  // workgroup-local stats
 
@@ -162,8 +197,8 @@ k_pe_tiles(PeParams P) {
         // ---- P0: header
         for (uint32_t i = tid; i <= ne; i += TPB) s_woff[i] = P.rd.woff[e0 + i];
         for (uint32_t i = tid; i < ne; i += TPB) s_meta[i] = P.rd.meta[e0 + i];
-        for (uint32_t i = tid; i < ept * SL; i += TPB) {
-            s_hnode[i] = EMPTY_NODE;
+        for (uint32_t i = tid; i < pool; i += TPB) {
+            s_hkey[i] = EMPTY_NODE;
             s_hcnt[i] = 0;
             s_hminp[i] = 0xFFFFFFFFu;
             s_hminj[i] = 0xFFFFFFFFu;
@@ -184,6 +219,7 @@ k_pe_tiles(PeParams P) {
             s_ns[2 * tid] = s_ns[2 * tid + 1] = 0;
         }
         __syncthreads();
+        if (P.debug_stop == 1u) continue;
         // ---- P1: probes
         for (uint32_t it = tid; it < NI; it += TPB) {
             uint32_t e = it / pmax, pi = it - e * pmax;
@@ -206,6 +242,7 @@ k_pe_tiles(PeParams P) {
             s_pb[it] = pb;
         }
         __syncthreads();
+        if (P.debug_stop == 2u) continue;
         // ---- P2: inclusive scan of s_pcnt[0..NI)
         {
             const uint32_t chunk = (NI + TPB - 1u) / TPB;
@@ -231,6 +268,7 @@ k_pe_tiles(PeParams P) {
                 }
         }
         __syncthreads();
+        if (P.debug_stop == 3u) continue;
         const uint32_t total = s_pcnt[NI - 1u];
         // ---- P3: one thread per posting
         for (uint32_t t = tid; t < total; t += TPB) {
@@ -243,14 +281,25 @@ k_pe_tiles(PeParams P) {
             const uint32_t excl = it ? s_pcnt[it - 1u] : 0u;
             const uint32_t cnt = s_pcnt[it] - excl;
             uint32_t pa = s_pa[it], pb = s_pb[it];
+            const uint32_t e = it / pmax, pi = it - e * pmax, j = pi * s;
             uint32_t node, pos, opp;
             if (cnt == 1u) {
                 node = pa; pos = pb & 0x7FFFFFFFu; opp = pb >> 31;
+                // Overlapping seeds (s <= w): if the previous probe of this end holds the single
+                // posting one stride back on the same diagonal, the bases in between match too,
+                // so that probe (or an earlier one) owns this match -- no memory traffic needed.
+                if (s <= w && pi) {
+                    const uint32_t excl2 = it > 1u ? s_pcnt[it - 2u] : 0u;
+                    if (excl - excl2 == 1u && s_pa[it - 1u] == node) {
+                        uint32_t pbp = s_pb[it - 1u];
+                        uint32_t want = opp ? pos + s : pos - s;
+                        if ((pbp >> 31) == opp && (pbp & 0x7FFFFFFFu) == want && (opp || pos >= s)) continue;
+                    }
+                }
             } else {
                 uint2 po = P.idx.postings[pa + (t - excl)];
                 node = po.x; pos = po.y & 0x7FFFFFFFu; opp = (po.y >> 31) ^ (pb >> 31);
             }
-            const uint32_t e = it / pmax, j = (it - e * pmax) * s;
             const uint32_t meta = s_meta[e];
             const uint32_t rlen = meta & VS_LEN_MASK;
             const VsNodeMeta nm = P.idx.meta[node];
@@ -263,47 +312,36 @@ k_pe_tiles(PeParams P) {
                 continue;
             const uint32_t add = len - K + 1u;
             const uint32_t minp = opp ? nm.len - qa - len : qa;
-            // LDS table of the end
-            uint32_t h = (node * 0x9E3779B1u) >> 29;
+            const uint32_t key = (e << 25) | node;
+            uint32_t at = (key * 0x9E3779B1u) >> pool_shift;
             bool placed = false;
-            for (uint32_t pr = 0; pr < SL; pr++) {
-                uint32_t at = e * SL + ((h + pr) & (SL - 1u));
-                uint32_t old = atomicCAS(&s_hnode[at], EMPTY_NODE, node);
-                if (old == EMPTY_NODE || old == node) {
+            for (uint32_t pr = 0; pr < 64u; pr++) {
+                uint32_t old = atomicCAS(&s_hkey[at], EMPTY_NODE, key);
+                if (old == EMPTY_NODE || old == key) {
                     atomicAdd(&s_hcnt[at], add);
                     atomicMin(&s_hminp[at], minp);
                     atomicMin(&s_hminj[at], a);
                     placed = true;
                     break;
                 }
+                at = (at + 1u) & (pool - 1u);
             }
             if (!placed) atomicOr(&s_state[e], 2u);
         }
         __syncthreads();
-        // ---- P4: acceptance test per slot
-        for (uint32_t i = tid; i < ne * SL; i += TPB) {
-            uint32_t node = s_hnode[i];
-            if (node != EMPTY_NODE) {
-                uint32_t e = i / SL;
+        if (P.debug_stop == 4u) continue;
+        // ---- P4: acceptance test per table slot; accepted nodes go to the end's list
+        for (uint32_t i = tid; i < pool; i += TPB) {
+            uint32_t key = s_hkey[i];
+            if (key != EMPTY_NODE) {
+                uint32_t e = key >> 25, node = key & 0x01FFFFFFu;
                 uint32_t rlen = s_meta[e] & VS_LEN_MASK;
                 uint32_t nlen = P.idx.meta[node].len;
-                if (!vs_accept(s_hcnt[i], s_hminp[i], s_hminj[i], nlen, rlen, K)) s_hnode[i] = EMPTY_NODE;
+                if (vs_accept(s_hcnt[i], s_hminp[i], s_hminj[i], nlen, rlen, K)) {
+                    uint32_t k2 = atomicAdd(&s_ns[e], 1u);
+                    if (k2 < LC) s_list[e * LC + k2] = node; else atomicOr(&s_state[e], 2u);
+                }
             }
-        }
-        __syncthreads();
-        // ---- P5a: compaction (one thread per end), in place at the front of the end's slots
-        if (tid < ne) {
-            uint32_t n = 0;
-            uint32_t keep[SL];
-#pragma unroll
-            for (uint32_t k2 = 0; k2 < SL; k2++) {
-                uint32_t v = s_hnode[tid * SL + k2];
-                keep[k2] = v;
-            }
-#pragma unroll
-            for (uint32_t k2 = 0; k2 < SL; k2++)
-                if (keep[k2] != EMPTY_NODE) s_hnode[tid * SL + n++] = keep[k2];
-            s_ns[tid] = n;
         }
         __syncthreads();
         // pairs with an overflowed end go to the slow list
@@ -317,24 +355,33 @@ k_pe_tiles(PeParams P) {
             }
         }
         __syncthreads();
-        // ---- P5b: counters
+        if (P.debug_stop == 5u) continue;
+        // ---- P5: counters.  One thread per (pair, list position a); the partner positions loop.
         const uint32_t N = P.idx.n_nodes;
         if (P.accumulate) {
-            const uint32_t combos = (ne / 2u) * SL * SL;
-            for (uint32_t i = tid; i < combos; i += TPB) {
-                uint32_t pr = i / (SL * SL), ab = i - pr * (SL * SL);
-                uint32_t a = ab / SL, b = ab - a * SL;
-                uint32_t ef = 2u * pr, er = ef + 1u;
+            const uint32_t items = (ne / 2u) * LC;
+            for (uint32_t i = tid; i < items; i += TPB) {
+                const uint32_t pr = i / LC, a = i - pr * LC;
+                const uint32_t ef = 2u * pr, er = ef + 1u;
                 if ((s_state[ef] & 3u) != 1u) continue;
-                uint32_t nl = s_ns[ef], nr = s_ns[er];
-                if (a < nl && b < nr) atomicAdd(&P.node_mat[(uint64_t)s_hnode[ef * SL + a] * N + s_hnode[er * SL + b]], 1u);
-                if (a < nl && b < nl) {
-                    uint32_t x = s_hnode[ef * SL + a], y = s_hnode[ef * SL + b];
-                    if (x < y || a == b) atomicAdd(&P.short_mat[(uint64_t)x * N + y], 1u);
+                const uint32_t nl = s_ns[ef], nr = s_ns[er];
+                if (a < nl) {
+                    const uint32_t x = s_list[ef * LC + a];
+                    uint32_t *row = P.node_mat + (uint64_t)x * N;
+                    for (uint32_t b = 0; b < nr; b++) atomicAdd(&row[s_list[er * LC + b]], 1u);
+                    uint32_t *srow = P.short_mat + (uint64_t)x * N;
+                    for (uint32_t b = 0; b < nl; b++) {
+                        uint32_t y = s_list[ef * LC + b];
+                        if (x < y || a == b) atomicAdd(&srow[y], 1u);
+                    }
                 }
-                if (a < nr && b < nr) {
-                    uint32_t x = s_hnode[er * SL + a], y = s_hnode[er * SL + b];
-                    if (x < y || a == b) atomicAdd(&P.short_mat[(uint64_t)x * N + y], 1u);
+                if (a < nr) {
+                    const uint32_t x = s_list[er * LC + a];
+                    uint32_t *srow = P.short_mat + (uint64_t)x * N;
+                    for (uint32_t b = 0; b < nr; b++) {
+                        uint32_t y = s_list[er * LC + b];
+                        if (x < y || a == b) atomicAdd(&srow[y], 1u);
+                    }
                 }
             }
         }
@@ -343,7 +390,7 @@ k_pe_tiles(PeParams P) {
                 if (s_state[i] & 2u) continue;  // the slow kernel reports these
                 uint32_t n = s_ns[i];
                 P.dbg_counts[e0 + i] = n;
-                for (uint32_t k2 = 0; k2 < n && k2 < P.dbg_cap; k2++) P.dbg_lists[(e0 + i) * P.dbg_cap + k2] = s_hnode[i * SL + k2];
+                for (uint32_t k2 = 0; k2 < n && k2 < P.dbg_cap; k2++) P.dbg_lists[(e0 + i) * P.dbg_cap + k2] = s_list[i * LC + k2];
             }
         }
     }
@@ -454,13 +501,21 @@ __global__ void __launch_bounds__(TPB) k_dense_zero_cnt(uint32_t *dense, uint64_
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-#define LDS_BUDGET_BYTES (48u * 1024u)
+#define LDS_BUDGET_BYTES (64u * 1024u)
 #define NI_CAP 4096u
 #define SLOW_GRID 256u
 
+static uint32_t pool_for(uint32_t ept, uint32_t *bits) {
+    uint32_t b = 6;
+    while ((1u << b) < 16u * ept) b++;
+    *bits = b;
+    return 1u << b;
+}
+
 static size_t lds_bytes(uint32_t ept, uint32_t pmax, uint32_t words_cap) {
-    size_t u = ((ept + 2u) & ~1u) + ept + (words_cap + 4u) + 3ull * ept * pmax + 4ull * ept * SL + ept + ept + 16u;
-    return u * sizeof(uint32_t);
+    uint32_t bits;
+    uint32_t pool = pool_for(ept, &bits);
+    return (size_t)tile_layout(ept, pmax, words_cap, pool).total * sizeof(uint32_t);
 }
 
 static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, uint32_t *d_short_mat, uint64_t *d_stats,
@@ -475,7 +530,10 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     const uint32_t maxlen = (uint32_t)reads->max_len;
     const uint32_t pmax = maxlen >= idx.w ? (maxlen - idx.w) / idx.s + 1u : 1u;
     const uint32_t wpe = (maxlen + 15u) / 16u;
+    if (idx.n_nodes > 0x01FFFFFEu) return vs_fail(ctx, VS_E_RANGE, "more than 2^25-2 nodes");
     uint32_t ept = 128;
+    if (const char *ev = getenv("VS_EPT")) ept = (uint32_t)atoi(ev) & ~1u;
+    if (ept < 2 || ept > 128) ept = 128;
     while (ept > 2 && (ept * pmax > NI_CAP || lds_bytes(ept, pmax, ept * wpe) > LDS_BUDGET_BYTES)) ept -= 2;
     size_t lds = lds_bytes(ept, pmax, ept * wpe);
     if (lds > 160u * 1024u)
@@ -490,12 +548,13 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     }
     if (!ctx->d_slow_count) VS_HIP(ctx, hipMalloc(&ctx->d_slow_count, 16));
     uint64_t need_dense = sizeof(uint32_t) * 5ull * (idx.n_nodes ? idx.n_nodes : 1) * SLOW_GRID;
-    if (ctx->dense_bytes < need_dense) {
+    if (ctx->dense_bytes < need_dense || ctx->dense_nodes != idx.n_nodes) {
         if (ctx->d_dense) VS_HIP(ctx, hipFree(ctx->d_dense));
         ctx->d_dense = nullptr;
         ctx->dense_bytes = 0;
         VS_HIP(ctx, hipMalloc(&ctx->d_dense, need_dense));
         ctx->dense_bytes = need_dense;
+        ctx->dense_nodes = idx.n_nodes;
         // cnt = 0, minp/minj = ~0 once; k_pe_slow restores this state after every end it sweeps
         uint64_t N = idx.n_nodes ? idx.n_nodes : 1;
         VS_HIP(ctx, hipMemsetAsync(ctx->d_dense, 0xFF, need_dense, st));
@@ -513,6 +572,11 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     P.ept = ept;
     P.pmax = pmax;
     P.words_cap = ept * wpe;
+    P.pool = pool_for(ept, &P.pool_bits);
+    {
+        const char *dbg = getenv("VS_DEBUG_STOP");
+        P.debug_stop = dbg ? (uint32_t)atoi(dbg) : 0u;
+    }
     P.n_tiles = (n_ends + ept - 1) / ept;
     P.slow_list = (uint32_t *)ctx->d_slow_list;
     P.slow_count = (uint32_t *)ctx->d_slow_count;
@@ -525,6 +589,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         VS_HIP(ctx, hipFuncSetAttribute((const void *)k_pe_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     uint64_t grid = P.n_tiles;
     uint64_t max_grid = (uint64_t)ctx->n_cu * 8u;
+    if (const char *ev = getenv("VS_GRID_PER_CU")) max_grid = (uint64_t)ctx->n_cu * (uint64_t)(atoi(ev) > 0 ? atoi(ev) : 8);
     if (grid > max_grid) grid = max_grid;
     VS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     hipLaunchKernelGGL(k_pe_tiles, dim3((unsigned)grid), dim3(TPB), lds, st, P);
