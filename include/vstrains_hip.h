@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VS_ABI_VERSION 1
+#define VS_ABI_VERSION 2
 
 enum {
     VS_OK = 0,
@@ -108,6 +108,58 @@ int vs_pe_map_ends(vs_ctx *ctx, const vs_reads *reads, uint32_t cap, uint32_t *l
  * stream: ms[0] = main kernel, ms[1] = overflow (slow-path) kernel, ms[2] = pairs sent to the
  * slow path.  Synchronises the stream. */
 int vs_pe_last_timing(vs_ctx *ctx, double ms[3]);
+
+/* ---- graph stages: K5 PE-link table ---------------------------------------------------------
+ * Replaces process_pe_info (utils/VStrains_IO.py:598-627) and every later read or rewrite of the
+ * pe_info dict (utils/VStrains_Decomposition.py:141-143,178,273,492-503,608-617,672-684;
+ * utils/VStrains_Utilities.py:488-499; utils/VStrains_Extension.py:62,766-799).
+ * The table is P0[i][j] = node[i][j] + node[j][i] + short[i][j] + short[j][i] for i != j and
+ * P0[i][i] = node[i][i] + short[i][i], int64, resident on the device; it is never rewritten:
+ * a lookup for nodes made by splits / contractions is a sum over two lists of original rows
+ * (see vstrains_amd/graph/ops.py for the equivalence, tests/test_graph_golden.py for the check
+ * against the literal dict). */
+typedef struct vs_links vs_links;
+/* d_node_mat / d_short_mat: DEVICE pointers to the N*N uint32 counters vs_pe_count filled. */
+int vs_links_from_counts(vs_ctx *ctx, const uint32_t *d_node_mat, const uint32_t *d_short_mat,
+                         uint32_t n, vs_links **out);
+/* Same from HOST int64 matrices (e.g. parsed back from pe_info / st_info text). */
+int vs_links_from_host(vs_ctx *ctx, const int64_t *node_mat, const int64_t *short_mat, uint32_t n,
+                       vs_links **out);
+void vs_links_free(vs_ctx *ctx, vs_links *links);
+int vs_links_size(const vs_links *links, uint32_t *n);
+int vs_links_to_host(vs_ctx *ctx, const vs_links *links, int64_t *out /* n*n */);
+/* A pool of index lists: list l is list_idx[list_off[l] .. list_off[l+1]) (rows of P0, repeats
+ * allowed, may be empty).  out[q] = sum over r in list qa[q], c in list qb[q] of P0[r][c].
+ * Host pointers. */
+int vs_links_block_sums(vs_ctx *ctx, const vs_links *links, const uint64_t *list_off,
+                        const uint32_t *list_idx, uint32_t n_lists, const uint32_t *qa,
+                        const uint32_t *qb, uint64_t n_queries, int64_t *out);
+/* out[g * n_groups + h] = block sum of group g x group h, for all pairs (final_link_info,
+ * Extension.py:766-799).  Host pointers. */
+int vs_links_group_matrix(vs_ctx *ctx, const vs_links *links, const uint64_t *list_off,
+                          const uint32_t *list_idx, uint32_t n_groups, int64_t *out);
+
+/* ---- graph stages: K6 vertex scan + chain ranking, K7 edge flow -------------------------------
+ * One call per re-initialised stage graph (store_reinit_graph, VStrains_IO.py:630-642).
+ * The graph is a CSR in adjacency order: row v = nbr/eidx[row_ptr[v] .. row_ptr[v+1]), its
+ * first n_out[v] entries are out-edges (target, edge index), the rest in-edges (source, edge
+ * index).  edge_black is indexed by edge index (n_edge_slots of them).  Host pointers; any
+ * output pointer may be NULL.
+ *   flow[e]        assign_edge_flow, VStrains_Utilities.py:14-31 (numpy.sum / numpy.mean order)
+ *   nontrivial[v]  is_non_trivial, VStrains_Utilities.py:162-172
+ *   fork_kind[v]   1: one black in / several black out, 2: several in / one out
+ *                  (VStrains_Decomposition.py:715,763)
+ *   chain_next[v]  target of v's simple out-edge or -1 (simp_path, VStrains_Utilities.py:398-402)
+ *   chain_top[v], chain_rank[v]  head of v's chain of simple edges and v's distance from it
+ *                  (pointer jumping; rank -1 on a ring of simple edges)
+ *   *zero_sum_edge smallest edge index whose flow would divide by a zero neighbour sum, or
+ *                  0xFFFFFFFF (the reference raises FloatingPointError there, vstrains:25) */
+int vs_graph_refresh(vs_ctx *ctx, uint32_t n_vertices, uint32_t n_edge_slots,
+                     const uint64_t *row_ptr, const uint32_t *n_out, const uint32_t *nbr,
+                     const uint32_t *eidx, const double *dp, const uint8_t *vertex_black,
+                     const uint8_t *edge_black, double *flow, uint8_t *nontrivial,
+                     uint8_t *fork_kind, int32_t *chain_next, int32_t *chain_top,
+                     int32_t *chain_rank, uint32_t *zero_sum_edge);
 
 /* ---- device memory helpers for C callers without another allocator ----------------------- */
 int vs_dev_alloc(vs_ctx *ctx, size_t bytes, void **out); /* zero-filled */

@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Generate whole-pipeline golden fixtures under tests/golden/graph/.
+
+Runs ONLY in the build container.  For every seeded synthetic case (``vstrains_amd.synth
+.make_pipeline_case``) it executes the REAL reference CLI (``/root/reference/vstrains``) as a
+subprocess.  The reference imports ``graph_tool`` and ``gfapy``, which cannot be installed here,
+so the subprocess gets ``tests/golden/gt_standin`` on PYTHONPATH (a test-only model of the slice
+of those libraries the reference touches; see its docstring).  Every case is run under both
+in-edge-order variants of the stand-in; ``case.json:inedge_invariant`` records whether all outputs
+agree (parity is unpinned at the graph-tool boundary).  The committed outputs are
+those of PYTHONHASHSEED=0; seeds 1-3 are run too and the files that change with the seed are
+listed in ``case.json:differs_under_other_hashseeds`` (the reference is not deterministic there).
+
+What is committed is data only: the inputs (graph.gfa, contigs.paths; reads are re-derived from
+the seed and pinned by digest), and the reference's outputs in digest form (sequences replaced
+by ``len:md5[:12]``; pe_info/st_info as their non-zero lines).  No reference source is copied.
+
+    python tests/golden/make_graph_golden.py [case ...]
+"""
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from vstrains_amd import synth  # noqa: E402
+
+REF_CLI = "/root/reference/vstrains"
+STANDIN = os.path.join(HERE, "gt_standin")
+OUT = os.path.join(HERE, "graph")
+
+# name -> (make_pipeline_case kwargs, extra CLI args)
+CASES = {
+    "two_strain_bubbles_k21": (dict(n_strains=2, genome_len=1500, snp_rate=0.004, k=21, n_pairs=3000,
+                                    read_len=100, seed=11, abundance_ratio=0.43, dp_noise=0.0), []),
+    "three_strain_k21": (dict(n_strains=3, genome_len=3000, snp_rate=0.01, k=21, n_pairs=6000,
+                              read_len=100, seed=3), []),
+    "three_strain_scrambled_k21": (dict(n_strains=3, genome_len=3000, snp_rate=0.01, k=21, n_pairs=6000,
+                                        read_len=100, seed=5, scramble=True), []),
+    "four_strain_k31_mc": (dict(n_strains=4, genome_len=4000, snp_rate=0.012, k=31, n_pairs=8000,
+                                read_len=120, seed=21, abundance_ratio=0.6), ["-mc", "20"]),
+    "five_strain_errors_k21": (dict(n_strains=5, genome_len=4000, snp_rate=0.01, k=21, n_pairs=10000,
+                                    read_len=100, seed=33, abundance_ratio=0.7, error_strain_depth=6.0,
+                                    scramble=True), []),
+    "hiv_like_k55": (dict(n_strains=4, genome_len=6000, snp_rate=0.012, k=55, n_pairs=10000,
+                          read_len=150, seed=42, abundance_ratio=0.65, scramble=True), []),
+    "repeat_k21": (dict(n_strains=3, genome_len=3000, snp_rate=0.008, k=21, n_pairs=6000, read_len=100,
+                        seed=8, repeat_len=120), []),
+    "six_strain_k21": (dict(n_strains=6, genome_len=5000, snp_rate=0.015, k=21, n_pairs=15000,
+                            read_len=100, seed=61, abundance_ratio=0.75, scramble=True,
+                            error_strain_depth=4.0), []),
+    "flat_cov_k21": (dict(n_strains=3, genome_len=2500, snp_rate=0.01, k=21, n_pairs=5000, read_len=100,
+                          seed=71, abundance_ratio=0.97, dp_noise=0.05), []),
+    "noisy_reads_k21": (dict(n_strains=4, genome_len=3500, snp_rate=0.012, k=21, n_pairs=8000,
+                             read_len=100, seed=81, abundance_ratio=0.55, sub_rate=0.004,
+                             scramble=True), []),
+}
+
+
+def md5(text):
+    return hashlib.md5(text.encode()).hexdigest()
+
+
+def seq_digest(seq):
+    return "%d:%s" % (len(seq), md5(seq)[:12])
+
+
+def digest_gfa(text):
+    out = []
+    for line in text.split("\n"):
+        f = line.split("\t")
+        if f[0] == "S" and len(f) >= 3:
+            f[2] = seq_digest(f[2])
+        out.append("\t".join(f))
+    return "\n".join(out)
+
+
+def digest_fasta(text):
+    out = []
+    for line in text.split("\n"):
+        out.append(line if (line.startswith(">") or line == "") else seq_digest(line))
+    return "\n".join(out)
+
+
+def sparse_info(text):
+    lines = text.split("\n")
+    keep = [l for l in lines if l and not l.endswith(":0")]
+    return "%d\n%s\n" % (sum(1 for l in lines if l), "\n".join(keep))
+
+
+def collect(out_dir):
+    """reference output tree -> {relative name: digest-form text}"""
+    res = {}
+    for sub in ("gfa", "tmp", "aln", ""):
+        d = os.path.join(out_dir, sub) if sub else out_dir
+        for name in sorted(os.listdir(d)):
+            p = os.path.join(d, name)
+            if not os.path.isfile(p) or name.endswith(".png") or name == "vstrains.log":
+                continue
+            with open(p) as fh:
+                text = fh.read()
+            rel = (sub + "/" + name) if sub else name
+            if name.endswith(".gfa"):
+                text = digest_gfa(text)
+            elif name.endswith(".fasta"):
+                text = digest_fasta(text)
+            elif name in ("pe_info", "st_info"):
+                text = sparse_info(text)
+            res[rel] = text
+    return res
+
+
+def run_reference(inp, extra, variant, hashseed=0, keep_log_to=None):
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "out")
+        env = dict(os.environ)
+        env["PYTHONPATH"] = STANDIN + os.pathsep + env.get("PYTHONPATH", "")
+        env["GT_STANDIN_INEDGE"] = variant
+        # the reference iterates sets of contig names (Decomposition.py:188,444): its contig_dict
+        # order, hence tie-breaks downstream, depend on the interpreter's string hash seed
+        env["PYTHONHASHSEED"] = str(hashseed)
+        cmd = [sys.executable, REF_CLI, "-a", "spades", "-g", inp["gfa"], "-p", inp["paths"], "-o", out,
+               "-fwd", inp["fwd"], "-rve", inp["rve"], "-d"] + extra
+        proc = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=tmp)
+        if keep_log_to and os.path.exists(os.path.join(out, "vstrains.log")):
+            shutil.copy(os.path.join(out, "vstrains.log"), keep_log_to)
+        if proc.returncode != 0:
+            return proc.returncode, {}, proc.stderr[-3000:]
+        return 0, collect(out), ""
+
+
+def emit(case):
+    kwargs, extra = CASES[case]
+    pc = synth.make_pipeline_case(**kwargs)
+    d = os.path.join(OUT, case)
+    if os.path.isdir(d):
+        shutil.rmtree(d)
+    os.makedirs(os.path.join(d, "in"))
+    fwd_text = synth.fastq_text(pc.fwd, "f")
+    rve_text = synth.fastq_text(pc.rve, "r")
+    with tempfile.TemporaryDirectory() as tmp:
+        inp = {"gfa": os.path.join(d, "in", "graph.gfa"), "paths": os.path.join(d, "in", "contigs.paths"),
+               "fwd": os.path.join(tmp, "fwd.fq"), "rve": os.path.join(tmp, "rve.fq")}
+        for key, text in (("gfa", pc.gfa_text), ("paths", pc.paths_text), ("fwd", fwd_text), ("rve", rve_text)):
+            with open(inp[key], "w") as fh:
+                fh.write(text)
+        log_dir = os.environ.get("VS_GOLDEN_LOGS")
+        log_to = os.path.join(log_dir, case + ".log") if log_dir else None
+        rc, files, err = run_reference(inp, extra, "rotate", 0, log_to)
+        rc2, files2, _ = run_reference(inp, extra, "plain", 0)
+        seed_variant = set()
+        for hs in (1, 2, 3):
+            rc3, files3, _ = run_reference(inp, extra, "rotate", hs)
+            seed_variant.update(k for k in files if files3.get(k) != files[k])
+    meta = {
+        "synth": kwargs, "cli_extra": extra, "returncode": rc, "k": pc.k,
+        "input_md5": {"gfa": md5(pc.gfa_text), "paths": md5(pc.paths_text), "fwd": md5(fwd_text),
+                      "rve": md5(rve_text)},
+        "inedge_invariant": bool(rc == rc2 and files == files2),
+        "differs_under_plain_inedge_order": sorted(k for k in files if files2.get(k) != files[k]),
+        "files": sorted(files),
+        "hashseed": 0,
+        "hashseed_invariant": not seed_variant,
+        "differs_under_other_hashseeds": sorted(seed_variant),
+    }
+    if rc != 0:
+        meta["stderr_tail"] = err
+    for rel, text in files.items():
+        p = os.path.join(d, "out", rel)
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        with open(p, "w") as fh:
+            fh.write(text)
+    with open(os.path.join(d, "case.json"), "w") as fh:
+        json.dump(meta, fh, indent=1, sort_keys=True)
+        fh.write("\n")
+    strains = files.get("strain.paths", "").count("NODE_")
+    print("%-30s rc=%d nodes=%d files=%d strains=%d inedge_invariant=%s hashseed_invariant=%s" % (
+        case, rc, len(pc.graph.ids), len(files), strains, meta["inedge_invariant"], meta["hashseed_invariant"]))
+    if rc != 0:
+        print(err)
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(CASES)
+    os.makedirs(OUT, exist_ok=True)
+    for name in names:
+        emit(name)

@@ -1,0 +1,100 @@
+"""Helpers shared by the graph-stage tests: load a golden case, run the pipeline, collect the
+outputs in the same digest form ``tests/golden/make_graph_golden.py`` stored."""
+import argparse
+import json
+import logging
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+import make_graph_golden as gold  # noqa: E402  (digest helpers + case table; runs nothing on import)
+from vstrains_amd import synth  # noqa: E402
+
+GOLDEN = os.path.join(HERE, "golden", "graph")
+
+
+def case_names():
+    return sorted(d for d in os.listdir(GOLDEN) if os.path.isfile(os.path.join(GOLDEN, d, "case.json")))
+
+
+class Case:
+    def __init__(self, name):
+        self.name = name
+        self.dir = os.path.join(GOLDEN, name)
+        with open(os.path.join(self.dir, "case.json")) as fh:
+            self.meta = json.load(fh)
+        self.expected = {}
+        for rel in self.meta["files"]:
+            with open(os.path.join(self.dir, "out", rel)) as fh:
+                self.expected[rel] = fh.read()
+
+    def inputs(self, tmp, with_reads=False):
+        """Re-derive the inputs from the seed and check them against the pinned digests."""
+        pc = synth.make_pipeline_case(**self.meta["synth"])
+        assert gold.md5(pc.gfa_text) == self.meta["input_md5"]["gfa"], "synthetic graph drifted"
+        assert gold.md5(pc.paths_text) == self.meta["input_md5"]["paths"], "synthetic contigs drifted"
+        paths = {"gfa": os.path.join(self.dir, "in", "graph.gfa"), "paths": os.path.join(self.dir, "in", "contigs.paths")}
+        if with_reads:
+            ft, rt = synth.fastq_text(pc.fwd, "f"), synth.fastq_text(pc.rve, "r")
+            assert gold.md5(ft) == self.meta["input_md5"]["fwd"], "synthetic reads drifted"
+            assert gold.md5(rt) == self.meta["input_md5"]["rve"]
+            for key, text in (("fwd", ft), ("rve", rt)):
+                paths[key] = os.path.join(tmp, key + ".fq")
+                with open(paths[key], "w") as fh:
+                    fh.write(text)
+        else:
+            paths["fwd"] = paths["rve"] = os.path.join(tmp, "unused.fq")
+        return paths
+
+    def args(self, inp, out):
+        extra = self.meta["cli_extra"]
+        min_cov = int(extra[extra.index("-mc") + 1]) if "-mc" in extra else None
+        for sub in ("gfa", "tmp", "paf", "aln"):
+            os.makedirs(os.path.join(out, sub))
+        return argparse.Namespace(gfa_file=inp["gfa"], path_file=inp["paths"], fwd=inp["fwd"], rve=inp["rve"],
+                                  output_dir=out, min_cov=min_cov, min_len=250, ref_file=None, dev=False)
+
+    def write_info_files(self, names, aln_dir):
+        """pe_info / st_info text rebuilt from the stored non-zero lines."""
+        os.makedirs(aln_dir, exist_ok=True)
+        for fname in ("pe_info", "st_info"):
+            lines = self.expected["aln/" + fname].split("\n")
+            total = int(lines[0])
+            assert total == len(names) ** 2
+            nz = {}
+            for l in lines[1:]:
+                if l:
+                    u, v, c = l.split(":")
+                    nz[(u, v)] = c
+            with open(os.path.join(aln_dir, fname), "w") as fh:
+                for u in names:
+                    fh.write("".join("%s:%s:%s\n" % (u, v, nz.get((u, v), "0")) for v in names))
+
+
+def quiet_logger(name="vstrains-test"):
+    lg = logging.getLogger(name)
+    lg.handlers[:] = [logging.NullHandler()]
+    lg.setLevel(logging.CRITICAL)
+    lg.propagate = False
+    return lg
+
+
+def compare(case, out_dir, skip=()):
+    got = gold.collect(out_dir)
+    problems = []
+    for rel in case.meta["files"]:
+        if rel in skip:
+            continue
+        if rel not in got:
+            problems.append("missing " + rel)
+        elif got[rel] != case.expected[rel]:
+            problems.append("differs " + rel)
+    extra = sorted(set(got) - set(case.meta["files"]))
+    if extra:
+        problems.append("unexpected files " + ",".join(extra))
+    return problems, got

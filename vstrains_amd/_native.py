@@ -35,6 +35,15 @@ SYMBOLS = {
     "vs_pe_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vs_pe_map_ends": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "vs_pe_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "vs_links_from_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "vs_links_from_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "vs_links_free": (None, [C.c_void_p, C.c_void_p]),
+    "vs_links_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "vs_links_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vs_links_block_sums": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                                      C.c_void_p, C.c_uint64, C.c_void_p]),
+    "vs_links_group_matrix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "vs_graph_refresh": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 13 + [C.POINTER(C.c_uint32)]),
     "vs_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vs_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vs_dev_zero": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

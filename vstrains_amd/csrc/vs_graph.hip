@@ -1,0 +1,546 @@
+// Graph-stage kernels (K5 PE-link table, K6 vertex scan / chain ranking, K7 edge
+// flow).  gfx950 only.  Everything here is integer / fp64 index work bound by memory latency
+// or HBM bandwidth; no MFMA.
+//
+// Reference lines (under /root/reference/utils/) each kernel stands in for are cited at the
+// kernels.  fp64 arithmetic must reproduce numpy bit for bit: the file is compiled with
+// -ffp-contract=off and the sums follow numpy's pairwise_sum order.
+#include "vs_internal.h"
+
+#include <vector>
+
+struct vs_links {
+    uint32_t n = 0;
+    int64_t *d_p0 = nullptr;  // [n*n] symmetric; diagonal = node[i][i] + short[i][i]
+};
+
+// ---------------------------------------------------------------------------------------------
+// K5a  P0 = symmetrised counts.  VStrains_IO.py:598-627 (process_pe_info): every line u:v:c of
+// pe_info and st_info is added under the key (min(u,v), max(u,v)); so for i != j the key holds
+// node[i][j] + node[j][i] + short[i][j] + short[j][i] and for i == j node[i][i] + short[i][i].
+// One workgroup handles the tile pair (I,J),(J,I), I <= J: every input element is read once
+// with row-contiguous (coalesced) loads, transposed through LDS, and both output tiles are
+// written row-contiguously.
+// ---------------------------------------------------------------------------------------------
+#define SYM_T 32
+template <typename TIn>
+__global__ void __launch_bounds__(256) k_links_symmetrize(const TIn *__restrict__ node, const TIn *__restrict__ shrt,
+                                                         uint32_t n, uint32_t tiles, int64_t *__restrict__ p0) {
+    __shared__ int64_t a[SYM_T][SYM_T + 1];  // sum tile (I,J)
+    __shared__ int64_t b[SYM_T][SYM_T + 1];  // sum tile (J,I)
+    // linear pair index -> (I, J) with I <= J
+    uint32_t p = blockIdx.x;
+    uint32_t I = 0;
+    uint32_t rowlen = tiles;
+    while (p >= rowlen) {
+        p -= rowlen;
+        I++;
+        rowlen--;
+    }
+    uint32_t J = I + p;
+    uint32_t tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;  // 32 x 8
+    for (uint32_t r = ty; r < SYM_T; r += 8) {
+        uint32_t gi = I * SYM_T + r, gj = J * SYM_T + tx;
+        int64_t v = 0;
+        if (gi < n && gj < n) v = (int64_t)node[(uint64_t)gi * n + gj] + (int64_t)shrt[(uint64_t)gi * n + gj];
+        a[r][tx] = v;
+        uint32_t hi = J * SYM_T + r, hj = I * SYM_T + tx;
+        int64_t w = 0;
+        if (hi < n && hj < n) w = (int64_t)node[(uint64_t)hi * n + hj] + (int64_t)shrt[(uint64_t)hi * n + hj];
+        b[r][tx] = w;
+    }
+    __syncthreads();
+    for (uint32_t r = ty; r < SYM_T; r += 8) {
+        uint32_t gi = I * SYM_T + r, gj = J * SYM_T + tx;
+        if (gi < n && gj < n) p0[(uint64_t)gi * n + gj] = (gi == gj) ? a[r][tx] : a[r][tx] + b[tx][r];
+        if (I != J) {
+            uint32_t hi = J * SYM_T + r, hj = I * SYM_T + tx;
+            if (hi < n && hj < n) p0[(uint64_t)hi * n + hj] = b[r][tx] + a[tx][r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5b  block sums: out[q] = sum_{r in list qa[q]} sum_{c in list qb[q]} P0[r][c].
+// Stands in for every pe_info[(min,max)] read of the stages after splits/contractions
+// (Decomposition.py:178,273; Extension.py:62) -- see vstrains_amd/graph/ops.py for why this sum
+// equals the rewritten dict entry.  One wavefront per query; lanes stride the column list.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_links_block_sums(const int64_t *__restrict__ p0, uint32_t n,
+                                                         const uint64_t *__restrict__ list_off,
+                                                         const uint32_t *__restrict__ list_idx,
+                                                         const uint32_t *__restrict__ qa, const uint32_t *__restrict__ qb,
+                                                         uint64_t n_queries, int64_t *__restrict__ out) {
+    uint64_t q = (uint64_t)blockIdx.x * (blockDim.x / VS_WAVE) + (threadIdx.x / VS_WAVE);
+    if (q >= n_queries) return;
+    uint32_t lane = threadIdx.x & (VS_WAVE - 1);
+    uint64_t a0 = list_off[qa[q]], a1 = list_off[qa[q] + 1];
+    uint64_t b0 = list_off[qb[q]], b1 = list_off[qb[q] + 1];
+    int64_t s = 0;
+    for (uint64_t i = a0; i < a1; i++) {
+        const int64_t *row = p0 + (uint64_t)list_idx[i] * n;
+        for (uint64_t j = b0 + lane; j < b1; j += VS_WAVE) s += row[list_idx[j]];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, VS_WAVE);
+    if (lane == 0) out[q] = s;
+}
+
+// K5c  grouped contraction C = A P0 A^T in two passes (Extension.py:766-799 final_link_info;
+// Utilities.py:488-495 row sums of a contracted path).  Pass 1: T[g][c] = sum_{r in G_g} P0[r][c]
+// (coalesced along c).  Pass 2: C[g][h] = sum_{c in G_h} T[g][c] (one wavefront per (g,h)).
+__global__ void __launch_bounds__(256) k_links_group_rows(const int64_t *__restrict__ p0, uint32_t n,
+                                                         const uint64_t *__restrict__ list_off,
+                                                         const uint32_t *__restrict__ list_idx,
+                                                         int64_t *__restrict__ t) {
+    uint32_t g = blockIdx.y;
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    int64_t s = 0;
+    for (uint64_t i = list_off[g]; i < list_off[g + 1]; i++) s += p0[(uint64_t)list_idx[i] * n + c];
+    t[(uint64_t)g * n + c] = s;
+}
+
+__global__ void __launch_bounds__(256) k_links_group_cols(const int64_t *__restrict__ t, uint32_t n, uint32_t n_groups,
+                                                         const uint64_t *__restrict__ list_off,
+                                                         const uint32_t *__restrict__ list_idx,
+                                                         int64_t *__restrict__ out) {
+    uint64_t pair = (uint64_t)blockIdx.x * (blockDim.x / VS_WAVE) + (threadIdx.x / VS_WAVE);
+    if (pair >= (uint64_t)n_groups * n_groups) return;
+    uint32_t g = (uint32_t)(pair / n_groups), h = (uint32_t)(pair % n_groups);
+    uint32_t lane = threadIdx.x & (VS_WAVE - 1);
+    int64_t s = 0;
+    const int64_t *row = t + (uint64_t)g * n;
+    for (uint64_t j = list_off[h] + lane; j < list_off[h + 1]; j += VS_WAVE) s += row[list_idx[j]];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, VS_WAVE);
+    if (lane == 0) out[pair] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// numpy.sum of a contiguous float64 vector = pairwise_sum over all elements
+// (numpy/_core/src/umath/loops_utils.h.src): n < 8 sequential from 0; n <= 128 eight running
+// accumulators combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) then the tail; larger n splits at
+// n/2 rounded down to a multiple of 8.  Elements are dp[nbr[base + i]].
+// ---------------------------------------------------------------------------------------------
+__device__ double vs_np_pairwise_le128(const double *__restrict__ dp, const uint32_t *__restrict__ nbr, uint64_t base, uint32_t n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (uint32_t i = 0; i < n; i++) res += dp[nbr[base + i]];
+        return res;
+    }
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = dp[nbr[base + j]];
+    uint32_t i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] += dp[nbr[base + i + j]];
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += dp[nbr[base + i]];
+    return res;
+}
+
+__device__ double vs_np_pairwise(const double *__restrict__ dp, const uint32_t *__restrict__ nbr, uint64_t base, uint32_t n) {
+    if (n <= 128) return vs_np_pairwise_le128(dp, nbr, base, n);
+    // degree > 128: numpy recurses on (n/2 rounded down to a multiple of 8, rest); explicit stack
+    uint64_t sb[34];
+    uint32_t sn[34];
+    double acc[34];
+    int state[34];
+    int sp = 0;
+    sb[0] = base;
+    sn[0] = n;
+    state[0] = 0;
+    double ret = 0.0;
+    while (sp >= 0) {
+        uint32_t cn = sn[sp];
+        if (cn <= 128) {
+            ret = vs_np_pairwise_le128(dp, nbr, sb[sp], cn);
+            sp--;
+            continue;
+        }
+        uint32_t n2 = cn / 2;
+        n2 -= n2 % 8;
+        if (state[sp] == 0) {
+            state[sp] = 1;
+            sb[sp + 1] = sb[sp];
+            sn[sp + 1] = n2;
+            state[sp + 1] = 0;
+            sp++;
+        } else if (state[sp] == 1) {
+            acc[sp] = ret;
+            state[sp] = 2;
+            sb[sp + 1] = sb[sp] + n2;
+            sn[sp + 1] = cn - n2;
+            state[sp + 1] = 0;
+            sp++;
+        } else {
+            ret = acc[sp] + ret;
+            sp--;
+        }
+    }
+    return ret;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6  vertex scan over the stage CSR (adjacency row = out-entries [0, n_out) then in-entries).
+//   nontrivial : is_non_trivial, Utilities.py:162-172 (black edges; ids are unique per vertex,
+//                so the id-set intersection is the set of vertices that are both a black
+//                in-source and a black out-target)
+//   fork_kind  : the tests of Decomposition.py:715 / :763 (black vertex, black edges)
+//   chain_pred : simple in-edge source (simp_path, Utilities.py:398-402: src.out_degree()==1 and
+//                target.in_degree()==1 and src != target; degrees count every edge)
+//   chain_next : simple out-edge target
+//   out_sum / in_sum : numpy.sum of neighbour dp in adjacency order (Utilities.py:20,23)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_vertex_scan(uint32_t nv, const uint64_t *__restrict__ row_ptr,
+                                                    const uint32_t *__restrict__ n_out, const uint32_t *__restrict__ nbr,
+                                                    const uint32_t *__restrict__ eidx, const double *__restrict__ dp,
+                                                    const uint8_t *__restrict__ vblack, const uint8_t *__restrict__ eblack,
+                                                    double *__restrict__ out_sum, double *__restrict__ in_sum,
+                                                    uint8_t *__restrict__ nontrivial, uint8_t *__restrict__ fork_kind,
+                                                    int32_t *__restrict__ chain_next, int32_t *__restrict__ chain_pred) {
+    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    uint64_t lo = row_ptr[v], hi = row_ptr[v + 1];
+    uint32_t no = n_out[v];
+    uint32_t ni = (uint32_t)(hi - lo) - no;
+    out_sum[v] = vs_np_pairwise(dp, nbr, lo, no);
+    in_sum[v] = vs_np_pairwise(dp, nbr, lo + no, ni);
+    uint32_t bin = 0, bout = 0, both = 0;
+    for (uint64_t i = lo + no; i < hi; i++) {
+        if (!eblack[eidx[i]]) continue;
+        bin++;
+        // count this source once if it is also a black out-target and was not seen earlier
+        uint32_t s = nbr[i];
+        bool first = true;
+        for (uint64_t k = lo + no; k < i; k++)
+            if (eblack[eidx[k]] && nbr[k] == s) { first = false; break; }
+        if (!first) continue;
+        for (uint64_t k = lo; k < lo + no; k++)
+            if (eblack[eidx[k]] && nbr[k] == s) { both++; break; }
+    }
+    for (uint64_t k = lo; k < lo + no; k++)
+        if (eblack[eidx[k]]) bout++;
+    uint32_t m = both > 1 ? both : 1;
+    nontrivial[v] = (bin > m && bout > m) ? 1 : 0;
+    uint8_t fk = 0;
+    if (vblack[v]) {
+        if (bin == 1 && bout > 1) fk = 1;
+        else if (bin > 1 && bout == 1) fk = 2;
+    }
+    fork_kind[v] = fk;
+    int32_t nx = -1, pd = -1;
+    if (no == 1) {
+        uint32_t t = nbr[lo];
+        uint32_t t_in = (uint32_t)(row_ptr[t + 1] - row_ptr[t]) - n_out[t];
+        if (t_in == 1 && t != v) nx = (int32_t)t;
+    }
+    if (ni == 1) {
+        uint32_t s = nbr[lo + no];
+        if (n_out[s] == 1 && s != v) pd = (int32_t)s;
+    }
+    chain_next[v] = nx;
+    chain_pred[v] = pd;
+}
+
+// K6b  list ranking of the simple chains by pointer jumping (double buffered): after
+// ceil(log2(V)) rounds anc[v] = -1 and rank[v] = distance of v from the head of its chain,
+// top[v] = that head.  Vertices on a ring of simple edges never reach -1 and are reported with
+// rank = -1 (the reference finds no head there either and leaves rings alone).
+__global__ void __launch_bounds__(256) k_chain_init(uint32_t nv, const int32_t *__restrict__ pred, int32_t *__restrict__ anc,
+                                                   int32_t *__restrict__ rank, int32_t *__restrict__ top) {
+    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    int32_t p = pred[v];
+    anc[v] = p;
+    rank[v] = p >= 0 ? 1 : 0;
+    top[v] = p >= 0 ? p : (int32_t)v;
+}
+
+__global__ void __launch_bounds__(256) k_chain_jump(uint32_t nv, const int32_t *__restrict__ anc_in, const int32_t *__restrict__ rank_in,
+                                                   const int32_t *__restrict__ top_in, int32_t *__restrict__ anc_out,
+                                                   int32_t *__restrict__ rank_out, int32_t *__restrict__ top_out) {
+    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    int32_t a = anc_in[v];
+    if (a >= 0) {
+        rank_out[v] = rank_in[v] + rank_in[a];
+        top_out[v] = top_in[a];
+        anc_out[v] = anc_in[a];
+    } else {
+        rank_out[v] = rank_in[v];
+        top_out[v] = top_in[v];
+        anc_out[v] = -1;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_chain_finish(uint32_t nv, const int32_t *__restrict__ anc, int32_t *__restrict__ rank) {
+    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < nv && anc[v] >= 0) rank[v] = -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K7  edge flow, Utilities.py:14-31: flow(u->v) = numpy.mean([ (dp_v/out_sum_u)*dp_u,
+// (dp_u/in_sum_v)*dp_v ]) = ((0.0 + a) + b) / 2.  One thread per out-entry of the CSR.
+// A zero sum is reported instead of dividing (the reference raises FloatingPointError under
+// numpy.seterr(all="raise"), vstrains:25).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_edge_flow(uint32_t nv, const uint64_t *__restrict__ row_ptr,
+                                                  const uint32_t *__restrict__ n_out, const uint32_t *__restrict__ nbr,
+                                                  const uint32_t *__restrict__ eidx, const double *__restrict__ dp,
+                                                  const double *__restrict__ out_sum, const double *__restrict__ in_sum,
+                                                  double *__restrict__ flow, uint32_t *__restrict__ bad) {
+    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= nv) return;
+    uint64_t lo = row_ptr[u];
+    uint32_t no = n_out[u];
+    double du = dp[u], os = out_sum[u];
+    for (uint32_t k = 0; k < no; k++) {
+        uint32_t v = nbr[lo + k];
+        double dv = dp[v], is = in_sum[v];
+        if (os == 0.0 || is == 0.0) {
+            atomicMin(bad, eidx[lo + k]);
+            continue;
+        }
+        double a = (dv / os) * du;
+        double b = (du / is) * dv;
+        flow[eidx[lo + k]] = (a + b) / 2.0;
+    }
+}
+
+// =============================================================================================
+// host entry points
+// =============================================================================================
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    template <typename T>
+    T *as() { return (T *)p; }
+};
+
+int dev_upload(vs_ctx *ctx, DevBuf &b, const void *host, size_t bytes) {
+    VS_HIP(ctx, hipMalloc(&b.p, bytes ? bytes : 16));
+    if (bytes) VS_HIP(ctx, hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return VS_OK;
+}
+int dev_alloc(vs_ctx *ctx, DevBuf &b, size_t bytes) {
+    VS_HIP(ctx, hipMalloc(&b.p, bytes ? bytes : 16));
+    return VS_OK;
+}
+#define VS_TRY(x)            \
+    do {                     \
+        int rc__ = (x);      \
+        if (rc__) return rc__; \
+    } while (0)
+
+template <typename TIn>
+int links_build(vs_ctx *ctx, const TIn *d_node, const TIn *d_short, uint32_t n, vs_links **out) {
+    vs_links *L = new vs_links();
+    L->n = n;
+    hipError_t e = hipMalloc((void **)&L->d_p0, (size_t)(n ? (uint64_t)n * n : 1) * sizeof(int64_t));
+    if (e != hipSuccess) {
+        delete L;
+        return vs_fail(ctx, VS_E_OOM, "vs_links: %s", hipGetErrorString(e));
+    }
+    if (n) {
+        uint32_t tiles = (n + SYM_T - 1) / SYM_T;
+        uint64_t pairs = (uint64_t)tiles * (tiles + 1) / 2;
+        hipLaunchKernelGGL((k_links_symmetrize<TIn>), dim3((unsigned)pairs), dim3(256), 0, ctx->stream, d_node, d_short, n,
+                           tiles, L->d_p0);
+        e = hipGetLastError();
+        if (e != hipSuccess) {
+            (void)hipFree(L->d_p0);
+            delete L;
+            return vs_fail(ctx, VS_E_HIP, "k_links_symmetrize: %s", hipGetErrorString(e));
+        }
+    }
+    *out = L;
+    return VS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int vs_links_from_counts(vs_ctx *ctx, const uint32_t *d_node_mat, const uint32_t *d_short_mat, uint32_t n, vs_links **out) {
+    if (!ctx || !out || (n && (!d_node_mat || !d_short_mat))) return vs_fail(ctx, VS_E_ARG, "vs_links_from_counts: bad argument");
+    VS_HIP(ctx, hipSetDevice(ctx->device));
+    return links_build<uint32_t>(ctx, d_node_mat, d_short_mat, n, out);
+}
+
+int vs_links_from_host(vs_ctx *ctx, const int64_t *node_mat, const int64_t *short_mat, uint32_t n, vs_links **out) {
+    if (!ctx || !out || (n && (!node_mat || !short_mat))) return vs_fail(ctx, VS_E_ARG, "vs_links_from_host: bad argument");
+    VS_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf a, b;
+    size_t bytes = (size_t)n * n * sizeof(int64_t);
+    VS_TRY(dev_upload(ctx, a, node_mat, bytes));
+    VS_TRY(dev_upload(ctx, b, short_mat, bytes));
+    int rc = links_build<int64_t>(ctx, a.as<int64_t>(), b.as<int64_t>(), n, out);
+    VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return rc;
+}
+
+void vs_links_free(vs_ctx *ctx, vs_links *links) {
+    if (!links) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (links->d_p0) (void)hipFree(links->d_p0);
+    delete links;
+}
+
+int vs_links_size(const vs_links *links, uint32_t *n) {
+    if (!links || !n) return VS_E_ARG;
+    *n = links->n;
+    return VS_OK;
+}
+
+int vs_links_to_host(vs_ctx *ctx, const vs_links *links, int64_t *out) {
+    if (!ctx || !links || !out) return vs_fail(ctx, VS_E_ARG, "vs_links_to_host: bad argument");
+    VS_HIP(ctx, hipSetDevice(ctx->device));
+    VS_HIP(ctx, hipMemcpyAsync(out, links->d_p0, (size_t)links->n * links->n * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VS_OK;
+}
+
+static int check_lists(vs_ctx *ctx, const vs_links *links, const uint64_t *list_off, const uint32_t *list_idx, uint32_t n_lists) {
+    for (uint32_t l = 0; l < n_lists; l++)
+        if (list_off[l + 1] < list_off[l]) return vs_fail(ctx, VS_E_ARG, "list offsets must not decrease");
+    for (uint64_t i = 0; i < list_off[n_lists]; i++)
+        if (list_idx[i] >= links->n) return vs_fail(ctx, VS_E_RANGE, "list index %u out of range (n=%u)", list_idx[i], links->n);
+    return VS_OK;
+}
+
+int vs_links_block_sums(vs_ctx *ctx, const vs_links *links, const uint64_t *list_off, const uint32_t *list_idx,
+                        uint32_t n_lists, const uint32_t *qa, const uint32_t *qb, uint64_t n_queries, int64_t *out) {
+    if (!ctx || !links || !list_off || (n_queries && (!qa || !qb || !out)))
+        return vs_fail(ctx, VS_E_ARG, "vs_links_block_sums: bad argument");
+    if (n_queries == 0) return VS_OK;
+    if (list_off[n_lists] && !list_idx) return vs_fail(ctx, VS_E_ARG, "vs_links_block_sums: list_idx is NULL");
+    VS_TRY(check_lists(ctx, links, list_off, list_idx, n_lists));
+    for (uint64_t q = 0; q < n_queries; q++)
+        if (qa[q] >= n_lists || qb[q] >= n_lists) return vs_fail(ctx, VS_E_RANGE, "query %llu names a list out of range", (unsigned long long)q);
+    VS_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf d_off, d_idx, d_qa, d_qb, d_out;
+    VS_TRY(dev_upload(ctx, d_off, list_off, (size_t)(n_lists + 1) * sizeof(uint64_t)));
+    VS_TRY(dev_upload(ctx, d_idx, list_idx, (size_t)list_off[n_lists] * sizeof(uint32_t)));
+    VS_TRY(dev_upload(ctx, d_qa, qa, (size_t)n_queries * sizeof(uint32_t)));
+    VS_TRY(dev_upload(ctx, d_qb, qb, (size_t)n_queries * sizeof(uint32_t)));
+    VS_TRY(dev_alloc(ctx, d_out, (size_t)n_queries * sizeof(int64_t)));
+    const unsigned waves = 256 / VS_WAVE;
+    hipLaunchKernelGGL(k_links_block_sums, dim3((unsigned)((n_queries + waves - 1) / waves)), dim3(256), 0, ctx->stream,
+                       links->d_p0, links->n, d_off.as<uint64_t>(), d_idx.as<uint32_t>(), d_qa.as<uint32_t>(),
+                       d_qb.as<uint32_t>(), n_queries, d_out.as<int64_t>());
+    VS_HIP(ctx, hipGetLastError());
+    VS_HIP(ctx, hipMemcpyAsync(out, d_out.p, (size_t)n_queries * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VS_OK;
+}
+
+int vs_links_group_matrix(vs_ctx *ctx, const vs_links *links, const uint64_t *list_off, const uint32_t *list_idx,
+                          uint32_t n_groups, int64_t *out) {
+    if (!ctx || !links || !list_off || (n_groups && !out)) return vs_fail(ctx, VS_E_ARG, "vs_links_group_matrix: bad argument");
+    if (n_groups == 0) return VS_OK;
+    if (list_off[n_groups] && !list_idx) return vs_fail(ctx, VS_E_ARG, "vs_links_group_matrix: list_idx is NULL");
+    VS_TRY(check_lists(ctx, links, list_off, list_idx, n_groups));
+    VS_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t n = links->n;
+    DevBuf d_off, d_idx, d_t, d_out;
+    VS_TRY(dev_upload(ctx, d_off, list_off, (size_t)(n_groups + 1) * sizeof(uint64_t)));
+    VS_TRY(dev_upload(ctx, d_idx, list_idx, (size_t)list_off[n_groups] * sizeof(uint32_t)));
+    VS_TRY(dev_alloc(ctx, d_t, (size_t)n_groups * (n ? n : 1) * sizeof(int64_t)));
+    VS_TRY(dev_alloc(ctx, d_out, (size_t)n_groups * n_groups * sizeof(int64_t)));
+    if (n) {
+        hipLaunchKernelGGL(k_links_group_rows, dim3((n + 255) / 256, n_groups), dim3(256), 0, ctx->stream, links->d_p0, n,
+                           d_off.as<uint64_t>(), d_idx.as<uint32_t>(), d_t.as<int64_t>());
+    }
+    uint64_t pairs = (uint64_t)n_groups * n_groups;
+    const unsigned waves = 256 / VS_WAVE;
+    hipLaunchKernelGGL(k_links_group_cols, dim3((unsigned)((pairs + waves - 1) / waves)), dim3(256), 0, ctx->stream,
+                       d_t.as<int64_t>(), n, n_groups, d_off.as<uint64_t>(), d_idx.as<uint32_t>(), d_out.as<int64_t>());
+    VS_HIP(ctx, hipGetLastError());
+    VS_HIP(ctx, hipMemcpyAsync(out, d_out.p, (size_t)pairs * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VS_OK;
+}
+
+int vs_graph_refresh(vs_ctx *ctx, uint32_t n_vertices, uint32_t n_edge_slots, const uint64_t *row_ptr, const uint32_t *n_out,
+                     const uint32_t *nbr, const uint32_t *eidx, const double *dp, const uint8_t *vertex_black,
+                     const uint8_t *edge_black, double *flow, uint8_t *nontrivial, uint8_t *fork_kind,
+                     int32_t *chain_next, int32_t *chain_top, int32_t *chain_rank, uint32_t *zero_sum_edge) {
+    if (!ctx || !row_ptr || (n_vertices && (!n_out || !dp || !vertex_black)))
+        return vs_fail(ctx, VS_E_ARG, "vs_graph_refresh: bad argument");
+    if (zero_sum_edge) *zero_sum_edge = 0xFFFFFFFFu;
+    if (n_vertices == 0) return VS_OK;
+    uint64_t n_adj = row_ptr[n_vertices];
+    if (n_adj && (!nbr || !eidx || !edge_black)) return vs_fail(ctx, VS_E_ARG, "vs_graph_refresh: adjacency arrays missing");
+    for (uint32_t v = 0; v < n_vertices; v++) {
+        if (row_ptr[v + 1] < row_ptr[v] || n_out[v] > row_ptr[v + 1] - row_ptr[v])
+            return vs_fail(ctx, VS_E_ARG, "vs_graph_refresh: malformed row %u", v);
+    }
+    for (uint64_t i = 0; i < n_adj; i++)
+        if (nbr[i] >= n_vertices || eidx[i] >= n_edge_slots) return vs_fail(ctx, VS_E_RANGE, "vs_graph_refresh: adjacency entry %llu out of range", (unsigned long long)i);
+    VS_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf d_row, d_no, d_nbr, d_eidx, d_dp, d_vb, d_eb, d_os, d_is, d_nt, d_fk, d_nx, d_pd, d_flow, d_bad;
+    DevBuf d_anc[2], d_rank[2], d_top[2];
+    VS_TRY(dev_upload(ctx, d_row, row_ptr, (size_t)(n_vertices + 1) * sizeof(uint64_t)));
+    VS_TRY(dev_upload(ctx, d_no, n_out, (size_t)n_vertices * sizeof(uint32_t)));
+    VS_TRY(dev_upload(ctx, d_nbr, nbr, (size_t)n_adj * sizeof(uint32_t)));
+    VS_TRY(dev_upload(ctx, d_eidx, eidx, (size_t)n_adj * sizeof(uint32_t)));
+    VS_TRY(dev_upload(ctx, d_dp, dp, (size_t)n_vertices * sizeof(double)));
+    VS_TRY(dev_upload(ctx, d_vb, vertex_black, (size_t)n_vertices));
+    VS_TRY(dev_upload(ctx, d_eb, edge_black, (size_t)n_edge_slots));
+    VS_TRY(dev_alloc(ctx, d_os, (size_t)n_vertices * sizeof(double)));
+    VS_TRY(dev_alloc(ctx, d_is, (size_t)n_vertices * sizeof(double)));
+    VS_TRY(dev_alloc(ctx, d_nt, n_vertices));
+    VS_TRY(dev_alloc(ctx, d_fk, n_vertices));
+    VS_TRY(dev_alloc(ctx, d_nx, (size_t)n_vertices * sizeof(int32_t)));
+    VS_TRY(dev_alloc(ctx, d_pd, (size_t)n_vertices * sizeof(int32_t)));
+    VS_TRY(dev_alloc(ctx, d_flow, (size_t)(n_edge_slots ? n_edge_slots : 1) * sizeof(double)));
+    VS_TRY(dev_alloc(ctx, d_bad, sizeof(uint32_t)));
+    for (int i = 0; i < 2; i++) {
+        VS_TRY(dev_alloc(ctx, d_anc[i], (size_t)n_vertices * sizeof(int32_t)));
+        VS_TRY(dev_alloc(ctx, d_rank[i], (size_t)n_vertices * sizeof(int32_t)));
+        VS_TRY(dev_alloc(ctx, d_top[i], (size_t)n_vertices * sizeof(int32_t)));
+    }
+    VS_HIP(ctx, hipMemsetAsync(d_bad.p, 0xFF, sizeof(uint32_t), ctx->stream));
+    VS_HIP(ctx, hipMemsetAsync(d_flow.p, 0, (size_t)(n_edge_slots ? n_edge_slots : 1) * sizeof(double), ctx->stream));
+    dim3 grid((n_vertices + 255) / 256), block(256);
+    hipLaunchKernelGGL(k_vertex_scan, grid, block, 0, ctx->stream, n_vertices, d_row.as<uint64_t>(), d_no.as<uint32_t>(),
+                       d_nbr.as<uint32_t>(), d_eidx.as<uint32_t>(), d_dp.as<double>(), d_vb.as<uint8_t>(), d_eb.as<uint8_t>(),
+                       d_os.as<double>(), d_is.as<double>(), d_nt.as<uint8_t>(), d_fk.as<uint8_t>(), d_nx.as<int32_t>(),
+                       d_pd.as<int32_t>());
+    hipLaunchKernelGGL(k_edge_flow, grid, block, 0, ctx->stream, n_vertices, d_row.as<uint64_t>(), d_no.as<uint32_t>(),
+                       d_nbr.as<uint32_t>(), d_eidx.as<uint32_t>(), d_dp.as<double>(), d_os.as<double>(), d_is.as<double>(),
+                       d_flow.as<double>(), d_bad.as<uint32_t>());
+    hipLaunchKernelGGL(k_chain_init, grid, block, 0, ctx->stream, n_vertices, d_pd.as<int32_t>(), d_anc[0].as<int32_t>(),
+                       d_rank[0].as<int32_t>(), d_top[0].as<int32_t>());
+    int cur = 0;
+    for (uint64_t span = 1; span < n_vertices; span <<= 1) {
+        hipLaunchKernelGGL(k_chain_jump, grid, block, 0, ctx->stream, n_vertices, d_anc[cur].as<int32_t>(),
+                           d_rank[cur].as<int32_t>(), d_top[cur].as<int32_t>(), d_anc[cur ^ 1].as<int32_t>(),
+                           d_rank[cur ^ 1].as<int32_t>(), d_top[cur ^ 1].as<int32_t>());
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(k_chain_finish, grid, block, 0, ctx->stream, n_vertices, d_anc[cur].as<int32_t>(), d_rank[cur].as<int32_t>());
+    VS_HIP(ctx, hipGetLastError());
+    uint32_t bad = 0xFFFFFFFFu;
+    if (flow && n_edge_slots) VS_HIP(ctx, hipMemcpyAsync(flow, d_flow.p, (size_t)n_edge_slots * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (nontrivial) VS_HIP(ctx, hipMemcpyAsync(nontrivial, d_nt.p, n_vertices, hipMemcpyDeviceToHost, ctx->stream));
+    if (fork_kind) VS_HIP(ctx, hipMemcpyAsync(fork_kind, d_fk.p, n_vertices, hipMemcpyDeviceToHost, ctx->stream));
+    if (chain_next) VS_HIP(ctx, hipMemcpyAsync(chain_next, d_nx.p, (size_t)n_vertices * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (chain_top) VS_HIP(ctx, hipMemcpyAsync(chain_top, d_top[cur].p, (size_t)n_vertices * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (chain_rank) VS_HIP(ctx, hipMemcpyAsync(chain_rank, d_rank[cur].p, (size_t)n_vertices * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    VS_HIP(ctx, hipMemcpyAsync(&bad, d_bad.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (zero_sum_edge) *zero_sum_edge = bad;
+    return VS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,506 @@
+"""Graph disentanglement: edge cleaning, branch splitting, simple-path contraction.
+
+Restates ``utils/VStrains_Decomposition.py`` (``edge_cleaning`` :822-905, ``balance_split``
+:91-530 with ``link_split`` :7-28 and ``cov_split`` :31-88, ``trivial_split`` :533-688,
+``global_trivial_split`` :691-819, ``iter_graph_disentanglement`` :908-1042) and
+``simp_path_compactification`` (``utils/VStrains_Utilities.py:383-574``) over ``AsmGraph``.
+
+The data-parallel parts go through ``ops.GraphOps`` / ``ops.LiveLinks`` (device kernels): edge
+flows and the vertex scan once per re-initialisation, PE-link sums batched once per pass.  The
+decisions themselves (which links to keep, how ids are spelled, in which order the maps grow) are
+inherently serial and stay on the host; they follow the reference decision for decision because
+the outputs are compared byte for byte.  The reference's ``-r`` debug plumbing is not part of
+the path and is not restated.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import numpy
+
+from .asm_graph import BLACK, GRAY, AsmGraph, EdgeMap, NodeMap
+from .contigs import (contig_steps, contigs_by_node, drop_duplicate_contigs, remap_contigs,
+                      trim_contigs)
+from .formats import ContigDict, path_length, path_sequence, read_stage_gfa, write_stage_gfa
+from .ops import GraphOps, GraphScan, LiveLinks, nontrivial_ids
+
+
+class Stage:
+    """One re-initialised graph: container, the two ordered maps, and its device scan."""
+
+    __slots__ = ("g", "nodes", "edges", "scan")
+
+    def __init__(self, g: AsmGraph, nodes: NodeMap, edges: EdgeMap, scan: Optional[GraphScan] = None):
+        self.g = g
+        self.nodes = nodes
+        self.edges = edges
+        self.scan = scan
+
+    def triple(self):
+        return self.g, self.nodes, self.edges
+
+
+def reinit(stage: Stage, ops: GraphOps, logger, filename: str) -> Stage:
+    """``store_reinit_graph`` (IO.py:630-642): write the stage GFA, rebuild the graph from that
+    file (drops gray objects, resets vertex order to map order), recompute every edge flow."""
+    write_stage_gfa(stage.g, stage.nodes, stage.edges, filename)
+    logger.info(filename + " is stored..")
+    g, nodes, edges = read_stage_gfa(filename)
+    ops.edge_flows(g)
+    return Stage(g, nodes, edges, ops.scan(g))
+
+
+def load_stage(filename: str, ops: GraphOps, with_flow: bool) -> Stage:
+    g, nodes, edges = read_stage_gfa(filename)
+    if with_flow:
+        ops.edge_flows(g)
+    return Stage(g, nodes, edges, ops.scan(g))
+
+
+# ---- small graph edits (Utilities.py:934-1000) -----------------------------------------------
+def _add_vertex(g: AsmGraph, nodes: NodeMap, name: str, dp, seq: str) -> int:
+    v = g.add_vertex(name, dp, seq, BLACK)
+    nodes[name] = v
+    return v
+
+
+def _retire_vertex(g: AsmGraph, nodes: NodeMap, name: str) -> int:
+    v = nodes.pop(name)
+    g.vblack[v] = GRAY
+    return v
+
+
+def _add_edge(g: AsmGraph, edges: EdgeMap, s: int, t: int, overlap: int, flow=0) -> int:
+    e = g.add_edge(s, t, overlap, flow, BLACK)
+    edges[(g.vid[s], g.vid[t])] = e
+    return e
+
+
+def _retire_edge(g: AsmGraph, edges: EdgeMap, a: str, b: str) -> int:
+    e = edges.pop((a, b))
+    g.eblack[e] = GRAY
+    return e
+
+
+def is_non_trivial(g: AsmGraph, v: int) -> bool:
+    us = [g.vid[g.esrc[e]] for e in g.black_in_edges(v)]
+    ws = [g.vid[g.etgt[e]] for e in g.black_out_edges(v)]
+    both = len(set(us) & set(ws))
+    return len(us) > max(both, 1) and len(ws) > max(both, 1)
+
+
+# ---- edge cleaning -----------------------------------------------------------------------------
+def edge_cleaning(g: AsmGraph, edges: EdgeMap, contigs: ContigDict, links: LiveLinks, logger) -> Dict[Tuple[str, str], bool]:
+    name = g.vid
+    assigned: Dict[Tuple[str, str], bool] = {}
+    for e in g.edges():
+        assigned[(name[g.esrc[e]], name[g.etgt[e]])] = False
+    steps = contig_steps(contigs)
+    open_edges = g.num_edges()
+    logger.debug("Total edges: " + str(open_edges))
+    before = 0
+    while True:
+        for v in range(g.num_vertices()):
+            pend_in = [e for e in g.in_edges(v) if not assigned[(name[g.esrc[e]], name[v])]]
+            pend_out = [e for e in g.out_edges(v) if not assigned[(name[v], name[g.etgt[e]])]]
+            if len(pend_in) == 1:
+                assigned[(name[g.esrc[pend_in[0]]], name[v])] = True
+                open_edges -= 1
+            if len(pend_out) == 1:
+                # evaluated on the lists taken before the in-edge above was marked, as the
+                # reference does; a self-loop is the only edge that could sit in both
+                assigned[(name[v], name[g.etgt[pend_out[0]]])] = True
+                open_edges -= 1
+        if before == open_edges:
+            break
+        before = open_edges
+    logger.debug("un-assigned edges after node-weight coverage iteration : {0}".format(open_edges))
+    for key in assigned:
+        if not assigned[key] and key in steps:
+            assigned[key] = True
+    taken_src = {u for (u, v), ok in assigned.items() if ok}
+    taken_tgt = {v for (u, v), ok in assigned.items() if ok}
+    for (u, v), ok in assigned.items():
+        if not ok and (u in taken_src or v in taken_tgt):
+            g.remove_edge(edges.pop((u, v)))
+            logger.debug("intersect unsupported edge: {0} -> {1}, removed".format(u, v))
+    return assigned
+
+
+# ---- balance split -----------------------------------------------------------------------------
+def _link_plan(sec, kept, in_use, in_cap, out_use, out_cap) -> None:
+    for u, w, pe in sorted(sec, key=lambda t: t[2], reverse=True):
+        if pe <= 0:
+            break
+        in_use[u] += 1
+        out_use[w] += 1
+        kept[(u, w)] = ((in_cap[u] + out_cap[w]) / 2, pe)
+
+
+def _coverage_plan(us, ws, links: LiveLinks, sec, kept, in_use, in_cap, out_use, out_cap) -> None:
+    for u, w, pe in sorted(sec, key=lambda t: t[2], reverse=True):
+        if pe <= 0:
+            break
+        if in_use[u] > 0 or out_use[w] > 0:
+            continue
+        in_use[u] += 1
+        out_use[w] += 1
+        kept[(u, w)] = ((in_cap[u] + out_cap[w]) / 2, pe)
+    for u in us:
+        if in_use[u] > 0:
+            continue
+        w_rank = sorted(ws, key=lambda x: abs(in_cap[u] - out_cap[x]))
+        w = w_rank[0]
+        u_rank = sorted(us, key=lambda x: abs(in_cap[x] - out_cap[w]))
+        if u_rank[0] == u and out_use[w] == 0 and (u, w) not in kept:
+            guard = 2 * abs(in_cap[u] - out_cap[w])
+            if abs(in_cap[u_rank[1]] - out_cap[w]) <= guard or abs(in_cap[u] - out_cap[w_rank[1]]) <= guard:
+                continue
+            in_use[u] += 1
+            out_use[w] += 1
+            kept[(u, w)] = ((in_cap[u] + out_cap[w]) / 2, links.get(u, w))
+
+
+def balance_split(stage: Stage, contigs: ContigDict, links: LiveLinks, logger, threshold, is_prim: bool) -> int:
+    logger.info(
+        "balance split using contigs&paired end links&coverage information.. isPrim: {0}".format(is_prim))
+    g, nodes, edges = stage.triple()
+    branches = nontrivial_ids(stage.scan, nodes)
+    # one batched device lookup for every (in-neighbour, out-neighbour) combination of the pass
+    wanted = []
+    for no, v in branches.items():
+        us = [g.vid[g.esrc[e]] for e in g.black_in_edges(v)]
+        ws = [g.vid[g.etgt[e]] for e in g.black_out_edges(v)]
+        wanted.extend((u, w) for u in us for w in ws)
+    links.prefetch(wanted)
+
+    by_node = contigs_by_node(contigs)
+    done: List[str] = []
+    for no, v in branches.items():
+        us = [g.vid[g.esrc[e]] for e in g.black_in_edges(v)]
+        ws = [g.vid[g.etgt[e]] for e in g.black_out_edges(v)]
+        logger.debug("current non trivial branch: {0}, in-degree: {1}, out-degree: {2}".format(no, len(us), len(ws)))
+        if any([links.is_fresh(x) for x in us]) or any([links.is_fresh(x) for x in ws]):
+            continue
+        if not is_non_trivial(g, v):
+            continue
+        if len(us) != len(ws):
+            continue
+
+        via_links = True
+        for leaf in us + ws:
+            if all(piece.count("*") > 0 for piece in leaf.split("&")):
+                via_links = False
+                break
+        if all([links.get(u, w) == 0 for u in us for w in ws]):
+            via_links = False
+
+        support = by_node.get(no, [])
+        through = set()
+        for cno in support:
+            ids = contigs[cno][0]
+            at = ids.index(no)
+            if 0 < at < len(ids) - 1:
+                through.add((ids[at - 1], ids[at + 1]))
+
+        kept: Dict[Tuple[str, str], Tuple[float, int]] = {}
+        sec: List[Tuple[str, str, int]] = []
+        in_use = dict.fromkeys(us, 0)
+        in_cap = {u: g.eflow[edges[(u, no)]] for u in us}
+        out_use = dict.fromkeys(ws, 0)
+        out_cap = {w: g.eflow[edges[(no, w)]] for w in ws}
+        for u in us:
+            for w in ws:
+                pe = links.get(u, w)
+                if (u, w) in through or u == w:
+                    in_use[u] += 1
+                    out_use[w] += 1
+                    kept[(u, w)] = ((in_cap[u] + out_cap[w]) / 2, pe)
+                else:
+                    sec.append((u, w, pe))
+        if is_prim:
+            if via_links:
+                _link_plan(sec, kept, in_use, in_cap, out_use, out_cap)
+        else:
+            _coverage_plan(us, ws, links, sec, kept, in_use, in_cap, out_use, out_cap)
+
+        if not (all(c == 1 for c in in_use.values()) and all(c == 1 for c in out_use.values())):
+            logger.debug("->Not satisfy N-N split, skip: {0}".format(kept))
+            continue
+        worst = max(abs(in_cap[u] - out_cap[w]) for (u, w) in kept.keys())
+        if worst > 4 * threshold:
+            continue
+        logger.debug("->perform split, all kept links: {0}".format(kept))
+
+        done.append(no)
+        sub_of: Dict[Tuple[str, str], str] = {}
+        for serial, ((u, w), (flow, _)) in enumerate(kept.items()):
+            sub = no + "*" + str(serial)
+            sv = _add_vertex(g, nodes, sub, flow, g.vseq[v])
+            _add_edge(g, edges, nodes[u], sv, g.eovl[edges[(u, no)]], flow)
+            _add_edge(g, edges, sv, nodes[w], g.eovl[edges[(no, w)]], flow)
+            sub_of[(u, w)] = sub
+
+        for cno in support:
+            ids, clen, ccov = contigs.pop(cno)
+            at = ids.index(no)
+            u = ids[at - 1] if at > 0 else None
+            w = ids[at + 1] if at < len(ids) - 1 else None
+            if u is not None and w is not None:
+                ids[at] = sub_of[(u, w)]
+                contigs[cno] = [ids, clen, ccov]
+            elif u is None and w is None:
+                for sub in sub_of.values():
+                    sv = nodes[sub]
+                    contigs[cno + "$" + str(sub.split("*")[-1])] = [[sub], len(g.vseq[sv]), g.vdp[sv]]
+            elif u is not None:
+                for (u2, _), sub in sub_of.items():
+                    if u == u2:
+                        ids[at] = sub
+                        contigs[cno + "$" + str(sub.split("*")[-1])] = [list(ids), clen, ccov]
+            else:
+                for (_, w2), sub in sub_of.items():
+                    if w == w2:
+                        ids[at] = sub
+                        contigs[cno + "$" + str(sub.split("*")[-1])] = [list(ids), clen, ccov]
+
+        for u in us:
+            _retire_edge(g, edges, u, no)
+        for w in ws:
+            _retire_edge(g, edges, no, w)
+        _retire_vertex(g, nodes, no)
+        by_node = contigs_by_node(contigs)
+        links.note_split(no, list(sub_of.values()), list(nodes.keys()))
+    links.end_pass()
+    logger.debug("No of branch be removed: " + str(len(set(done))))
+    logger.info("done")
+    return len(set(done))
+
+
+# ---- trivial splits ----------------------------------------------------------------------------
+def _fork_letters(i: int) -> str:
+    return chr(ord("A") + i)
+
+
+def trivial_split(stage: Stage, links: LiveLinks, logger):
+    """Around every non-trivial branch: fork an in-neighbour with (>1 in, 1 out) into one copy
+    per in-edge, an out-neighbour with (1 in, >1 out) into one copy per out-edge."""
+    logger.info("graph trivial split on NT related vertices..")
+    g, nodes, edges = stage.triple()
+    branches = nontrivial_ids(stage.scan, nodes)
+    forks = 0
+    id_mapping: Dict[str, Dict[str, None]] = {name: {} for name in nodes.keys()}
+    for ntno, ntv in branches.items():
+        if not g.vblack[ntv]:
+            continue
+        for iv in set(g.in_neighbors(ntv)):
+            if not g.vblack[iv]:
+                continue
+            ino = g.vid[iv]
+            id_mapping.setdefault(ino, {})
+            ines = g.black_in_edges(iv)
+            outes = g.black_out_edges(iv)
+            if len(ines) > 1 and len(outes) == 1:
+                g.vblack[iv] = GRAY
+                g.eblack[g.edge(iv, ntv)] = GRAY
+                for i, ine in enumerate(ines):
+                    src = g.esrc[ine]
+                    sv = _add_vertex(g, nodes, ino + "*" + _fork_letters(i), g.eflow[ine], g.vseq[iv])
+                    g.eblack[ine] = GRAY
+                    _add_edge(g, edges, src, sv, g.eovl[ine], g.eflow[ine])
+                    _add_edge(g, edges, sv, ntv, g.eovl[g.edge(iv, ntv)], g.eflow[ine])
+                    id_mapping[ino][g.vid[sv]] = None
+                    links.note_fork(g.vid[sv], list(nodes.keys()))
+                forks += 1
+                links.note_drop(ino)
+        for ov in set(g.out_neighbors(ntv)):
+            if not g.vblack[ov]:
+                continue
+            ono = g.vid[ov]
+            id_mapping.setdefault(ono, {})
+            ines = g.black_in_edges(ov)
+            outes = g.black_out_edges(ov)
+            if len(ines) == 1 and len(outes) > 1:
+                g.vblack[ov] = GRAY
+                g.eblack[g.edge(ntv, ov)] = GRAY
+                for i, oute in enumerate(outes):
+                    tgt = g.etgt[oute]
+                    sv = _add_vertex(g, nodes, ono + "*" + _fork_letters(i), g.eflow[oute], g.vseq[ov])
+                    g.eblack[oute] = GRAY
+                    _add_edge(g, edges, sv, tgt, g.eovl[oute], g.eflow[oute])
+                    _add_edge(g, edges, ntv, sv, g.eovl[g.edge(ntv, ov)], g.eflow[oute])
+                    id_mapping[ono][g.vid[sv]] = None
+                    links.note_fork(g.vid[sv], list(nodes.keys()))
+                forks += 1
+                links.note_drop(ono)
+    links.end_pass()
+    logger.debug("Total split-ted trivial branch count: {0}".format(forks))
+    return forks, id_mapping
+
+
+def global_trivial_split(stage: Stage, logger):
+    """Fixpoint of single-sided forks over ALL vertices (Decomposition.py:691-819)."""
+    logger.info("graph trivial split..")
+    g, nodes, edges = stage.triple()
+    bound = len(nodes) ** 2
+    forks = 0
+    id_mapping: Dict[str, Dict[str, None]] = {name: {} for name in nodes.keys()}
+    progressed = True
+    while progressed and forks < bound:
+        progressed = False
+        for name in list(nodes.keys()):
+            v = nodes[name]
+            if not g.vblack[v]:
+                continue
+            id_mapping.setdefault(name, {})
+            ines = g.black_in_edges(v)
+            outes = g.black_out_edges(v)
+            if len(ines) == 1 and len(outes) > 1:
+                g.vblack[v] = GRAY
+                ine = ines[0]
+                src = g.esrc[ine]
+                g.eblack[ine] = GRAY
+                for i, oute in enumerate(outes):
+                    tgt = g.etgt[oute]
+                    sv = _add_vertex(g, nodes, name + "*" + _fork_letters(i), g.eflow[oute], g.vseq[v])
+                    g.eblack[oute] = GRAY
+                    _add_edge(g, edges, sv, tgt, g.eovl[oute], g.eflow[oute])
+                    _add_edge(g, edges, src, sv, g.eovl[ine], g.eflow[oute])
+                    id_mapping[name][g.vid[sv]] = None
+                progressed = True
+                forks += 1
+            elif len(ines) > 1 and len(outes) == 1:
+                g.vblack[v] = GRAY
+                oute = outes[0]
+                tgt = g.etgt[oute]
+                g.eblack[oute] = GRAY
+                for i, ine in enumerate(ines):
+                    src = g.esrc[ine]
+                    sv = _add_vertex(g, nodes, name + "*" + _fork_letters(i), g.eflow[ine], g.vseq[v])
+                    g.eblack[ine] = GRAY
+                    _add_edge(g, edges, src, sv, g.eovl[ine], g.eflow[ine])
+                    _add_edge(g, edges, sv, tgt, g.eovl[oute], g.eflow[ine])
+                    id_mapping[name][g.vid[sv]] = None
+                progressed = True
+                forks += 1
+    if forks >= bound:
+        logger.warning("Strange topology detected, exit trivial split immediately")
+        return None, id_mapping
+    logger.debug("No of trivial branch be removed: " + str(forks))
+    logger.info("done")
+    return forks, id_mapping
+
+
+# ---- simple-path contraction -------------------------------------------------------------------
+def simple_chains(stage: Stage) -> List[List[int]]:
+    """Maximal chains of simple edges (``simp_path`` Utilities.py:383-418) as vertex lists, in the
+    order the reference discovers them: heads in edge-map order.  ``scan.chain_next`` /
+    ``chain_head`` come from the device scan of this (freshly re-initialised) graph."""
+    g, nodes, edges = stage.triple()
+    nxt = stage.scan.chain_next
+    head = stage.scan.chain_head
+    chains: List[List[int]] = []
+    emitted = set()
+    for e in edges.values():
+        s = g.esrc[e]
+        if head[s] and nxt[s] == g.etgt[e] and s not in emitted:
+            emitted.add(s)
+            chain = [s]
+            cur = s
+            while nxt[cur] >= 0:
+                cur = nxt[cur]
+                chain.append(cur)
+            chains.append(chain)
+    return chains
+
+
+def contract_simple_paths(stage: Stage, contigs: Optional[ContigDict], links: Optional[LiveLinks], logger) -> None:
+    logger.info("non-branching path contraction..")
+    g, nodes, edges = stage.triple()
+    chains = simple_chains(stage)
+    plan = []
+    for chain in chains:
+        ids = [g.vid[v] for v in chain]
+        plan.append((ids, chain, numpy.mean([g.vdp[v] for v in chain])))
+
+    merged_into = {name: name for name in nodes.keys()}
+    built = []  # [first id, last id, new vertex, in-edge triples, out-edge triples]
+    for ids, chain, cov in plan:
+        first, last = ids[0], ids[-1]
+        new_id = "&".join(ids)
+        seq = path_sequence(g, chain)
+        ins = [(g.vid[g.esrc[e]], first, g.eovl[e]) for e in g.in_edges(chain[0])]
+        outs = [(last, g.vid[g.etgt[e]], g.eovl[e]) for e in g.out_edges(chain[-1])]
+        for i, name in enumerate(ids):
+            merged_into[name] = new_id
+            _retire_vertex(g, nodes, name)
+            if i != len(ids) - 1:
+                _retire_edge(g, edges, ids[i], ids[i + 1])
+        cv = _add_vertex(g, nodes, new_id, cov, seq)
+        built.append((first, last, cv, ins, outs))
+        if links is not None:
+            links.note_merge(new_id, ids, list(nodes.keys()))
+
+    for _, _, cv, ins, outs in built:
+        me = g.vid[cv]
+        for u, _, ovl in ins:
+            if u in nodes and (u, me) not in edges:
+                _add_edge(g, edges, nodes[u], cv, ovl)
+            for _, other_last, other_v, _, _ in built:
+                if other_last == u and (g.vid[other_v], me) not in edges:
+                    _add_edge(g, edges, other_v, cv, ovl)
+        for _, w, ovl in outs:
+            if w in nodes and (me, w) not in edges:
+                _add_edge(g, edges, cv, nodes[w], ovl)
+            for other_first, _, other_v, _, _ in built:
+                if other_first == w and (me, g.vid[other_v]) not in edges:
+                    _add_edge(g, edges, cv, other_v, ovl)
+
+    if contigs is not None:
+        for cno, (ids, _, cov) in list(contigs.items()):
+            folded: List[str] = []
+            for name in ids:
+                to = merged_into[name]
+                if to == name:
+                    folded.append(name)
+                elif len(folded) == 0 or to != folded[-1]:
+                    folded.append(to)
+            contigs[cno] = [folded, path_length(g, [nodes[n] for n in folded]), cov]
+    logger.info("done")
+
+
+# ---- the loop ----------------------------------------------------------------------------------
+def iter_graph_disentanglement(stage: Stage, contigs: ContigDict, links: LiveLinks, ops: GraphOps, logger,
+                               threshold, temp_dir: str) -> Stage:
+    bound = len(stage.nodes) ** 2
+    it = 0
+    removed_total = 0
+    label = "A"
+    for is_prim in (True, False):
+        may_fork = True
+        while it < bound:
+            n_split = balance_split(stage, contigs, links, logger, threshold, is_prim)
+            stage = reinit(stage, ops, logger, "{0}/gfa/split_graph_L{1}d.gfa".format(temp_dir, label))
+            contract_simple_paths(stage, contigs, links, logger)
+            stage = reinit(stage, ops, logger, "{0}/gfa/split_graph_L{1}dc.gfa".format(temp_dir, label))
+            if n_split > 0:
+                may_fork = True
+            elif may_fork:
+                prev_ids = list(stage.nodes.keys())
+                _, id_mapping = trivial_split(stage, links, logger)
+                stage = reinit(stage, ops, logger, "{0}/gfa/split_graph_L{1}dct.gfa".format(temp_dir, label))
+                remap_contigs(stage.g, stage.nodes, stage.edges, contigs, id_mapping, prev_ids, logger)
+                contract_simple_paths(stage, contigs, links, logger)
+                stage = reinit(stage, ops, logger, "{0}/gfa/split_graph_L{1}dctd.gfa".format(temp_dir, label))
+            drop_duplicate_contigs(contigs, logger)
+            trim_contigs(stage.g, stage.nodes, contigs, logger)
+            removed_total += n_split
+            it += 1
+            label = chr(ord(label) + 1)
+            if n_split == 0:
+                if may_fork:
+                    may_fork = False
+                else:
+                    break
+    logger.debug("Total non-trivial branches removed: " + str(removed_total))
+    return reinit(stage, ops, logger, "{0}/gfa/split_graph_final.gfa".format(temp_dir))

@@ -1,0 +1,119 @@
+"""The stage sequence of ``utils/VStrains_SPAdes.py:25-280`` (``run``): same order, same
+intermediate files under ``OUT/{gfa,tmp,aln}``, same final ``strain.fasta`` / ``strain.paths``.
+
+``backend`` supplies the device side: PE-link inference (boundary 1 of SURVEY.md 8b, here an
+in-process call instead of a ``python VStrains_PE_Inference.py`` subprocess) and the graph
+kernels.  The default backend is the HIP one and fails loudly without a GPU; tests inject the
+checker from ``oracle/``.
+"""
+from __future__ import annotations
+
+import sys
+import time
+from typing import Dict
+
+import numpy
+
+from . import disentangle as dis
+from . import extend as ext
+from . import prep
+from .contigs import drop_duplicate_contigs, resolve_contigs, restore_repeats, trim_contigs
+from .formats import read_stage_gfa, write_contig_fasta, write_contig_paths, write_stage_gfa
+
+
+def _stored(logger, filename: str) -> None:
+    logger.info(filename + " is stored..")
+
+
+def run(args, logger, backend=None):
+    if backend is None:
+        from .hip_ops import HipBackend
+
+        backend = HipBackend(getattr(args, "device", 0))
+    ops = backend.graph_ops
+    out = args.output_dir
+    timings: Dict[str, float] = {}
+    t_all = time.time()
+
+    logger.info("VStrains-SPAdes started")
+    logger.info(">>>STAGE: parsing graph and contigs")
+    g, nodes, edges = prep.load_assembly_graph(args.gfa_file, logger)
+    write_stage_gfa(g, nodes, edges, "{0}/gfa/graph_L0.gfa".format(out))
+    _stored(logger, "{0}/gfa/graph_L0.gfa".format(out))
+    g0, nodes0, edges0 = read_stage_gfa("{0}/gfa/graph_L0.gfa".format(out))
+    g0, nodes0, edges0, idx_mapping = prep.reindexing(g0, nodes0, edges0)
+    write_stage_gfa(g0, nodes0, edges0, "{0}/gfa/graph_L0r.gfa".format(out))
+    _stored(logger, "{0}/gfa/graph_L0r.gfa".format(out))
+
+    if args.min_cov is not None:
+        threshold = args.min_cov
+        logger.info("user-defined node minimum coverage: {0}".format(threshold))
+    else:
+        threshold = prep.threshold_estimation(g0, logger)
+        logger.info("computed node minimum coverage: {0}".format(threshold))
+
+    contigs, contig_info = prep.spades_paths_parser(g0, nodes0, edges0, idx_mapping, logger, args.path_file,
+                                                    args.min_len, threshold)
+    original_contigs = {cno: [list(ids), clen, ccov] for cno, (ids, clen, ccov) in contigs.items()}
+    write_contig_paths(contigs, "{0}/tmp/init_contigs.paths".format(out))
+    write_contig_fasta(g0, nodes0, contigs, "{0}/tmp/init_contigs.fasta".format(out))
+
+    logger.info(">>>STAGE: preprocess")
+    prep.graph_simplification(g0, nodes0, edges0, None, logger, threshold)
+    write_stage_gfa(g0, nodes0, edges0, "{0}/gfa/s_graph_L1.gfa".format(out))
+    _stored(logger, "{0}/gfa/s_graph_L1.gfa".format(out))
+    g1, nodes1, edges1 = read_stage_gfa("{0}/gfa/s_graph_L1.gfa".format(out))
+    for cno, (ids, _, _) in list(contigs.items()):
+        if any([c not in nodes1 for c in ids]):
+            contigs.pop(cno)
+            logger.debug("unreliable contig with low coverage: {0}".format(cno))
+
+    ksize = g1.eovl[next(iter(g1.edges()))] if g1.num_edges() > 0 else 0
+    logger.info("graph kmer size: {0}".format(ksize))
+    if ksize <= 0:
+        logger.error("invalid kmer-size, the graph does not contain any edges, exit..")
+        sys.exit(1)
+
+    # ---- PE-link inference (device) --------------------------------------------------------------
+    t0 = time.time()
+    table = backend.pe_links("{0}/gfa/s_graph_L1.gfa".format(out), "{0}/aln".format(out), args.fwd, args.rve,
+                             ksize, list(nodes1.keys()))
+    timings["pe_inference_s"] = time.time() - t0
+    logger.info("paired end information stored")
+    t_extract = time.time()
+    links = backend.live_links(table)
+
+    stage1 = dis.Stage(g1, nodes1, edges1)
+    dis.edge_cleaning(g1, edges1, contigs, links, logger)
+    stage2 = dis.reinit(stage1, ops, logger, "{0}/gfa/es_graph_L2.gfa".format(out))
+    write_contig_paths(contigs, "{0}/tmp/pre_contigs.paths".format(out))
+    write_contig_fasta(stage2.g, stage2.nodes, contigs, "{0}/tmp/pre_contigs.fasta".format(out))
+
+    delta = 0.05 * numpy.median([stage2.g.vdp[v] for v in range(stage2.g.num_vertices())])
+    stagef = dis.iter_graph_disentanglement(stage2, contigs, links, ops, logger, delta, out)
+    write_contig_paths(contigs, "{0}/tmp/post_contigs.paths".format(out))
+    write_contig_fasta(stagef.g, stagef.nodes, contigs, "{0}/tmp/post_contigs.fasta".format(out))
+
+    logger.info(">>>STAGE: contig path extension")
+    full_link = ext.best_matching(stagef, contigs, links, logger)
+    ext.increment_nt_branch_coverage(stagef, logger)
+    write_stage_gfa(stagef.g, stagef.nodes, stagef.edges, "{0}/gfa/split_graph_final.gfa".format(out))
+    _stored(logger, "{0}/gfa/split_graph_final.gfa".format(out))
+    p_delta = 0.05 * numpy.median([stagef.g.vdp[v] for v in range(stagef.g.num_vertices())])
+    strains, usages = ext.path_extension(stagef, contigs, full_link, table, ops, logger, p_delta, out)
+
+    logger.info(">>>STAGE: final process")
+    resolve_contigs(strains)
+    gl, nodesl, _ = read_stage_gfa("{0}/gfa/es_graph_L2.gfa".format(out))
+    trim_contigs(gl, nodesl, strains, logger)
+    drop_duplicate_contigs(strains, logger)
+    write_contig_paths(strains, "{0}/tmp/tmp_strain.paths".format(out), None, False)
+    restore_repeats(g0, nodes0, strains, contig_info, original_contigs, logger)
+    timings["strain_extract_s"] = time.time() - t_extract
+
+    logger.info(">>>STAGE: generate result")
+    write_contig_fasta(g0, nodes0, strains, "{0}/strain.fasta".format(out))
+    write_contig_paths(strains, "{0}/strain.paths".format(out), idx_mapping, True)
+    logger.info("VStrains-SPAdes finished")
+    timings["total_s"] = time.time() - t_all
+    return timings

@@ -223,3 +223,104 @@ def contigs_paths_text(graph: SynthGraph, contigs: Sequence[Sequence[int]], covs
         out.append(name + "'\n")
         out.append(",".join(graph.ids[i] + "-" for i in reversed(nodes)) + "\n")
     return "".join(out)
+
+
+# ---------------------------------------------------------------------------------------------
+# Whole-pipeline cases (assembly graph in SPAdes orientation conventions + contigs.paths + reads)
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class PipelineCase:
+    gfa_text: str
+    paths_text: str
+    fwd: List[str]
+    rve: List[str]
+    k: int
+    graph: SynthGraph
+    strains: StrainSet
+
+
+def spades_like_gfa(graph: SynthGraph, flip: Sequence[bool], swap: Sequence[bool]) -> str:
+    """GFA1 text the way an assembler emits it: segment ``i`` is stored reverse-complemented when
+    ``flip[i]``; link ``j`` is written in its reverse-complement form when ``swap[j]``.  Input of
+    ``gfa_to_graph`` (reference ``utils/VStrains_IO.py:27-134``)."""
+    out = []
+    for i, (name, s, d) in enumerate(zip(graph.ids, graph.seqs, graph.dp)):
+        out.append("S\t%s\t%s\tDP:f:%s\n" % (name, revcomp(s) if flip[i] else s, repr(float(d))))
+    for j, (u, v) in enumerate(graph.links):
+        ou = "-" if flip[u] else "+"
+        ov = "-" if flip[v] else "+"
+        if swap[j]:
+            inv = {"+": "-", "-": "+"}
+            out.append("L\t%s\t%s\t%s\t%s\t%dM\n" % (graph.ids[v], inv[ov], graph.ids[u], inv[ou], graph.k))
+        else:
+            out.append("L\t%s\t%s\t%s\t%s\t%dM\n" % (graph.ids[u], ou, graph.ids[v], ov, graph.k))
+    return "".join(out)
+
+
+def spades_like_paths(graph: SynthGraph, flip: Sequence[bool], contigs: Sequence[Sequence[int]],
+                      covs: Sequence[float]) -> str:
+    out = []
+    sign = lambda i, fwd: ("+" if fwd else "-") if not flip[i] else ("-" if fwd else "+")  # noqa: E731
+    for c, (nodes, cov) in enumerate(zip(contigs, covs)):
+        length = sum(len(graph.seqs[i]) for i in nodes) - graph.k * (len(nodes) - 1)
+        name = "NODE_%d_length_%d_cov_%s" % (c + 1, length, repr(float(cov)))
+        out.append(name + "\n")
+        out.append(",".join(graph.ids[i] + sign(i, True) for i in nodes) + "\n")
+        out.append(name + "'\n")
+        out.append(",".join(graph.ids[i] + sign(i, False) for i in reversed(nodes)) + "\n")
+    return "".join(out)
+
+
+def make_pipeline_case(
+    n_strains: int,
+    genome_len: int,
+    snp_rate: float,
+    k: int,
+    n_pairs: int,
+    read_len: int,
+    seed: int,
+    abundance_ratio: float = 0.8,
+    total_depth: float = 1000.0,
+    dp_noise: float = 0.02,
+    scramble: bool = False,
+    error_strain_depth: float = 0.0,
+    contig_pieces: int = 3,
+    sub_rate: float = 0.0,
+    repeat_len: int = 0,
+) -> PipelineCase:
+    """A seeded, self-contained stand-in for "SPAdes output + reads" of a viral quasispecies."""
+    rng = np.random.default_rng(seed + 77)
+    st = make_strains(n_strains, genome_len, snp_rate, seed, abundance_ratio, total_depth)
+    if repeat_len > 0:
+        # one exact tandem-free repeat: copy a block from the first third into the last third
+        a = genome_len // 5
+        b = 3 * genome_len // 5
+        st = StrainSet([g[:b] + g[a : a + repeat_len] + g[b + repeat_len :] for g in st.genomes], st.abundance)
+    reads_from = st
+    graph_from = st
+    if error_strain_depth > 0.0:
+        g0 = st.genomes[0]
+        arr = bytearray(g0.encode())
+        for pos in rng.choice(len(arr), size=max(2, len(arr) // 700), replace=False):
+            arr[pos] = b"ACGT"[(b"ACGT".index(arr[pos]) + 1 + int(rng.integers(0, 3))) % 4]
+        graph_from = StrainSet(st.genomes + [arr.decode()], st.abundance + [error_strain_depth])
+    g = compact_dbg(graph_from, k)
+    if dp_noise > 0.0:
+        g.dp = [float(d * (1.0 + dp_noise * rng.standard_normal())) for d in g.dp]
+    n = len(g.ids)
+    flip = [bool(scramble and rng.random() < 0.5) for _ in range(n)]
+    swap = [bool(scramble and rng.random() < 0.5) for _ in g.links]
+    contigs: List[List[int]] = [[i] for i in range(n)]
+    covs: List[float] = [g.dp[i] for i in range(n)]
+    for s, p in enumerate(g.strain_paths[:n_strains]):
+        if len(p) < 2:
+            continue
+        for _ in range(contig_pieces):
+            ln = int(rng.integers(2, min(len(p), 8) + 1))
+            a = int(rng.integers(0, len(p) - ln + 1))
+            piece = list(p[a : a + ln])
+            contigs.append(piece)
+            covs.append(float(min(g.dp[i] for i in piece)))
+    fwd, rve = sample_pairs(reads_from, n_pairs, read_len, seed + 1, sub_rate=sub_rate)
+    return PipelineCase(spades_like_gfa(g, flip, swap), spades_like_paths(g, flip, contigs, covs),
+                        fwd, rve, k, g, st)
