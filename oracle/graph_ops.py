@@ -55,8 +55,20 @@ class NumpyGraphOps:
                 if g.in_degree(t) == 1 and t != v:
                     nxt[v] = t
                     has_simple_in[t] = True
-        head = [nxt[v] >= 0 and not has_simple_in[v] for v in range(nv)]
-        return GraphScan(nontrivial, fork, nxt, head)
+        top = list(range(nv))
+        rank = [0] * nv
+        for v in range(nv):
+            if nxt[v] >= 0 and not has_simple_in[v]:
+                cur, d = v, 0
+                while nxt[cur] >= 0:
+                    cur = nxt[cur]
+                    d += 1
+                    top[cur] = v
+                    rank[cur] = d
+        for v in range(nv):  # rings of simple edges have no head
+            if has_simple_in[v] and top[v] == v:
+                rank[v] = -1
+        return GraphScan(nontrivial, fork, nxt, top, rank)
 
 
 class DictPeLinks:

@@ -1,0 +1,198 @@
+"""GPU parity of the graph-stage kernels (through the C ABI) and of the whole vstrains-compatible
+pipeline: device ops vs the checker in oracle/graph_ops.py on the same inputs, and the full CLI
+(PE-link inference on the device + graph stages) vs the reference's golden outputs."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from graph_case import Case, case_names, compare, quiet_logger
+from oracle import graph_ops as chk
+from vstrains_amd.graph import disentangle as dis
+from vstrains_amd.graph.asm_graph import AsmGraph
+from vstrains_amd.graph.formats import read_stage_gfa
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def backend():
+    from vstrains_amd.graph.hip_ops import HipBackend
+
+    return HipBackend(0)
+
+
+def random_graph(rng, nv, ne, gray_frac=0.0, hub=0):
+    g = AsmGraph()
+    for i in range(nv):
+        g.add_vertex(str(i), rng.uniform(0.5, 2000.0), "ACGT", rng.random() >= gray_frac)
+    seen = set()
+    tries = 0
+    while g.num_edges() < ne and tries < 50 * ne:
+        tries += 1
+        s, t = rng.randrange(nv), rng.randrange(nv)
+        if hub and rng.random() < 0.3:
+            s = 0
+        if hub and rng.random() < 0.3:
+            t = 1
+        if (s, t) in seen:
+            continue
+        seen.add((s, t))
+        g.add_edge(s, t, 21, 0.0, rng.random() >= gray_frac)
+    return g
+
+
+def assert_same_ops(ops, g):
+    ref = chk.NumpyGraphOps()
+    want_scan = ref.scan(g)
+    got_scan = ops.scan(g)
+    assert got_scan.nontrivial == want_scan.nontrivial
+    assert got_scan.fork_kind == want_scan.fork_kind
+    assert got_scan.chain_next == want_scan.chain_next
+    assert got_scan.chain_rank == want_scan.chain_rank
+    for v in range(g.num_vertices()):
+        if want_scan.chain_rank[v] >= 0:
+            assert got_scan.chain_top[v] == want_scan.chain_top[v], v
+    h = AsmGraph.__new__(AsmGraph)
+    for slot in AsmGraph.__slots__:
+        setattr(h, slot, getattr(g, slot))
+    h.eflow = list(g.eflow)
+    ref.edge_flows(h)
+    ops._key = None
+    ops.edge_flows(g)
+    for e in g.edges():
+        assert g.eflow[e] == h.eflow[e], (e, g.eflow[e], h.eflow[e])  # bit-exact fp64
+
+
+@pytest.mark.parametrize("nv,ne,gray,hub", [(1, 0, 0.0, 0), (5, 4, 0.0, 0), (40, 60, 0.0, 0), (300, 420, 0.2, 0),
+                                            (2000, 2600, 0.05, 0), (400, 1500, 0.0, 1), (3000, 2999, 0.0, 0)])
+def test_refresh_kernels_match_numpy_checker(backend, nv, ne, gray, hub):
+    rng = random.Random(nv * 7 + ne)
+    if ne == nv - 1 and nv > 100:  # one long simple chain plus a ring: list ranking depth
+        g = AsmGraph()
+        for i in range(nv):
+            g.add_vertex(str(i), rng.uniform(1, 100), "A", True)
+        order = list(range(nv - 50))
+        rng.shuffle(order)
+        for a, b in zip(order, order[1:]):
+            g.add_edge(a, b, 21, 0.0, True)
+        ring = list(range(nv - 50, nv))
+        for a, b in zip(ring, ring[1:] + ring[:1]):
+            g.add_edge(a, b, 21, 0.0, True)
+    else:
+        g = random_graph(rng, nv, ne, gray, hub)
+    assert_same_ops(backend.graph_ops, g)
+
+
+def test_flow_sum_order_for_large_degrees(backend):
+    """numpy's pairwise summation changes shape at 8 and 128 addends; hubs of every size class."""
+    rng = random.Random(5)
+    g = AsmGraph()
+    for i in range(1200):
+        g.add_vertex(str(i), rng.uniform(0.001, 5000.0), "A", True)
+    v = 10
+    for hub, deg in ((0, 7), (1, 8), (2, 9), (3, 127), (4, 128), (5, 129), (6, 300), (7, 1000)):
+        for k in range(deg):
+            g.add_edge(hub, 10 + (v % 1100), 21, 0.0, True)
+            g.add_edge(10 + ((v * 7) % 1100), hub, 21, 0.0, True)
+            v += 1
+    assert_same_ops(backend.graph_ops, g)
+
+
+def test_zero_neighbour_sum_raises_like_numpy_seterr(backend):
+    g = AsmGraph()
+    a = g.add_vertex("a", 5.0, "A", True)
+    b = g.add_vertex("b", 0.0, "A", True)
+    g.add_edge(a, b, 21, 0.0, True)
+    backend.graph_ops._key = None
+    with pytest.raises(FloatingPointError):
+        backend.graph_ops.edge_flows(g)
+
+
+@pytest.mark.parametrize("n", [1, 3, 33, 70, 257])
+def test_link_table_matches_process_pe_info(backend, n):
+    from vstrains_amd.graph.hip_ops import HipPeLinks
+
+    rng = np.random.default_rng(n)
+    names = [str(i) for i in range(n)]
+    node = rng.integers(0, 50, size=(n, n)) * (rng.random((n, n)) < 0.3)
+    short = np.triu(rng.integers(0, 90, size=(n, n)) * (rng.random((n, n)) < 0.4))
+    dev = HipPeLinks.from_matrices(backend.ctx, names, node, short)
+    ref = chk.DictPeLinks(names, node, short)
+    p0 = dev.to_numpy()
+    for i in range(n):
+        for j in range(n):
+            a, b = names[i], names[j]
+            assert p0[i, j] == ref.table[(min(a, b), max(a, b))]
+    py = random.Random(n)
+    queries = []
+    for _ in range(200):
+        rows = [py.randrange(n) for _ in range(py.randrange(0, 6))]
+        cols = [py.randrange(n) for _ in range(py.choice([0, 1, 2, 5, 70, 130]))]
+        queries.append((rows, cols))
+    assert dev.block_sums(queries) == ref.block_sums(queries)
+    groups = [[py.randrange(n) for _ in range(py.randrange(0, 5))] for _ in range(min(n, 40))]
+    assert np.array_equal(dev.group_matrix(groups), ref.group_matrix(groups))
+
+
+def test_link_table_from_device_counters(backend):
+    """vs_links_from_counts reads the uint32 counters vs_pe_count filled, in place."""
+    import torch
+    from vstrains_amd.graph.hip_ops import HipPeLinks
+
+    n = 45
+    rng = np.random.default_rng(2)
+    node = rng.integers(0, 2 ** 31 - 1, size=(n, n), dtype=np.int64)  # near the counter range
+    short = np.triu(rng.integers(0, 2 ** 31 - 1, size=(n, n), dtype=np.int64))
+
+    class Counter:
+        pass
+
+    c = Counter()
+    c.n = n
+    c.torch = torch
+    c.device = torch.device("cuda:0")
+    c.mats = torch.from_numpy(np.stack([node, short]).astype(np.uint32).view(np.int32)).to(c.device)
+    dev = HipPeLinks.from_counter(backend.ctx, c, [str(i) for i in range(n)])
+    want = node + node.T + short + short.T
+    want[np.arange(n), np.arange(n)] = node.diagonal() + short.diagonal()
+    assert np.array_equal(dev.to_numpy(), want)
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_stage_graphs_of_golden_cases(backend, name, tmp_path):
+    """Every stage graph a golden case passes through: device flows/scan == numpy checker."""
+    from vstrains_amd.graph import pipeline
+    import test_graph_golden as T
+
+    case = Case(name)
+    inp = case.inputs(str(tmp_path))
+    out = str(tmp_path / "out")
+    pipeline.run(case.args(inp, out), quiet_logger(), T.CheckerBackend(case, False))
+    n = 0
+    for fn in sorted(os.listdir(os.path.join(out, "gfa"))):
+        if fn in ("graph_L0.gfa", "graph_L0r.gfa"):
+            continue
+        g, _, _ = read_stage_gfa(os.path.join(out, "gfa", fn))
+        assert_same_ops(backend.graph_ops, g)
+        n += 1
+    assert n > 5
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_full_cli_on_device_matches_reference(backend, name, tmp_path):
+    """The vstrains-compatible CLI end to end on the GPU: FASTQ -> pe_info/st_info (HIP PE-link
+    inference) -> graph stages with HIP ops -> strain.paths / strain.fasta, all files compared
+    with what the reference wrote."""
+    from vstrains_amd import cli
+
+    case = Case(name)
+    inp = case.inputs(str(tmp_path), with_reads=True)
+    out = str(tmp_path / "out")
+    argv = ["-a", "spades", "-g", inp["gfa"], "-p", inp["paths"], "-o", out, "-fwd", inp["fwd"], "-rve", inp["rve"]]
+    argv += case.meta["cli_extra"]
+    cli.main(argv, backend=backend)
+    problems, _ = compare(case, out)
+    binding = [p for p in problems if p.split(" ", 1)[1] not in case.meta["differs_under_other_hashseeds"]]
+    assert not binding, binding

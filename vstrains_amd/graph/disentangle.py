@@ -394,23 +394,20 @@ def global_trivial_split(stage: Stage, logger):
 # ---- simple-path contraction -------------------------------------------------------------------
 def simple_chains(stage: Stage) -> List[List[int]]:
     """Maximal chains of simple edges (``simp_path`` Utilities.py:383-418) as vertex lists, in the
-    order the reference discovers them: heads in edge-map order.  ``scan.chain_next`` /
-    ``chain_head`` come from the device scan of this (freshly re-initialised) graph."""
+    order the reference discovers them: heads in edge-map order.  The scan already ranked every
+    vertex inside its chain (``chain_top`` / ``chain_rank``, pointer jumping on the device), so a
+    chain is a bucket sorted by rank."""
     g, nodes, edges = stage.triple()
-    nxt = stage.scan.chain_next
-    head = stage.scan.chain_head
+    nxt, top, rank = stage.scan.chain_next, stage.scan.chain_top, stage.scan.chain_rank
+    members: Dict[int, List[Tuple[int, int]]] = {}
+    for v in range(g.num_vertices()):
+        if rank[v] > 0:
+            members.setdefault(top[v], []).append((rank[v], v))
     chains: List[List[int]] = []
-    emitted = set()
     for e in edges.values():
         s = g.esrc[e]
-        if head[s] and nxt[s] == g.etgt[e] and s not in emitted:
-            emitted.add(s)
-            chain = [s]
-            cur = s
-            while nxt[cur] >= 0:
-                cur = nxt[cur]
-                chain.append(cur)
-            chains.append(chain)
+        if rank[s] == 0 and nxt[s] >= 0 and s in members:
+            chains.append([s] + [v for _, v in sorted(members.pop(s))])
     return chains
 
 

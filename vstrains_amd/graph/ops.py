@@ -31,13 +31,14 @@ from .asm_graph import AsmGraph, NodeMap
 class GraphScan:
     """Per-vertex facts of one graph snapshot (all by vertex index)."""
 
-    __slots__ = ("nontrivial", "fork_kind", "chain_next", "chain_head")
+    __slots__ = ("nontrivial", "fork_kind", "chain_next", "chain_top", "chain_rank")
 
-    def __init__(self, nontrivial, fork_kind, chain_next, chain_head):
+    def __init__(self, nontrivial, fork_kind, chain_next, chain_top, chain_rank):
         self.nontrivial = nontrivial  # bool: non-trivial branch (Utilities.py:162-172)
         self.fork_kind = fork_kind    # 0 none, 1: 1 in / >1 out, 2: >1 in / 1 out (black edges)
         self.chain_next = chain_next  # target of the vertex's simple out-edge, or -1 (:398-402)
-        self.chain_head = chain_head  # bool: has a simple out-edge and no simple in-edge
+        self.chain_top = chain_top    # head of the chain of simple edges the vertex lies on (itself if none)
+        self.chain_rank = chain_rank  # distance from that head; -1 on a ring of simple edges
 
 
 class GraphOps:

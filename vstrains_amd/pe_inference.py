@@ -15,16 +15,10 @@ from . import pe as host
 BATCH_PAIRS = 1 << 20
 
 
-def run(gfa: str, out_dir: str, fwd: str, rve: str, kmer_size: int, device: int = 0):
-    # PE_Inference.py:93-96: the output directory is wiped and recreated
-    if out_dir[-1] == "/":
-        out_dir = out_dir[:-1]
-    shutil.rmtree(out_dir, ignore_errors=True)
-    os.makedirs(out_dir, exist_ok=True)
-
-    glb_start = time.time()
+def count_links(ctx, gfa: str, fwd: str, rve: str, kmer_size: int):
+    """Index the nodes of ``gfa`` and count every pair of the two FASTQ files; the counters stay
+    on the device.  Returns ``(node ids in file order, PeCounter)``."""
     ids, seqs = host.read_gfa_segments(gfa)  # :100-112
-    ctx = host.Context(device)
     ctx.build_index(seqs, kmer_size)  # :114-135  (KeyError on a bad node base, as :13)
     counter = host.PeCounter(ctx)
 
@@ -41,16 +35,35 @@ def run(gfa: str, out_dir: str, fwd: str, rve: str, kmer_size: int, device: int 
         counter.add(block)
         ctx.sync()
         block.free()
-    node_mat, short_mat, stats = counter.result()
+    return ids, counter
 
-    out_file = "{0}/pe_info".format(out_dir)  # :190-207
+
+def write_info_files(out_dir: str, ids, counter):
+    """pe_info / st_info text, PE_Inference.py:190-207.  Returns the host copies and stats."""
+    node_mat, short_mat, stats = counter.result()
+    out_file = "{0}/pe_info".format(out_dir)
     out_file2 = "{0}/st_info".format(out_dir)
     host.write_matrix_text(out_file, ids, node_mat)
     host.write_matrix_text(out_file2, ids, short_mat)
+    return out_file, stats
 
+
+def run(gfa: str, out_dir: str, fwd: str, rve: str, kmer_size: int, device: int = 0, ctx=None):
+    # PE_Inference.py:93-96: the output directory is wiped and recreated
+    if out_dir[-1] == "/":
+        out_dir = out_dir[:-1]
+    shutil.rmtree(out_dir, ignore_errors=True)
+    os.makedirs(out_dir, exist_ok=True)
+
+    glb_start = time.time()
+    if ctx is None:
+        ctx = host.Context(device)
+    ids, counter = count_links(ctx, gfa, fwd, rve, kmer_size)
+    out_file, stats = write_info_files(out_dir, ids, counter)
     glb_elapsed = time.time() - glb_start
     print("Global time elapsed: ", glb_elapsed)  # :209-211
     print("result stored in: ", out_file)
+    run.last = (ids, counter)
     return stats
 
 
