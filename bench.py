@@ -10,6 +10,10 @@ everything resident in HBM: zero the counters, vs_pe_count over all pairs (seed 
 acceptance test, node_mat/short_mat atomics) and, for N > 1, the RCCL all-reduce of the counters.
 Weak scaling: every rank works on its own R pairs (disjoint slices of one seeded stream).
 
+After the timed PE steps rank 0 runs the graph stages once on the counters of the last step
+(edge cleaning, disentanglement, path extraction: `strain_extract_s`, the second half of
+BASELINE.json's metric; replicas only, no collective).
+
 Prints ONE JSON line (rank 0).  `roofline` uses the algorithmic bytes per pair of SURVEY.md 8(d)
 (2*ceil(L/4) + 2*(L-k)*8 + 16 = 1612 B at L=150,k=55) over the main kernel's HIP-event time;
 `cpu_baseline` times the C restatement of the reference algorithm (oracle/, 1 thread) on a
@@ -31,15 +35,54 @@ import torch
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def workload(k=55, n_strains=15, genome_len=10800, snp_rate=0.09, seed=1003):
-    from vstrains_amd import synth
+def workload(out_dir, k=55, n_strains=15, genome_len=10800, snp_rate=0.09, seed=1003):
+    """configs[2] inputs: synthetic strains -> assembler-style GFA + contigs.paths, taken through
+    the pipeline's own preparation (strand canonisation, reindexing, coverage cut-off) so that PE
+    inference runs on the real ``s_graph_L1`` and the graph stages can follow on the same state."""
+    import argparse as ap
+    import logging
 
-    st = synth.make_strains(n_strains, genome_len, snp_rate, seed=seed)
-    g = synth.compact_dbg(st, k)
+    from vstrains_amd import synth
+    from vstrains_amd.graph import pipeline
+
+    pc = synth.make_pipeline_case(n_strains=n_strains, genome_len=genome_len, snp_rate=snp_rate, k=k, n_pairs=0,
+                                  read_len=150, seed=seed)
+    st = pc.strains
+    for sub in ("gfa", "tmp", "paf", "aln"):
+        os.makedirs(os.path.join(out_dir, sub), exist_ok=True)
+    with open(os.path.join(out_dir, "input.gfa"), "w") as fh:
+        fh.write(pc.gfa_text)
+    with open(os.path.join(out_dir, "input.paths"), "w") as fh:
+        fh.write(pc.paths_text)
+    logger = logging.getLogger("vstrains-bench")
+    logger.handlers[:] = [logging.NullHandler()]
+    logger.propagate = False
+    args = ap.Namespace(gfa_file=os.path.join(out_dir, "input.gfa"), path_file=os.path.join(out_dir, "input.paths"),
+                        output_dir=out_dir, min_cov=None, min_len=250)
+    pre = pipeline.prepare(args, logger)
+    names = list(pre.nodes1.keys())
+    seqs = [pre.g1.vseq[pre.nodes1[n]] for n in names]
     ab = np.array(st.abundance)
     cum = np.minimum(np.floor(np.cumsum(ab) / ab.sum() * 2 ** 32), 2 ** 32 - 1).astype(np.uint32)
     cum[-1] = 0xFFFFFFFF
-    return st, g, cum
+    return st, pre, names, seqs, cum, logger, len(pc.graph.ids)
+
+
+def strain_extract(ctx, counter, pre, names, logger, out_dir):
+    """The second half of the metric: pe counters (resident in HBM) -> strain.paths, i.e.
+    VStrains_SPAdes.py:134-272 with the graph kernels on the device."""
+    from vstrains_amd.graph import pipeline
+    from vstrains_amd.graph.hip_ops import HipBackend, HipPeLinks
+
+    backend = HipBackend(ctx=ctx)
+    t0 = time.perf_counter()
+    table = HipPeLinks.from_counter(ctx, counter, names)
+    strains = pipeline.extract_strains(pre, table, backend, logger, out_dir)
+    secs = time.perf_counter() - t0
+    n_stage_graphs = len([f for f in os.listdir(os.path.join(out_dir, "gfa")) if f.endswith(".gfa")])
+    return {"seconds": secs, "strains": len(strains), "stage_graphs_written": n_stage_graphs,
+            "graph_refresh_launches": backend.graph_ops.calls, "link_table_launches": table.calls,
+            "longest_strain_bp": max([rec[1] for rec in strains.values()] or [0])}
 
 
 def main():
@@ -72,7 +115,16 @@ def main():
     seed = 20250001
     sub_thresh = int(0.005 * 2 ** 32)
     n_thresh = int(0.001 * 2 ** 32)
-    st, g, cum = workload(k=k)
+    import tempfile
+
+    work_dir = tempfile.mkdtemp(prefix="vstrains_bench_")
+    st, pre, names, seqs, cum, logger, n_input_nodes = workload(work_dir, k=k)
+
+    class _G:  # the node set PE inference runs on (= s_graph_L1)
+        pass
+
+    g = _G()
+    g.seqs = seqs
     ctx = host.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     t0 = time.time()
@@ -155,8 +207,15 @@ def main():
             "pe_stats": {"n_reads": stats[0], "short_reads": stats[1], "used_reads": stats[2],
                          "node_mat_sum": int(node_mat.sum()), "short_mat_sum": int(short_mat.sum()),
                          "slow_pairs_per_step": ctx.last_timing()["slow_pairs"]},
-            "strain_extract_s": None,
         }
+        out["config"]["input_gfa_nodes"] = n_input_nodes
+        try:
+            ex = strain_extract(ctx, counter, pre, names, logger, work_dir)
+            out["strain_extract_s"] = ex.pop("seconds")
+            out["strain_extract"] = ex
+        except Exception as err:  # the PE line must still be reported
+            out["strain_extract_s"] = None
+            out["strain_extract"] = {"error": repr(err)}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(ctx, host, st, g, cum, seed, L, k, sub_thresh, n_thresh, R, args.cpu_seconds)
         print(json.dumps(out))

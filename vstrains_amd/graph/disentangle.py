@@ -21,7 +21,8 @@ import numpy
 from .asm_graph import BLACK, GRAY, AsmGraph, EdgeMap, NodeMap
 from .contigs import (contig_steps, contigs_by_node, drop_duplicate_contigs, remap_contigs,
                       trim_contigs)
-from .formats import ContigDict, path_length, path_sequence, read_stage_gfa, write_stage_gfa
+from .formats import (ContigDict, path_length, path_sequence, read_stage_gfa, stage_graph_from_state,
+                      write_stage_gfa)
 from .ops import GraphOps, GraphScan, LiveLinks, nontrivial_ids
 
 
@@ -45,7 +46,8 @@ def reinit(stage: Stage, ops: GraphOps, logger, filename: str) -> Stage:
     file (drops gray objects, resets vertex order to map order), recompute every edge flow."""
     write_stage_gfa(stage.g, stage.nodes, stage.edges, filename)
     logger.info(filename + " is stored..")
-    g, nodes, edges = read_stage_gfa(filename)
+    # same graph read_stage_gfa(filename) would give (float(repr(dp)) == dp), without the parse
+    g, nodes, edges = stage_graph_from_state(stage.g, stage.nodes, stage.edges)
     ops.edge_flows(g)
     return Stage(g, nodes, edges, ops.scan(g))
 

@@ -196,10 +196,10 @@ class HipPeLinks(PeLinks):
 class HipBackend:
     """What ``pipeline.run`` needs from the device: PE-link inference + the graph kernels."""
 
-    def __init__(self, device: int = 0, write_info_text: bool = True):
+    def __init__(self, device: int = 0, write_info_text: bool = True, ctx=None):
         from .. import pe as host
 
-        self.ctx = host.Context(device)  # raises NativeError without a HIP device
+        self.ctx = ctx if ctx is not None else host.Context(device)  # raises NativeError without a HIP device
         self.graph_ops = HipGraphOps(self.ctx)
         self.write_info_text = write_info_text
         self.pe_stats = None

@@ -25,17 +25,19 @@ def _stored(logger, filename: str) -> None:
     logger.info(filename + " is stored..")
 
 
-def run(args, logger, backend=None):
-    if backend is None:
-        from .hip_ops import HipBackend
+class Prepared:
+    """Everything the stages after PE-link inference need (state at VStrains_SPAdes.py:117)."""
 
-        backend = HipBackend(getattr(args, "device", 0))
-    ops = backend.graph_ops
+    def __init__(self, g0, nodes0, idx_mapping, contigs, contig_info, original_contigs, g1, nodes1, edges1, ksize):
+        self.g0, self.nodes0, self.idx_mapping = g0, nodes0, idx_mapping
+        self.contigs, self.contig_info, self.original_contigs = contigs, contig_info, original_contigs
+        self.g1, self.nodes1, self.edges1, self.ksize = g1, nodes1, edges1, ksize
+
+
+def prepare(args, logger) -> Prepared:
+    """VStrains_SPAdes.py:30-116: parse, canonise strands, reindex, coverage cut-off, contigs,
+    simplification; leaves ``gfa/s_graph_L1.gfa`` for PE-link inference."""
     out = args.output_dir
-    timings: Dict[str, float] = {}
-    t_all = time.time()
-
-    logger.info("VStrains-SPAdes started")
     logger.info(">>>STAGE: parsing graph and contigs")
     g, nodes, edges = prep.load_assembly_graph(args.gfa_file, logger)
     write_stage_gfa(g, nodes, edges, "{0}/gfa/graph_L0.gfa".format(out))
@@ -73,18 +75,18 @@ def run(args, logger, backend=None):
     if ksize <= 0:
         logger.error("invalid kmer-size, the graph does not contain any edges, exit..")
         sys.exit(1)
+    return Prepared(g0, nodes0, idx_mapping, contigs, contig_info, original_contigs, g1, nodes1, edges1, ksize)
 
-    # ---- PE-link inference (device) --------------------------------------------------------------
-    t0 = time.time()
-    table = backend.pe_links("{0}/gfa/s_graph_L1.gfa".format(out), "{0}/aln".format(out), args.fwd, args.rve,
-                             ksize, list(nodes1.keys()))
-    timings["pe_inference_s"] = time.time() - t0
-    logger.info("paired end information stored")
-    t_extract = time.time()
+
+def extract_strains(pre: Prepared, table, backend, logger, out: str):
+    """VStrains_SPAdes.py:140-272: edge cleaning, disentanglement, path extraction, final files.
+    ``table``: the PE-link table (``ops.PeLinks``) over the nodes of ``s_graph_L1``.  This is the
+    "end-to-end strain-extract" leg of BASELINE.json's metric."""
+    ops = backend.graph_ops
+    contigs = pre.contigs
     links = backend.live_links(table)
-
-    stage1 = dis.Stage(g1, nodes1, edges1)
-    dis.edge_cleaning(g1, edges1, contigs, links, logger)
+    stage1 = dis.Stage(pre.g1, pre.nodes1, pre.edges1)
+    dis.edge_cleaning(pre.g1, pre.edges1, contigs, links, logger)
     stage2 = dis.reinit(stage1, ops, logger, "{0}/gfa/es_graph_L2.gfa".format(out))
     write_contig_paths(contigs, "{0}/tmp/pre_contigs.paths".format(out))
     write_contig_fasta(stage2.g, stage2.nodes, contigs, "{0}/tmp/pre_contigs.fasta".format(out))
@@ -108,12 +110,34 @@ def run(args, logger, backend=None):
     trim_contigs(gl, nodesl, strains, logger)
     drop_duplicate_contigs(strains, logger)
     write_contig_paths(strains, "{0}/tmp/tmp_strain.paths".format(out), None, False)
-    restore_repeats(g0, nodes0, strains, contig_info, original_contigs, logger)
-    timings["strain_extract_s"] = time.time() - t_extract
+    restore_repeats(pre.g0, pre.nodes0, strains, pre.contig_info, pre.original_contigs, logger)
 
     logger.info(">>>STAGE: generate result")
-    write_contig_fasta(g0, nodes0, strains, "{0}/strain.fasta".format(out))
-    write_contig_paths(strains, "{0}/strain.paths".format(out), idx_mapping, True)
+    write_contig_fasta(pre.g0, pre.nodes0, strains, "{0}/strain.fasta".format(out))
+    write_contig_paths(strains, "{0}/strain.paths".format(out), pre.idx_mapping, True)
+    return strains
+
+
+def run(args, logger, backend=None):
+    if backend is None:
+        from .hip_ops import HipBackend
+
+        backend = HipBackend(getattr(args, "device", 0))
+    out = args.output_dir
+    timings: Dict[str, float] = {}
+    t_all = time.time()
+    logger.info("VStrains-SPAdes started")
+    pre = prepare(args, logger)
+
+    t0 = time.time()
+    table = backend.pe_links("{0}/gfa/s_graph_L1.gfa".format(out), "{0}/aln".format(out), args.fwd, args.rve,
+                             pre.ksize, list(pre.nodes1.keys()))
+    timings["pe_inference_s"] = time.time() - t0
+    logger.info("paired end information stored")
+
+    t0 = time.time()
+    extract_strains(pre, table, backend, logger, out)
+    timings["strain_extract_s"] = time.time() - t0
     logger.info("VStrains-SPAdes finished")
     timings["total_s"] = time.time() - t_all
     return timings
