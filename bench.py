@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--k", type=int, default=55)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time (0 = skip)")
+    ap.add_argument("--no-extract", action="store_true", help="skip the strain-extract leg (kernel experiments)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -153,6 +154,7 @@ def main():
     barrier()
     kernel_ms = []
     slow_ms = []
+    sort_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -161,6 +163,7 @@ def main():
         t = ctx.last_timing()
         kernel_ms.append(t["main_ms"])
         slow_ms.append(t["slow_ms"])
+        sort_ms.append(t["sort_ms"])
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -202,6 +205,7 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "kernel": "k_pe_tiles", "kernel_ms_avg": avg_kernel_ms, "slow_kernel_ms_avg": float(np.mean(slow_ms)),
+                "locus_sort_ms_avg": float(np.mean(sort_ms)),
                 "algorithmic_bytes_per_pair": b_alg,
             },
             "pe_stats": {"n_reads": stats[0], "short_reads": stats[1], "used_reads": stats[2],
@@ -210,6 +214,8 @@ def main():
         }
         out["config"]["input_gfa_nodes"] = n_input_nodes
         try:
+            if args.no_extract:
+                raise RuntimeError("skipped (--no-extract)")
             ex = strain_extract(ctx, counter, pre, names, logger, work_dir)
             out["strain_extract_s"] = ex.pop("seconds")
             out["strain_extract"] = ex

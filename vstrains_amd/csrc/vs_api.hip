@@ -75,6 +75,8 @@ void vs_ctx_destroy(vs_ctx *ctx) {
     if (ctx->d_slow_list) (void)hipFree(ctx->d_slow_list);
     if (ctx->d_slow_count) (void)hipFree(ctx->d_slow_count);
     if (ctx->d_dense) (void)hipFree(ctx->d_dense);
+    for (void *q : {ctx->d_locus_keys, ctx->d_perm, ctx->d_locus_hist, ctx->d_scan_tmp})
+        if (q) (void)hipFree(q);
     for (int i = 0; i < 4; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     delete ctx;

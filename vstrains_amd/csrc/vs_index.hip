@@ -157,7 +157,7 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
 
     // device buffers: permanent
     size_t b_meta = sizeof(VsNodeMeta) * (n_nodes ? n_nodes : 1);
-    size_t b_words = sizeof(uint32_t) * (words + 4);
+    size_t b_words = sizeof(uint32_t) * (words + VS_PAD_WORDS);
     size_t b_table = sizeof(VsSlot) * n_slots;
     size_t b_post = sizeof(uint2) * (npos ? npos : 1);
     VS_HIP(ctx, hipMalloc(&ctx->d_meta, b_meta));

@@ -9,11 +9,12 @@
 #include "../../include/vstrains_hip.h"
 
 #define VS_WAVE 64
+#define VS_PAD_WORDS 16  // zero words behind every packed text buffer (window reads may overshoot)
 
 // ---- packed text ---------------------------------------------------------------------------
 // 2 bits per base (A=0 C=1 G=2 T=3), 16 bases per uint32 word, base i of a sequence sits in
 // word i/16 at bits 2*(i%16) (LSB first).  Every sequence starts on a word boundary and every
-// buffer carries two zero pad words so that a 3-word window read never leaves the allocation.
+// buffer carries VS_PAD_WORDS zero words so that window reads never leave the allocation.
 
 struct VsNodeMeta {
     uint32_t woff;  // first word of the node in fwd_words / rc_words
@@ -73,6 +74,10 @@ struct vs_ctx {
     void *d_dense = nullptr;       // dense per-workgroup state for the slow path
     uint64_t dense_bytes = 0;
     uint32_t dense_nodes = 0xFFFFFFFFu;  // node count the dense layout was initialised for
+    // locus order scratch (k_pe_locus / k_pe_permute)
+    void *d_locus_keys = nullptr, *d_perm = nullptr, *d_locus_hist = nullptr, *d_scan_tmp = nullptr;
+    uint64_t locus_cap = 0, hist_cap = 0;
+    double last_sort_ms = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     double last_ms[3] = {0, 0, 0};
     int n_cu = 256;

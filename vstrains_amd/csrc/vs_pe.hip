@@ -16,8 +16,9 @@
 //   Every MEM holds a seed at a read offset divisible by s; the MEM is credited by the first
 //   such seed only (left extension < s), so nothing is counted twice.
 //
-// Work split per 256-thread workgroup and tile of `ept` read ends (ept/2 pairs):
-//   P0  tile header + packed reads -> LDS (coalesced dword loads)
+// Work split per 256-thread workgroup and tile of `ept` read ends (ept/2 pairs, taken in locus
+// order, see k_pe_locus):
+//   P0  tile header + packed reads -> LDS (one wpe-word slot per end)
 //   P1  one thread per (end, probe): seed, canonical form, open-address table probe (one 16-B
 //       load per slot visited); posting count per probe -> LDS
 //   P2  workgroup inclusive scan of the posting counts
@@ -25,7 +26,8 @@
 //       repeat seed's many postings spread over lanes): left/right extension on 64-bit windows
 //       (XOR + clz/ctz), LDS atomics into an 8-slot per-end table keyed by node
 //   P4  acceptance test per occupied slot (integer form, see oracle/pe_oracle.py)
-//   P5  per-end compaction, then node_mat / short_mat global atomics
+//   P5  one thread per node_mat / short_mat increment (global atomics; tiles are locus-sorted
+//       and taken in contiguous runs, so the same cells are hit again while still in L2)
 // Ends that touch more than 8 nodes overflow the LDS table; their pairs go to a list that a
 // second, fully general kernel (dense per-workgroup node state in HBM) works through.
 #include <stdlib.h>
@@ -35,6 +37,8 @@
 #define TPB 256
 #define LC 16u  // accepted nodes kept per read end in LDS (more -> slow path)
 #define EMPTY_NODE 0xFFFFFFFFu
+#define PPT 4u               // postings per thread and expansion chunk
+#define CHUNK (TPB * PPT)
 
 struct PeParams {
     VsIndexDev idx;
@@ -47,6 +51,10 @@ struct PeParams {
     uint32_t *dbg_lists, *dbg_counts;
     uint32_t dbg_cap;
     uint32_t accumulate;
+    const uint32_t *perm;  // pair order of the tiles (locus-sorted) or NULL = input order
+    uint32_t wpe;          // LDS words reserved per read end
+    uint32_t tiles_per_wg; // contiguous run of tiles per workgroup
+    uint64_t n_pairs;
 };
 
 struct Mem {  // one credited maximal exact match
@@ -56,6 +64,10 @@ struct Mem {  // one credited maximal exact match
 // Extension of a seed hit.  rw/rbase: packed read (LDS or global) and its first base; tw/tbase:
 // packed node strand.  mk/mbase: validity mask of the read or NULL.  Returns false when the
 // match is owned by an earlier probe or is shorter than K.
+// The first left window and the first two right windows are loaded before anything is decided
+// (independent loads, one memory round trip); most hits are settled by them.  Windows may reach
+// past the end of a read / node: every packed buffer carries VS_PAD_WORDS of padding and the
+// bits beyond the valid range are never used.
 template <typename RW>
 __device__ __forceinline__ bool vs_extend(const RW *rw, uint64_t rbase, uint32_t rlen, const uint32_t *tw,
                                           uint64_t tbase, uint32_t tlen, uint32_t j, uint32_t q, uint32_t w,
@@ -63,24 +75,63 @@ __device__ __forceinline__ bool vs_extend(const RW *rw, uint64_t rbase, uint32_t
                                           uint32_t *a_out, uint32_t *qa_out, uint32_t *len_out) {
     uint32_t c = s < j ? s : j;
     c = c < q ? c : q;
+    const uint32_t n0 = c < 32u ? c : 32u;
+    const uint32_t rj = j + w, rq = q + w;
+    uint32_t rem = rlen - rj;
+    {
+        const uint32_t rem2 = tlen - rq;
+        rem = rem < rem2 ? rem : rem2;
+    }
+    uint64_t xl = vs_win64(rw, rbase + j - n0) ^ vs_win64(tw, tbase + q - n0);
+    uint64_t xr0 = vs_win64(rw, rbase + rj) ^ vs_win64(tw, tbase + rq);
+    uint64_t xr1 = vs_win64(rw, rbase + rj + 32u) ^ vs_win64(tw, tbase + rq + 32u);
+    if (mk) {
+        xl |= vs_win64(mk, mbase + j - n0);
+        xr0 |= vs_win64(mk, mbase + rj);
+        xr1 |= vs_win64(mk, mbase + rj + 32u);
+    }
+    xl &= vs_lowmask(2u * n0);
     uint32_t left = 0;
-    while (left < c) {  // backwards, 32 bases at a time
-        uint32_t n = c - left < 32u ? c - left : 32u;
-        uint64_t x = vs_win64(rw, rbase + j - left - n) ^ vs_win64(tw, tbase + q - left - n);
-        if (mk) x |= vs_win64(mk, mbase + j - left - n);
-        x &= vs_lowmask(2u * n);
-        if (x) {
-            left += n - 1u - (uint32_t)((63 - __clzll((long long)x)) >> 1);
-            break;
+    if (xl) {
+        left = n0 - 1u - (uint32_t)((63 - __clzll((long long)xl)) >> 1);
+    } else {
+        left = n0;
+        while (left < c) {  // s > 32 only (k > 85): further windows backwards
+            uint32_t n = c - left < 32u ? c - left : 32u;
+            uint64_t x = vs_win64(rw, rbase + j - left - n) ^ vs_win64(tw, tbase + q - left - n);
+            if (mk) x |= vs_win64(mk, mbase + j - left - n);
+            x &= vs_lowmask(2u * n);
+            if (x) {
+                left += n - 1u - (uint32_t)((63 - __clzll((long long)x)) >> 1);
+                break;
+            }
+            left += n;
         }
-        left += n;
     }
     if (left >= s) return false;  // an earlier probe lies inside this match and owns it
-    uint32_t rj = j + w, rq = q + w;
-    uint32_t rem = rlen - rj;
-    uint32_t rem2 = tlen - rq;
-    rem = rem < rem2 ? rem : rem2;
     uint32_t ext = 0;
+    if (rem) {
+        if (xr0) {
+            uint32_t m = (uint32_t)(__ffsll((long long)xr0) - 1) >> 1;
+            ext = m < rem ? m : rem;
+            rem = 0;
+        } else {
+            uint32_t adv = rem < 32u ? rem : 32u;
+            ext = adv;
+            rem -= adv;
+            if (rem) {
+                if (xr1) {
+                    uint32_t m = (uint32_t)(__ffsll((long long)xr1) - 1) >> 1;
+                    ext += m < rem ? m : rem;
+                    rem = 0;
+                } else {
+                    adv = rem < 32u ? rem : 32u;
+                    ext += adv;
+                    rem -= adv;
+                }
+            }
+        }
+    }
     while (rem) {
         uint64_t x = vs_win64(rw, rbase + rj + ext) ^ vs_win64(tw, tbase + rq + ext);
         if (mk) x |= vs_win64(mk, mbase + rj + ext);
@@ -141,15 +192,16 @@ extern __shared__ __attribute__((aligned(16))) uint32_t vs_lds[];
 
 // LDS carve shared by the kernel and the host-side size computation
 struct TileLayout {
-    uint32_t woff, meta, words, pcnt, pa, pb, hkey, hcnt, hminp, hminj, ns, state, list, misc, total;
+    uint32_t woff, gend, meta, words, pcnt, pa, pb, hkey, hcnt, hminp, hminj, ns, state, list, uoff, owner, misc, total;
 };
 __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, uint32_t words_cap, uint32_t pool) {
     TileLayout t;
     uint32_t o = 0;
     const uint32_t NI = ept * pmax;
-    t.woff = o;  o += (ept + 2u) & ~1u;
+    t.woff = o;  o += (ept + 2u) & ~1u;  // global word offset of every end of the tile
+    t.gend = o;  o += ept;               // global end index
     t.meta = o;  o += ept;
-    t.words = o; o += words_cap + 4u;
+    t.words = o; o += words_cap + 8u;
     t.pcnt = o;  o += NI;
     t.pa = o;    o += NI;
     t.pb = o;    o += NI;
@@ -160,6 +212,8 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
     t.ns = o;    o += ept;
     t.state = o; o += ept;
     t.list = o;  o += ept * LC;
+    t.uoff = o;  o += 66u;            // exclusive scan of the counter updates per pair (<= 64 pairs)
+    t.owner = o; o += CHUNK;          // probe owning each posting of the chunk being expanded
     t.misc = o;  o += 16u;
     t.total = o;
     return t;
@@ -173,9 +227,10 @@ k_pe_tiles(PeParams P) {
     const uint32_t w = P.idx.w, s = P.idx.s, K = P.idx.K;
     const uint32_t pool = P.pool, pool_shift = 32u - P.pool_bits;
     const TileLayout T = tile_layout(ept, pmax, P.words_cap, pool);
-    uint32_t *s_woff = vs_lds + T.woff;
+    uint32_t *s_gwoff = vs_lds + T.woff;   // global word offsets (mask reads, slow path)
+    uint32_t *s_gend = vs_lds + T.gend;
     uint32_t *s_meta = vs_lds + T.meta;
-    uint32_t *s_words = vs_lds + T.words;
+    uint32_t *s_words = vs_lds + T.words;  // end e occupies words [e*wpe, (e+1)*wpe)
     uint32_t *s_pcnt = vs_lds + T.pcnt;    // posting counts per probe, then their inclusive scan
     uint32_t *s_pa = vs_lds + T.pa;
     uint32_t *s_pb = vs_lds + T.pb;
@@ -187,16 +242,30 @@ k_pe_tiles(PeParams P) {
     uint32_t *s_state = vs_lds + T.state;  // bit0: end belongs to a used pair, bit1: overflow
     uint32_t *s_list = vs_lds + T.list;    // accepted node ids, LC per end
     uint32_t *s_misc = vs_lds + T.misc;
+    uint32_t *s_uoff = vs_lds + T.uoff;
+    uint32_t *s_owner = vs_lds + T.owner;
+    const uint32_t wpe = P.wpe;
+    const uint32_t ppt = ept / 2u;
 
     if (tid < 3) s_misc[8 + tid] = 0;  // workgroup-local stats
-
-    for (uint64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
-        const uint64_t e0 = tile * ept;
-        const uint32_t ne = (uint32_t)((P.rd.n_ends - e0) < ept ? (P.rd.n_ends - e0) : ept);
+    // a workgroup takes a contiguous run of the locus-sorted tiles: consecutive tiles hit the same
+    // counter cells and node text, which keeps them in this XCD's L2
+    const uint64_t tile_lo = (uint64_t)blockIdx.x * P.tiles_per_wg;
+    const uint64_t tile_hi = tile_lo + P.tiles_per_wg < P.n_tiles ? tile_lo + P.tiles_per_wg : P.n_tiles;
+    for (uint64_t tile = tile_lo; tile < tile_hi; tile++) {
+        const uint64_t p0 = tile * ppt;
+        const uint32_t npair = (uint32_t)((P.n_pairs - p0) < ppt ? (P.n_pairs - p0) : ppt);
+        const uint32_t ne = 2u * npair;
         __syncthreads();  // previous tile fully consumed
-        // ---- P0: header
-        for (uint32_t i = tid; i <= ne; i += TPB) s_woff[i] = P.rd.woff[e0 + i];
-        for (uint32_t i = tid; i < ne; i += TPB) s_meta[i] = P.rd.meta[e0 + i];
+        // ---- P0: which pairs (through the locus order when there is one), their headers
+        for (uint32_t i = tid; i < ne; i += TPB) {
+            const uint64_t p = p0 + (i >> 1);
+            const uint32_t gp = P.perm ? P.perm[p] : (uint32_t)p;
+            const uint32_t ge = 2u * gp + (i & 1u);
+            s_gend[i] = ge;
+            s_gwoff[i] = P.rd.woff[ge];
+            s_meta[i] = P.rd.meta[ge];
+        }
         for (uint32_t i = tid; i < pool; i += TPB) {
             s_hkey[i] = EMPTY_NODE;
             s_hcnt[i] = 0;
@@ -204,11 +273,18 @@ k_pe_tiles(PeParams P) {
             s_hminj[i] = 0xFFFFFFFFu;
         }
         __syncthreads();
-        const uint32_t w0 = s_woff[0];
-        const uint32_t nw = s_woff[ne] - w0;
-        for (uint32_t i = tid; i < nw + 3u; i += TPB) s_words[i] = i < nw ? P.rd.words[w0 + i] : 0u;
+        // packed reads: one end per wpe-word slot (gather; consecutive lanes read consecutive words)
+        for (uint32_t i = tid; i < ne * wpe + 8u; i += TPB) {
+            uint32_t v = 0u;
+            if (i < ne * wpe) {
+                const uint32_t e = i / wpe, k = i - e * wpe;
+                const uint32_t nw = ((s_meta[e] & VS_LEN_MASK) + 15u) >> 4;
+                if (k < nw) v = P.rd.words[s_gwoff[e] + k];
+            }
+            s_words[i] = v;
+        }
         // pair classification (PE_Inference.py:160-165): one thread per pair
-        if (tid < ne / 2u) {
+        if (tid < npair) {
             uint32_t mf = s_meta[2 * tid], mr = s_meta[2 * tid + 1];
             uint32_t cls;
             if (((mf | mr) >> 24) & VS_FLAG_N) cls = 0;
@@ -229,11 +305,11 @@ k_pe_tiles(PeParams P) {
                 uint32_t rlen = meta & VS_LEN_MASK;
                 uint32_t j = pi * s;
                 if (j + w <= rlen) {
-                    uint64_t rb = (uint64_t)(s_woff[e] - w0) * 16u + j;
+                    uint64_t rb = (uint64_t)(e * wpe) * 16u + j;
                     uint64_t f = vs_win64(s_words, rb) & vs_lowmask(2u * w);
                     bool ok = true;
                     if ((meta >> 24) & VS_FLAG_INVALID)
-                        ok = (vs_win64(P.rd.mask, (uint64_t)s_woff[e] * 16u + j) & vs_lowmask(2u * w)) == 0ull;
+                        ok = (vs_win64(P.rd.mask, (uint64_t)s_gwoff[e] * 16u + j) & vs_lowmask(2u * w)) == 0ull;
                     if (ok) cnt = vs_probe(P.idx, f, &pa, &pb);
                 }
             }
@@ -270,63 +346,98 @@ k_pe_tiles(PeParams P) {
         __syncthreads();
         if (P.debug_stop == 3u) continue;
         const uint32_t total = s_pcnt[NI - 1u];
-        // ---- P3: one thread per posting
-        for (uint32_t t = tid; t < total; t += TPB) {
-            uint32_t lo = 0, hi = NI - 1u;
-            while (lo < hi) {
-                uint32_t mid = (lo + hi) >> 1;
-                if (s_pcnt[mid] > t) hi = mid; else lo = mid + 1u;
+        // ---- P3: one thread per posting.  Expansion of the per-probe posting counts (CSR-style
+        // frontier expansion) in chunks of CHUNK postings: every probe marks the first position it
+        // owns in the chunk, a workgroup-wide running maximum fills the gaps, and each thread ends
+        // up with the owners of its PPT consecutive postings in registers.
+        for (uint32_t c0 = 0; c0 < total; c0 += CHUNK) {
+            for (uint32_t i = tid; i < CHUNK; i += TPB) s_owner[i] = 0;
+            __syncthreads();
+            for (uint32_t it = tid; it < NI; it += TPB) {
+                const uint32_t incl = s_pcnt[it], excl = it ? s_pcnt[it - 1u] : 0u;
+                if (incl > excl) {
+                    const uint32_t lo = excl > c0 ? excl : c0;
+                    const uint32_t hi = incl < c0 + CHUNK ? incl : c0 + CHUNK;
+                    if (lo < hi) s_owner[lo - c0] = it + 1u;
+                }
             }
-            const uint32_t it = lo;
-            const uint32_t excl = it ? s_pcnt[it - 1u] : 0u;
-            const uint32_t cnt = s_pcnt[it] - excl;
-            uint32_t pa = s_pa[it], pb = s_pb[it];
-            const uint32_t e = it / pmax, pi = it - e * pmax, j = pi * s;
-            uint32_t node, pos, opp;
-            if (cnt == 1u) {
-                node = pa; pos = pb & 0x7FFFFFFFu; opp = pb >> 31;
-                // Overlapping seeds (s <= w): if the previous probe of this end holds the single
-                // posting one stride back on the same diagonal, the bases in between match too,
-                // so that probe (or an earlier one) owns this match -- no memory traffic needed.
-                if (s <= w && pi) {
-                    const uint32_t excl2 = it > 1u ? s_pcnt[it - 2u] : 0u;
-                    if (excl - excl2 == 1u && s_pa[it - 1u] == node) {
-                        uint32_t pbp = s_pb[it - 1u];
-                        uint32_t want = opp ? pos + s : pos - s;
-                        if ((pbp >> 31) == opp && (pbp & 0x7FFFFFFFu) == want && (opp || pos >= s)) continue;
+            __syncthreads();
+            uint32_t own[PPT];
+            uint32_t run = 0;
+#pragma unroll
+            for (uint32_t k2 = 0; k2 < PPT; k2++) {
+                const uint32_t v = s_owner[tid * PPT + k2];
+                run = v > run ? v : run;
+                own[k2] = run;
+            }
+            uint32_t incl = run;
+            const uint32_t lane = tid & 63u;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t2 = __shfl_up(incl, d, 64);
+                if (lane >= (uint32_t)d && t2 > incl) incl = t2;
+            }
+            if (lane == 63u) s_misc[4u + (tid >> 6)] = incl;
+            uint32_t carry = __shfl_up(incl, 1, 64);
+            if (lane == 0u) carry = 0;
+            __syncthreads();
+            for (uint32_t wv = 0; wv < (tid >> 6); wv++) carry = s_misc[4u + wv] > carry ? s_misc[4u + wv] : carry;
+#pragma unroll
+            for (uint32_t k2 = 0; k2 < PPT; k2++) {
+                const uint32_t t = c0 + tid * PPT + k2;
+                if (t >= total) break;
+                const uint32_t it = (own[k2] > carry ? own[k2] : carry) - 1u;
+                const uint32_t excl = it ? s_pcnt[it - 1u] : 0u;
+                const uint32_t cnt = s_pcnt[it] - excl;
+                uint32_t pa = s_pa[it], pb = s_pb[it];
+                const uint32_t e = it / pmax, pi = it - e * pmax, j = pi * s;
+                uint32_t node, pos, opp;
+                if (cnt == 1u) {
+                    node = pa; pos = pb & 0x7FFFFFFFu; opp = pb >> 31;
+                    // Overlapping seeds (s <= w): if the previous probe of this end holds the single
+                    // posting one stride back on the same diagonal, the bases in between match too,
+                    // so that probe (or an earlier one) owns this match -- no memory traffic needed.
+                    if (s <= w && pi) {
+                        const uint32_t excl2 = it > 1u ? s_pcnt[it - 2u] : 0u;
+                        if (excl - excl2 == 1u && s_pa[it - 1u] == node) {
+                            uint32_t pbp = s_pb[it - 1u];
+                            uint32_t want = opp ? pos + s : pos - s;
+                            if ((pbp >> 31) == opp && (pbp & 0x7FFFFFFFu) == want && (opp || pos >= s)) continue;
+                        }
                     }
+                } else {
+                    uint2 po = P.idx.postings[pa + (t - excl)];
+                    node = po.x; pos = po.y & 0x7FFFFFFFu; opp = (po.y >> 31) ^ (pb >> 31);
                 }
-            } else {
-                uint2 po = P.idx.postings[pa + (t - excl)];
-                node = po.x; pos = po.y & 0x7FFFFFFFu; opp = (po.y >> 31) ^ (pb >> 31);
-            }
-            const uint32_t meta = s_meta[e];
-            const uint32_t rlen = meta & VS_LEN_MASK;
-            const VsNodeMeta nm = P.idx.meta[node];
-            const uint32_t *tw = opp ? P.idx.rc_words : P.idx.fwd_words;
-            const uint32_t q = opp ? nm.len - pos - w : pos;
-            const uint32_t *mk = ((meta >> 24) & VS_FLAG_INVALID) ? P.rd.mask : nullptr;
-            uint32_t a, qa, len;
-            if (!vs_extend(s_words, (uint64_t)(s_woff[e] - w0) * 16u, rlen, tw, (uint64_t)nm.woff * 16u, nm.len, j, q, w, s, K,
-                           mk, (uint64_t)s_woff[e] * 16u, &a, &qa, &len))
-                continue;
-            const uint32_t add = len - K + 1u;
-            const uint32_t minp = opp ? nm.len - qa - len : qa;
-            const uint32_t key = (e << 25) | node;
-            uint32_t at = (key * 0x9E3779B1u) >> pool_shift;
-            bool placed = false;
-            for (uint32_t pr = 0; pr < 64u; pr++) {
-                uint32_t old = atomicCAS(&s_hkey[at], EMPTY_NODE, key);
-                if (old == EMPTY_NODE || old == key) {
-                    atomicAdd(&s_hcnt[at], add);
-                    atomicMin(&s_hminp[at], minp);
-                    atomicMin(&s_hminj[at], a);
-                    placed = true;
-                    break;
+                const uint32_t meta = s_meta[e];
+                const uint32_t rlen = meta & VS_LEN_MASK;
+                const VsNodeMeta nm = P.idx.meta[node];
+                const uint32_t *tw = opp ? P.idx.rc_words : P.idx.fwd_words;
+                const uint32_t q = opp ? nm.len - pos - w : pos;
+                const uint32_t *mk = ((meta >> 24) & VS_FLAG_INVALID) ? P.rd.mask : nullptr;
+                uint32_t a, qa, len;
+                if (!vs_extend(s_words, (uint64_t)(e * wpe) * 16u, rlen, tw, (uint64_t)nm.woff * 16u, nm.len, j, q, w, s, K,
+                               mk, (uint64_t)s_gwoff[e] * 16u, &a, &qa, &len))
+                    continue;
+                const uint32_t add = len - K + 1u;
+                const uint32_t minp = opp ? nm.len - qa - len : qa;
+                const uint32_t key = (e << 25) | node;
+                uint32_t at = (key * 0x9E3779B1u) >> pool_shift;
+                bool placed = false;
+                for (uint32_t pr = 0; pr < 64u; pr++) {
+                    uint32_t old = atomicCAS(&s_hkey[at], EMPTY_NODE, key);
+                    if (old == EMPTY_NODE || old == key) {
+                        atomicAdd(&s_hcnt[at], add);
+                        atomicMin(&s_hminp[at], minp);
+                        atomicMin(&s_hminj[at], a);
+                        placed = true;
+                        break;
+                    }
+                    at = (at + 1u) & (pool - 1u);
                 }
-                at = (at + 1u) & (pool - 1u);
+                if (!placed) atomicOr(&s_state[e], 2u);
             }
-            if (!placed) atomicOr(&s_state[e], 2u);
+            __syncthreads();  // the owner array is reused by the next chunk
         }
         __syncthreads();
         if (P.debug_stop == 4u) continue;
@@ -345,43 +456,60 @@ k_pe_tiles(PeParams P) {
         }
         __syncthreads();
         // pairs with an overflowed end go to the slow list
-        if (tid < ne / 2u) {
+        if (tid < npair) {
             uint32_t st = s_state[2 * tid] | s_state[2 * tid + 1];
             if ((st & 1u) && (st & 2u)) {
                 uint32_t at = atomicAdd(P.slow_count, 1u);
-                P.slow_list[at] = (uint32_t)(e0 / 2u) + tid;
+                P.slow_list[at] = s_gend[2 * tid] >> 1;
                 s_state[2 * tid] |= 2u;
                 s_state[2 * tid + 1] |= 2u;
             }
         }
         __syncthreads();
         if (P.debug_stop == 5u) continue;
-        // ---- P5: counters.  One thread per (pair, list position a); the partner positions loop.
+        // ---- P5: counters (PE_Inference.py:174-188), one thread per increment.  A pair with lists
+        // l (nl nodes) and r (nr nodes) makes nl*nr node_mat increments and, per end,
+        // n(n+1)/2 short_mat increments: positions a <= b give the cell (min, max) of the two
+        // node ids -- the reference's "i <= i2 over ascending indices" (:174-184).
         const uint32_t N = P.idx.n_nodes;
         if (P.accumulate) {
-            const uint32_t items = (ne / 2u) * LC;
-            for (uint32_t i = tid; i < items; i += TPB) {
-                const uint32_t pr = i / LC, a = i - pr * LC;
-                const uint32_t ef = 2u * pr, er = ef + 1u;
-                if ((s_state[ef] & 3u) != 1u) continue;
-                const uint32_t nl = s_ns[ef], nr = s_ns[er];
-                if (a < nl) {
-                    const uint32_t x = s_list[ef * LC + a];
-                    uint32_t *row = P.node_mat + (uint64_t)x * N;
-                    for (uint32_t b = 0; b < nr; b++) atomicAdd(&row[s_list[er * LC + b]], 1u);
-                    uint32_t *srow = P.short_mat + (uint64_t)x * N;
-                    for (uint32_t b = 0; b < nl; b++) {
-                        uint32_t y = s_list[ef * LC + b];
-                        if (x < y || a == b) atomicAdd(&srow[y], 1u);
-                    }
+            if (tid < 64u) {  // npair <= 64: one wave scans the increment counts
+                uint32_t u = 0;
+                if (tid < npair && (s_state[2u * tid] & 3u) == 1u) {
+                    const uint32_t nl = s_ns[2u * tid], nr = s_ns[2u * tid + 1u];
+                    u = nl * nr + nl * (nl + 1u) / 2u + nr * (nr + 1u) / 2u;
                 }
-                if (a < nr) {
-                    const uint32_t x = s_list[er * LC + a];
-                    uint32_t *srow = P.short_mat + (uint64_t)x * N;
-                    for (uint32_t b = 0; b < nr; b++) {
-                        uint32_t y = s_list[er * LC + b];
-                        if (x < y || a == b) atomicAdd(&srow[y], 1u);
-                    }
+                uint32_t incl = u;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    uint32_t t2 = __shfl_up(incl, d, 64);
+                    if (tid >= (uint32_t)d) incl += t2;
+                }
+                s_uoff[tid + 1u] = incl;
+                if (tid == 0) s_uoff[0] = 0;
+            }
+            __syncthreads();
+            const uint32_t U = s_uoff[npair];
+            for (uint32_t t = tid; t < U; t += TPB) {
+                uint32_t lo = 0, hi = npair;  // last pair with uoff <= t
+                while (hi - lo > 1u) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_uoff[mid] <= t) lo = mid; else hi = mid;
+                }
+                uint32_t r = t - s_uoff[lo];
+                const uint32_t ef = 2u * lo, er = ef + 1u;
+                const uint32_t nl = s_ns[ef], nr = s_ns[er];
+                if (r < nl * nr) {
+                    const uint32_t a = r / nr;
+                    atomicAdd(P.node_mat + (uint64_t)s_list[ef * LC + a] * N + s_list[er * LC + (r - a * nr)], 1u);
+                } else {
+                    r -= nl * nr;
+                    uint32_t base = ef * LC, n = nl;
+                    if (r >= nl * (nl + 1u) / 2u) { r -= nl * (nl + 1u) / 2u; base = er * LC; n = nr; }
+                    uint32_t a = 0;
+                    while (r >= n - a) { r -= n - a; a++; }
+                    const uint32_t x = s_list[base + a], y = s_list[base + a + r];
+                    atomicAdd(P.short_mat + (uint64_t)(x < y ? x : y) * N + (x < y ? y : x), 1u);
                 }
             }
         }
@@ -389,13 +517,55 @@ k_pe_tiles(PeParams P) {
             for (uint32_t i = tid; i < ne; i += TPB) {
                 if (s_state[i] & 2u) continue;  // the slow kernel reports these
                 uint32_t n = s_ns[i];
-                P.dbg_counts[e0 + i] = n;
-                for (uint32_t k2 = 0; k2 < n && k2 < P.dbg_cap; k2++) P.dbg_lists[(e0 + i) * P.dbg_cap + k2] = s_list[i * LC + k2];
+                const uint64_t ge = s_gend[i];
+                P.dbg_counts[ge] = n;
+                for (uint32_t k2 = 0; k2 < n && k2 < P.dbg_cap; k2++) P.dbg_lists[ge * P.dbg_cap + k2] = s_list[i * LC + k2];
             }
         }
     }
     __syncthreads();
     if (tid < 3 && P.stats && s_misc[8 + tid]) atomicAdd(&P.stats[tid], (unsigned long long)s_misc[8 + tid]);
+}
+
+// ---- locus order -----------------------------------------------------------------------------------
+// Pairs are handed to k_pe_tiles sorted by the first node their forward read's seeds hit, so that
+// a tile holds pairs from one locus: they touch the same few node_mat / short_mat cells (summed in
+// LDS before any global atomic) and the same node text (L1/L2 hits).  Any order gives the same
+// counters (integer addition commutes); this one only changes how many global atomics it takes.
+// key: node index, N = no seed of the forward read hits, N+1 = pair dropped by the N / length
+// filters (still counted in the stats by k_pe_tiles).
+__global__ void __launch_bounds__(TPB)
+k_pe_locus(VsIndexDev idx, VsReadsDev rd, uint64_t n_pairs, uint32_t *__restrict__ keys, uint32_t *__restrict__ hist) {
+    const uint64_t p = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+    if (p >= n_pairs) return;
+    const uint32_t mf = rd.meta[2 * p], mr = rd.meta[2 * p + 1];
+    const uint32_t N = idx.n_nodes, w = idx.w, s = idx.s, K = idx.K;
+    uint32_t key = N;
+    if ((((mf | mr) >> 24) & VS_FLAG_N) || (mf & VS_LEN_MASK) < K || (mr & VS_LEN_MASK) < K) {
+        key = N + 1u;
+    } else {
+        const uint32_t rlen = mf & VS_LEN_MASK;
+        const uint64_t base = (uint64_t)rd.woff[2 * p] * 16u;
+        const bool inv = (mf >> 24) & VS_FLAG_INVALID;
+        for (uint32_t j = 0; j + w <= rlen; j += s) {
+            if (inv && (vs_win64(rd.mask, base + j) & vs_lowmask(2u * w))) continue;
+            uint32_t pa, pb;
+            const uint32_t c = vs_probe(idx, vs_win64(rd.words, base + j) & vs_lowmask(2u * w), &pa, &pb);
+            if (c) {
+                key = c == 1u ? pa : idx.postings[pa].x;
+                break;
+            }
+        }
+    }
+    keys[p] = key;
+    atomicAdd(&hist[key], 1u);
+}
+
+__global__ void __launch_bounds__(TPB)
+k_pe_permute(uint64_t n_pairs, const uint32_t *__restrict__ keys, uint32_t *__restrict__ cursor, uint32_t *__restrict__ perm) {
+    const uint64_t p = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+    if (p >= n_pairs) return;
+    perm[atomicAdd(&cursor[keys[p]], 1u)] = (uint32_t)p;
 }
 
 // ---- slow path: any number of nodes per end ------------------------------------------------------
@@ -531,9 +701,9 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     const uint32_t pmax = maxlen >= idx.w ? (maxlen - idx.w) / idx.s + 1u : 1u;
     const uint32_t wpe = (maxlen + 15u) / 16u;
     if (idx.n_nodes > 0x01FFFFFEu) return vs_fail(ctx, VS_E_RANGE, "more than 2^25-2 nodes");
-    uint32_t ept = 128;
+    uint32_t ept = 64;
     if (const char *ev = getenv("VS_EPT")) ept = (uint32_t)atoi(ev) & ~1u;
-    if (ept < 2 || ept > 128) ept = 128;
+    if (ept < 2 || ept > 128) ept = 64;
     while (ept > 2 && (ept * pmax > NI_CAP || lds_bytes(ept, pmax, ept * wpe) > LDS_BUDGET_BYTES)) ept -= 2;
     size_t lds = lds_bytes(ept, pmax, ept * wpe);
     if (lds > 160u * 1024u)
@@ -563,6 +733,30 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     }
     VS_HIP(ctx, hipMemsetAsync(ctx->d_slow_count, 0, 16, st));
 
+    // locus order of the pairs (see k_pe_locus); VS_NO_SORT=1 keeps the input order
+    const bool use_sort = !(getenv("VS_NO_SORT") && atoi(getenv("VS_NO_SORT")) != 0) && n_pairs >= 4096 && n_pairs < 0xFFFFFFF0ull;
+    if (use_sort) {
+        const uint64_t nk = (uint64_t)idx.n_nodes + 2u;
+        if (ctx->locus_cap < n_pairs) {
+            if (ctx->d_locus_keys) VS_HIP(ctx, hipFree(ctx->d_locus_keys));
+            if (ctx->d_perm) VS_HIP(ctx, hipFree(ctx->d_perm));
+            ctx->d_locus_keys = ctx->d_perm = nullptr;
+            ctx->locus_cap = 0;
+            VS_HIP(ctx, hipMalloc(&ctx->d_locus_keys, sizeof(uint32_t) * n_pairs));
+            VS_HIP(ctx, hipMalloc(&ctx->d_perm, sizeof(uint32_t) * n_pairs));
+            ctx->locus_cap = n_pairs;
+        }
+        if (ctx->hist_cap < nk) {
+            if (ctx->d_locus_hist) VS_HIP(ctx, hipFree(ctx->d_locus_hist));
+            if (ctx->d_scan_tmp) VS_HIP(ctx, hipFree(ctx->d_scan_tmp));
+            ctx->d_locus_hist = ctx->d_scan_tmp = nullptr;
+            ctx->hist_cap = 0;
+            VS_HIP(ctx, hipMalloc(&ctx->d_locus_hist, sizeof(uint32_t) * nk));
+            VS_HIP(ctx, hipMalloc(&ctx->d_scan_tmp, sizeof(uint64_t) * (nk / 2048 + 4)));
+            ctx->hist_cap = nk;
+        }
+    }
+
     PeParams P;
     P.idx = idx;
     P.rd = reads->dev();
@@ -577,7 +771,10 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         const char *dbg = getenv("VS_DEBUG_STOP");
         P.debug_stop = dbg ? (uint32_t)atoi(dbg) : 0u;
     }
-    P.n_tiles = (n_ends + ept - 1) / ept;
+    P.n_pairs = n_pairs;
+    P.n_tiles = (n_pairs + ept / 2 - 1) / (ept / 2);
+    P.wpe = wpe;
+    P.perm = use_sort ? (const uint32_t *)ctx->d_perm : nullptr;
     P.slow_list = (uint32_t *)ctx->d_slow_list;
     P.slow_count = (uint32_t *)ctx->d_slow_count;
     P.dbg_lists = d_dbg_lists;
@@ -591,6 +788,21 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     uint64_t max_grid = (uint64_t)ctx->n_cu * 8u;
     if (const char *ev = getenv("VS_GRID_PER_CU")) max_grid = (uint64_t)ctx->n_cu * (uint64_t)(atoi(ev) > 0 ? atoi(ev) : 8);
     if (grid > max_grid) grid = max_grid;
+    P.tiles_per_wg = (uint32_t)((P.n_tiles + grid - 1) / grid);
+    grid = (P.n_tiles + P.tiles_per_wg - 1) / P.tiles_per_wg;
+    VS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+    if (use_sort) {
+        const uint64_t nk = (uint64_t)idx.n_nodes + 2u;
+        VS_HIP(ctx, hipMemsetAsync(ctx->d_locus_hist, 0, sizeof(uint32_t) * nk, st));
+        const unsigned pg = (unsigned)((n_pairs + TPB - 1) / TPB);
+        hipLaunchKernelGGL(k_pe_locus, dim3(pg), dim3(TPB), 0, st, idx, reads->dev(), n_pairs, (uint32_t *)ctx->d_locus_keys,
+                           (uint32_t *)ctx->d_locus_hist);
+        int rc = vs_scan_u32(ctx, (const uint32_t *)ctx->d_locus_hist, (uint32_t *)ctx->d_locus_hist, nk,
+                             (uint64_t *)ctx->d_scan_tmp, nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_pe_permute, dim3(pg), dim3(TPB), 0, st, n_pairs, (const uint32_t *)ctx->d_locus_keys,
+                           (uint32_t *)ctx->d_locus_hist, (uint32_t *)ctx->d_perm);
+    }
     VS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     hipLaunchKernelGGL(k_pe_tiles, dim3((unsigned)grid), dim3(TPB), lds, st, P);
     VS_HIP(ctx, hipEventRecord(ctx->ev[1], st));
@@ -605,16 +817,18 @@ extern "C" int vs_pe_count(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_
     return pe_launch(ctx, reads, d_node_mat, d_short_mat, d_stats, nullptr, nullptr, 0);
 }
 
-extern "C" int vs_pe_last_timing(vs_ctx *ctx, double ms[3]) {
+extern "C" int vs_pe_last_timing(vs_ctx *ctx, double ms[4]) {
     if (!ctx || !ms) return VS_E_ARG;
     VS_HIP(ctx, hipSetDevice(ctx->device));
     VS_HIP(ctx, hipEventSynchronize(ctx->ev[2]));
-    float a = 0, b = 0;
+    float a = 0, b = 0, c = 0;
     VS_HIP(ctx, hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
     VS_HIP(ctx, hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
+    VS_HIP(ctx, hipEventElapsedTime(&c, ctx->ev[3], ctx->ev[0]));
+    ctx->last_sort_ms = c;
     uint32_t n_slow = 0;
     VS_HIP(ctx, hipMemcpy(&n_slow, ctx->d_slow_count, sizeof n_slow, hipMemcpyDeviceToHost));
-    ms[0] = a; ms[1] = b; ms[2] = (double)n_slow;
+    ms[0] = a; ms[1] = b; ms[2] = (double)n_slow; ms[3] = c;
     ctx->last_ms[0] = a; ctx->last_ms[1] = b; ctx->last_ms[2] = n_slow;
     return VS_OK;
 }

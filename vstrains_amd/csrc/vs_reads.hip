@@ -60,15 +60,15 @@ k_unpack_reads(VsReadsDev rd, const uint64_t *__restrict__ out_off, uint8_t *__r
 static int alloc_reads(vs_ctx *ctx, vs_reads *r, bool with_mask) {
     size_t b_woff = sizeof(uint32_t) * (r->n_ends + 1);
     size_t b_meta = sizeof(uint32_t) * (r->n_ends ? r->n_ends : 1);
-    size_t b_words = sizeof(uint32_t) * (r->n_words + 4);
+    size_t b_words = sizeof(uint32_t) * (r->n_words + VS_PAD_WORDS);
     VS_HIP(ctx, hipMalloc(&r->d_woff, b_woff));
     VS_HIP(ctx, hipMalloc(&r->d_meta, b_meta));
     VS_HIP(ctx, hipMalloc(&r->d_words, b_words));
-    VS_HIP(ctx, hipMemsetAsync((char *)r->d_words + sizeof(uint32_t) * r->n_words, 0, 4 * sizeof(uint32_t), ctx->stream));
+    VS_HIP(ctx, hipMemsetAsync((char *)r->d_words + sizeof(uint32_t) * r->n_words, 0, VS_PAD_WORDS * sizeof(uint32_t), ctx->stream));
     r->bytes = b_woff + b_meta + b_words;
     if (with_mask) {
         VS_HIP(ctx, hipMalloc(&r->d_mask, b_words));
-        VS_HIP(ctx, hipMemsetAsync((char *)r->d_mask + sizeof(uint32_t) * r->n_words, 0, 4 * sizeof(uint32_t), ctx->stream));
+        VS_HIP(ctx, hipMemsetAsync((char *)r->d_mask + sizeof(uint32_t) * r->n_words, 0, VS_PAD_WORDS * sizeof(uint32_t), ctx->stream));
         r->bytes += b_words;
     }
     return VS_OK;
@@ -143,7 +143,7 @@ extern "C" int vs_reads_pack(vs_ctx *ctx, const uint8_t *ascii, const uint64_t *
             if ((e1 = hipStreamSynchronize(st)) != hipSuccess) break;
             r->n_invalid = h_cnt;
             if (h_cnt) {  // rare: some end holds a byte outside ACGTN -> build the validity mask too
-                size_t b_words = sizeof(uint32_t) * (words + 4);
+                size_t b_words = sizeof(uint32_t) * (words + VS_PAD_WORDS);
                 if ((e1 = hipMalloc(&r->d_mask, b_words)) != hipSuccess) break;
                 if ((e1 = hipMemsetAsync(r->d_mask, 0, b_words, st)) != hipSuccess) break;
                 r->bytes += b_words;
