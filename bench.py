@@ -155,6 +155,7 @@ def main():
     kernel_ms = []
     slow_ms = []
     sort_ms = []
+    acc_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -164,6 +165,7 @@ def main():
         kernel_ms.append(t["main_ms"])
         slow_ms.append(t["slow_ms"])
         sort_ms.append(t["sort_ms"])
+        acc_ms.append(t["accumulate_ms"])
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -206,6 +208,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "kernel": "k_pe_tiles", "kernel_ms_avg": avg_kernel_ms, "slow_kernel_ms_avg": float(np.mean(slow_ms)),
                 "locus_sort_ms_avg": float(np.mean(sort_ms)),
+                "accumulate_ms_avg": float(np.mean(acc_ms)),
                 "algorithmic_bytes_per_pair": b_alg,
             },
             "pe_stats": {"n_reads": stats[0], "short_reads": stats[1], "used_reads": stats[2],

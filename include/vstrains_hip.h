@@ -105,10 +105,11 @@ int vs_pe_map_ends(vs_ctx *ctx, const vs_reads *reads, uint32_t cap, uint32_t *l
                    uint32_t *counts);
 
 /* Timing of the most recent vs_pe_count on this ctx, measured with HIP events on the ctx
- * stream: ms[0] = main kernel (k_pe_tiles), ms[1] = overflow (slow-path) kernel, ms[2] = pairs
- * sent to the slow path, ms[3] = locus ordering of the pairs in front of the main kernel
- * (k_pe_locus + scan + k_pe_permute).  Synchronises the stream. */
-int vs_pe_last_timing(vs_ctx *ctx, double ms[4]);
+ * stream: ms[0] = mapping kernel (k_pe_tiles), ms[1] = overflow (slow-path) kernel, ms[2] =
+ * pairs sent to the slow path, ms[3] = locus ordering of the pairs in front of the mapping
+ * kernel (k_pe_locus + scan + k_pe_permute), ms[4] = counter kernel (k_pe_accumulate).
+ * Synchronises the stream. */
+int vs_pe_last_timing(vs_ctx *ctx, double ms[5]);
 
 /* ---- graph stages: K5 PE-link table ---------------------------------------------------------
  * Replaces process_pe_info (utils/VStrains_IO.py:598-627) and every later read or rewrite of the

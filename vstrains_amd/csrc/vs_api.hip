@@ -43,7 +43,7 @@ int vs_ctx_create(int device, vs_ctx **out) {
     ctx->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < 5; i++) {
         e = hipEventCreate(&ctx->ev[i]);
         if (e != hipSuccess) {
             int rc = vs_fail(nullptr, VS_E_HIP, "hipEventCreate: %s", hipGetErrorString(e));
@@ -75,9 +75,9 @@ void vs_ctx_destroy(vs_ctx *ctx) {
     if (ctx->d_slow_list) (void)hipFree(ctx->d_slow_list);
     if (ctx->d_slow_count) (void)hipFree(ctx->d_slow_count);
     if (ctx->d_dense) (void)hipFree(ctx->d_dense);
-    for (void *q : {ctx->d_locus_keys, ctx->d_perm, ctx->d_locus_hist, ctx->d_scan_tmp})
+    for (void *q : {ctx->d_locus_keys, ctx->d_perm, ctx->d_locus_hist, ctx->d_scan_tmp, ctx->d_lists, ctx->d_list_counts})
         if (q) (void)hipFree(q);
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 5; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     delete ctx;
 }

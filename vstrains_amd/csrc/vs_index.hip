@@ -150,6 +150,7 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
     woff[n_nodes] = (uint32_t)words;
     seed_off[n_nodes] = npos;
     if (npos > 0x3FFFFFF0ull) return vs_fail(ctx, VS_E_RANGE, "too many seed positions (%llu)", (unsigned long long)npos);
+    if (words >= (1ull << 28)) return vs_fail(ctx, VS_E_RANGE, "node text of %llu packed words exceeds 2^32 bases", (unsigned long long)words);
     uint32_t bits = 4;
     while ((1ull << bits) < 2 * npos + 2) bits++;
     const uint64_t n_slots = 1ull << bits;

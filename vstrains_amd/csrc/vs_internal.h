@@ -78,7 +78,10 @@ struct vs_ctx {
     void *d_locus_keys = nullptr, *d_perm = nullptr, *d_locus_hist = nullptr, *d_scan_tmp = nullptr;
     uint64_t locus_cap = 0, hist_cap = 0;
     double last_sort_ms = 0;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // per-end accepted lists between k_pe_tiles and k_pe_accumulate
+    void *d_lists = nullptr, *d_list_counts = nullptr;
+    uint64_t lists_cap = 0;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double last_ms[3] = {0, 0, 0};
     int n_cu = 256;
 };
@@ -128,6 +131,24 @@ __device__ __forceinline__ uint64_t vs_win64(const uint32_t *w, uint64_t base) {
     uint64_t hi = (uint64_t)w[i + 2];
     return sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
 }
+
+// Same with a 32-bit base offset (LDS tiles, node texts below 2^32 bases): no 64-bit address math.
+__device__ __forceinline__ uint64_t vs_win64_u32(const uint32_t *w, uint32_t base) {
+    const uint32_t i = base >> 4;
+    const uint32_t sh = (base & 15u) * 2u;
+    const uint32_t w0 = w[i], w1 = w[i + 1], w2 = w[i + 2];
+    // funnel shifts: (w1:w0) >> sh and (w2:w1) >> sh, sh in 0..30
+    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
+    const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+__device__ __forceinline__ uint64_t vs_win(const uint32_t *w, uint32_t base) { return vs_win64_u32(w, base); }
+__device__ __forceinline__ uint64_t vs_win(const uint32_t *w, uint64_t base) { return vs_win64(w, base); }
+
+// x / d with a precomputed magic = floor(2^32 / d) + 1 (0 stands for d == 1); exact while
+// x * d < 2^32, which holds for the tile-sized operands used here
+__device__ __forceinline__ uint32_t vs_fastdiv(uint32_t x, uint32_t magic) { return magic ? __umulhi(x, magic) : x; }
 
 __device__ __forceinline__ uint64_t vs_lowmask(uint32_t bits) {  // bits in 0..64
     return bits >= 64u ? ~0ull : ((1ull << bits) - 1ull);

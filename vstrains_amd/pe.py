@@ -222,9 +222,9 @@ class Context:
                                                  C.c_void_p(short_mat_ptr), C.c_void_p(stats_ptr)))
 
     def last_timing(self):
-        a = (C.c_double * 4)()
+        a = (C.c_double * 5)()
         nat.check(self._h, nat.lib().vs_pe_last_timing(self._h, a))
-        return dict(main_ms=a[0], slow_ms=a[1], slow_pairs=int(a[2]), sort_ms=a[3])
+        return dict(main_ms=a[0], slow_ms=a[1], slow_pairs=int(a[2]), sort_ms=a[3], accumulate_ms=a[4])
 
     def map_ends(self, reads: ReadBlock, cap: int = 64) -> List[List[int]]:
         n = reads.info["ends"]
