@@ -27,5 +27,6 @@ for f in sorted(glob.glob(out + "/*/**/*counter_collection.csv", recursive=True)
         res[kn][cn + "#rows"] = n
 json.dump(res, open(out + "/summary.json", "w"), indent=1)
 for kn, d in res.items():
-    if "k_pe" in kn: print(kn, json.dumps(d))
+    if "k_pe" in kn or "k_locus" in kn:
+        print(kn, {k: round(v / max(d.get(k + "#rows", 1), 1)) for k, v in d.items() if not k.endswith("#rows")})
 PY

@@ -496,15 +496,15 @@ k_pe_tiles(PeParams P) {
 // Scattered global atomics run at ~2e10/s chip-wide and would bound the whole step (5.4e8 increments
 // at configs[2]), so a workgroup (1024 threads, one per CU, a contiguous run of pairs = a few loci)
 // first sums increments per cell in a 16k-slot LDS table and issues ONE global atomic per cell when
-// the table is written out.  One wavefront expands 64 pairs at a time, one lane per increment.
+// the table is written out.  One wavefront expands 64 pairs at a time, one lane per list row.
 #define ACC_TPB 1024
 #define ACC_BITS 14
 #define ACC_SLOTS (1u << ACC_BITS)
 #define ACC_LDS_BYTES ((2u * ACC_SLOTS + (ACC_TPB / 64) * 66u + 2u) * 4u)
 __global__ void __launch_bounds__(ACC_TPB)
 k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_slots_pairs,
-                uint32_t pairs_per_wg, uint32_t N, uint32_t use_table, uint32_t *__restrict__ node_mat,
-                uint32_t *__restrict__ short_mat) {
+                uint32_t pairs_per_wg, uint32_t N, uint32_t use_table, uint32_t fill_limit,
+                uint32_t *__restrict__ node_mat, uint32_t *__restrict__ short_mat) {
     uint32_t *s_key = vs_lds;                      // [ACC_SLOTS]
     uint32_t *s_cnt = vs_lds + ACC_SLOTS;          // [ACC_SLOTS]
     uint32_t(*s_pref)[66] = (uint32_t(*)[66])(vs_lds + 2u * ACC_SLOTS);  // [ACC_TPB / 64][66]
@@ -518,13 +518,18 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
     const uint64_t hi = lo + pairs_per_wg < n_slots_pairs ? lo + pairs_per_wg : n_slots_pairs;
     const uint32_t NN = N * N;
     for (uint64_t base = lo; base < hi; base += ACC_TPB) {  // ACC_TPB pairs per round, 64 per wavefront
-        const uint64_t p = base + wv * 64u + lane;
+        const uint64_t wbase = base + wv * 64u;             // wave-uniform
+        const uint32_t *wcounts = counts + 2u * wbase;
+        const uint32_t *wlists = lists + 2u * wbase * LC;
         uint32_t nl = 0, nr = 0;
-        if (p < hi) {
-            const uint2 c = *(const uint2 *)(counts + 2u * p);
+        if (wbase + lane < hi) {
+            const uint2 c = *(const uint2 *)(wcounts + 2u * lane);
             nl = c.x; nr = c.y;
         }
-        const uint32_t u = nl * nr + nl * (nl + 1u) / 2u + nr * (nr + 1u) / 2u;
+        // One lane per list ROW: a pair has nl node_mat rows (left node x against every right node),
+        // nl short_mat rows of the left list (position a against positions b >= a) and nr of the
+        // right list.  The lane walks its row; lanes of one pair read the same partner list.
+        const uint32_t u = 2u * nl + nr;
         uint32_t incl = u;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -533,57 +538,66 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
         }
         s_pref[wv][lane + 1u] = incl;
         if (lane == 0) s_pref[wv][0] = 0;
+        if (lane == 63u) s_pref[wv][65] = 0xFFFFFFFFu;  // sentinel: the look-ahead below never runs off
         const uint32_t U = __shfl(incl, 63, 64);
-        // (same wavefront wrote and reads s_pref: no workgroup barrier needed, only the LDS wait)
+        // (the same wavefront wrote and reads s_pref: no workgroup barrier, only the LDS wait)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t t = lane; t < U; t += 64u) {
-            uint32_t a0 = 0, a1 = 64u;  // last pair of this wavefront with pref <= t
-            while (a1 - a0 > 1u) {
-                const uint32_t mid = (a0 + a1) >> 1;
-                if (s_pref[wv][mid] <= t) a0 = mid; else a1 = mid;
-            }
-            uint32_t r = t - s_pref[wv][a0];
-            const uint64_t q = base + wv * 64u + a0;
-            const uint2 c = *(const uint2 *)(counts + 2u * q);
-            const uint32_t ql = c.x, qr = c.y;
-            const uint32_t *lf = lists + 2u * q * LC, *lr = lf + LC;
-            uint32_t mat, x, y;
-            if (r < ql * qr) {
-                const uint32_t a = r / qr;
-                mat = 0u; x = lf[a]; y = lr[r - a * qr];
-            } else {
-                r -= ql * qr;
-                const uint32_t *l = lf;
-                uint32_t n = ql;
-                if (r >= ql * (ql + 1u) / 2u) { r -= ql * (ql + 1u) / 2u; l = lr; n = qr; }
-                uint32_t a = 0;
-                while (r >= n - a) { r -= n - a; a++; }
-                const uint32_t g = l[a], h = l[a + r];
-                mat = 1u; x = g < h ? g : h; y = g < h ? h : g;
-            }
-            bool done = false;
-            if (use_table) {
-                const uint32_t key = mat * NN + x * N + y;  // use_table => 2*N*N < 2^32
-                uint32_t at = (key * 0x9E3779B1u) >> (32u - ACC_BITS);
-                for (uint32_t pr = 0; pr < 8u && !done; pr++) {
-                    uint32_t kx = s_key[at];
-                    if (kx == EMPTY_NODE) {
-                        kx = atomicCAS(&s_key[at], EMPTY_NODE, key);
-                        if (kx == EMPTY_NODE) { atomicAdd(&s_used, 1u); kx = key; }
-                    }
-                    if (kx == key) {
-                        atomicAdd(&s_cnt[at], 1u);
-                        done = true;
-                    }
-                    at = (at + 1u) & (ACC_SLOTS - 1u);
+        uint32_t cur = 0;  // wave-uniform: first pair whose rows reach into the current window
+        for (uint32_t t0 = 0; t0 < U; t0 += 64u) {
+            while (s_pref[wv][cur + 1u] <= t0) cur++;
+            const uint32_t t = t0 + lane;
+            uint32_t x = 0, mat = 0, off = 0, bi = 0, be = 0;  // row: fixed node, matrix, partner list, range
+            if (t < U) {
+                uint32_t a0 = cur;  // last pair of this wavefront with pref <= t
+                a0 += s_pref[wv][a0 + 1u] <= t ? 1u : 0u;
+                a0 += s_pref[wv][a0 + 1u] <= t ? 1u : 0u;
+                while (s_pref[wv][a0 + 1u] <= t) a0++;
+                uint32_t r = t - s_pref[wv][a0];
+                const uint2 c = *(const uint2 *)(wcounts + 2u * a0);
+                const uint32_t ql = c.x, qr = c.y;
+                const uint32_t row = 2u * a0 * LC;
+                if (r < ql) {                 // node_mat row: left node r against all right nodes
+                    x = wlists[row + r]; mat = 0u; off = row + LC; bi = 0; be = qr;
+                } else if (r < 2u * ql) {     // short_mat row of the left list
+                    r -= ql;
+                    x = wlists[row + r]; mat = 1u; off = row; bi = r; be = ql;
+                } else {                      // short_mat row of the right list
+                    r -= 2u * ql;
+                    x = wlists[row + LC + r]; mat = 1u; off = row + LC; bi = r; be = qr;
                 }
-                if (!done) atomicAdd(&s_lost, 1u);
             }
-            if (!done) atomicAdd((mat ? short_mat : node_mat) + (uint64_t)x * N + y, 1u);
+            uint32_t ynext = bi < be ? wlists[off + bi] : 0u;  // one partner ahead: hides the load latency
+            while (__ballot(bi < be)) {
+                const uint32_t yv = ynext;
+                ynext = bi + 1u < be ? wlists[off + bi + 1u] : 0u;
+                if (bi < be) {
+                    const uint32_t cx = (mat && yv < x) ? yv : x, cy = (mat && yv < x) ? x : yv;
+                    bool done = false;
+                    if (use_table) {
+                        const uint32_t key = mat * NN + cx * N + cy;  // use_table => 2*N*N < 2^32
+                        uint32_t at = (key * 0x9E3779B1u) >> (32u - ACC_BITS);
+                        for (uint32_t pr = 0; pr < 8u && !done; pr++) {
+                            uint32_t kx = s_key[at];
+                            if (kx == EMPTY_NODE) {
+                                kx = atomicCAS(&s_key[at], EMPTY_NODE, key);
+                                if (kx == EMPTY_NODE) { atomicAdd(&s_used, 1u); kx = key; }
+                            }
+                            if (kx == key) {
+                                atomicAdd(&s_cnt[at], 1u);
+                                done = true;
+                            }
+                            at = (at + 1u) & (ACC_SLOTS - 1u);
+                        }
+                        if (!done) atomicAdd(&s_lost, 1u);
+                    }
+                    if (!done) atomicAdd((mat ? short_mat : node_mat) + (uint64_t)cx * N + cy, 1u);
+                    bi++;
+                }
+            }
         }
         __syncthreads();
-        const bool spill = s_used * 4u > ACC_SLOTS * 3u || s_lost > 4096u;
+        const bool spill = s_used > fill_limit || s_lost > 4096u;
         __syncthreads();
         if (spill) {
             for (uint32_t i = tid; i < ACC_SLOTS; i += ACC_TPB) {
@@ -963,13 +977,17 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         uint32_t per_wg = (uint32_t)((slots_pairs + acc_grid - 1) / acc_grid);
         per_wg = (per_wg + ACC_TPB - 1) / ACC_TPB * ACC_TPB;
         acc_grid = (uint32_t)((slots_pairs + per_wg - 1) / per_wg);
+        // the table is written out once this many of its slots are taken: linear probing stays
+        // short at a low fill, and cells of loci the run has left do not pile up (VS_ACC_FILL: percent)
+        uint32_t fill_limit = ACC_SLOTS / 8u;
+        if (const char *fv = getenv("VS_ACC_FILL")) fill_limit = (uint32_t)((uint64_t)ACC_SLOTS * (uint32_t)atoi(fv) / 100u);
         const char *ev = getenv("VS_NO_AGG");
         const uint32_t use_table = (!(ev && atoi(ev) != 0) && 2ull * idx.n_nodes * idx.n_nodes < 0xFFFFFFFFull) ? 1u : 0u;
         VS_HIP(ctx, hipFuncSetAttribute((const void *)k_pe_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES));
         VS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
         hipLaunchKernelGGL(k_pe_accumulate, dim3(acc_grid), dim3(ACC_TPB), ACC_LDS_BYTES, st, (const uint32_t *)ctx->d_lists,
-                           (const uint32_t *)ctx->d_list_counts, slots_pairs, per_wg, idx.n_nodes, use_table, d_node_mat,
-                           d_short_mat);
+                           (const uint32_t *)ctx->d_list_counts, slots_pairs, per_wg, idx.n_nodes, use_table, fill_limit,
+                           d_node_mat, d_short_mat);
     }
     VS_HIP(ctx, hipEventRecord(ctx->ev[1], st));
     hipLaunchKernelGGL(k_pe_slow, dim3(SLOW_GRID), dim3(TPB), 0, st, P, (uint32_t *)ctx->d_dense, (uint32_t)n_pairs);
