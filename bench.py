@@ -68,6 +68,24 @@ def workload(out_dir, k=55, n_strains=15, genome_len=10800, snp_rate=0.09, seed=
     return st, pre, names, seqs, cum, logger, len(pc.graph.ids)
 
 
+def pmc_traffic(pairs):
+    """HBM bytes of one k_pe_tiles launch from the committed rocprofv3 PMC passes (profiles/,
+    collected with tools_profile.sh on the default workload; counters cannot be read inside this
+    process).  2 x FETCH_SIZE (the guide's gfx950 rule for wide reads) + WRITE_SIZE, both in KB."""
+    path = os.path.join(ROOT, "profiles", "r1", "pmc_summary_bench_10m_v2.json")
+    if pairs != 10_000_000 or not os.path.exists(path):
+        return {"traffic": None}
+    try:
+        with open(path) as fh:
+            k = json.load(fh)["k_pe_tiles"]
+        fetch = k["FETCH_SIZE"]["per_dispatch_mean"] * 1024.0
+        write = k["WRITE_SIZE"]["per_dispatch_mean"] * 1024.0
+        return {"traffic": 2.0 * fetch + write, "traffic_unit": "B per k_pe_tiles launch",
+                "traffic_source": "profiles/r1/pmc_summary_bench_10m_v2.json (2*FETCH_SIZE + WRITE_SIZE; not live)"}
+    except Exception:
+        return {"traffic": None}
+
+
 def strain_extract(ctx, counter, pre, names, logger, out_dir):
     """The second half of the metric: pe counters (resident in HBM) -> strain.paths, i.e.
     VStrains_SPAdes.py:134-272 with the graph kernels on the device."""
@@ -216,6 +234,7 @@ def main():
                          "slow_pairs_per_step": ctx.last_timing()["slow_pairs"]},
         }
         out["config"]["input_gfa_nodes"] = n_input_nodes
+        out["roofline"].update(pmc_traffic(R))
         try:
             if args.no_extract:
                 raise RuntimeError("skipped (--no-extract)")
