@@ -56,6 +56,11 @@ CASES = {
                             error_strain_depth=4.0), []),
     "flat_cov_k21": (dict(n_strains=3, genome_len=2500, snp_rate=0.01, k=21, n_pairs=5000, read_len=100,
                           seed=71, abundance_ratio=0.97, dp_noise=0.05), []),
+    "gapped_paths_kc_tags_k21": (dict(n_strains=3, genome_len=3000, snp_rate=0.01, k=21, n_pairs=6000,
+                                      read_len=100, seed=91, abundance_ratio=0.6, scramble=True,
+                                      depth_tags="kc", gapped_contigs=4), []),
+    "self_loops_k21": (dict(n_strains=3, genome_len=2500, snp_rate=0.01, k=21, n_pairs=5000, read_len=100,
+                            seed=95, abundance_ratio=0.55, self_loops=2, contig_pieces=5), ["-ml", "100"]),
     "noisy_reads_k21": (dict(n_strains=4, genome_len=3500, snp_rate=0.012, k=21, n_pairs=8000,
                              read_len=100, seed=81, abundance_ratio=0.55, sub_rate=0.004,
                              scramble=True), []),
@@ -130,7 +135,8 @@ def run_reference(inp, extra, variant, hashseed=0, keep_log_to=None):
         if keep_log_to and os.path.exists(os.path.join(out, "vstrains.log")):
             shutil.copy(os.path.join(out, "vstrains.log"), keep_log_to)
         if proc.returncode != 0:
-            return proc.returncode, {}, proc.stderr[-3000:]
+            # keep what was written before the failure (the files up to s_graph_L1 pin the upstream steps)
+            return proc.returncode, collect(out), proc.stderr[-3000:]
         return 0, collect(out), ""
 
 

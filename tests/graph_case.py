@@ -54,10 +54,11 @@ class Case:
     def args(self, inp, out):
         extra = self.meta["cli_extra"]
         min_cov = int(extra[extra.index("-mc") + 1]) if "-mc" in extra else None
+        min_len = int(extra[extra.index("-ml") + 1]) if "-ml" in extra else 250
         for sub in ("gfa", "tmp", "paf", "aln"):
             os.makedirs(os.path.join(out, sub))
         return argparse.Namespace(gfa_file=inp["gfa"], path_file=inp["paths"], fwd=inp["fwd"], rve=inp["rve"],
-                                  output_dir=out, min_cov=min_cov, min_len=250, ref_file=None, dev=False)
+                                  output_dir=out, min_cov=min_cov, min_len=min_len, ref_file=None, dev=False)
 
     def write_info_files(self, names, aln_dir):
         """pe_info / st_info text rebuilt from the stored non-zero lines."""

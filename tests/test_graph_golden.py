@@ -7,6 +7,7 @@ import pytest
 
 from graph_case import Case, case_names, compare, quiet_logger
 from oracle import graph_ops as chk
+from oracle import pe_oracle
 from vstrains_amd.graph import pipeline
 from vstrains_amd.graph.ops import LiveLinks
 
@@ -21,6 +22,10 @@ class CheckerBackend:
 
     def pe_links(self, gfa, aln_dir, fwd, rve, ksize, names):
         assert ksize == self.case.meta["k"]
+        # the reference's PE script dies with KeyError on a node base outside ACGT (self-loop
+        # segments are lower-cased upstream); the oracle restates that, so does the device index
+        _, seqs = pe_oracle.read_gfa_segments(gfa)
+        pe_oracle.build_table(seqs, ksize + 1)
         self.case.write_info_files(names, aln_dir)
         return chk.DictPeLinks.from_files(names, os.path.join(aln_dir, "pe_info"), os.path.join(aln_dir, "st_info"))
 
@@ -32,10 +37,15 @@ class CheckerBackend:
 @pytest.mark.parametrize("name", case_names())
 def test_pipeline_matches_reference_outputs(name, literal, tmp_path):
     case = Case(name)
-    assert case.meta["returncode"] == 0
     inp = case.inputs(str(tmp_path))
     out = str(tmp_path / "out")
-    pipeline.run(case.args(inp, out), quiet_logger(), CheckerBackend(case, literal))
+    if case.meta["returncode"] != 0:
+        # the reference exits non-zero (its PE subprocess raises KeyError); so must this build, after
+        # writing the same files up to that point
+        with pytest.raises(KeyError):
+            pipeline.run(case.args(inp, out), quiet_logger(), CheckerBackend(case, literal))
+    else:
+        pipeline.run(case.args(inp, out), quiet_logger(), CheckerBackend(case, literal))
     # files the reference itself does not produce deterministically (they change with
     # PYTHONHASHSEED, see case.json) are compared too, but only the deterministic ones are binding
     problems, _ = compare(case, out)

@@ -169,7 +169,11 @@ def test_stage_graphs_of_golden_cases(backend, name, tmp_path):
     case = Case(name)
     inp = case.inputs(str(tmp_path))
     out = str(tmp_path / "out")
-    pipeline.run(case.args(inp, out), quiet_logger(), T.CheckerBackend(case, False))
+    if case.meta["returncode"] != 0:
+        with pytest.raises(KeyError):
+            pipeline.run(case.args(inp, out), quiet_logger(), T.CheckerBackend(case, False))
+    else:
+        pipeline.run(case.args(inp, out), quiet_logger(), T.CheckerBackend(case, False))
     n = 0
     for fn in sorted(os.listdir(os.path.join(out, "gfa"))):
         if fn in ("graph_L0.gfa", "graph_L0r.gfa"):
@@ -177,7 +181,7 @@ def test_stage_graphs_of_golden_cases(backend, name, tmp_path):
         g, _, _ = read_stage_gfa(os.path.join(out, "gfa", fn))
         assert_same_ops(backend.graph_ops, g)
         n += 1
-    assert n > 5
+    assert n > 5 or case.meta["returncode"] != 0
 
 
 @pytest.mark.parametrize("name", case_names())
@@ -192,7 +196,11 @@ def test_full_cli_on_device_matches_reference(backend, name, tmp_path):
     out = str(tmp_path / "out")
     argv = ["-a", "spades", "-g", inp["gfa"], "-p", inp["paths"], "-o", out, "-fwd", inp["fwd"], "-rve", inp["rve"]]
     argv += case.meta["cli_extra"]
-    cli.main(argv, backend=backend)
+    if case.meta["returncode"] != 0:
+        with pytest.raises(KeyError):  # the reference's PE subprocess dies the same way
+            cli.main(argv, backend=backend)
+    else:
+        cli.main(argv, backend=backend)
     problems, _ = compare(case, out)
     binding = [p for p in problems if p.split(" ", 1)[1] not in case.meta["differs_under_other_hashseeds"]]
     assert not binding, binding

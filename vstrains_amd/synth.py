@@ -239,13 +239,22 @@ class PipelineCase:
     strains: StrainSet
 
 
-def spades_like_gfa(graph: SynthGraph, flip: Sequence[bool], swap: Sequence[bool]) -> str:
+def spades_like_gfa(graph: SynthGraph, flip: Sequence[bool], swap: Sequence[bool], depth_tags: str = "dp",
+                    self_loops: Sequence[int] = ()) -> str:
     """GFA1 text the way an assembler emits it: segment ``i`` is stored reverse-complemented when
     ``flip[i]``; link ``j`` is written in its reverse-complement form when ``swap[j]``.  Input of
-    ``gfa_to_graph`` (reference ``utils/VStrains_IO.py:27-134``)."""
+    ``gfa_to_graph`` (reference ``utils/VStrains_IO.py:27-134``).  ``depth_tags="kc"`` writes the
+    SPAdes style ``LN:i`` / ``KC:i`` pair instead of ``DP:f`` (:56-77); ``self_loops`` adds
+    ``L x + x +`` records, which the reference answers by lower-casing the segment (:117-120)."""
     out = []
     for i, (name, s, d) in enumerate(zip(graph.ids, graph.seqs, graph.dp)):
-        out.append("S\t%s\t%s\tDP:f:%s\n" % (name, revcomp(s) if flip[i] else s, repr(float(d))))
+        seq = revcomp(s) if flip[i] else s
+        if depth_tags == "kc":
+            out.append("S\t%s\t%s\tLN:i:%d\tKC:i:%d\n" % (name, seq, len(seq), max(1, int(round(d * len(seq))))))
+        else:
+            out.append("S\t%s\t%s\tDP:f:%s\n" % (name, seq, repr(float(d))))
+    for i in self_loops:
+        out.append("L\t%s\t+\t%s\t+\t%dM\n" % (graph.ids[i], graph.ids[i], graph.k))
     for j, (u, v) in enumerate(graph.links):
         ou = "-" if flip[u] else "+"
         ov = "-" if flip[v] else "+"
@@ -258,16 +267,27 @@ def spades_like_gfa(graph: SynthGraph, flip: Sequence[bool], swap: Sequence[bool
 
 
 def spades_like_paths(graph: SynthGraph, flip: Sequence[bool], contigs: Sequence[Sequence[int]],
-                      covs: Sequence[float]) -> str:
+                      covs: Sequence[float], gaps: Dict[int, int] = None) -> str:
+    """``gaps[c] = g`` writes contig ``c`` as two sub-paths split after ``g`` nodes, the first line
+    ending in ``;`` (SPAdes' notation for a gap; reference ``utils/VStrains_IO.py:412-442``)."""
     out = []
     sign = lambda i, fwd: ("+" if fwd else "-") if not flip[i] else ("-" if fwd else "+")  # noqa: E731
+    gaps = gaps or {}
+
+    def lines(nodes, fwd, cut):
+        toks = [graph.ids[i] + sign(i, fwd) for i in nodes]
+        if cut is None or cut <= 0 or cut >= len(toks):
+            return ",".join(toks) + "\n"
+        return ",".join(toks[:cut]) + ";\n" + ",".join(toks[cut:]) + "\n"
+
     for c, (nodes, cov) in enumerate(zip(contigs, covs)):
         length = sum(len(graph.seqs[i]) for i in nodes) - graph.k * (len(nodes) - 1)
         name = "NODE_%d_length_%d_cov_%s" % (c + 1, length, repr(float(cov)))
+        cut = gaps.get(c)
         out.append(name + "\n")
-        out.append(",".join(graph.ids[i] + sign(i, True) for i in nodes) + "\n")
+        out.append(lines(list(nodes), True, cut))
         out.append(name + "'\n")
-        out.append(",".join(graph.ids[i] + sign(i, False) for i in reversed(nodes)) + "\n")
+        out.append(lines(list(reversed(nodes)), False, None if cut is None else len(nodes) - cut))
     return "".join(out)
 
 
@@ -287,6 +307,9 @@ def make_pipeline_case(
     contig_pieces: int = 3,
     sub_rate: float = 0.0,
     repeat_len: int = 0,
+    depth_tags: str = "dp",
+    gapped_contigs: int = 0,
+    self_loops: int = 0,
 ) -> PipelineCase:
     """A seeded, self-contained stand-in for "SPAdes output + reads" of a viral quasispecies."""
     rng = np.random.default_rng(seed + 77)
@@ -322,5 +345,10 @@ def make_pipeline_case(
             contigs.append(piece)
             covs.append(float(min(g.dp[i] for i in piece)))
     fwd, rve = sample_pairs(reads_from, n_pairs, read_len, seed + 1, sub_rate=sub_rate)
-    return PipelineCase(spades_like_gfa(g, flip, swap), spades_like_paths(g, flip, contigs, covs),
-                        fwd, rve, k, g, st)
+    gaps: Dict[int, int] = {}
+    multi = [c for c, nodes in enumerate(contigs) if len(nodes) >= 4]
+    for c in multi[:gapped_contigs]:
+        gaps[c] = len(contigs[c]) // 2
+    loops = [int(x) for x in rng.choice(n, size=min(self_loops, n), replace=False)] if self_loops else []
+    return PipelineCase(spades_like_gfa(g, flip, swap, depth_tags, loops),
+                        spades_like_paths(g, flip, contigs, covs, gaps), fwd, rve, k, g, st)
