@@ -127,6 +127,11 @@ def main(argv=None, backend=None):
     old_err = numpy.seterr(all="raise")  # vstrains:25
     try:
         timings = pipeline.run(args, logger, backend)
+    except BaseException:
+        logger.removeHandler(to_file)
+        logger.removeHandler(console)
+        to_file.close()
+        raise
     finally:
         numpy.seterr(**old_err)
 
