@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--k", type=int, default=55)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time (0 = skip)")
     ap.add_argument("--no-extract", action="store_true", help="skip the strain-extract leg (kernel experiments)")
+    ap.add_argument("--ingest-pairs", type=int, default=1_000_000,
+                    help="pairs written as FASTQ text and timed through the native ingest (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -244,6 +246,8 @@ def main():
         except Exception as err:  # the PE line must still be reported
             out["strain_extract_s"] = None
             out["strain_extract"] = {"error": repr(err)}
+        if world == 1 and args.ingest_pairs > 0 and not args.no_extract:
+            out["fastq_ingest"] = fastq_ingest(ctx, host, st, cum, seed, L, k, sub_thresh, n_thresh, args.ingest_pairs, work_dir)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(ctx, host, st, g, cum, seed, L, k, sub_thresh, n_thresh, R, args.cpu_seconds)
         print(json.dumps(out))
@@ -252,6 +256,38 @@ def main():
 
         dist.barrier()
         dist.destroy_process_group()
+
+
+def fastq_ingest(ctx, host, st, cum, seed, L, k, sub_thresh, n_thresh, M, work_dir):
+    """PCIe-inclusive leg (never `value`): FASTQ text on disk -> native multi-threaded ingest
+    (vs_fastq_open / vs_fastq_block) -> packed on the device -> counters."""
+    from oracle import pe_oracle_c
+
+    fw, rv = pe_oracle_c.synth_pairs(st.genomes, cum, seed, 0, M, L, sub_thresh, n_thresh)
+    paths = []
+    qual = b"I" * L
+    for tag, arr in (("f", fw), ("r", rv)):
+        path = os.path.join(work_dir, "ingest_%s.fq" % tag)
+        with open(path, "wb") as fh:
+            rows = [b"@%s%d\n%s\n+\n%s\n" % (tag.encode(), i, arr[i].tobytes(), qual) for i in range(M)]
+            fh.write(b"".join(rows))
+        paths.append(path)
+    size = sum(os.path.getsize(p) for p in paths)
+    t0 = time.perf_counter()
+    fq = host.FastqPair(paths[0], paths[1], ctx)
+    t1 = time.perf_counter()
+    counter = host.PeCounter(ctx)
+    block = fq.block(0, len(fq))
+    ctx.sync()
+    t2 = time.perf_counter()
+    counter.add(block)
+    ctx.sync()
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    fq.close()
+    return {"pairs": len(fq), "fastq_bytes": size, "host_threads": os.cpu_count(),
+            "open_index_s": t1 - t0, "gather_upload_pack_s": t2 - t1, "count_s": t3 - t2,
+            "pairs_per_s": len(fq) / (t3 - t0), "note": "files in page cache; PCIe-inclusive; never reported as value"}
 
 
 def cpu_baseline(ctx, host, st, g, cum, seed, L, k, sub_thresh, n_thresh, R, target_s):

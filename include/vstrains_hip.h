@@ -77,6 +77,26 @@ int vs_reads_info(const vs_reads *reads, uint64_t info[5]);
 int vs_reads_unpack(vs_ctx *ctx, const vs_reads *reads, uint8_t *out, uint32_t *lens,
                     uint8_t *flags);
 
+/* ---- FASTQ ingest (host, multi-threaded) -----------------------------------------------------
+ * Replaces PE_Inference.py:146-159: both files read in text mode (universal newlines), record r
+ * = lines 4r..4r+3, sequence = line 4r+1 minus its last character (the newline, or a real
+ * character on a final line without one), n_pairs = min(lines_f // 4, lines_r // 4).
+ * vs_fastq_open maps and indexes both files on the host cores (VS_HOST_THREADS overrides the
+ * count); vs_fastq_block turns pairs [first, first+count) into a device read block. */
+typedef struct vs_fastq vs_fastq;
+int vs_fastq_open(vs_ctx *ctx, const char *fwd_path, const char *rve_path, vs_fastq **out);
+void vs_fastq_close(vs_fastq *fq);
+/* info[0] = pairs, [1] = lines of the forward file, [2] = lines of the reverse file */
+int vs_fastq_info(const vs_fastq *fq, uint64_t info[3]);
+int vs_fastq_sequence(const vs_fastq *fq, int which, uint64_t record, uint8_t *buf, uint32_t cap,
+                      uint32_t *len);
+/* off[2*count+1] byte offsets of the interleaved ends (2r forward, 2r+1 reverse); ascii (may be
+ * NULL to get the sizes only) receives the bytes.  Host pointers. */
+int vs_fastq_gather(const vs_fastq *fq, uint64_t first, uint64_t count, uint64_t *off,
+                    uint8_t *ascii);
+int vs_fastq_block(vs_ctx *ctx, const vs_fastq *fq, uint64_t first, uint64_t count,
+                   vs_reads **out);
+
 /* Synthetic pairs generated on the device from a seed (bench workload; the CPU twin is
  * oracle/pe_oracle.c:peo_synth_pairs).  genomes: concatenated ACGT ASCII (host), goff
  * [n_strains+1]; cum[s]: inclusive upper bound of strain s in a uniform u32 draw (last =

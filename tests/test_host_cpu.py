@@ -121,3 +121,57 @@ def test_shard_range_covers_everything_once():
             assert spans[0][0] == 0 and spans[-1][1] == n
             for a, b in zip(spans, spans[1:]):
                 assert a[1] == b[0]
+
+
+@pytest.mark.parametrize("name,d,meta", pe_cases(ok_only=False), ids=[c[0] for c in pe_cases(ok_only=False)])
+def test_native_fastq_ingest_matches_reference_semantics(name, d, meta):
+    """vs_fastq_* (C++, multi-threaded, host only) against the oracle's restatement of
+    readlines() + line[:-1] (PE_Inference.py:146-159): CRLF, missing final newline, unequal files."""
+    from vstrains_amd import pe as host
+
+    wf = pe_oracle.fastq_sequences(os.path.join(d, "fwd.fq"))
+    wr = pe_oracle.fastq_sequences(os.path.join(d, "rve.fq"))
+    for threads in ("1", "3", "8"):
+        os.environ["VS_HOST_THREADS"] = threads
+        try:
+            fq = host.FastqPair(os.path.join(d, "fwd.fq"), os.path.join(d, "rve.fq"))
+        finally:
+            os.environ.pop("VS_HOST_THREADS")
+        n = min(len(wf), len(wr))
+        assert len(fq) == n
+        for p in range(n):
+            assert fq.sequence(0, p) == wf[p]
+            assert fq.sequence(1, p) == wr[p]
+        if n:
+            data, off = fq.gather(0, n)
+            for p in range(n):
+                assert bytes(data[int(off[2 * p]):int(off[2 * p + 1])]).decode("latin-1") == wf[p]
+                assert bytes(data[int(off[2 * p + 1]):int(off[2 * p + 2])]).decode("latin-1") == wr[p]
+        fq.close()
+
+
+def test_native_fastq_ingest_odd_inputs(tmp_path):
+    from vstrains_amd import pe as host
+
+    cases = {
+        "empty": b"",
+        "one_line": b"@r",
+        "lone_cr": b"@a\rACGT\r+\rIIII\r@b\rGG\r+\rII",
+        "crlf_tail": b"@a\r\nACGT\r\n+\r\nIIII\r\n@b\r\nGGTT\r\n+\r\nIIII",
+        "blank_lines": b"\n\n\n\n@a\n\n+\n\n",
+        "three_lines": b"@a\nACGT\n+\n",
+    }
+    for name, raw in cases.items():
+        f = tmp_path / (name + "_f.fq")
+        f.write_bytes(raw)
+        want = pe_oracle.fastq_sequences(str(f))
+        fq = host.FastqPair(str(f), str(f))
+        assert len(fq) == len(want), name
+        assert [fq.sequence(0, i) for i in range(len(want))] == want, name
+        fq.close()
+    bad = tmp_path / "bad.fq"
+    bad.write_bytes(b"@a\nAC\xc3\xa9T\n+\nIIII\n")
+    with pytest.raises(ValueError):
+        host.FastqPair(str(bad), str(bad))
+    with pytest.raises(FileNotFoundError):
+        host.FastqPair(str(tmp_path / "nope.fq"), str(bad))

@@ -1,0 +1,260 @@
+// FASTQ ingest (host side, multi-threaded): the reference reads both files with readlines() in
+// text mode, takes record r as lines 4r..4r+3 and uses line 4r+1 minus its LAST CHARACTER as the
+// sequence (utils/VStrains_PE_Inference.py:146-159).  Text mode means universal newlines: "\r\n"
+// and a lone "\r" both end a line.  A final line without a newline still loses its last (real)
+// character.  total = min(len_f // 4, len_r // 4).
+//
+// vs_fastq_open maps both files and indexes the sequence lines (newline counting and line
+// location split over the host cores); vs_fastq_block gathers the sequences of a record range
+// into one interleaved ASCII buffer (forward, reverse, forward, ...) on all cores and hands it to
+// vs_reads_pack, which packs on the device.  No Python objects, no per-record allocation.
+#include <errno.h>
+#include <fcntl.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <thread>
+#include <vector>
+
+#include "vs_internal.h"
+
+namespace {
+
+struct FqFile {
+    const uint8_t *data = nullptr;
+    size_t size = 0;
+    int fd = -1;
+    std::vector<uint8_t> translated;   // only when the file holds '\r': universal-newline copy
+    std::vector<uint64_t> seq_start;   // per record: first byte of line 4r+1
+    std::vector<uint32_t> seq_len;     // ... its length after dropping the last character
+    uint64_t n_lines = 0;
+    const uint8_t *text() const { return translated.empty() ? data : translated.data(); }
+    size_t text_size() const { return translated.empty() ? size : translated.size(); }
+};
+
+unsigned n_threads() {
+    unsigned n = std::thread::hardware_concurrency();
+    if (const char *ev = getenv("VS_HOST_THREADS")) n = (unsigned)atoi(ev);
+    return std::max(1u, std::min(n, 64u));
+}
+
+template <typename F>
+void parallel_for(unsigned parts, F fn) {
+    std::vector<std::thread> th;
+    for (unsigned p = 1; p < parts; p++) th.emplace_back(fn, p);
+    fn(0u);
+    for (auto &t : th) t.join();
+}
+
+int map_file(vs_ctx *ctx, const char *path, FqFile &f) {
+    f.fd = open(path, O_RDONLY);
+    if (f.fd < 0) return vs_fail(ctx, VS_E_ARG, "cannot open %s: %s", path, strerror(errno));
+    struct stat st;
+    if (fstat(f.fd, &st) != 0) return vs_fail(ctx, VS_E_ARG, "cannot stat %s: %s", path, strerror(errno));
+    f.size = (size_t)st.st_size;
+    if (f.size) {
+        void *p = mmap(nullptr, f.size, PROT_READ, MAP_PRIVATE, f.fd, 0);
+        if (p == MAP_FAILED) return vs_fail(ctx, VS_E_OOM, "cannot map %s: %s", path, strerror(errno));
+        f.data = (const uint8_t *)p;
+        madvise(p, f.size, MADV_SEQUENTIAL);
+    }
+    return VS_OK;
+}
+
+// Index the sequence lines of one file.
+int index_file(vs_ctx *ctx, const char *path, FqFile &f) {
+    const unsigned T = n_threads();
+    // bytes >= 0x80 would be decoded (or rejected) by Python's text mode; not reproduced
+    {
+        std::vector<int> bad(T, 0), cr(T, 0);
+        parallel_for(T, [&](unsigned p) {
+            size_t lo = f.size * p / T, hi = f.size * (p + 1) / T;
+            for (size_t i = lo; i < hi; i++) {
+                uint8_t c = f.data[i];
+                if (c >= 0x80) { bad[p] = 1; break; }
+                if (c == '\r') cr[p] = 1;
+            }
+        });
+        for (unsigned p = 0; p < T; p++)
+            if (bad[p]) return vs_fail(ctx, VS_E_ARG, "%s holds non-ASCII bytes; the reference's text-mode decoding is not reproduced", path);
+        bool any_cr = false;
+        for (unsigned p = 0; p < T; p++) any_cr |= cr[p] != 0;
+        if (any_cr) {  // rare: make the universal-newline view once, then index that
+            f.translated.reserve(f.size);
+            for (size_t i = 0; i < f.size; i++) {
+                uint8_t c = f.data[i];
+                if (c == '\r') {
+                    f.translated.push_back('\n');
+                    if (i + 1 < f.size && f.data[i + 1] == '\n') i++;
+                } else {
+                    f.translated.push_back(c);
+                }
+            }
+            if (f.translated.empty() && f.size) f.translated.push_back('\n');
+        }
+    }
+    const uint8_t *txt = f.text();
+    const size_t n = f.text_size();
+    // pass 1: newlines per part
+    std::vector<uint64_t> nl(T + 1, 0);
+    parallel_for(T, [&](unsigned p) {
+        size_t lo = n * p / T, hi = n * (p + 1) / T;
+        uint64_t c = 0;
+        const uint8_t *q = txt + lo, *end = txt + hi;
+        while (q < end) {
+            const uint8_t *r = (const uint8_t *)memchr(q, '\n', (size_t)(end - q));
+            if (!r) break;
+            c++;
+            q = r + 1;
+        }
+        nl[p + 1] = c;
+    });
+    for (unsigned p = 0; p < T; p++) nl[p + 1] += nl[p];
+    const uint64_t n_newlines = nl[T];
+    const bool open_tail = n > 0 && txt[n - 1] != '\n';
+    f.n_lines = n_newlines + (open_tail ? 1 : 0);
+    const uint64_t n_rec = f.n_lines / 4;
+    f.seq_start.assign(n_rec, 0);
+    f.seq_len.assign(n_rec, 0);
+    // pass 2: the newline that ends line L (0-based) is newline number L; a sequence line has
+    // L % 4 == 1; it starts right after newline L-1
+    parallel_for(T, [&](unsigned p) {
+        size_t lo = n * p / T, hi = n * (p + 1) / T;
+        uint64_t line = nl[p];  // index of the line that the next newline in this part ends
+        // start of that line: after the previous newline (possibly in an earlier part)
+        size_t start = 0;
+        if (lo > 0) {
+            const uint8_t *r = (const uint8_t *)memrchr(txt, '\n', lo);
+            start = r ? (size_t)(r - txt) + 1 : 0;
+        }
+        const uint8_t *q = txt + lo, *end = txt + hi;
+        while (q < end) {
+            const uint8_t *r = (const uint8_t *)memchr(q, '\n', (size_t)(end - q));
+            if (!r) break;
+            if ((line & 3u) == 1u && (line >> 2) < n_rec) {
+                f.seq_start[line >> 2] = start;
+                f.seq_len[line >> 2] = (uint32_t)((size_t)(r - txt) - start);  // the dropped char is the newline
+            }
+            start = (size_t)(r - txt) + 1;
+            line++;
+            q = r + 1;
+        }
+    });
+    if (open_tail) {  // last line without newline: it loses a real character
+        const uint64_t line = n_newlines;
+        if ((line & 3u) == 1u && (line >> 2) < n_rec) {
+            const uint8_t *r = n ? (const uint8_t *)memrchr(txt, '\n', n) : nullptr;
+            size_t start = r ? (size_t)(r - txt) + 1 : 0;
+            f.seq_start[line >> 2] = start;
+            f.seq_len[line >> 2] = (uint32_t)(n - start - 1);
+        }
+    }
+    for (uint64_t r = 0; r < n_rec; r++)
+        if (f.seq_len[r] > VS_LEN_MASK) return vs_fail(ctx, VS_E_RANGE, "%s: record %llu has a %u-byte sequence line", path, (unsigned long long)r, f.seq_len[r]);
+    return VS_OK;
+}
+
+void close_file(FqFile &f) {
+    if (f.data) munmap((void *)f.data, f.size);
+    if (f.fd >= 0) close(f.fd);
+    f.data = nullptr;
+    f.fd = -1;
+}
+
+}  // namespace
+
+struct vs_fastq {
+    FqFile f[2];
+    uint64_t n_pairs = 0;
+};
+
+extern "C" {
+
+int vs_fastq_open(vs_ctx *ctx, const char *fwd_path, const char *rve_path, vs_fastq **out) {
+    if (!fwd_path || !rve_path || !out) return vs_fail(ctx, VS_E_ARG, "vs_fastq_open: bad argument");
+    *out = nullptr;
+    vs_fastq *fq = new vs_fastq();
+    const char *paths[2] = {fwd_path, rve_path};
+    for (int i = 0; i < 2; i++) {
+        int rc = map_file(ctx, paths[i], fq->f[i]);
+        if (rc == VS_OK) rc = index_file(ctx, paths[i], fq->f[i]);
+        if (rc != VS_OK) {
+            close_file(fq->f[0]);
+            close_file(fq->f[1]);
+            delete fq;
+            return rc;
+        }
+    }
+    fq->n_pairs = std::min(fq->f[0].seq_start.size(), fq->f[1].seq_start.size());  // PE_Inference.py:154
+    *out = fq;
+    return VS_OK;
+}
+
+void vs_fastq_close(vs_fastq *fq) {
+    if (!fq) return;
+    close_file(fq->f[0]);
+    close_file(fq->f[1]);
+    delete fq;
+}
+
+int vs_fastq_info(const vs_fastq *fq, uint64_t info[3]) {
+    if (!fq || !info) return VS_E_ARG;
+    info[0] = fq->n_pairs;
+    info[1] = fq->f[0].n_lines;
+    info[2] = fq->f[1].n_lines;
+    return VS_OK;
+}
+
+// Sequence of record `record` of file `which` (0 forward, 1 reverse) into buf (cap bytes); *len
+// receives its length.  Host only (tests, small tools).
+int vs_fastq_sequence(const vs_fastq *fq, int which, uint64_t record, uint8_t *buf, uint32_t cap, uint32_t *len) {
+    if (!fq || which < 0 || which > 1 || !len) return VS_E_ARG;
+    const FqFile &f = fq->f[which];
+    if (record >= f.seq_start.size()) return VS_E_RANGE;
+    *len = f.seq_len[record];
+    if (buf && cap >= *len && *len) memcpy(buf, f.text() + f.seq_start[record], *len);
+    return VS_OK;
+}
+
+// Host gather only: interleaved ASCII + offsets of pairs [first, first+count) (tests / callers
+// that want the bytes).  ascii must hold off[2*count] bytes; call with ascii == NULL to size it.
+int vs_fastq_gather(const vs_fastq *fq, uint64_t first, uint64_t count, uint64_t *off, uint8_t *ascii) {
+    if (!fq || !off || first + count > fq->n_pairs) return VS_E_ARG;
+    off[0] = 0;
+    for (uint64_t r = 0; r < count; r++) {
+        off[2 * r + 1] = off[2 * r] + fq->f[0].seq_len[first + r];
+        off[2 * r + 2] = off[2 * r + 1] + fq->f[1].seq_len[first + r];
+    }
+    if (!ascii) return VS_OK;
+    const unsigned T = n_threads();
+    parallel_for(T, [&](unsigned p) {
+        uint64_t lo = count * p / T, hi = count * (p + 1) / T;
+        for (uint64_t r = lo; r < hi; r++) {
+            for (int w = 0; w < 2; w++) {
+                const FqFile &f = fq->f[w];
+                const uint32_t l = f.seq_len[first + r];
+                if (l) memcpy(ascii + off[2 * r + w], f.text() + f.seq_start[first + r], l);
+            }
+        }
+    });
+    return VS_OK;
+}
+
+// Pairs [first, first+count) of the two files as a device read block (replaces
+// PE_Inference.py:158-159 for that range).
+int vs_fastq_block(vs_ctx *ctx, const vs_fastq *fq, uint64_t first, uint64_t count, vs_reads **out) {
+    if (!ctx || !fq || !out) return vs_fail(ctx, VS_E_ARG, "vs_fastq_block: bad argument");
+    if (first + count > fq->n_pairs) return vs_fail(ctx, VS_E_RANGE, "vs_fastq_block: pairs %llu..%llu of %llu", (unsigned long long)first, (unsigned long long)(first + count), (unsigned long long)fq->n_pairs);
+    std::vector<uint64_t> off(2 * count + 1);
+    int rc = vs_fastq_gather(fq, first, count, off.data(), nullptr);
+    if (rc) return vs_fail(ctx, rc, "vs_fastq_block: gather failed");
+    std::vector<uint8_t> ascii(off[2 * count] ? off[2 * count] : 1);
+    rc = vs_fastq_gather(fq, first, count, off.data(), ascii.data());
+    if (rc) return vs_fail(ctx, rc, "vs_fastq_block: gather failed");
+    return vs_reads_pack(ctx, ascii.data(), off.data(), 2 * count, out);
+}
+
+}  // extern "C"

@@ -85,6 +85,29 @@ __device__ __forceinline__ bool vs_extend(const uint32_t *rw, RB rbase, uint32_t
         const uint32_t rem2 = tlen - rq;
         rem = rem < rem2 ? rem : rem2;
     }
+    if (!mk && s <= 32u && rlen <= 128u + w + 32u) {
+        // common case (no masked read bytes, one left window, at most four right windows... but the
+        // seed can sit anywhere, so rem <= rlen - w): everything is loaded up front and the answer
+        // comes out of selects -- no data-dependent branch, no loop
+        uint64_t xl = (vs_win(rw, rbase + j - n0) ^ vs_win(tw, tbase + q - n0)) & vs_lowmask(2u * n0);
+        const uint64_t x0 = vs_win(rw, rbase + rj) ^ vs_win(tw, tbase + rq);
+        const uint64_t x1 = vs_win(rw, rbase + rj + 32u) ^ vs_win(tw, tbase + rq + 32u);
+        const uint64_t x2 = vs_win(rw, rbase + rj + 64u) ^ vs_win(tw, tbase + rq + 64u);
+        const uint64_t x3 = vs_win(rw, rbase + rj + 96u) ^ vs_win(tw, tbase + rq + 96u);
+        const uint64_t x4 = vs_win(rw, rbase + rj + 128u) ^ vs_win(tw, tbase + rq + 128u);
+        const uint32_t left = xl ? n0 - 1u - (uint32_t)((63 - __clzll((long long)xl)) >> 1) : n0;
+        uint32_t ext = x4 ? 128u + ((uint32_t)(__ffsll((long long)x4) - 1) >> 1) : 160u;
+        ext = x3 ? 96u + ((uint32_t)(__ffsll((long long)x3) - 1) >> 1) : ext;
+        ext = x2 ? 64u + ((uint32_t)(__ffsll((long long)x2) - 1) >> 1) : ext;
+        ext = x1 ? 32u + ((uint32_t)(__ffsll((long long)x1) - 1) >> 1) : ext;
+        ext = x0 ? ((uint32_t)(__ffsll((long long)x0) - 1) >> 1) : ext;
+        ext = ext < rem ? ext : rem;
+        const uint32_t len = left + w + ext;
+        *a_out = j - left;
+        *qa_out = q - left;
+        *len_out = len;
+        return left < s && len >= K;
+    }
     uint64_t xl = vs_win(rw, rbase + j - n0) ^ vs_win(tw, tbase + q - n0);
     uint64_t xr0 = vs_win(rw, rbase + rj) ^ vs_win(tw, tbase + rq);
     uint64_t xr1 = vs_win(rw, rbase + rj + 32u) ^ vs_win(tw, tbase + rq + 32u);
@@ -381,38 +404,55 @@ k_pe_tiles(PeParams P) {
             if (lane == 0u) carry = 0;
             __syncthreads();
             for (uint32_t wv = 0; wv < (tid >> 6); wv++) carry = s_misc[4u + wv] > carry ? s_misc[4u + wv] : carry;
+            // The thread's PPT postings go through three stages with every stage done for all of
+            // them before the next one starts: A) which posting (LDS) and its node (one global load
+            // for multi-posting seeds), B) node header, C) text windows + decision.  Stages hold no
+            // early exits, so the loads of the PPT postings are in flight together.
+            bool live[PPT];
+            uint32_t p_e[PPT], p_j[PPT], p_node[PPT], p_pos[PPT], p_opp[PPT];
 #pragma unroll
             for (uint32_t k2 = 0; k2 < PPT; k2++) {
                 const uint32_t t = c0 + tid * PPT + k2;
-                if (t >= total) break;
-                const uint32_t it = (own[k2] > carry ? own[k2] : carry) - 1u;
+                live[k2] = t < total;
+                const uint32_t it = live[k2] ? (own[k2] > carry ? own[k2] : carry) - 1u : 0u;
                 const uint32_t excl = it ? s_pcnt[it - 1u] : 0u;
                 const uint32_t cnt = s_pcnt[it] - excl;
-                uint32_t pa = s_pa[it], pb = s_pb[it];
-                const uint32_t e = vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax, j = pi * s;
-                uint32_t node, pos, opp;
-                if (cnt == 1u) {
-                    node = pa; pos = pb & 0x7FFFFFFFu; opp = pb >> 31;
+                const uint32_t pa = s_pa[it], pb = s_pb[it];
+                const uint32_t e = vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
+                p_e[k2] = e;
+                p_j[k2] = pi * s;
+                uint32_t node = pa, pos = pb & 0x7FFFFFFFu, opp = pb >> 31;
+                if (live[k2] && cnt != 1u) {
+                    const uint2 po = P.idx.postings[pa + (t - excl)];
+                    node = po.x; pos = po.y & 0x7FFFFFFFu; opp = (po.y >> 31) ^ (pb >> 31);
+                } else if (live[k2] && s <= w && pi) {
                     // Overlapping seeds (s <= w): if the previous probe of this end holds the single
                     // posting one stride back on the same diagonal, the bases in between match too,
                     // so that probe (or an earlier one) owns this match -- no memory traffic needed.
-                    if (s <= w && pi) {
-                        const uint32_t excl2 = it > 1u ? s_pcnt[it - 2u] : 0u;
-                        if (excl - excl2 == 1u && s_pa[it - 1u] == node) {
-                            uint32_t pbp = s_pb[it - 1u];
-                            uint32_t want = opp ? pos + s : pos - s;
-                            if ((pbp >> 31) == opp && (pbp & 0x7FFFFFFFu) == want && (opp || pos >= s)) continue;
-                        }
+                    const uint32_t excl2 = it > 1u ? s_pcnt[it - 2u] : 0u;
+                    if (excl - excl2 == 1u && s_pa[it - 1u] == node) {
+                        const uint32_t pbp = s_pb[it - 1u];
+                        const uint32_t want = opp ? pos + s : pos - s;
+                        if ((pbp >> 31) == opp && (pbp & 0x7FFFFFFFu) == want && (opp || pos >= s)) live[k2] = false;
                     }
-                } else {
-                    uint2 po = P.idx.postings[pa + (t - excl)];
-                    node = po.x; pos = po.y & 0x7FFFFFFFu; opp = (po.y >> 31) ^ (pb >> 31);
                 }
+                p_node[k2] = node; p_pos[k2] = pos; p_opp[k2] = opp;
+            }
+            VsNodeMeta p_nm[PPT];
+#pragma unroll
+            for (uint32_t k2 = 0; k2 < PPT; k2++) {
+                p_nm[k2].woff = 0; p_nm[k2].len = 0;
+                if (live[k2]) p_nm[k2] = P.idx.meta[p_node[k2]];
+            }
+#pragma unroll
+            for (uint32_t k2 = 0; k2 < PPT; k2++) {
+                if (!live[k2]) continue;
+                const uint32_t e = p_e[k2], j = p_j[k2], node = p_node[k2], opp = p_opp[k2];
+                const VsNodeMeta nm = p_nm[k2];
                 const uint32_t meta = s_meta[e];
                 const uint32_t rlen = meta & VS_LEN_MASK;
-                const VsNodeMeta nm = P.idx.meta[node];
                 const uint32_t *tw = opp ? P.idx.rc_words : P.idx.fwd_words;
-                const uint32_t q = opp ? nm.len - pos - w : pos;
+                const uint32_t q = opp ? nm.len - p_pos[k2] - w : p_pos[k2];
                 const uint32_t *mk = ((meta >> 24) & VS_FLAG_INVALID) ? P.rd.mask : nullptr;
                 uint32_t a, qa, len;
                 if (!vs_extend(s_words, e * wpe * 16u, rlen, tw, nm.woff * 16u, nm.len, j, q, w, s, K,

@@ -70,6 +70,64 @@ class FastqSeqs:
         return self.n_records
 
 
+class FastqPair:
+    """Both FASTQ files mapped and indexed by the library's multi-threaded host ingest
+    (``vs_fastq_*``; the product path -- ``FastqSeqs`` below is the numpy restatement kept for
+    host-side tests).  ``ctx`` may be None for host-only use."""
+
+    def __init__(self, fwd: str, rve: str, ctx: "Context" = None):
+        self._ctx = ctx
+        h = C.c_void_p()
+        rc = nat.lib().vs_fastq_open(ctx._h if ctx is not None else None, fwd.encode(), rve.encode(), C.byref(h))
+        if rc != nat.VS_OK:
+            msg = nat.lib().vs_last_error(ctx._h if ctx is not None else None).decode("utf-8", "replace")
+            if "non-ASCII" in msg:
+                raise ValueError(msg)
+            if "cannot open" in msg:
+                raise FileNotFoundError(msg)
+            raise nat.NativeError(rc, msg)
+        self._h = h
+        info = (C.c_uint64 * 3)()
+        nat.lib().vs_fastq_info(h, info)
+        self.n_pairs = int(info[0])
+        self.lines = (int(info[1]), int(info[2]))
+
+    def __len__(self):
+        return self.n_pairs
+
+    def close(self):
+        if self._h:
+            nat.lib().vs_fastq_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sequence(self, which: int, record: int) -> str:
+        n = C.c_uint32(0)
+        rc = nat.lib().vs_fastq_sequence(self._h, which, record, None, 0, C.byref(n))
+        if rc != nat.VS_OK:
+            raise IndexError(record)
+        buf = np.zeros(max(n.value, 1), dtype=np.uint8)
+        nat.lib().vs_fastq_sequence(self._h, which, record, buf.ctypes.data, buf.size, C.byref(n))
+        return bytes(buf[: n.value]).decode("latin-1")
+
+    def gather(self, first: int, count: int) -> Tuple[np.ndarray, np.ndarray]:
+        off = np.zeros(2 * count + 1, dtype=np.uint64)
+        assert nat.lib().vs_fastq_gather(self._h, first, count, off.ctypes.data, None) == nat.VS_OK
+        data = np.zeros(max(int(off[-1]), 1), dtype=np.uint8)
+        assert nat.lib().vs_fastq_gather(self._h, first, count, off.ctypes.data, data.ctypes.data) == nat.VS_OK
+        return data, off
+
+    def block(self, first: int, count: int) -> "ReadBlock":
+        h = C.c_void_p()
+        nat.check(self._ctx._h, nat.lib().vs_fastq_block(self._ctx._h, self._h, first, count, C.byref(h)))
+        return ReadBlock(self._ctx, h)
+
+
 def interleave_pairs(fwd: FastqSeqs, rve: FastqSeqs, lo: int, hi: int) -> Tuple[np.ndarray, np.ndarray]:
     """Ends 2r / 2r+1 = forward / reverse sequence of pair r, lo <= r < hi, as one byte array
     plus offsets (the layout vs_reads_pack takes)."""

@@ -23,18 +23,17 @@ def count_links(ctx, gfa: str, fwd: str, rve: str, kmer_size: int):
     counter = host.PeCounter(ctx)
 
     print("Start aligning reads to gfa nodes")  # :146
-    fq_f = host.FastqSeqs(fwd)
-    fq_r = host.FastqSeqs(rve)
-    total = min(len(fq_f), len(fq_r))  # :154
+    fq = host.FastqPair(fwd, rve, ctx)  # :146-154, native multi-threaded ingest
+    total = len(fq)
     for lo in range(0, total, BATCH_PAIRS):
         hi = min(total, lo + BATCH_PAIRS)
         for mark in range(((lo + 99999) // 100000) * 100000, hi, 100000):
             print("Number of processed reads: ", mark)  # :156-157
-        data, off = host.interleave_pairs(fq_f, fq_r, lo, hi)
-        block = ctx.pack(data, off)
+        block = fq.block(lo, hi - lo)
         counter.add(block)
         ctx.sync()
         block.free()
+    fq.close()
     return ids, counter
 
 
