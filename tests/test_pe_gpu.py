@@ -45,13 +45,10 @@ def _gpu_matrices(host, ctx, seqs, fwd, rve, k):
 @pytest.mark.parametrize("name,d,meta", pe_cases(), ids=[c[0] for c in pe_cases()])
 def test_golden_files_bit_exact(host, ctx, name, d, meta):
     ids, seqs = host.read_gfa_segments(os.path.join(d, "graph.gfa"))
-    fq_f = host.FastqSeqs(os.path.join(d, "fwd.fq"))
-    fq_r = host.FastqSeqs(os.path.join(d, "rve.fq"))
-    total = min(len(fq_f), len(fq_r))
+    fq = host.FastqPair(os.path.join(d, "fwd.fq"), os.path.join(d, "rve.fq"), ctx)  # native ingest
     ctx.build_index(seqs, meta["k"])
     counter = host.PeCounter(ctx)
-    data, off = host.interleave_pairs(fq_f, fq_r, 0, total)
-    block = ctx.pack(data, off)
+    block = fq.block(0, len(fq))
     counter.add(block)
     node_mat, short_mat, stats = counter.result()
     assert pe_oracle.matrix_text(ids, node_mat) == _read(os.path.join(d, "pe_info"))

@@ -40,40 +40,9 @@ def read_gfa_segments(path: str) -> Tuple[List[str], List[str]]:
     return ids, seqs
 
 
-class FastqSeqs:
-    """Sequence lines of a FASTQ file as (buffer, starts, lengths) without Python strings.
-    Record r is lines 4r..4r+3 of ``readlines()``; the sequence is line 4r+1 minus its last
-    character (PE_Inference.py:149-159)."""
-
-    def __init__(self, path: str):
-        with open(path, "rb") as fh:
-            raw = _universal_newlines(fh.read())
-        if raw and max(raw) >= 0x80:
-            raise ValueError("%s holds non-ASCII bytes; text-mode decoding of the reference is not reproduced" % path)
-        buf = np.frombuffer(raw, dtype=np.uint8)
-        nl = np.flatnonzero(buf == 10)
-        n_lines = nl.size + (1 if (buf.size and (nl.size == 0 or nl[-1] != buf.size - 1)) else 0)
-        starts = np.empty(n_lines, dtype=np.int64)
-        ends = np.empty(n_lines, dtype=np.int64)  # exclusive end after dropping the last character
-        if n_lines:
-            starts[0] = 0
-            starts[1:] = nl[: n_lines - 1] + 1
-            ends[: nl.size] = nl  # the dropped character is the newline itself
-            if n_lines > nl.size:
-                ends[-1] = max(buf.size - 1, starts[-1])  # last line without newline: chop a real char
-        self.buf = buf
-        self.n_records = n_lines // 4
-        self.starts = starts[1::4][: self.n_records].copy()
-        self.lens = (ends[1::4][: self.n_records] - self.starts).astype(np.int64)
-
-    def __len__(self):
-        return self.n_records
-
-
 class FastqPair:
     """Both FASTQ files mapped and indexed by the library's multi-threaded host ingest
-    (``vs_fastq_*``; the product path -- ``FastqSeqs`` below is the numpy restatement kept for
-    host-side tests).  ``ctx`` may be None for host-only use."""
+    (``vs_fastq_*``).  ``ctx`` may be None for host-only use (indexing, ``sequence``, ``gather``)."""
 
     def __init__(self, fwd: str, rve: str, ctx: "Context" = None):
         self._ctx = ctx
@@ -126,29 +95,6 @@ class FastqPair:
         h = C.c_void_p()
         nat.check(self._ctx._h, nat.lib().vs_fastq_block(self._ctx._h, self._h, first, count, C.byref(h)))
         return ReadBlock(self._ctx, h)
-
-
-def interleave_pairs(fwd: FastqSeqs, rve: FastqSeqs, lo: int, hi: int) -> Tuple[np.ndarray, np.ndarray]:
-    """Ends 2r / 2r+1 = forward / reverse sequence of pair r, lo <= r < hi, as one byte array
-    plus offsets (the layout vs_reads_pack takes)."""
-    n = hi - lo
-    lens = np.empty(2 * n, dtype=np.int64)
-    lens[0::2] = fwd.lens[lo:hi]
-    lens[1::2] = rve.lens[lo:hi]
-    off = np.zeros(2 * n + 1, dtype=np.uint64)
-    np.cumsum(lens, out=off[1:].view(np.int64))
-    total = int(off[-1])
-    out = np.empty(max(total, 1), dtype=np.uint8)
-    if total:
-        src = np.empty(2 * n, dtype=np.int64)
-        src[0::2] = fwd.starts[lo:hi]
-        src[1::2] = rve.starts[lo:hi] + fwd.buf.size  # index into the concatenation below
-        both = np.concatenate([fwd.buf, rve.buf])
-        # gather: position t of the output comes from src[e] + (t - off[e])
-        e_of_t = np.repeat(np.arange(2 * n, dtype=np.int64), lens)
-        idx = src[e_of_t] + (np.arange(total, dtype=np.int64) - off[:-1].astype(np.int64)[e_of_t])
-        out[:total] = both[idx]
-    return out, off
 
 
 def encode_seqs(seqs: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
