@@ -93,10 +93,21 @@ def strain_extract(ctx, counter, pre, names, logger, out_dir):
     from vstrains_amd.graph.hip_ops import HipBackend, HipPeLinks
 
     backend = HipBackend(ctx=ctx)
+    prof = None
+    if os.environ.get("VS_PROFILE_EXTRACT"):
+        import cProfile
+
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     table = HipPeLinks.from_counter(ctx, counter, names)
     strains = pipeline.extract_strains(pre, table, backend, logger, out_dir)
     secs = time.perf_counter() - t0
+    if prof is not None:
+        import pstats
+
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(30)
     n_stage_graphs = len([f for f in os.listdir(os.path.join(out_dir, "gfa")) if f.endswith(".gfa")])
     return {"seconds": secs, "strains": len(strains), "stage_graphs_written": n_stage_graphs,
             "graph_refresh_launches": backend.graph_ops.calls, "link_table_launches": table.calls,

@@ -94,8 +94,7 @@ int vs_fastq_sequence(const vs_fastq *fq, int which, uint64_t record, uint8_t *b
  * NULL to get the sizes only) receives the bytes.  Host pointers. */
 int vs_fastq_gather(const vs_fastq *fq, uint64_t first, uint64_t count, uint64_t *off,
                     uint8_t *ascii);
-int vs_fastq_block(vs_ctx *ctx, const vs_fastq *fq, uint64_t first, uint64_t count,
-                   vs_reads **out);
+int vs_fastq_block(vs_ctx *ctx, vs_fastq *fq, uint64_t first, uint64_t count, vs_reads **out);
 
 /* Synthetic pairs generated on the device from a seed (bench workload; the CPU twin is
  * oracle/pe_oracle.c:peo_synth_pairs).  genomes: concatenated ACGT ASCII (host), goff

@@ -77,6 +77,8 @@ void vs_ctx_destroy(vs_ctx *ctx) {
     if (ctx->d_dense) (void)hipFree(ctx->d_dense);
     for (void *q : {ctx->d_locus_keys, ctx->d_perm, ctx->d_locus_hist, ctx->d_scan_tmp, ctx->d_lists, ctx->d_list_counts})
         if (q) (void)hipFree(q);
+    for (void *q : ctx->scratch)
+        if (q) (void)hipFree(q);
     for (int i = 0; i < 5; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     delete ctx;

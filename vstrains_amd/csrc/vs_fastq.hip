@@ -169,6 +169,11 @@ void close_file(FqFile &f) {
 struct vs_fastq {
     FqFile f[2];
     uint64_t n_pairs = 0;
+    // pinned staging for vs_fastq_block (grow-only): the gather writes here, the upload reads here
+    uint8_t *stage = nullptr;
+    size_t stage_cap = 0;
+    uint64_t *stage_off = nullptr;
+    size_t stage_off_cap = 0;
 };
 
 extern "C" {
@@ -195,6 +200,8 @@ int vs_fastq_open(vs_ctx *ctx, const char *fwd_path, const char *rve_path, vs_fa
 
 void vs_fastq_close(vs_fastq *fq) {
     if (!fq) return;
+    if (fq->stage) (void)hipHostFree(fq->stage);
+    if (fq->stage_off) (void)hipHostFree(fq->stage_off);
     close_file(fq->f[0]);
     close_file(fq->f[1]);
     delete fq;
@@ -245,16 +252,31 @@ int vs_fastq_gather(const vs_fastq *fq, uint64_t first, uint64_t count, uint64_t
 
 // Pairs [first, first+count) of the two files as a device read block (replaces
 // PE_Inference.py:158-159 for that range).
-int vs_fastq_block(vs_ctx *ctx, const vs_fastq *fq, uint64_t first, uint64_t count, vs_reads **out) {
+int vs_fastq_block(vs_ctx *ctx, vs_fastq *fq, uint64_t first, uint64_t count, vs_reads **out) {
     if (!ctx || !fq || !out) return vs_fail(ctx, VS_E_ARG, "vs_fastq_block: bad argument");
     if (first + count > fq->n_pairs) return vs_fail(ctx, VS_E_RANGE, "vs_fastq_block: pairs %llu..%llu of %llu", (unsigned long long)first, (unsigned long long)(first + count), (unsigned long long)fq->n_pairs);
-    std::vector<uint64_t> off(2 * count + 1);
-    int rc = vs_fastq_gather(fq, first, count, off.data(), nullptr);
+    VS_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t need_off = sizeof(uint64_t) * (2 * count + 1);
+    if (fq->stage_off_cap < need_off) {
+        if (fq->stage_off) VS_HIP(ctx, hipHostFree(fq->stage_off));
+        fq->stage_off = nullptr;
+        fq->stage_off_cap = 0;
+        VS_HIP(ctx, hipHostMalloc((void **)&fq->stage_off, need_off + need_off / 4, hipHostMallocDefault));
+        fq->stage_off_cap = need_off + need_off / 4;
+    }
+    int rc = vs_fastq_gather(fq, first, count, fq->stage_off, nullptr);
     if (rc) return vs_fail(ctx, rc, "vs_fastq_block: gather failed");
-    std::vector<uint8_t> ascii(off[2 * count] ? off[2 * count] : 1);
-    rc = vs_fastq_gather(fq, first, count, off.data(), ascii.data());
+    const size_t need = fq->stage_off[2 * count] ? fq->stage_off[2 * count] : 1;
+    if (fq->stage_cap < need) {
+        if (fq->stage) VS_HIP(ctx, hipHostFree(fq->stage));
+        fq->stage = nullptr;
+        fq->stage_cap = 0;
+        VS_HIP(ctx, hipHostMalloc((void **)&fq->stage, need + need / 4, hipHostMallocDefault));
+        fq->stage_cap = need + need / 4;
+    }
+    rc = vs_fastq_gather(fq, first, count, fq->stage_off, fq->stage);
     if (rc) return vs_fail(ctx, rc, "vs_fastq_block: gather failed");
-    return vs_reads_pack(ctx, ascii.data(), off.data(), 2 * count, out);
+    return vs_reads_pack(ctx, fq->stage, fq->stage_off, 2 * count, out);
 }
 
 }  // extern "C"

@@ -315,24 +315,40 @@ __global__ void __launch_bounds__(256) k_edge_flow(uint32_t nv, const uint64_t *
 // host entry points
 // =============================================================================================
 namespace {
+// A view of one of the context's grow-only scratch slots: the graph stages call these entry
+// points hundreds of times per run with similar sizes, so nothing is allocated after warm-up.
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
-    }
     template <typename T>
     T *as() { return (T *)p; }
 };
 
-int dev_upload(vs_ctx *ctx, DevBuf &b, const void *host, size_t bytes) {
-    VS_HIP(ctx, hipMalloc(&b.p, bytes ? bytes : 16));
+int slot_reserve(vs_ctx *ctx, int slot, DevBuf &b, size_t bytes) {
+    if (bytes < 16) bytes = 16;
+    if (ctx->scratch_cap[slot] < bytes) {
+        VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch[slot]) VS_HIP(ctx, hipFree(ctx->scratch[slot]));
+        ctx->scratch[slot] = nullptr;
+        ctx->scratch_cap[slot] = 0;
+        size_t cap = bytes + bytes / 2;
+        VS_HIP(ctx, hipMalloc(&ctx->scratch[slot], cap));
+        ctx->scratch_cap[slot] = cap;
+    }
+    b.p = ctx->scratch[slot];
+    return VS_OK;
+}
+
+struct SlotCounter {
+    int next = 0;
+};
+
+int dev_upload(vs_ctx *ctx, SlotCounter &sc, DevBuf &b, const void *host, size_t bytes) {
+    int rc = slot_reserve(ctx, sc.next++, b, bytes);
+    if (rc) return rc;
     if (bytes) VS_HIP(ctx, hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     return VS_OK;
 }
-int dev_alloc(vs_ctx *ctx, DevBuf &b, size_t bytes) {
-    VS_HIP(ctx, hipMalloc(&b.p, bytes ? bytes : 16));
-    return VS_OK;
-}
+int dev_alloc(vs_ctx *ctx, SlotCounter &sc, DevBuf &b, size_t bytes) { return slot_reserve(ctx, sc.next++, b, bytes); }
 #define VS_TRY(x)            \
     do {                     \
         int rc__ = (x);      \
@@ -376,10 +392,11 @@ int vs_links_from_counts(vs_ctx *ctx, const uint32_t *d_node_mat, const uint32_t
 int vs_links_from_host(vs_ctx *ctx, const int64_t *node_mat, const int64_t *short_mat, uint32_t n, vs_links **out) {
     if (!ctx || !out || (n && (!node_mat || !short_mat))) return vs_fail(ctx, VS_E_ARG, "vs_links_from_host: bad argument");
     VS_HIP(ctx, hipSetDevice(ctx->device));
+    SlotCounter sc;
     DevBuf a, b;
     size_t bytes = (size_t)n * n * sizeof(int64_t);
-    VS_TRY(dev_upload(ctx, a, node_mat, bytes));
-    VS_TRY(dev_upload(ctx, b, short_mat, bytes));
+    VS_TRY(dev_upload(ctx, sc, a, node_mat, bytes));
+    VS_TRY(dev_upload(ctx, sc, b, short_mat, bytes));
     int rc = links_build<int64_t>(ctx, a.as<int64_t>(), b.as<int64_t>(), n, out);
     VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return rc;
@@ -427,12 +444,13 @@ int vs_links_block_sums(vs_ctx *ctx, const vs_links *links, const uint64_t *list
     for (uint64_t q = 0; q < n_queries; q++)
         if (qa[q] >= n_lists || qb[q] >= n_lists) return vs_fail(ctx, VS_E_RANGE, "query %llu names a list out of range", (unsigned long long)q);
     VS_HIP(ctx, hipSetDevice(ctx->device));
+    SlotCounter sc;
     DevBuf d_off, d_idx, d_qa, d_qb, d_out;
-    VS_TRY(dev_upload(ctx, d_off, list_off, (size_t)(n_lists + 1) * sizeof(uint64_t)));
-    VS_TRY(dev_upload(ctx, d_idx, list_idx, (size_t)list_off[n_lists] * sizeof(uint32_t)));
-    VS_TRY(dev_upload(ctx, d_qa, qa, (size_t)n_queries * sizeof(uint32_t)));
-    VS_TRY(dev_upload(ctx, d_qb, qb, (size_t)n_queries * sizeof(uint32_t)));
-    VS_TRY(dev_alloc(ctx, d_out, (size_t)n_queries * sizeof(int64_t)));
+    VS_TRY(dev_upload(ctx, sc, d_off, list_off, (size_t)(n_lists + 1) * sizeof(uint64_t)));
+    VS_TRY(dev_upload(ctx, sc, d_idx, list_idx, (size_t)list_off[n_lists] * sizeof(uint32_t)));
+    VS_TRY(dev_upload(ctx, sc, d_qa, qa, (size_t)n_queries * sizeof(uint32_t)));
+    VS_TRY(dev_upload(ctx, sc, d_qb, qb, (size_t)n_queries * sizeof(uint32_t)));
+    VS_TRY(dev_alloc(ctx, sc, d_out, (size_t)n_queries * sizeof(int64_t)));
     const unsigned waves = 256 / VS_WAVE;
     hipLaunchKernelGGL(k_links_block_sums, dim3((unsigned)((n_queries + waves - 1) / waves)), dim3(256), 0, ctx->stream,
                        links->d_p0, links->n, d_off.as<uint64_t>(), d_idx.as<uint32_t>(), d_qa.as<uint32_t>(),
@@ -451,11 +469,12 @@ int vs_links_group_matrix(vs_ctx *ctx, const vs_links *links, const uint64_t *li
     VS_TRY(check_lists(ctx, links, list_off, list_idx, n_groups));
     VS_HIP(ctx, hipSetDevice(ctx->device));
     uint32_t n = links->n;
+    SlotCounter sc;
     DevBuf d_off, d_idx, d_t, d_out;
-    VS_TRY(dev_upload(ctx, d_off, list_off, (size_t)(n_groups + 1) * sizeof(uint64_t)));
-    VS_TRY(dev_upload(ctx, d_idx, list_idx, (size_t)list_off[n_groups] * sizeof(uint32_t)));
-    VS_TRY(dev_alloc(ctx, d_t, (size_t)n_groups * (n ? n : 1) * sizeof(int64_t)));
-    VS_TRY(dev_alloc(ctx, d_out, (size_t)n_groups * n_groups * sizeof(int64_t)));
+    VS_TRY(dev_upload(ctx, sc, d_off, list_off, (size_t)(n_groups + 1) * sizeof(uint64_t)));
+    VS_TRY(dev_upload(ctx, sc, d_idx, list_idx, (size_t)list_off[n_groups] * sizeof(uint32_t)));
+    VS_TRY(dev_alloc(ctx, sc, d_t, (size_t)n_groups * (n ? n : 1) * sizeof(int64_t)));
+    VS_TRY(dev_alloc(ctx, sc, d_out, (size_t)n_groups * n_groups * sizeof(int64_t)));
     if (n) {
         hipLaunchKernelGGL(k_links_group_rows, dim3((n + 255) / 256, n_groups), dim3(256), 0, ctx->stream, links->d_p0, n,
                            d_off.as<uint64_t>(), d_idx.as<uint32_t>(), d_t.as<int64_t>());
@@ -487,27 +506,28 @@ int vs_graph_refresh(vs_ctx *ctx, uint32_t n_vertices, uint32_t n_edge_slots, co
     for (uint64_t i = 0; i < n_adj; i++)
         if (nbr[i] >= n_vertices || eidx[i] >= n_edge_slots) return vs_fail(ctx, VS_E_RANGE, "vs_graph_refresh: adjacency entry %llu out of range", (unsigned long long)i);
     VS_HIP(ctx, hipSetDevice(ctx->device));
+    SlotCounter sc;
     DevBuf d_row, d_no, d_nbr, d_eidx, d_dp, d_vb, d_eb, d_os, d_is, d_nt, d_fk, d_nx, d_pd, d_flow, d_bad;
     DevBuf d_anc[2], d_rank[2], d_top[2];
-    VS_TRY(dev_upload(ctx, d_row, row_ptr, (size_t)(n_vertices + 1) * sizeof(uint64_t)));
-    VS_TRY(dev_upload(ctx, d_no, n_out, (size_t)n_vertices * sizeof(uint32_t)));
-    VS_TRY(dev_upload(ctx, d_nbr, nbr, (size_t)n_adj * sizeof(uint32_t)));
-    VS_TRY(dev_upload(ctx, d_eidx, eidx, (size_t)n_adj * sizeof(uint32_t)));
-    VS_TRY(dev_upload(ctx, d_dp, dp, (size_t)n_vertices * sizeof(double)));
-    VS_TRY(dev_upload(ctx, d_vb, vertex_black, (size_t)n_vertices));
-    VS_TRY(dev_upload(ctx, d_eb, edge_black, (size_t)n_edge_slots));
-    VS_TRY(dev_alloc(ctx, d_os, (size_t)n_vertices * sizeof(double)));
-    VS_TRY(dev_alloc(ctx, d_is, (size_t)n_vertices * sizeof(double)));
-    VS_TRY(dev_alloc(ctx, d_nt, n_vertices));
-    VS_TRY(dev_alloc(ctx, d_fk, n_vertices));
-    VS_TRY(dev_alloc(ctx, d_nx, (size_t)n_vertices * sizeof(int32_t)));
-    VS_TRY(dev_alloc(ctx, d_pd, (size_t)n_vertices * sizeof(int32_t)));
-    VS_TRY(dev_alloc(ctx, d_flow, (size_t)(n_edge_slots ? n_edge_slots : 1) * sizeof(double)));
-    VS_TRY(dev_alloc(ctx, d_bad, sizeof(uint32_t)));
+    VS_TRY(dev_upload(ctx, sc, d_row, row_ptr, (size_t)(n_vertices + 1) * sizeof(uint64_t)));
+    VS_TRY(dev_upload(ctx, sc, d_no, n_out, (size_t)n_vertices * sizeof(uint32_t)));
+    VS_TRY(dev_upload(ctx, sc, d_nbr, nbr, (size_t)n_adj * sizeof(uint32_t)));
+    VS_TRY(dev_upload(ctx, sc, d_eidx, eidx, (size_t)n_adj * sizeof(uint32_t)));
+    VS_TRY(dev_upload(ctx, sc, d_dp, dp, (size_t)n_vertices * sizeof(double)));
+    VS_TRY(dev_upload(ctx, sc, d_vb, vertex_black, (size_t)n_vertices));
+    VS_TRY(dev_upload(ctx, sc, d_eb, edge_black, (size_t)n_edge_slots));
+    VS_TRY(dev_alloc(ctx, sc, d_os, (size_t)n_vertices * sizeof(double)));
+    VS_TRY(dev_alloc(ctx, sc, d_is, (size_t)n_vertices * sizeof(double)));
+    VS_TRY(dev_alloc(ctx, sc, d_nt, n_vertices));
+    VS_TRY(dev_alloc(ctx, sc, d_fk, n_vertices));
+    VS_TRY(dev_alloc(ctx, sc, d_nx, (size_t)n_vertices * sizeof(int32_t)));
+    VS_TRY(dev_alloc(ctx, sc, d_pd, (size_t)n_vertices * sizeof(int32_t)));
+    VS_TRY(dev_alloc(ctx, sc, d_flow, (size_t)(n_edge_slots ? n_edge_slots : 1) * sizeof(double)));
+    VS_TRY(dev_alloc(ctx, sc, d_bad, sizeof(uint32_t)));
     for (int i = 0; i < 2; i++) {
-        VS_TRY(dev_alloc(ctx, d_anc[i], (size_t)n_vertices * sizeof(int32_t)));
-        VS_TRY(dev_alloc(ctx, d_rank[i], (size_t)n_vertices * sizeof(int32_t)));
-        VS_TRY(dev_alloc(ctx, d_top[i], (size_t)n_vertices * sizeof(int32_t)));
+        VS_TRY(dev_alloc(ctx, sc, d_anc[i], (size_t)n_vertices * sizeof(int32_t)));
+        VS_TRY(dev_alloc(ctx, sc, d_rank[i], (size_t)n_vertices * sizeof(int32_t)));
+        VS_TRY(dev_alloc(ctx, sc, d_top[i], (size_t)n_vertices * sizeof(int32_t)));
     }
     VS_HIP(ctx, hipMemsetAsync(d_bad.p, 0xFF, sizeof(uint32_t), ctx->stream));
     VS_HIP(ctx, hipMemsetAsync(d_flow.p, 0, (size_t)(n_edge_slots ? n_edge_slots : 1) * sizeof(double), ctx->stream));

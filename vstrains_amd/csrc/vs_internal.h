@@ -81,6 +81,9 @@ struct vs_ctx {
     // per-end accepted lists between k_pe_tiles and k_pe_accumulate
     void *d_lists = nullptr, *d_list_counts = nullptr;
     uint64_t lists_cap = 0;
+    // grow-only device scratch slots of the graph-stage entry points (no hipMalloc per call)
+    void *scratch[32] = {};
+    size_t scratch_cap[32] = {};
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double last_ms[3] = {0, 0, 0};
     int n_cu = 256;

@@ -63,21 +63,53 @@ def read_stage_gfa(filename: str) -> Tuple[AsmGraph, NodeMap, EdgeMap]:
 
 def stage_graph_from_state(g: AsmGraph, nodes: NodeMap, edges: EdgeMap) -> Tuple[AsmGraph, NodeMap, EdgeMap]:
     """The graph ``read_stage_gfa(write_stage_gfa(...))`` would give, without the file: same
-    filtering and order; ``float(repr(x)) == x`` so dp survives exactly."""
+    filtering and order; ``float(repr(x)) == x`` so dp survives exactly.  This runs once per
+    re-initialisation (~100 times per run), so the rows are built in place instead of through
+    ``add_vertex`` / ``add_edge`` calls -- same placement rule as ``AsmGraph.add_edge``."""
     ng = AsmGraph()
     nn: NodeMap = {}
     ne: EdgeMap = {}
+    vblack, vid, vdp, vseq = g.vblack, g.vid, g.vdp, g.vseq
+    n_vid, n_vdp, n_vseq = ng.vid, ng.vdp, ng.vseq
     for v in nodes.values():
-        if g.vblack[v]:
-            nn[g.vid[v]] = ng.add_vertex(g.vid[v], g.vdp[v], g.vseq[v], BLACK)
-    for (u, w), e in edges.items():
-        vu = nodes.get(u)
-        vw = nodes.get(w)
-        if vu is None or vw is None:
+        if vblack[v]:
+            nn[vid[v]] = len(n_vid)
+            n_vid.append(vid[v])
+            n_vdp.append(vdp[v])
+            n_vseq.append(vseq[v])
+    nv = len(n_vid)
+    ng.vblack = [BLACK] * nv
+    adj = [[] for _ in range(nv)]
+    nout = [0] * nv
+    esrc, etgt, eovl = ng.esrc, ng.etgt, ng.eovl
+    eblack, eovl_src = g.eblack, g.eovl
+    get = nn.get
+    for key, e in edges.items():
+        s = get(key[0])
+        t = get(key[1])
+        if s is None or t is None or not eblack[e]:
             continue
-        if not (g.vblack[vu] and g.vblack[vw] and g.eblack[e]):
-            continue
-        ne[(u, w)] = ng.add_edge(nn[u], nn[w], g.eovl[e], None, BLACK)
+        # (a vertex missing from ``nn`` is either unmapped or gray: the reference's three tests)
+        ei = len(esrc)
+        esrc.append(s)
+        etgt.append(t)
+        eovl.append(eovl_src[e])
+        row = adj[s]
+        slot = nout[s]
+        if slot < len(row):
+            row.append(row[slot])
+            row[slot] = (t, ei)
+        else:
+            row.append((t, ei))
+        nout[s] = slot + 1
+        adj[t].append((s, ei))
+        ne[key] = ei
+    ne_count = len(esrc)
+    ng.adj = adj
+    ng.nout = nout
+    ng.eflow = [0.0] * ne_count
+    ng.eblack = [BLACK] * ne_count
+    ng._n_edges = ne_count
     return ng, nn, ne
 
 
