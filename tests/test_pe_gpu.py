@@ -227,3 +227,26 @@ def test_device_read_generator_equals_cpu_twin(host, ctx):
     ref_node, ref_short, ref_stats = orc.count_pairs(f, r)
     assert np.array_equal(node_mat, ref_node) and np.array_equal(short_mat, ref_short)
     assert stats == tuple(int(x) for x in ref_stats)
+
+
+@pytest.mark.parametrize("env", [
+    {"VS_NO_SORT": "1"}, {"VS_NO_AGG": "1"}, {"VS_LOCUS_GLOBAL": "1"}, {"VS_EPT": "32"}, {"VS_EPT": "128"},
+    {"VS_EPT": "6", "VS_GRID_PER_CU": "1"}, {"VS_ACC_FILL": "1"}, {"VS_ACC_FILL": "100"},
+], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_every_kernel_variant_gives_the_same_counters(host, ctx, env, monkeypatch):
+    """The tuning switches select other code paths (input order instead of locus order, global
+    atomics instead of the LDS cell table, the global-atomic sort, other tile sizes, table
+    flushed constantly / never): all of them must produce the oracle's counters."""
+    from vstrains_amd import synth
+
+    st = synth.make_strains(5, 4000, 0.04, seed=31)
+    g = synth.compact_dbg(st, 41)
+    fwd, rve = synth.sample_pairs(st, 12000, 120, seed=32, sub_rate=0.01, n_rate=0.01)
+    orc = pe_oracle_c.Oracle(g.seqs, 41)
+    want = orc.count_pairs(fwd, rve)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    (node_mat, short_mat, stats), _ = _gpu_matrices(host, ctx, g.seqs, fwd, rve, 41)
+    assert np.array_equal(node_mat, want[0])
+    assert np.array_equal(short_mat, want[1])
+    assert stats == tuple(int(x) for x in want[2])

@@ -981,7 +981,8 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     VS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
     if (use_sort) {
         const uint64_t nk = (uint64_t)idx.n_nodes + 2u;
-        if (nk <= LOCUS_LDS_KEYS) {
+        const bool lds_sort = nk <= LOCUS_LDS_KEYS && !(getenv("VS_LOCUS_GLOBAL") && atoi(getenv("VS_LOCUS_GLOBAL")) != 0);
+        if (lds_sort) {
             const uint32_t n_wg = LOCUS_WGS;
             const uint32_t chunk = (uint32_t)((n_pairs + n_wg - 1) / n_wg);
             const size_t lds_keys = sizeof(uint32_t) * nk;
