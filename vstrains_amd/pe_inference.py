@@ -11,8 +11,20 @@ import sys
 import time
 
 from . import pe as host
+from .dist import shard_range
 
 BATCH_PAIRS = 1 << 20
+
+
+def _rank_world():
+    try:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    return 0, 1
 
 
 def count_links(ctx, gfa: str, fwd: str, rve: str, kmer_size: int):
@@ -25,15 +37,22 @@ def count_links(ctx, gfa: str, fwd: str, rve: str, kmer_size: int):
     print("Start aligning reads to gfa nodes")  # :146
     fq = host.FastqPair(fwd, rve, ctx)  # :146-154, native multi-threaded ingest
     total = len(fq)
-    for lo in range(0, total, BATCH_PAIRS):
-        hi = min(total, lo + BATCH_PAIRS)
-        for mark in range(((lo + 99999) // 100000) * 100000, hi, 100000):
-            print("Number of processed reads: ", mark)  # :156-157
+    # one process per GPU (torchrun): this rank counts its contiguous block of the pairs and the
+    # counters are summed over ranks afterwards (RCCL all-reduce); a single process takes everything
+    rank, world = _rank_world()
+    first, last = shard_range(total, rank, world)
+    for lo in range(first, last, BATCH_PAIRS):
+        hi = min(last, lo + BATCH_PAIRS)
+        if rank == 0:
+            for mark in range(((lo + 99999) // 100000) * 100000, hi, 100000):
+                print("Number of processed reads: ", mark)  # :156-157 (rank 0's own block under torchrun)
         block = fq.block(lo, hi - lo)
         counter.add(block)
         ctx.sync()
         block.free()
     fq.close()
+    if world > 1:
+        counter.all_reduce()
     return ids, counter
 
 
@@ -58,11 +77,13 @@ def run(gfa: str, out_dir: str, fwd: str, rve: str, kmer_size: int, device: int 
     if ctx is None:
         ctx = host.Context(device)
     ids, counter = count_links(ctx, gfa, fwd, rve, kmer_size)
+    run.last = (ids, counter)
+    if _rank_world()[0] != 0:
+        return None  # every rank holds the summed counters; rank 0 writes the files
     out_file, stats = write_info_files(out_dir, ids, counter)
     glb_elapsed = time.time() - glb_start
     print("Global time elapsed: ", glb_elapsed)  # :209-211
     print("result stored in: ", out_file)
-    run.last = (ids, counter)
     return stats
 
 
@@ -77,7 +98,22 @@ def main(argv=None):
     parser.add_argument("-k", "--kmer_size", dest="kmer_size", type=int, default=128, help="unique kmer size")
     parser.add_argument("--device", dest="device", type=int, default=0, help="HIP device ordinal (extension)")
     args = parser.parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:  # launched by torchrun: one rank per GPU, counters all-reduced over RCCL
+        import torch
+        import torch.distributed as dist
+
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        args.device = local
     run(args.gfa, args.dir, args.fwd, args.rve, args.kmer_size, args.device)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
