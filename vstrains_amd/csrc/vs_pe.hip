@@ -37,7 +37,9 @@
 #define TPB 256
 #define LC 16u  // accepted nodes kept per read end in LDS (more -> slow path)
 #define EMPTY_NODE 0xFFFFFFFFu
+#ifndef PPT
 #define PPT 4u               // postings per thread and expansion chunk
+#endif
 #define CHUNK (TPB * PPT)
 
 struct PeParams {
