@@ -538,11 +538,44 @@ k_pe_tiles(PeParams P) {
 // Scattered global atomics run at ~2e10/s chip-wide and would bound the whole step (5.4e8 increments
 // at configs[2]), so a workgroup (1024 threads, one per CU, a contiguous run of pairs = a few loci)
 // first sums increments per cell in a 16k-slot LDS table and issues ONE global atomic per cell when
-// the table is written out.  One wavefront expands 64 pairs at a time, one lane per list row.
+// the table is written out.  One wavefront expands 64 pairs at a time, one lane per run of at
+// most four increments.
 #define ACC_TPB 1024
 #define ACC_BITS 14
 #define ACC_SLOTS (1u << ACC_BITS)
-#define ACC_LDS_BYTES ((2u * ACC_SLOTS + (ACC_TPB / 64) * 66u + 2u) * 4u)
+#define ACC_LDS_BYTES ((2u * ACC_SLOTS + (ACC_TPB / 64) * 66u + (LC + 1u) + (LC + 1u) * 40u + 2u) * 4u)
+// Work units: a list row is cut into runs of at most ACC_RUN partners, one lane per run, so that
+// every lane of a wavefront has about the same (small, fully unrolled) amount of work:
+//   node_mat : left node a against right positions [4c, 4c+4)           -> nl * ceil(nr/4) runs
+//   short_mat: list position a against positions [a+4c, a+4c+4) (b >= a) -> g(n) runs per list,
+//              g(n) = sum_{m=1..n} ceil(m/4)
+#define ACC_RUN 4u
+#define ACC_GMAX 40u  // g(16)
+__device__ __forceinline__ void vs_cell_add(uint32_t *s_key, uint32_t *s_cnt, uint32_t &s_used, uint32_t &s_lost, bool use_table,
+                                            uint32_t mat, uint32_t x, uint32_t yv, uint32_t N, uint32_t NN,
+                                            uint32_t *node_mat, uint32_t *short_mat) {
+    const uint32_t cx = (mat && yv < x) ? yv : x, cy = (mat && yv < x) ? x : yv;
+    bool done = false;
+    if (use_table) {
+        const uint32_t key = mat * NN + cx * N + cy;  // use_table => 2*N*N < 2^32
+        uint32_t at = (key * 0x9E3779B1u) >> (32u - ACC_BITS);
+        for (uint32_t pr = 0; pr < 8u && !done; pr++) {
+            uint32_t kx = s_key[at];
+            if (kx == EMPTY_NODE) {
+                kx = atomicCAS(&s_key[at], EMPTY_NODE, key);
+                if (kx == EMPTY_NODE) { atomicAdd(&s_used, 1u); kx = key; }
+            }
+            if (kx == key) {
+                atomicAdd(&s_cnt[at], 1u);
+                done = true;
+            }
+            at = (at + 1u) & (ACC_SLOTS - 1u);
+        }
+        if (!done) atomicAdd(&s_lost, 1u);
+    }
+    if (!done) atomicAdd((mat ? short_mat : node_mat) + (uint64_t)cx * N + cy, 1u);
+}
+
 __global__ void __launch_bounds__(ACC_TPB)
 k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_slots_pairs,
                 uint32_t pairs_per_wg, uint32_t N, uint32_t use_table, uint32_t fill_limit,
@@ -550,10 +583,21 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
     uint32_t *s_key = vs_lds;                      // [ACC_SLOTS]
     uint32_t *s_cnt = vs_lds + ACC_SLOTS;          // [ACC_SLOTS]
     uint32_t(*s_pref)[66] = (uint32_t(*)[66])(vs_lds + 2u * ACC_SLOTS);  // [ACC_TPB / 64][66]
-    uint32_t &s_used = vs_lds[2u * ACC_SLOTS + (ACC_TPB / 64) * 66u];
-    uint32_t &s_lost = vs_lds[2u * ACC_SLOTS + (ACC_TPB / 64) * 66u + 1u];
+    uint32_t *s_g = vs_lds + 2u * ACC_SLOTS + (ACC_TPB / 64) * 66u;      // [LC + 1]: g(n)
+    uint32_t *s_ua = s_g + (LC + 1u);                                     // [LC + 1][ACC_GMAX]: run -> position a
+    uint32_t &s_used = s_ua[(LC + 1u) * ACC_GMAX];
+    uint32_t &s_lost = s_ua[(LC + 1u) * ACC_GMAX + 1u];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     for (uint32_t i = tid; i < ACC_SLOTS; i += ACC_TPB) { s_key[i] = EMPTY_NODE; s_cnt[i] = 0; }
+    if (tid <= LC) {
+        uint32_t gsum = 0;
+        for (uint32_t m = 1; m <= tid; m++) gsum += (m + ACC_RUN - 1u) / ACC_RUN;
+        s_g[tid] = gsum;
+        // runs of an n-list in order: position a = 0 first (n - a partners), then a = 1, ...
+        uint32_t r = 0;
+        for (uint32_t a2 = 0; a2 < tid; a2++)
+            for (uint32_t c = 0; c < (tid - a2 + ACC_RUN - 1u) / ACC_RUN; c++) s_ua[tid * ACC_GMAX + r++] = a2;
+    }
     if (tid == 0) { s_used = 0; s_lost = 0; }
     __syncthreads();
     const uint64_t lo = (uint64_t)blockIdx.x * pairs_per_wg;
@@ -568,10 +612,7 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
             const uint2 c = *(const uint2 *)(wcounts + 2u * lane);
             nl = c.x; nr = c.y;
         }
-        // One lane per list ROW: a pair has nl node_mat rows (left node x against every right node),
-        // nl short_mat rows of the left list (position a against positions b >= a) and nr of the
-        // right list.  The lane walks its row; lanes of one pair read the same partner list.
-        const uint32_t u = 2u * nl + nr;
+        const uint32_t u = nl * ((nr + ACC_RUN - 1u) / ACC_RUN) + s_g[nl] + s_g[nr];
         uint32_t incl = u;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -585,58 +626,42 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
         // (the same wavefront wrote and reads s_pref: no workgroup barrier, only the LDS wait)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        uint32_t cur = 0;  // wave-uniform: first pair whose rows reach into the current window
+        uint32_t cur = 0;  // wave-uniform: first pair whose runs reach into the current window
         for (uint32_t t0 = 0; t0 < U; t0 += 64u) {
             while (s_pref[wv][cur + 1u] <= t0) cur++;
             const uint32_t t = t0 + lane;
-            uint32_t x = 0, mat = 0, off = 0, bi = 0, be = 0;  // row: fixed node, matrix, partner list, range
-            if (t < U) {
-                uint32_t a0 = cur;  // last pair of this wavefront with pref <= t
-                a0 += s_pref[wv][a0 + 1u] <= t ? 1u : 0u;
-                a0 += s_pref[wv][a0 + 1u] <= t ? 1u : 0u;
-                while (s_pref[wv][a0 + 1u] <= t) a0++;
-                uint32_t r = t - s_pref[wv][a0];
-                const uint2 c = *(const uint2 *)(wcounts + 2u * a0);
-                const uint32_t ql = c.x, qr = c.y;
-                const uint32_t row = 2u * a0 * LC;
-                if (r < ql) {                 // node_mat row: left node r against all right nodes
-                    x = wlists[row + r]; mat = 0u; off = row + LC; bi = 0; be = qr;
-                } else if (r < 2u * ql) {     // short_mat row of the left list
-                    r -= ql;
-                    x = wlists[row + r]; mat = 1u; off = row; bi = r; be = ql;
-                } else {                      // short_mat row of the right list
-                    r -= 2u * ql;
-                    x = wlists[row + LC + r]; mat = 1u; off = row + LC; bi = r; be = qr;
-                }
+            if (t >= U) break;
+            uint32_t a0 = cur;  // last pair of this wavefront with pref <= t
+            a0 += s_pref[wv][a0 + 1u] <= t ? 1u : 0u;
+            a0 += s_pref[wv][a0 + 1u] <= t ? 1u : 0u;
+            a0 += s_pref[wv][a0 + 1u] <= t ? 1u : 0u;
+            while (s_pref[wv][a0 + 1u] <= t) a0++;
+            uint32_t r = t - s_pref[wv][a0];
+            const uint2 c = *(const uint2 *)(wcounts + 2u * a0);
+            const uint32_t ql = c.x, qr = c.y;
+            const uint32_t row = 2u * a0 * LC;
+            const uint32_t cq = (qr + ACC_RUN - 1u) / ACC_RUN;
+            uint32_t x, mat, off, bi, be;
+            if (r < ql * cq) {  // node_mat: left node a, right positions of run c
+                const uint32_t a = cq == 1u ? r : cq == 2u ? r >> 1 : cq == 4u ? r >> 2 : (r * 43691u) >> 17;
+                x = wlists[row + a]; mat = 0u; off = row + LC; bi = ACC_RUN * (r - a * cq); be = qr;
+            } else {
+                r -= ql * cq;
+                uint32_t n = ql;
+                off = row;
+                if (r >= s_g[ql]) { r -= s_g[ql]; n = qr; off = row + LC; }
+                const uint32_t a = s_ua[n * ACC_GMAX + r];
+                const uint32_t crun = r - (s_g[n] - s_g[n - a]);  // runs of positions before a: g(n) - g(n-a)
+                x = wlists[off + a]; mat = 1u; bi = a + ACC_RUN * crun; be = n;
             }
-            uint32_t ynext = bi < be ? wlists[off + bi] : 0u;  // one partner ahead: hides the load latency
-            while (__ballot(bi < be)) {
-                const uint32_t yv = ynext;
-                ynext = bi + 1u < be ? wlists[off + bi + 1u] : 0u;
-                if (bi < be) {
-                    const uint32_t cx = (mat && yv < x) ? yv : x, cy = (mat && yv < x) ? x : yv;
-                    bool done = false;
-                    if (use_table) {
-                        const uint32_t key = mat * NN + cx * N + cy;  // use_table => 2*N*N < 2^32
-                        uint32_t at = (key * 0x9E3779B1u) >> (32u - ACC_BITS);
-                        for (uint32_t pr = 0; pr < 8u && !done; pr++) {
-                            uint32_t kx = s_key[at];
-                            if (kx == EMPTY_NODE) {
-                                kx = atomicCAS(&s_key[at], EMPTY_NODE, key);
-                                if (kx == EMPTY_NODE) { atomicAdd(&s_used, 1u); kx = key; }
-                            }
-                            if (kx == key) {
-                                atomicAdd(&s_cnt[at], 1u);
-                                done = true;
-                            }
-                            at = (at + 1u) & (ACC_SLOTS - 1u);
-                        }
-                        if (!done) atomicAdd(&s_lost, 1u);
-                    }
-                    if (!done) atomicAdd((mat ? short_mat : node_mat) + (uint64_t)cx * N + cy, 1u);
-                    bi++;
-                }
-            }
+            // up to ACC_RUN partners, loaded together (the row holds LC entries; reading a few words
+            // past `be` stays inside the lists buffer, which carries padding, and is ignored)
+            const uint32_t y0 = wlists[off + bi], y1 = wlists[off + bi + 1u], y2 = wlists[off + bi + 2u],
+                           y3 = wlists[off + bi + 3u];
+            vs_cell_add(s_key, s_cnt, s_used, s_lost, use_table, mat, x, y0, N, NN, node_mat, short_mat);  // bi < be always
+            if (bi + 1u < be) vs_cell_add(s_key, s_cnt, s_used, s_lost, use_table, mat, x, y1, N, NN, node_mat, short_mat);
+            if (bi + 2u < be) vs_cell_add(s_key, s_cnt, s_used, s_lost, use_table, mat, x, y2, N, NN, node_mat, short_mat);
+            if (bi + 3u < be) vs_cell_add(s_key, s_cnt, s_used, s_lost, use_table, mat, x, y3, N, NN, node_mat, short_mat);
         }
         __syncthreads();
         const bool spill = s_used > fill_limit || s_lost > 4096u;
@@ -938,7 +963,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         if (ctx->d_list_counts) VS_HIP(ctx, hipFree(ctx->d_list_counts));
         ctx->d_lists = ctx->d_list_counts = nullptr;
         ctx->lists_cap = 0;
-        VS_HIP(ctx, hipMalloc(&ctx->d_lists, sizeof(uint32_t) * list_ends * LC));
+        VS_HIP(ctx, hipMalloc(&ctx->d_lists, sizeof(uint32_t) * (list_ends * LC + 16)));
         VS_HIP(ctx, hipMalloc(&ctx->d_list_counts, sizeof(uint32_t) * (list_ends + 2)));
         ctx->lists_cap = list_ends;
     }
