@@ -66,6 +66,44 @@ struct Mem {  // one credited maximal exact match
     uint32_t cnt, minp, minj;
 };
 
+// Straight-line form of vs_extend for the common block shape (no masked read bytes anywhere in
+// the block, probe stride <= 32, reads <= 191 bases with w = 31): one left window, five right
+// windows, everything loaded up front, the answer out of selects -- no data-dependent branch.
+// The host picks the kernel instantiation (k_pe_tiles<true>) when the whole block qualifies.
+template <typename RB>
+__device__ __forceinline__ bool vs_extend_fast(const uint32_t *rw, RB rbase, uint32_t rlen, const uint32_t *tw,
+                                               uint32_t tbase, uint32_t tlen, uint32_t j, uint32_t q, uint32_t w,
+                                               uint32_t s, uint32_t K, uint32_t *a_out, uint32_t *qa_out,
+                                               uint32_t *len_out) {
+    uint32_t c = s < j ? s : j;
+    c = c < q ? c : q;
+    const uint32_t n0 = c;  // s <= 32
+    const uint32_t rj = j + w, rq = q + w;
+    uint32_t rem = rlen - rj;
+    {
+        const uint32_t rem2 = tlen - rq;
+        rem = rem < rem2 ? rem : rem2;
+    }
+    const uint64_t xl = (vs_win(rw, rbase + j - n0) ^ vs_win(tw, tbase + q - n0)) & vs_lowmask(2u * n0);
+    const uint64_t x0 = vs_win(rw, rbase + rj) ^ vs_win(tw, tbase + rq);
+    const uint64_t x1 = vs_win(rw, rbase + rj + 32u) ^ vs_win(tw, tbase + rq + 32u);
+    const uint64_t x2 = vs_win(rw, rbase + rj + 64u) ^ vs_win(tw, tbase + rq + 64u);
+    const uint64_t x3 = vs_win(rw, rbase + rj + 96u) ^ vs_win(tw, tbase + rq + 96u);
+    const uint64_t x4 = vs_win(rw, rbase + rj + 128u) ^ vs_win(tw, tbase + rq + 128u);
+    const uint32_t left = xl ? n0 - 1u - (uint32_t)((63 - __clzll((long long)xl)) >> 1) : n0;
+    uint32_t ext = x4 ? 128u + ((uint32_t)(__ffsll((long long)x4) - 1) >> 1) : 160u;
+    ext = x3 ? 96u + ((uint32_t)(__ffsll((long long)x3) - 1) >> 1) : ext;
+    ext = x2 ? 64u + ((uint32_t)(__ffsll((long long)x2) - 1) >> 1) : ext;
+    ext = x1 ? 32u + ((uint32_t)(__ffsll((long long)x1) - 1) >> 1) : ext;
+    ext = x0 ? ((uint32_t)(__ffsll((long long)x0) - 1) >> 1) : ext;
+    ext = ext < rem ? ext : rem;
+    const uint32_t len = left + w + ext;
+    *a_out = j - left;
+    *qa_out = q - left;
+    *len_out = len;
+    return left < s && len >= K;
+}
+
 // Extension of a seed hit.  rw/rbase: packed read (LDS or global) and its first base; tw/tbase:
 // packed node strand.  mk/mbase: validity mask of the read or NULL.  Returns false when the
 // match is owned by an earlier probe or is shorter than K.
@@ -86,29 +124,6 @@ __device__ __forceinline__ bool vs_extend(const uint32_t *rw, RB rbase, uint32_t
     {
         const uint32_t rem2 = tlen - rq;
         rem = rem < rem2 ? rem : rem2;
-    }
-    if (!mk && s <= 32u && rlen <= 128u + w + 32u) {
-        // common case (no masked read bytes, one left window, at most four right windows... but the
-        // seed can sit anywhere, so rem <= rlen - w): everything is loaded up front and the answer
-        // comes out of selects -- no data-dependent branch, no loop
-        uint64_t xl = (vs_win(rw, rbase + j - n0) ^ vs_win(tw, tbase + q - n0)) & vs_lowmask(2u * n0);
-        const uint64_t x0 = vs_win(rw, rbase + rj) ^ vs_win(tw, tbase + rq);
-        const uint64_t x1 = vs_win(rw, rbase + rj + 32u) ^ vs_win(tw, tbase + rq + 32u);
-        const uint64_t x2 = vs_win(rw, rbase + rj + 64u) ^ vs_win(tw, tbase + rq + 64u);
-        const uint64_t x3 = vs_win(rw, rbase + rj + 96u) ^ vs_win(tw, tbase + rq + 96u);
-        const uint64_t x4 = vs_win(rw, rbase + rj + 128u) ^ vs_win(tw, tbase + rq + 128u);
-        const uint32_t left = xl ? n0 - 1u - (uint32_t)((63 - __clzll((long long)xl)) >> 1) : n0;
-        uint32_t ext = x4 ? 128u + ((uint32_t)(__ffsll((long long)x4) - 1) >> 1) : 160u;
-        ext = x3 ? 96u + ((uint32_t)(__ffsll((long long)x3) - 1) >> 1) : ext;
-        ext = x2 ? 64u + ((uint32_t)(__ffsll((long long)x2) - 1) >> 1) : ext;
-        ext = x1 ? 32u + ((uint32_t)(__ffsll((long long)x1) - 1) >> 1) : ext;
-        ext = x0 ? ((uint32_t)(__ffsll((long long)x0) - 1) >> 1) : ext;
-        ext = ext < rem ? ext : rem;
-        const uint32_t len = left + w + ext;
-        *a_out = j - left;
-        *qa_out = q - left;
-        *len_out = len;
-        return left < s && len >= K;
     }
     uint64_t xl = vs_win(rw, rbase + j - n0) ^ vs_win(tw, tbase + q - n0);
     uint64_t xr0 = vs_win(rw, rbase + rj) ^ vs_win(tw, tbase + rq);
@@ -246,6 +261,7 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
     return t;
 }
 
+template <bool FAST>
 __global__ void __launch_bounds__(TPB)
 k_pe_tiles(PeParams P) {
     const uint32_t tid = threadIdx.x;
@@ -457,9 +473,13 @@ k_pe_tiles(PeParams P) {
                 const uint32_t q = opp ? nm.len - p_pos[k2] - w : p_pos[k2];
                 const uint32_t *mk = ((meta >> 24) & VS_FLAG_INVALID) ? P.rd.mask : nullptr;
                 uint32_t a, qa, len;
-                if (!vs_extend(s_words, e * wpe * 16u, rlen, tw, nm.woff * 16u, nm.len, j, q, w, s, K,
-                               mk, (uint64_t)s_gwoff[e] * 16u, &a, &qa, &len))
-                    continue;
+                bool credited;
+                if (FAST)
+                    credited = vs_extend_fast(s_words, e * wpe * 16u, rlen, tw, nm.woff * 16u, nm.len, j, q, w, s, K, &a, &qa, &len);
+                else
+                    credited = vs_extend(s_words, e * wpe * 16u, rlen, tw, nm.woff * 16u, nm.len, j, q, w, s, K,
+                                         mk, (uint64_t)s_gwoff[e] * 16u, &a, &qa, &len);
+                if (!credited) continue;
                 const uint32_t add = len - K + 1u;
                 const uint32_t minp = opp ? nm.len - qa - len : qa;
                 const uint32_t key = (e << 25) | node;
@@ -997,8 +1017,12 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     P.dbg_cap = dbg_cap;
     P.accumulate = d_node_mat ? 1u : 0u;
 
+    // straight-line extension when the whole block qualifies (see vs_extend_fast)
+    const bool fast = !reads->d_mask && idx.s <= 32u && maxlen <= 128u + idx.w + 32u &&
+                      !(getenv("VS_NO_FAST") && atoi(getenv("VS_NO_FAST")) != 0);
+    const void *tiles_fn = fast ? (const void *)k_pe_tiles<true> : (const void *)k_pe_tiles<false>;
     if (lds > 64u * 1024u)
-        VS_HIP(ctx, hipFuncSetAttribute((const void *)k_pe_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VS_HIP(ctx, hipFuncSetAttribute(tiles_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     uint64_t grid = P.n_tiles;
     uint64_t max_grid = (uint64_t)ctx->n_cu * 8u;
     if (const char *ev = getenv("VS_GRID_PER_CU")) max_grid = (uint64_t)ctx->n_cu * (uint64_t)(atoi(ev) > 0 ? atoi(ev) : 8);
@@ -1034,7 +1058,10 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     }
     VS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     if (!d_node_mat) VS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
-    hipLaunchKernelGGL(k_pe_tiles, dim3((unsigned)grid), dim3(TPB), lds, st, P);
+    if (fast)
+        hipLaunchKernelGGL(k_pe_tiles<true>, dim3((unsigned)grid), dim3(TPB), lds, st, P);
+    else
+        hipLaunchKernelGGL(k_pe_tiles<false>, dim3((unsigned)grid), dim3(TPB), lds, st, P);
     if (d_node_mat) {
         // the last tile may be partly empty: its unused rows must read as length 0
         const uint64_t used_ends = 2ull * n_pairs;
