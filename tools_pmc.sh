@@ -17,7 +17,7 @@ res = collections.OrderedDict()
 for f in sorted(glob.glob(out + "/*/**/*counter_collection.csv", recursive=True)):
     acc = collections.defaultdict(lambda: [0.0, 0])
     for row in csv.DictReader(open(f)):
-        k = (row["Kernel_Name"].split("(")[0], row["Counter_Name"])
+        k = (row["Kernel_Name"].split("(")[0].replace("void ", ""), row["Counter_Name"])
         acc[k][0] += float(row["Counter_Value"]); acc[k][1] += 1
     disp = collections.Counter()
     for (kn, cn), (v, n) in acc.items():

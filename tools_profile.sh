@@ -2,7 +2,7 @@
 # GPU-side: kernel trace + HBM counters for the bench command (outputs under gpurun_out/prof_$1)
 R="$GRAFT_REPO_ROOT"; TAG="${1:-r1}"; OUT="$R/gpurun_out/prof_$TAG"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" --steps 5 --warmup 1 --cpu-seconds 0 > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" --steps 5 --warmup 1 --cpu-seconds 0 --ingest-pairs 0 > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$R/bench.py" --steps 2 --warmup 1 --cpu-seconds 0 --no-extract > "$OUT/pmc_fetch_bench.json" 2> "$OUT/pmc_fetch.err"
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$R/bench.py" --steps 2 --warmup 1 --cpu-seconds 0 --no-extract > "$OUT/pmc_write_bench.json" 2> "$OUT/pmc_write.err"
 timeout 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum --output-format csv -d "$OUT/pmc_l2" -- python3 "$R/bench.py" --steps 2 --warmup 1 --cpu-seconds 0 --no-extract > "$OUT/pmc_l2_bench.json" 2> "$OUT/pmc_l2.err"
@@ -13,7 +13,7 @@ res = {}
 for f in sorted(glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True)):
     acc = collections.defaultdict(lambda: [0.0, set()])
     for row in csv.DictReader(open(f)):
-        k = (row["Kernel_Name"].split("(")[0], row["Counter_Name"])
+        k = (row["Kernel_Name"].split("(")[0].replace("void ", ""), row["Counter_Name"])
         acc[k][0] += float(row["Counter_Value"]); acc[k][1].add(row["Dispatch_Id"])
     for (kn, cn), (v, ids) in acc.items():
         res.setdefault(kn, {})[cn] = {"per_dispatch_mean": v / max(len(ids), 1), "dispatches": len(ids)}
