@@ -310,6 +310,7 @@ def make_pipeline_case(
     depth_tags: str = "dp",
     gapped_contigs: int = 0,
     self_loops: int = 0,
+    circular: bool = False,
 ) -> PipelineCase:
     """A seeded, self-contained stand-in for "SPAdes output + reads" of a viral quasispecies."""
     rng = np.random.default_rng(seed + 77)
@@ -319,8 +320,15 @@ def make_pipeline_case(
         a = genome_len // 5
         b = 3 * genome_len // 5
         st = StrainSet([g[:b] + g[a : a + repeat_len] + g[b + repeat_len :] for g in st.genomes], st.abundance)
+    if circular:
+        # circular genomes: the graph closes on itself (k bases of the start repeated at the end),
+        # reads are sampled across the junction too
+        st = StrainSet([g + g[: 3 * read_len + k] for g in st.genomes], st.abundance)
     reads_from = st
     graph_from = st
+    if circular:
+        graph_from = StrainSet([g[: len(g) - 3 * read_len] for g in st.genomes], st.abundance)
+        st_graph_only = graph_from
     if error_strain_depth > 0.0:
         g0 = st.genomes[0]
         arr = bytearray(g0.encode())
