@@ -204,3 +204,108 @@ def test_full_cli_on_device_matches_reference(backend, name, tmp_path):
     problems, _ = compare(case, out)
     binding = [p for p in problems if p.split(" ", 1)[1] not in case.meta["differs_under_other_hashseeds"]]
     assert not binding, binding
+
+
+def test_full_size_graph_stages_properties(backend, tmp_path):
+    """BASELINE configs[2] graph (4.5 k-node input GFA, ~4.1 k nodes after the coverage cut-off):
+    the reference cannot run this size, so the stages are checked through properties --
+    every device link sum equals the same sum over the counters taken on the host, every stage
+    graph's device flows / scan equal the numpy checker, every extracted strain is a walk of
+    graph_L0 whose FASTA record is the overlap-aware concatenation of its segments, and a second
+    run writes the same files."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import numpy as np
+    from vstrains_amd import pe as host
+    from vstrains_amd.graph import pipeline
+    from vstrains_amd.graph.formats import gfa_records
+    from vstrains_amd.graph.hip_ops import HipPeLinks
+
+    ctx = backend.ctx
+    runs = []
+    for attempt in range(2):
+        out = str(tmp_path / ("run%d" % attempt))
+        st, pre, names, seqs, cum, logger, _ = bench.workload(out, k=55)
+        ctx.build_index(seqs, 55)
+        counter = host.PeCounter(ctx)
+        block = ctx.synth_pairs(st.genomes, cum, 20250001, 0, 2_000_000, 150, int(0.005 * 2 ** 32), int(0.001 * 2 ** 32))
+        counter.add(block)
+        ctx.sync()
+        block.free()
+        table = HipPeLinks.from_counter(ctx, counter, names)
+        if attempt == 0:
+            node_mat, short_mat, _ = counter.result()
+            p0 = node_mat + node_mat.T + short_mat + short_mat.T
+            d = np.arange(len(names))
+            p0[d, d] = node_mat.diagonal() + short_mat.diagonal()
+            assert np.array_equal(table.to_numpy(), p0)
+            seen = []
+            real_sums, real_group = table.block_sums, table.group_matrix
+
+            def block_sums(queries):
+                res = real_sums(queries)
+                seen.append((list(queries), list(res)))
+                return res
+
+            def group_matrix(groups):
+                res = real_group(groups)
+                a = np.zeros((len(groups), len(names)), dtype=np.int64)
+                for i, grp in enumerate(groups):
+                    for x in grp:
+                        a[i, x] += 1
+                # A * P0 * A^T on the host, in two steps that stay exact in int64
+                rows = np.stack([p0[list(grp)].sum(axis=0) if len(grp) else np.zeros(len(names), np.int64) for grp in groups])
+                want = np.stack([rows[:, list(grp)].sum(axis=1) if len(grp) else np.zeros(len(groups), np.int64) for grp in groups], axis=1)
+                assert np.array_equal(res, want)
+                return res
+
+            table.block_sums, table.group_matrix = block_sums, group_matrix
+        pipeline.extract_strains(pre, table, backend, logger, out)
+        runs.append(out)
+        if attempt == 0:
+            n_q = 0
+            for queries, res in seen:
+                for (rows, cols), got in zip(queries, res):
+                    want = int(p0[np.ix_(list(rows), list(cols))].sum()) if len(rows) and len(cols) else 0
+                    assert got == want
+                    n_q += 1
+            assert n_q > 1000
+    out = runs[0]
+    # device flows / scan on every stage graph of the run
+    n_graphs = 0
+    for fn in sorted(os.listdir(os.path.join(out, "gfa"))):
+        if fn in ("graph_L0.gfa", "graph_L0r.gfa") or not fn.endswith(".gfa"):
+            continue
+        if n_graphs % 6 == 0:  # every sixth graph keeps the test under a minute; all kinds are hit
+            g, _, _ = read_stage_gfa(os.path.join(out, "gfa", fn))
+            assert_same_ops(backend.graph_ops, g)
+        n_graphs += 1
+    assert n_graphs > 50
+    # strains are walks of graph_L0 and the FASTA is their concatenation
+    segs, links = gfa_records(os.path.join(out, "gfa", "graph_L0.gfa"))
+    seq_of = {rec[1]: rec[2] for rec in segs}
+    ovl = {(rec[1], rec[3]): int(rec[5][:-1]) for rec in links}
+    paths = open(os.path.join(out, "strain.paths")).read().split("\n")
+    fasta = open(os.path.join(out, "strain.fasta")).read().split("\n")
+    n_strains = 0
+    for i in range(0, len(paths) - 1, 2):
+        name, ids = paths[i], paths[i + 1].split(",")
+        l0 = ["-" + x[:-1] if x.endswith("-") else x for x in ids]  # graph_L0 names flipped segments "-id"
+        text = ""
+        for a, b in zip(l0, l0[1:]):
+            assert (a, b) in ovl, (name, a, b)
+        for j, a in enumerate(l0):
+            text += seq_of[a] if j == len(l0) - 1 else seq_of[a][: len(seq_of[a]) - ovl[(a, l0[j + 1])]]
+        assert fasta[i + 1] == text
+        assert int(name.split("_")[2]) == len(text)
+        n_strains += 1
+    assert n_strains > 5
+    # determinism: the second run wrote the same files
+    for sub in ("gfa", "tmp", ""):
+        d0 = os.path.join(runs[0], sub) if sub else runs[0]
+        for fn in sorted(os.listdir(d0)):
+            p0f = os.path.join(d0, fn)
+            if os.path.isfile(p0f) and not fn.startswith("input."):
+                assert open(p0f).read() == open(os.path.join(runs[1], sub, fn) if sub else os.path.join(runs[1], fn)).read(), fn

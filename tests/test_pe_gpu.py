@@ -250,3 +250,50 @@ def test_every_kernel_variant_gives_the_same_counters(host, ctx, env, monkeypatc
     assert np.array_equal(node_mat, want[0])
     assert np.array_equal(short_mat, want[1])
     assert stats == tuple(int(x) for x in want[2])
+
+
+def test_full_size_block_properties(host, ctx):
+    """BASELINE configs[2] size (10 M pairs of 2x150 bp, ~4.5 k nodes) through size-independent
+    properties: the counters of one 10 M block equal the sum over two 5 M halves and over four
+    unequal pieces (any partition gives the same integer sums -- what read-block sharding relies on),
+    the three pair classes add up to 10 M, short_mat is upper triangular with a positive diagonal
+    wherever a row has any count, and a 200 k-pair prefix equals the CPU oracle bit for bit."""
+    from vstrains_amd import synth
+
+    st = synth.make_strains(15, 10800, 0.09, seed=1003)
+    g = synth.compact_dbg(st, 55)
+    ab = np.array(st.abundance)
+    cum = np.minimum(np.floor(np.cumsum(ab) / ab.sum() * 2 ** 32), 2 ** 32 - 1).astype(np.uint32)
+    cum[-1] = 0xFFFFFFFF
+    sub, nth, seed, L, R = int(0.005 * 2 ** 32), int(0.001 * 2 ** 32), 77, 150, 10_000_000
+    ctx.build_index(g.seqs, 55)
+
+    def count(pieces):
+        counter = host.PeCounter(ctx)
+        for first, n in pieces:
+            block = ctx.synth_pairs(st.genomes, cum, seed, first, n, L, sub, nth)
+            counter.add(block)
+            ctx.sync()
+            block.free()
+        return counter.result()
+
+    whole = count([(0, R)])
+    halves = count([(0, R // 2), (R // 2, R - R // 2)])
+    ragged = count([(0, 1), (1, 4095), (4096, 3_000_001), (3_004_097, R - 3_004_097)])
+    for other in (halves, ragged):
+        assert np.array_equal(whole[0], other[0]) and np.array_equal(whole[1], other[1]) and whole[2] == other[2]
+    node_mat, short_mat, stats = whole
+    assert sum(stats) == R and stats[2] > 0.99 * R
+    assert np.array_equal(short_mat, np.triu(short_mat))
+    rows_with_counts = short_mat.sum(axis=1) > 0
+    assert (short_mat.diagonal()[rows_with_counts] > 0).all()
+    assert node_mat.sum() > 0 and short_mat.sum() > node_mat.sum()
+    # prefix against the oracle
+    M = 200_000
+    fw, rv = pe_oracle_c.synth_pairs(st.genomes, cum, seed, 0, M, L, sub, nth)
+    off = np.arange(M + 1, dtype=np.uint64) * np.uint64(L)
+    orc = pe_oracle_c.Oracle(g.seqs, 55)
+    ref = orc.count_pairs_raw(fw.reshape(-1), off, rv.reshape(-1), off, M)
+    got = count([(0, M)])
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    assert got[2] == tuple(int(x) for x in ref[2])
