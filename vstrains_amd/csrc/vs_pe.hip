@@ -30,6 +30,7 @@
 //       and taken in contiguous runs, so the same cells are hit again while still in L2)
 // Ends that touch more than 8 nodes overflow the LDS table; their pairs go to a list that a
 // second, fully general kernel (dense per-workgroup node state in HBM) works through.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "vs_internal.h"
@@ -57,6 +58,7 @@ struct PeParams {
     uint32_t wpe;          // LDS words reserved per read end
     uint32_t tiles_per_wg; // contiguous run of tiles per workgroup
     uint32_t magic_pmax, magic_wpe;  // vs_fastdiv constants
+    uint32_t count_postings;         // VS_DEBUG_POSTINGS: sum the postings expanded (diagnostics)
     uint32_t *out_lists;             // [n_tiles * ept * LC] accepted node ids per end, tile order
     uint32_t *out_counts;            // [n_tiles * ept] list lengths (0 for ends that add nothing)
     uint64_t n_pairs;
@@ -386,6 +388,7 @@ k_pe_tiles(PeParams P) {
         __syncthreads();
         if (P.debug_stop == 3u) continue;
         const uint32_t total = s_pcnt[NI - 1u];
+        if (P.count_postings && tid == 0) atomicAdd((unsigned long long *)(P.slow_count + 2), (unsigned long long)total);
         // ---- P3: one thread per posting.  Expansion of the per-probe posting counts (CSR-style
         // frontier expansion) in chunks of CHUNK postings: every probe marks the first position it
         // owns in the chunk, a workgroup-wide running maximum fills the gaps, and each thread ends
@@ -1007,6 +1010,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     P.n_pairs = n_pairs;
     P.n_tiles = (n_pairs + ept / 2 - 1) / (ept / 2);
     P.wpe = wpe;
+    P.count_postings = getenv("VS_DEBUG_POSTINGS") ? 1u : 0u;
     P.magic_pmax = pmax > 1u ? (uint32_t)(0x100000000ull / pmax) + 1u : 0u;
     P.magic_wpe = wpe > 1u ? (uint32_t)(0x100000000ull / wpe) + 1u : 0u;
     P.perm = use_sort ? (const uint32_t *)ctx->d_perm : nullptr;
@@ -1111,6 +1115,11 @@ extern "C" int vs_pe_last_timing(vs_ctx *ctx, double ms[5]) {
     uint32_t n_slow = 0;
     VS_HIP(ctx, hipMemcpy(&n_slow, ctx->d_slow_count, sizeof n_slow, hipMemcpyDeviceToHost));
     ms[0] = a; ms[1] = b; ms[2] = (double)n_slow; ms[3] = c; ms[4] = d;
+    if (getenv("VS_DEBUG_POSTINGS")) {
+        unsigned long long np = 0;
+        VS_HIP(ctx, hipMemcpy(&np, (char *)ctx->d_slow_count + 8, sizeof np, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[vs] postings expanded by the last vs_pe_count: %llu\n", np);
+    }
     ctx->last_ms[0] = a; ctx->last_ms[1] = b; ctx->last_ms[2] = n_slow;
     return VS_OK;
 }
