@@ -99,12 +99,12 @@ class LiveLinks:
         return name in self._fresh
 
     def prefetch(self, pairs: Iterable[Tuple[str, str]]) -> None:
-        want = []
+        wanted: Dict[Tuple[str, str], None] = {}
         for a, b in pairs:
             key = (a, b) if a <= b else (b, a)
-            if key not in self._cache and key not in want:
-                want.append(key)
-        want = list(dict.fromkeys(want))
+            if key not in self._cache:
+                wanted[key] = None
+        want = list(wanted)
         if not want:
             return
         sums = self.table.block_sums([self._query(a, b) for a, b in want])
