@@ -574,6 +574,24 @@ k_pe_tiles(PeParams P) {
 //              g(n) = sum_{m=1..n} ceil(m/4)
 #define ACC_RUN 4u
 #define ACC_GMAX 40u  // g(16)
+// Slow side of vs_cell_add: the slot is empty or holds another cell.  Kept out of line so that
+// the common case (the cell is already in the table) stays a short straight-line sequence.
+__device__ __noinline__ bool vs_cell_claim(uint32_t *s_key, uint32_t *s_cnt, uint32_t *s_used, uint32_t key, uint32_t at) {
+    for (uint32_t pr = 0; pr < 8u; pr++) {
+        uint32_t kx = s_key[at];
+        if (kx == EMPTY_NODE) {
+            kx = atomicCAS(&s_key[at], EMPTY_NODE, key);
+            if (kx == EMPTY_NODE) { atomicAdd(s_used, 1u); kx = key; }
+        }
+        if (kx == key) {
+            atomicAdd(&s_cnt[at], 1u);
+            return true;
+        }
+        at = (at + 1u) & (ACC_SLOTS - 1u);
+    }
+    return false;
+}
+
 __device__ __forceinline__ void vs_cell_add(uint32_t *s_key, uint32_t *s_cnt, uint32_t &s_used, uint32_t &s_lost, bool use_table,
                                             uint32_t mat, uint32_t x, uint32_t yv, uint32_t N, uint32_t NN,
                                             uint32_t *node_mat, uint32_t *short_mat) {
@@ -581,20 +599,14 @@ __device__ __forceinline__ void vs_cell_add(uint32_t *s_key, uint32_t *s_cnt, ui
     bool done = false;
     if (use_table) {
         const uint32_t key = mat * NN + cx * N + cy;  // use_table => 2*N*N < 2^32
-        uint32_t at = (key * 0x9E3779B1u) >> (32u - ACC_BITS);
-        for (uint32_t pr = 0; pr < 8u && !done; pr++) {
-            uint32_t kx = s_key[at];
-            if (kx == EMPTY_NODE) {
-                kx = atomicCAS(&s_key[at], EMPTY_NODE, key);
-                if (kx == EMPTY_NODE) { atomicAdd(&s_used, 1u); kx = key; }
-            }
-            if (kx == key) {
-                atomicAdd(&s_cnt[at], 1u);
-                done = true;
-            }
-            at = (at + 1u) & (ACC_SLOTS - 1u);
+        const uint32_t at = (key * 0x9E3779B1u) >> (32u - ACC_BITS);
+        if (s_key[at] == key) {
+            atomicAdd(&s_cnt[at], 1u);
+            done = true;
+        } else {
+            done = vs_cell_claim(s_key, s_cnt, &s_used, key, at);
+            if (!done) atomicAdd(&s_lost, 1u);
         }
-        if (!done) atomicAdd(&s_lost, 1u);
     }
     if (!done) atomicAdd((mat ? short_mat : node_mat) + (uint64_t)cx * N + cy, 1u);
 }
