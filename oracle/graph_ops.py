@@ -24,6 +24,10 @@ import numpy
 
 
 class NumpyGraphOps:
+    def refresh(self, g):
+        self.edge_flows(g)
+        return self.scan(g)
+
     def edge_flows(self, g) -> None:
         for e in g.edges():
             u, v = g.esrc[e], g.etgt[e]

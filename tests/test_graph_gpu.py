@@ -59,7 +59,6 @@ def assert_same_ops(ops, g):
         setattr(h, slot, getattr(g, slot))
     h.eflow = list(g.eflow)
     ref.edge_flows(h)
-    ops._key = None
     ops.edge_flows(g)
     for e in g.edges():
         assert g.eflow[e] == h.eflow[e], (e, g.eflow[e], h.eflow[e])  # bit-exact fp64
@@ -105,7 +104,6 @@ def test_zero_neighbour_sum_raises_like_numpy_seterr(backend):
     a = g.add_vertex("a", 5.0, "A", True)
     b = g.add_vertex("b", 0.0, "A", True)
     g.add_edge(a, b, 21, 0.0, True)
-    backend.graph_ops._key = None
     with pytest.raises(FloatingPointError):
         backend.graph_ops.edge_flows(g)
 

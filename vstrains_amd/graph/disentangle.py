@@ -48,8 +48,7 @@ def reinit(stage: Stage, ops: GraphOps, logger, filename: str) -> Stage:
     logger.info(filename + " is stored..")
     # same graph read_stage_gfa(filename) would give (float(repr(dp)) == dp), without the parse
     g, nodes, edges = stage_graph_from_state(stage.g, stage.nodes, stage.edges)
-    ops.edge_flows(g)
-    return Stage(g, nodes, edges, ops.scan(g))
+    return Stage(g, nodes, edges, ops.refresh(g))
 
 
 def load_stage(filename: str, ops: GraphOps, with_flow: bool) -> Stage:

@@ -19,20 +19,15 @@ def _ptr(a: np.ndarray):
 
 
 class HipGraphOps(GraphOps):
-    """K6 + K7: one ``vs_graph_refresh`` per graph snapshot serves both ``edge_flows`` and
-    ``scan`` (the reference recomputes flows after every re-initialisation and asks for the
-    branch / simple-edge facts of the same snapshot right after)."""
+    """K6 + K7: one ``vs_graph_refresh`` call computes the flows and the scan of a graph snapshot
+    (the reference recomputes flows after every re-initialisation and asks for the branch /
+    simple-edge facts of the same snapshot right after: ``refresh``)."""
 
     def __init__(self, ctx):
         self.ctx = ctx
-        self._key = None
-        self._res = None
         self.calls = 0
 
     def _refresh(self, g: AsmGraph):
-        key = (id(g), g.num_vertices(), len(g.esrc), g.num_edges(), tuple(g.vdp[:4]))
-        if self._key == key:
-            return self._res
         nv = g.num_vertices()
         row_ptr, n_out, nbr, eidx = g.csr_arrays()
         a_row = np.asarray(row_ptr, dtype=np.uint64)
@@ -55,12 +50,10 @@ class HipGraphOps(GraphOps):
             a_eb.ctypes.data, flow.ctypes.data, nt.ctypes.data, fk.ctypes.data, nxt.ctypes.data, top.ctypes.data,
             rank.ctypes.data, C.byref(bad)))
         self.calls += 1
-        self._key = key
-        self._res = (flow, nt, fk, nxt, top, rank, bad.value)
-        return self._res
+        return flow, nt, fk, nxt, top, rank, bad.value
 
-    def edge_flows(self, g: AsmGraph) -> None:
-        flow, _, _, _, _, _, bad = self._refresh(g)
+    @staticmethod
+    def _apply_flows(g: AsmGraph, flow, bad) -> None:
         if bad != 0xFFFFFFFF:
             # numpy.seterr(all="raise") in the reference's main process (vstrains:25)
             raise FloatingPointError("divide by zero encountered in edge flow of edge %s -> %s"
@@ -69,11 +62,24 @@ class HipGraphOps(GraphOps):
         for e in g.edges():
             g.eflow[e] = vals[e]
 
-    def scan(self, g: AsmGraph) -> GraphScan:
-        _, nt, fk, nxt, top, rank, _ = self._refresh(g)
+    @staticmethod
+    def _as_scan(g: AsmGraph, nt, fk, nxt, top, rank) -> GraphScan:
         nv = g.num_vertices()
         return GraphScan(nt[:nv].astype(bool).tolist(), fk[:nv].tolist(), nxt[:nv].tolist(), top[:nv].tolist(),
                          rank[:nv].tolist())
+
+    def edge_flows(self, g: AsmGraph) -> None:
+        flow, _, _, _, _, _, bad = self._refresh(g)
+        self._apply_flows(g, flow, bad)
+
+    def scan(self, g: AsmGraph) -> GraphScan:
+        _, nt, fk, nxt, top, rank, _ = self._refresh(g)
+        return self._as_scan(g, nt, fk, nxt, top, rank)
+
+    def refresh(self, g: AsmGraph) -> GraphScan:
+        flow, nt, fk, nxt, top, rank, bad = self._refresh(g)
+        self._apply_flows(g, flow, bad)
+        return self._as_scan(g, nt, fk, nxt, top, rank)
 
 
 class HipPeLinks(PeLinks):

@@ -51,6 +51,11 @@ class GraphOps:
     def scan(self, g: AsmGraph) -> GraphScan:
         raise NotImplementedError
 
+    def refresh(self, g: AsmGraph) -> GraphScan:
+        """Both at once for a freshly re-initialised graph (one device call in the HIP backend)."""
+        self.edge_flows(g)
+        return self.scan(g)
+
 
 class PeLinks:
     """K5: the symmetrised PE-link matrix ``P0`` over the nodes of ``s_graph_L1`` and sums over it.
