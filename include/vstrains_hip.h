@@ -96,6 +96,12 @@ int vs_fastq_gather(const vs_fastq *fq, uint64_t first, uint64_t count, uint64_t
                     uint8_t *ascii);
 int vs_fastq_block(vs_ctx *ctx, vs_fastq *fq, uint64_t first, uint64_t count, vs_reads **out);
 
+/* pe_info / st_info text (PE_Inference.py:194-205): "{id_i}:{id_j}:{count}\n" for all i, j in
+ * row-major order, zeros included.  ids: the n node names concatenated, id_off[n+1]; mat: HOST
+ * n*n int64.  Formatted on all host cores, one write(). */
+int vs_write_matrix_text(vs_ctx *ctx, const char *path, const uint8_t *ids, const uint64_t *id_off,
+                         uint32_t n, const int64_t *mat);
+
 /* Synthetic pairs generated on the device from a seed (bench workload; the CPU twin is
  * oracle/pe_oracle.c:peo_synth_pairs).  genomes: concatenated ACGT ASCII (host), goff
  * [n_strains+1]; cum[s]: inclusive upper bound of strain s in a uniform u32 draw (last =

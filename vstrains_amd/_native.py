@@ -35,6 +35,7 @@ SYMBOLS = {
     "vs_fastq_sequence": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "vs_fastq_gather": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "vs_fastq_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "vs_write_matrix_text": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "vs_synth_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
                                  C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                  C.POINTER(C.c_void_p)]),

@@ -280,3 +280,83 @@ int vs_fastq_block(vs_ctx *ctx, vs_fastq *fq, uint64_t first, uint64_t count, vs
 }
 
 }  // extern "C"
+
+// ---- pe_info / st_info text -------------------------------------------------------------------
+// utils/VStrains_PE_Inference.py:194-205 writes "{id_i}:{id_j}:{count}\n" for all i, j in
+// row-major order, zeros included: N^2 lines (16.7 M at 4 k nodes).  Rows are sized and formatted
+// on all host cores into one buffer, then written with a single write().
+namespace {
+inline uint32_t dec_digits(uint64_t v) {
+    uint32_t d = 1;
+    while (v >= 10) { v /= 10; d++; }
+    return d;
+}
+inline char *put_dec(char *p, uint64_t v) {
+    char tmp[24];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+}  // namespace
+
+extern "C" int vs_write_matrix_text(vs_ctx *ctx, const char *path, const uint8_t *ids, const uint64_t *id_off, uint32_t n,
+                                    const int64_t *mat) {
+    if (!path || !id_off || (n && (!ids || !mat))) return vs_fail(ctx, VS_E_ARG, "vs_write_matrix_text: bad argument");
+    for (uint64_t i = 0; i < (uint64_t)n * n; i++)
+        if (mat[i] < 0) return vs_fail(ctx, VS_E_ARG, "vs_write_matrix_text: negative count");
+    const unsigned T = n_threads();
+    std::vector<uint64_t> row_off((size_t)n + 1, 0);
+    uint64_t ids_total = id_off[n] - id_off[0];
+    parallel_for(T, [&](unsigned p) {
+        uint32_t lo = (uint32_t)((uint64_t)n * p / T), hi = (uint32_t)((uint64_t)n * (p + 1) / T);
+        for (uint32_t i = lo; i < hi; i++) {
+            uint64_t li = id_off[i + 1] - id_off[i];
+            uint64_t bytes = (uint64_t)n * (li + 3) + ids_total;  // id_i ':' id_j ':' ... '\n'
+            const int64_t *row = mat + (uint64_t)i * n;
+            for (uint32_t j = 0; j < n; j++) bytes += dec_digits((uint64_t)row[j]);
+            row_off[i + 1] = bytes;
+        }
+    });
+    for (uint32_t i = 0; i < n; i++) row_off[i + 1] += row_off[i];
+    const uint64_t total = row_off[n];
+    char *buf = (char *)malloc(total ? total : 1);
+    if (!buf) return vs_fail(ctx, VS_E_OOM, "vs_write_matrix_text: %llu bytes", (unsigned long long)total);
+    parallel_for(T, [&](unsigned p) {
+        uint32_t lo = (uint32_t)((uint64_t)n * p / T), hi = (uint32_t)((uint64_t)n * (p + 1) / T);
+        for (uint32_t i = lo; i < hi; i++) {
+            char *q = buf + row_off[i];
+            const uint8_t *idi = ids + id_off[i];
+            const uint64_t li = id_off[i + 1] - id_off[i];
+            const int64_t *row = mat + (uint64_t)i * n;
+            for (uint32_t j = 0; j < n; j++) {
+                memcpy(q, idi, li); q += li;
+                *q++ = ':';
+                const uint64_t lj = id_off[j + 1] - id_off[j];
+                memcpy(q, ids + id_off[j], lj); q += lj;
+                *q++ = ':';
+                q = put_dec(q, (uint64_t)row[j]);
+                *q++ = '\n';
+            }
+        }
+    });
+    int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) {
+        free(buf);
+        return vs_fail(ctx, VS_E_ARG, "cannot open %s for writing: %s", path, strerror(errno));
+    }
+    uint64_t done = 0;
+    while (done < total) {
+        ssize_t w = write(fd, buf + done, (size_t)std::min<uint64_t>(total - done, 1u << 30));
+        if (w < 0) {
+            int e = errno;
+            close(fd);
+            free(buf);
+            return vs_fail(ctx, VS_E_ARG, "write to %s failed: %s", path, strerror(e));
+        }
+        done += (uint64_t)w;
+    }
+    close(fd);
+    free(buf);
+    return VS_OK;
+}

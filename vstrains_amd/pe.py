@@ -285,9 +285,14 @@ class PeCounter:
 # ---- outputs -------------------------------------------------------------------------------------
 def write_matrix_text(path: str, ids: Sequence[str], mat: np.ndarray):
     """``{id_i}:{id_j}:{count}`` for all i, j in row-major order, zeros included
-    (PE_Inference.py:194-205)."""
-    tails = [":%s:" % j for j in ids]
-    with open(path, "w") as fh:
-        for i, idi in enumerate(ids):
-            row = mat[i].tolist()
-            fh.write("".join([idi + t + str(v) + "\n" for t, v in zip(tails, row)]))
+    (PE_Inference.py:194-205) -- N^2 lines, formatted by the library on all host cores."""
+    names = [s.encode("latin-1") for s in ids]
+    off = np.zeros(len(names) + 1, dtype=np.uint64)
+    if names:
+        off[1:] = np.cumsum([len(b) for b in names], dtype=np.uint64)
+    blob = np.frombuffer(b"".join(names) or b"\0", dtype=np.uint8)
+    m = np.ascontiguousarray(mat, dtype=np.int64)
+    rc = nat.lib().vs_write_matrix_text(None, path.encode(), blob.ctypes.data, off.ctypes.data, len(names),
+                                        m.ctypes.data if m.size else None)
+    if rc != nat.VS_OK:
+        raise OSError(nat.lib().vs_last_error(None).decode("utf-8", "replace"))
