@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""GPU-side: wall time of the whole vstrains-compatible command on a configs[2]-shaped input
+(15-strain synthetic, ~4.5 k-node GFA) with M read pairs written as FASTQ text.
+
+    python tools/e2e_cli.py [M]        (default 2,000,000)
+"""
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from oracle import pe_oracle_c  # noqa: E402  (only its read generator, to write the input files)
+from vstrains_amd import cli, synth  # noqa: E402
+
+
+def main():
+    M = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+    L = 150
+    tmp = tempfile.mkdtemp(prefix="vstrains_e2e_")
+    t0 = time.time()
+    pc = synth.make_pipeline_case(n_strains=15, genome_len=10800, snp_rate=0.09, k=55, n_pairs=0, read_len=L, seed=1003)
+    st = pc.strains
+    ab = np.array(st.abundance)
+    cum = np.minimum(np.floor(np.cumsum(ab) / ab.sum() * 2 ** 32), 2 ** 32 - 1).astype(np.uint32)
+    cum[-1] = 0xFFFFFFFF
+    paths = {"gfa": os.path.join(tmp, "graph.gfa"), "paths": os.path.join(tmp, "contigs.paths")}
+    open(paths["gfa"], "w").write(pc.gfa_text)
+    open(paths["paths"], "w").write(pc.paths_text)
+    qual = b"I" * L
+    for tag in ("f", "r"):
+        paths[tag] = os.path.join(tmp, "reads_%s.fq" % tag)
+    CH = 500_000
+    with open(paths["f"], "wb") as ff, open(paths["r"], "wb") as fr:
+        for first in range(0, M, CH):
+            n = min(CH, M - first)
+            fw, rv = pe_oracle_c.synth_pairs(st.genomes, cum, 20250001, first, n, L, int(0.005 * 2 ** 32), int(0.001 * 2 ** 32))
+            ff.write(b"".join(b"@f%d\n%s\n+\n%s\n" % (first + i, fw[i].tobytes(), qual) for i in range(n)))
+            fr.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (first + i, rv[i].tobytes(), qual) for i in range(n)))
+    prep_s = time.time() - t0
+    out = os.path.join(tmp, "out")
+    t1 = time.time()
+    timings = cli.main(["-a", "spades", "-g", paths["gfa"], "-p", paths["paths"], "-o", out, "-fwd", paths["f"], "-rve", paths["r"]])
+    wall = time.time() - t1
+    n_strains = open(os.path.join(out, "strain.paths")).read().count("NODE_")
+    print(json.dumps({"pairs": M, "fastq_bytes": os.path.getsize(paths["f"]) + os.path.getsize(paths["r"]),
+                      "input_generation_s": prep_s, "cli_wall_s": wall, "stages": timings, "strains": n_strains,
+                      "gfa_nodes": len(pc.graph.ids)}))
+
+
+if __name__ == "__main__":
+    main()
