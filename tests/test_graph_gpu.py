@@ -307,3 +307,18 @@ def test_full_size_graph_stages_properties(backend, tmp_path):
             p0f = os.path.join(d0, fn)
             if os.path.isfile(p0f) and not fn.startswith("input."):
                 assert open(p0f).read() == open(os.path.join(runs[1], sub, fn) if sub else os.path.join(runs[1], fn)).read(), fn
+
+
+def test_cli_without_pe_text_gives_the_same_strains(tmp_path):
+    """--no-pe-text: the N^2-line hand-off files are skipped, the counters go to the graph stages
+    in device memory; everything else is byte-identical."""
+    from vstrains_amd import cli
+
+    case = Case("three_strain_k21")
+    inp = case.inputs(str(tmp_path), with_reads=True)
+    out = str(tmp_path / "out")
+    cli.main(["-a", "spades", "-g", inp["gfa"], "-p", inp["paths"], "-o", out, "-fwd", inp["fwd"], "-rve", inp["rve"],
+              "--no-pe-text"])
+    assert not os.path.exists(os.path.join(out, "aln", "pe_info"))
+    problems, _ = compare(case, out, skip=("aln/pe_info", "aln/st_info"))
+    assert not problems, problems

@@ -42,6 +42,9 @@ def build_parser():
     p.add_argument("-rve", "--rve_file", dest="rve", required=True, default=None, type=str,
                    help="paired-end sequencing reads, reverse strand (.fastq format)")
     p.add_argument("--device", dest="device", default=0, type=int, help="HIP device ordinal (extension)")
+    p.add_argument("--no-pe-text", dest="no_pe_text", action="store_true", default=False,
+                   help="extension: do not write the N^2-line aln/pe_info and aln/st_info (the graph stages read "
+                        "the counters from device memory either way)")
     return p
 
 
@@ -123,6 +126,11 @@ def main(argv=None, backend=None):
     to_file.setFormatter(stamped)
 
     from .graph import pipeline
+
+    if backend is None and args.no_pe_text:
+        from .graph.hip_ops import HipBackend
+
+        backend = HipBackend(args.device, write_info_text=False)
 
     old_err = numpy.seterr(all="raise")  # vstrains:25
     try:
