@@ -295,19 +295,32 @@ k_pe_tiles(PeParams P) {
     // a workgroup takes a contiguous run of the locus-sorted tiles (node text stays in L1/L2)
     const uint64_t tile_lo = (uint64_t)blockIdx.x * P.tiles_per_wg;
     const uint64_t tile_hi = tile_lo + P.tiles_per_wg < P.n_tiles ? tile_lo + P.tiles_per_wg : P.n_tiles;
+    // The headers of a tile (pair order -> end index -> word offset, length) are two dependent
+    // global loads; they are fetched one tile ahead into registers (one end per thread, ept <= TPB)
+    // so that their latency is covered by the previous tile's work.
+    uint32_t pf_gend = 0, pf_gwoff = 0, pf_meta = 0;
+    auto prefetch_headers = [&](uint64_t t) {
+        if (t < tile_hi && tid < ept) {
+            const uint64_t p = t * ppt + (tid >> 1);
+            if (p < P.n_pairs) {
+                const uint32_t gp = P.perm ? P.perm[p] : (uint32_t)p;
+                pf_gend = 2u * gp + (tid & 1u);
+                pf_gwoff = P.rd.woff[pf_gend];
+                pf_meta = P.rd.meta[pf_gend];
+            }
+        }
+    };
+    prefetch_headers(tile_lo);
     for (uint64_t tile = tile_lo; tile < tile_hi; tile++) {
         const uint64_t p0 = tile * ppt;
         const uint32_t npair = (uint32_t)((P.n_pairs - p0) < ppt ? (P.n_pairs - p0) : ppt);
         const uint32_t ne = 2u * npair;
         __syncthreads();  // previous tile fully consumed
         // ---- P0: which pairs (through the locus order when there is one), their headers
-        for (uint32_t i = tid; i < ne; i += TPB) {
-            const uint64_t p = p0 + (i >> 1);
-            const uint32_t gp = P.perm ? P.perm[p] : (uint32_t)p;
-            const uint32_t ge = 2u * gp + (i & 1u);
-            s_gend[i] = ge;
-            s_gwoff[i] = P.rd.woff[ge];
-            s_meta[i] = P.rd.meta[ge];
+        if (tid < ne) {
+            s_gend[tid] = pf_gend;
+            s_gwoff[tid] = pf_gwoff;
+            s_meta[tid] = pf_meta;
         }
         for (uint32_t i = tid; i < pool; i += TPB) {
             s_hkey[i] = EMPTY_NODE;
@@ -316,6 +329,7 @@ k_pe_tiles(PeParams P) {
             s_hminj[i] = 0xFFFFFFFFu;
         }
         __syncthreads();
+        prefetch_headers(tile + 1u);
         // packed reads: one end per wpe-word slot (gather; consecutive lanes read consecutive words)
         for (uint32_t i = tid; i < ne * wpe + 8u; i += TPB) {
             uint32_t v = 0u;
