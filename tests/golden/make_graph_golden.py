@@ -61,6 +61,10 @@ CASES = {
                                       depth_tags="kc", gapped_contigs=4), []),
     "self_loops_k21": (dict(n_strains=3, genome_len=2500, snp_rate=0.01, k=21, n_pairs=5000, read_len=100,
                             seed=95, abundance_ratio=0.55, self_loops=2, contig_pieces=5), ["-ml", "100"]),
+    "few_reads_k21": (dict(n_strains=4, genome_len=3000, snp_rate=0.012, k=21, n_pairs=40, read_len=100,
+                           seed=151, abundance_ratio=0.55, scramble=True), []),
+    "high_cutoff_k21": (dict(n_strains=5, genome_len=3000, snp_rate=0.012, k=21, n_pairs=5000, read_len=100,
+                             seed=161, abundance_ratio=0.5, scramble=True), ["-mc", "150"]),
     "circular_k21": (dict(n_strains=3, genome_len=2400, snp_rate=0.01, k=21, n_pairs=6000, read_len=100,
                           seed=141, abundance_ratio=0.6, circular=True, scramble=True), []),
     "ten_strain_k31": (dict(n_strains=10, genome_len=6000, snp_rate=0.02, k=31, n_pairs=20000, read_len=125,
