@@ -588,56 +588,82 @@ k_pe_tiles(PeParams P) {
 //              g(n) = sum_{m=1..n} ceil(m/4)
 #define ACC_RUN 4u
 #define ACC_GMAX 40u  // g(16)
+// The cell table comes in two widths: 32-bit keys (mat * N*N + x * N + y; 16 k slots) while
+// 2*N*N fits 32 bits (N <= 46340), 64-bit keys (mat << 60 | x * N + y; 8 k slots) above that.
+template <typename KT> struct AccTable;
+template <> struct AccTable<uint32_t> {
+    static constexpr uint32_t BITS = ACC_BITS;
+    static constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+    __device__ static uint32_t key(uint32_t mat, uint32_t x, uint32_t y, uint32_t N) { return (mat * N + x) * N + y; }
+    __device__ static uint32_t slot(uint32_t k) { return (k * 0x9E3779B1u) >> (32u - BITS); }
+    __device__ static uint32_t mat_of(uint32_t k, uint32_t N) { return k >= N * N ? 1u : 0u; }
+    __device__ static uint64_t cell_of(uint32_t k, uint32_t N) { return k >= N * N ? (uint64_t)(k - N * N) : (uint64_t)k; }
+};
+template <> struct AccTable<unsigned long long> {
+    static constexpr uint32_t BITS = ACC_BITS - 1u;
+    static constexpr unsigned long long EMPTY = ~0ull;
+    __device__ static unsigned long long key(uint32_t mat, uint32_t x, uint32_t y, uint32_t N) {
+        return ((unsigned long long)mat << 60) | ((unsigned long long)x * N + y);
+    }
+    __device__ static uint32_t slot(unsigned long long k) { return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> (64u - BITS)); }
+    __device__ static uint32_t mat_of(unsigned long long k, uint32_t) { return (uint32_t)(k >> 60); }
+    __device__ static uint64_t cell_of(unsigned long long k, uint32_t) { return k & ((1ull << 60) - 1ull); }
+};
+
 // Slow side of vs_cell_add: the slot is empty or holds another cell.  Kept out of line so that
 // the common case (the cell is already in the table) stays a short straight-line sequence.
-__device__ __noinline__ bool vs_cell_claim(uint32_t *s_key, uint32_t *s_cnt, uint32_t *s_used, uint32_t key, uint32_t at) {
+template <typename KT>
+__device__ __noinline__ bool vs_cell_claim(KT *s_key, uint32_t *s_cnt, uint32_t *s_used, KT key, uint32_t at) {
     for (uint32_t pr = 0; pr < 8u; pr++) {
-        uint32_t kx = s_key[at];
-        if (kx == EMPTY_NODE) {
-            kx = atomicCAS(&s_key[at], EMPTY_NODE, key);
-            if (kx == EMPTY_NODE) { atomicAdd(s_used, 1u); kx = key; }
+        KT kx = s_key[at];
+        if (kx == AccTable<KT>::EMPTY) {
+            kx = atomicCAS(&s_key[at], AccTable<KT>::EMPTY, key);
+            if (kx == AccTable<KT>::EMPTY) { atomicAdd(s_used, 1u); kx = key; }
         }
         if (kx == key) {
             atomicAdd(&s_cnt[at], 1u);
             return true;
         }
-        at = (at + 1u) & (ACC_SLOTS - 1u);
+        at = (at + 1u) & ((1u << AccTable<KT>::BITS) - 1u);
     }
     return false;
 }
 
-__device__ __forceinline__ void vs_cell_add(uint32_t *s_key, uint32_t *s_cnt, uint32_t &s_used, uint32_t &s_lost, bool use_table,
-                                            uint32_t mat, uint32_t x, uint32_t yv, uint32_t N, uint32_t NN,
+template <typename KT>
+__device__ __forceinline__ void vs_cell_add(KT *s_key, uint32_t *s_cnt, uint32_t &s_used, uint32_t &s_lost, bool use_table,
+                                            uint32_t mat, uint32_t x, uint32_t yv, uint32_t N,
                                             uint32_t *node_mat, uint32_t *short_mat) {
     const uint32_t cx = (mat && yv < x) ? yv : x, cy = (mat && yv < x) ? x : yv;
     bool done = false;
     if (use_table) {
-        const uint32_t key = mat * NN + cx * N + cy;  // use_table => 2*N*N < 2^32
-        const uint32_t at = (key * 0x9E3779B1u) >> (32u - ACC_BITS);
+        const KT key = AccTable<KT>::key(mat, cx, cy, N);
+        const uint32_t at = AccTable<KT>::slot(key);
         if (s_key[at] == key) {
             atomicAdd(&s_cnt[at], 1u);
             done = true;
         } else {
-            done = vs_cell_claim(s_key, s_cnt, &s_used, key, at);
+            done = vs_cell_claim<KT>(s_key, s_cnt, &s_used, key, at);
             if (!done) atomicAdd(&s_lost, 1u);
         }
     }
     if (!done) atomicAdd((mat ? short_mat : node_mat) + (uint64_t)cx * N + cy, 1u);
 }
 
+template <typename KT>
 __global__ void __launch_bounds__(ACC_TPB)
 k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_slots_pairs,
                 uint32_t pairs_per_wg, uint32_t N, uint32_t use_table, uint32_t fill_limit,
                 uint32_t *__restrict__ node_mat, uint32_t *__restrict__ short_mat) {
-    uint32_t *s_key = vs_lds;                      // [ACC_SLOTS]
-    uint32_t *s_cnt = vs_lds + ACC_SLOTS;          // [ACC_SLOTS]
+    constexpr uint32_t SLOTS = 1u << AccTable<KT>::BITS;
+    KT *s_key = (KT *)vs_lds;                      // [SLOTS] keys: ACC_SLOTS words either way
+    uint32_t *s_cnt = vs_lds + ACC_SLOTS;          // [SLOTS]
     uint32_t(*s_pref)[66] = (uint32_t(*)[66])(vs_lds + 2u * ACC_SLOTS);  // [ACC_TPB / 64][66]
     uint32_t *s_g = vs_lds + 2u * ACC_SLOTS + (ACC_TPB / 64) * 66u;      // [LC + 1]: g(n)
     uint32_t *s_ua = s_g + (LC + 1u);                                     // [LC + 1][ACC_GMAX]: run -> position a
     uint32_t &s_used = s_ua[(LC + 1u) * ACC_GMAX];
     uint32_t &s_lost = s_ua[(LC + 1u) * ACC_GMAX + 1u];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    for (uint32_t i = tid; i < ACC_SLOTS; i += ACC_TPB) { s_key[i] = EMPTY_NODE; s_cnt[i] = 0; }
+    for (uint32_t i = tid; i < SLOTS; i += ACC_TPB) { s_key[i] = AccTable<KT>::EMPTY; s_cnt[i] = 0; }
     if (tid <= LC) {
         uint32_t gsum = 0;
         for (uint32_t m = 1; m <= tid; m++) gsum += (m + ACC_RUN - 1u) / ACC_RUN;
@@ -651,7 +677,6 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
     __syncthreads();
     const uint64_t lo = (uint64_t)blockIdx.x * pairs_per_wg;
     const uint64_t hi = lo + pairs_per_wg < n_slots_pairs ? lo + pairs_per_wg : n_slots_pairs;
-    const uint32_t NN = N * N;
     for (uint64_t base = lo; base < hi; base += ACC_TPB) {  // ACC_TPB pairs per round, 64 per wavefront
         const uint64_t wbase = base + wv * 64u;             // wave-uniform
         const uint32_t *wcounts = counts + 2u * wbase;
@@ -707,21 +732,20 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
             // past `be` stays inside the lists buffer, which carries padding, and is ignored)
             const uint32_t y0 = wlists[off + bi], y1 = wlists[off + bi + 1u], y2 = wlists[off + bi + 2u],
                            y3 = wlists[off + bi + 3u];
-            vs_cell_add(s_key, s_cnt, s_used, s_lost, use_table, mat, x, y0, N, NN, node_mat, short_mat);  // bi < be always
-            if (bi + 1u < be) vs_cell_add(s_key, s_cnt, s_used, s_lost, use_table, mat, x, y1, N, NN, node_mat, short_mat);
-            if (bi + 2u < be) vs_cell_add(s_key, s_cnt, s_used, s_lost, use_table, mat, x, y2, N, NN, node_mat, short_mat);
-            if (bi + 3u < be) vs_cell_add(s_key, s_cnt, s_used, s_lost, use_table, mat, x, y3, N, NN, node_mat, short_mat);
+            vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, use_table, mat, x, y0, N, node_mat, short_mat);  // bi < be always
+            if (bi + 1u < be) vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, use_table, mat, x, y1, N, node_mat, short_mat);
+            if (bi + 2u < be) vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, use_table, mat, x, y2, N, node_mat, short_mat);
+            if (bi + 3u < be) vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, use_table, mat, x, y3, N, node_mat, short_mat);
         }
         __syncthreads();
         const bool spill = s_used > fill_limit || s_lost > 4096u;
         __syncthreads();
         if (spill) {
-            for (uint32_t i = tid; i < ACC_SLOTS; i += ACC_TPB) {
-                const uint32_t key = s_key[i];
-                if (key != EMPTY_NODE) {
-                    const uint32_t mat = key >= NN ? 1u : 0u;
-                    atomicAdd((mat ? short_mat : node_mat) + (key - mat * NN), s_cnt[i]);
-                    s_key[i] = EMPTY_NODE;
+            for (uint32_t i = tid; i < SLOTS; i += ACC_TPB) {
+                const KT key = s_key[i];
+                if (key != AccTable<KT>::EMPTY) {
+                    atomicAdd((AccTable<KT>::mat_of(key, N) ? short_mat : node_mat) + AccTable<KT>::cell_of(key, N), s_cnt[i]);
+                    s_key[i] = AccTable<KT>::EMPTY;
                     s_cnt[i] = 0;
                 }
             }
@@ -730,12 +754,10 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
         }
     }
     __syncthreads();
-    for (uint32_t i = tid; i < ACC_SLOTS; i += ACC_TPB) {
-        const uint32_t key = s_key[i];
-        if (key != EMPTY_NODE) {
-            const uint32_t mat = key >= NN ? 1u : 0u;
-            atomicAdd((mat ? short_mat : node_mat) + (key - mat * NN), s_cnt[i]);
-        }
+    for (uint32_t i = tid; i < SLOTS; i += ACC_TPB) {
+        const KT key = s_key[i];
+        if (key != AccTable<KT>::EMPTY)
+            atomicAdd((AccTable<KT>::mat_of(key, N) ? short_mat : node_mat) + AccTable<KT>::cell_of(key, N), s_cnt[i]);
     }
 }
 
@@ -1102,17 +1124,28 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         uint32_t per_wg = (uint32_t)((slots_pairs + acc_grid - 1) / acc_grid);
         per_wg = (per_wg + ACC_TPB - 1) / ACC_TPB * ACC_TPB;
         acc_grid = (uint32_t)((slots_pairs + per_wg - 1) / per_wg);
+        // 32-bit cell keys while 2*N*N fits, 64-bit keys (half the slots) above; VS_ACC_WIDE=1 forces
+        // the wide table, VS_NO_AGG=1 turns the table off (every increment a global atomic)
+        const bool wide = 2ull * idx.n_nodes * idx.n_nodes >= 0xFFFFFFFFull || (getenv("VS_ACC_WIDE") && atoi(getenv("VS_ACC_WIDE")) != 0);
+        const uint32_t slots = wide ? ACC_SLOTS / 2u : ACC_SLOTS;
         // the table is written out once this many of its slots are taken: linear probing stays
         // short at a low fill, and cells of loci the run has left do not pile up (VS_ACC_FILL: percent)
-        uint32_t fill_limit = ACC_SLOTS / 8u;
-        if (const char *fv = getenv("VS_ACC_FILL")) fill_limit = (uint32_t)((uint64_t)ACC_SLOTS * (uint32_t)atoi(fv) / 100u);
+        uint32_t fill_limit = slots / 8u;
+        if (const char *fv = getenv("VS_ACC_FILL")) fill_limit = (uint32_t)((uint64_t)slots * (uint32_t)atoi(fv) / 100u);
         const char *ev = getenv("VS_NO_AGG");
-        const uint32_t use_table = (!(ev && atoi(ev) != 0) && 2ull * idx.n_nodes * idx.n_nodes < 0xFFFFFFFFull) ? 1u : 0u;
-        VS_HIP(ctx, hipFuncSetAttribute((const void *)k_pe_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES));
+        const uint32_t use_table = (ev && atoi(ev) != 0) ? 0u : 1u;
         VS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
-        hipLaunchKernelGGL(k_pe_accumulate, dim3(acc_grid), dim3(ACC_TPB), ACC_LDS_BYTES, st, (const uint32_t *)ctx->d_lists,
-                           (const uint32_t *)ctx->d_list_counts, slots_pairs, per_wg, idx.n_nodes, use_table, fill_limit,
-                           d_node_mat, d_short_mat);
+        if (wide) {
+            VS_HIP(ctx, hipFuncSetAttribute((const void *)k_pe_accumulate<unsigned long long>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES));
+            hipLaunchKernelGGL(k_pe_accumulate<unsigned long long>, dim3(acc_grid), dim3(ACC_TPB), ACC_LDS_BYTES, st,
+                               (const uint32_t *)ctx->d_lists, (const uint32_t *)ctx->d_list_counts, slots_pairs, per_wg,
+                               idx.n_nodes, use_table, fill_limit, d_node_mat, d_short_mat);
+        } else {
+            VS_HIP(ctx, hipFuncSetAttribute((const void *)k_pe_accumulate<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES));
+            hipLaunchKernelGGL(k_pe_accumulate<uint32_t>, dim3(acc_grid), dim3(ACC_TPB), ACC_LDS_BYTES, st,
+                               (const uint32_t *)ctx->d_lists, (const uint32_t *)ctx->d_list_counts, slots_pairs, per_wg,
+                               idx.n_nodes, use_table, fill_limit, d_node_mat, d_short_mat);
+        }
     }
     VS_HIP(ctx, hipEventRecord(ctx->ev[1], st));
     hipLaunchKernelGGL(k_pe_slow, dim3(SLOW_GRID), dim3(TPB), 0, st, P, (uint32_t *)ctx->d_dense, (uint32_t)n_pairs);
