@@ -297,3 +297,24 @@ def test_full_size_block_properties(host, ctx):
     got = count([(0, M)])
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
     assert got[2] == tuple(int(x) for x in ref[2])
+
+
+def test_many_nodes_sort_and_counters(host, ctx):
+    """20 k nodes: the LDS histogram of the locus sort needs more than 64 KB (dynamic LDS attribute),
+    and the counter matrices are 2 x 1.6 GB; counts against the oracle on a chain graph."""
+    rng = np.random.default_rng(5)
+    k, n_nodes, step = 55, 20000, 40
+    genome = "".join("ACGT"[i] for i in rng.integers(0, 4, size=n_nodes * step + k + 200))
+    seqs = [genome[i * step: i * step + step + k] for i in range(n_nodes)]  # consecutive nodes overlap by k
+    n = 30000
+    starts = rng.integers(0, len(genome) - 600, size=n)
+    from vstrains_amd import synth
+
+    fwd = [genome[a: a + 150] for a in starts]
+    rve = [synth.revcomp(genome[a + 250: a + 400]) for a in starts]
+    orc = pe_oracle_c.Oracle(seqs, k)
+    want = orc.count_pairs(fwd, rve)
+    (node_mat, short_mat, stats), _ = _gpu_matrices(host, ctx, seqs, fwd, rve, k)
+    assert np.array_equal(node_mat, want[0]) and np.array_equal(short_mat, want[1])
+    assert stats == tuple(int(x) for x in want[2])
+    assert node_mat.sum() > n

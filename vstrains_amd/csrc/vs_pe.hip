@@ -790,7 +790,7 @@ __device__ __forceinline__ uint32_t vs_locus_key(const VsIndexDev &idx, const Vs
 //   vs_scan_u32     : exclusive scan of cnt[] in (key, workgroup) order = first slot of every
 //                     (key, workgroup) run in the sorted order -- stable, deterministic
 //   k_locus_scatter : workgroup g loads its column as LDS cursors and places its pairs
-#define LOCUS_LDS_KEYS 16384u
+#define LOCUS_LDS_KEYS 36864u  // 144 KB of LDS counters
 #define LOCUS_WGS 1024u
 __global__ void __launch_bounds__(TPB)
 k_locus_count(VsIndexDev idx, VsReadsDev rd, uint64_t n_pairs, uint32_t chunk, uint32_t n_wg, uint32_t *__restrict__ keys,
@@ -1089,6 +1089,10 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
             const uint32_t n_wg = LOCUS_WGS;
             const uint32_t chunk = (uint32_t)((n_pairs + n_wg - 1) / n_wg);
             const size_t lds_keys = sizeof(uint32_t) * nk;
+            if (lds_keys > 64u * 1024u) {
+                VS_HIP(ctx, hipFuncSetAttribute((const void *)k_locus_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_keys));
+                VS_HIP(ctx, hipFuncSetAttribute((const void *)k_locus_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_keys));
+            }
             hipLaunchKernelGGL(k_locus_count, dim3(n_wg), dim3(TPB), lds_keys, st, idx, reads->dev(), n_pairs, chunk, n_wg,
                                (uint32_t *)ctx->d_locus_keys, (uint32_t *)ctx->d_locus_hist);
             int rc = vs_scan_u32(ctx, (const uint32_t *)ctx->d_locus_hist, (uint32_t *)ctx->d_locus_hist, nk * n_wg,
