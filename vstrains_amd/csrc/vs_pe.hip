@@ -72,6 +72,8 @@ struct Mem {  // one credited maximal exact match
 // the block, probe stride <= 32, reads <= 191 bases with w = 31): one left window, five right
 // windows, everything loaded up front, the answer out of selects -- no data-dependent branch.
 // The host picks the kernel instantiation (k_pe_tiles<true>) when the whole block qualifies.
+struct __attribute__((packed, aligned(4))) VsQuad { uint32_t x, y, z, w; };  // 16-byte load at dword alignment
+
 template <typename RB>
 __device__ __forceinline__ bool vs_extend_fast(const uint32_t *rw, RB rbase, uint32_t rlen, const uint32_t *tw,
                                                uint32_t tbase, uint32_t tlen, uint32_t j, uint32_t q, uint32_t w,
@@ -86,12 +88,24 @@ __device__ __forceinline__ bool vs_extend_fast(const uint32_t *rw, RB rbase, uin
         const uint32_t rem2 = tlen - rq;
         rem = rem < rem2 ? rem : rem2;
     }
+    // Node text to the right of the seed: eleven words cover the five windows; they come as 16-byte
+    // loads, and the second / third only when the match can reach that far (rem) -- on a graph of
+    // short nodes one load settles most postings.  Words not loaded read as zero: whatever they make
+    // of the comparison lies beyond `rem` and is clipped.
+    const uint32_t tr = tbase + rq, ti = tr >> 4, sh = (tr & 15u) * 2u;
+    const VsQuad q0 = *(const VsQuad *)(tw + ti);
+    VsQuad q1 = {0u, 0u, 0u, 0u}, q2 = {0u, 0u, 0u, 0u};
+    if (rem > 48u) q1 = *(const VsQuad *)(tw + ti + 4u);
+    if (rem > 112u) q2 = *(const VsQuad *)(tw + ti + 8u);
+    auto tw64 = [&](uint32_t w0, uint32_t w1, uint32_t w2) {
+        return (uint64_t)__builtin_amdgcn_alignbit(w1, w0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, sh) << 32);
+    };
     const uint64_t xl = (vs_win(rw, rbase + j - n0) ^ vs_win(tw, tbase + q - n0)) & vs_lowmask(2u * n0);
-    const uint64_t x0 = vs_win(rw, rbase + rj) ^ vs_win(tw, tbase + rq);
-    const uint64_t x1 = vs_win(rw, rbase + rj + 32u) ^ vs_win(tw, tbase + rq + 32u);
-    const uint64_t x2 = vs_win(rw, rbase + rj + 64u) ^ vs_win(tw, tbase + rq + 64u);
-    const uint64_t x3 = vs_win(rw, rbase + rj + 96u) ^ vs_win(tw, tbase + rq + 96u);
-    const uint64_t x4 = vs_win(rw, rbase + rj + 128u) ^ vs_win(tw, tbase + rq + 128u);
+    const uint64_t x0 = vs_win(rw, rbase + rj) ^ tw64(q0.x, q0.y, q0.z);
+    const uint64_t x1 = vs_win(rw, rbase + rj + 32u) ^ tw64(q0.z, q0.w, q1.x);
+    const uint64_t x2 = vs_win(rw, rbase + rj + 64u) ^ tw64(q1.x, q1.y, q1.z);
+    const uint64_t x3 = vs_win(rw, rbase + rj + 96u) ^ tw64(q1.z, q1.w, q2.x);
+    const uint64_t x4 = vs_win(rw, rbase + rj + 128u) ^ tw64(q2.x, q2.y, q2.z);
     const uint32_t left = xl ? n0 - 1u - (uint32_t)((63 - __clzll((long long)xl)) >> 1) : n0;
     uint32_t ext = x4 ? 128u + ((uint32_t)(__ffsll((long long)x4) - 1) >> 1) : 160u;
     ext = x3 ? 96u + ((uint32_t)(__ffsll((long long)x3) - 1) >> 1) : ext;
