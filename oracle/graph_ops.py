@@ -18,7 +18,7 @@ Pinned by ``tests/golden/graph/*`` (outputs of the real reference run behind the
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import numpy
 
@@ -159,7 +159,7 @@ class DictLiveLinks:
     def get(self, a: str, b: str):
         return self.table[self._key(a, b)]
 
-    def note_split(self, removed: str, subs: List[str], live_ids: List[str]) -> None:
+    def note_split(self, removed: str, subs: List[str], live_ids: Iterable[str]) -> None:
         for s in subs:
             for n in live_ids:
                 self.table[self._key(s, n)] = None
@@ -167,7 +167,7 @@ class DictLiveLinks:
             if pu == removed or pv == removed:
                 self.table.pop((pu, pv))
 
-    def note_fork(self, sub: str, live_ids: List[str]) -> None:
+    def note_fork(self, sub: str, live_ids: Iterable[str]) -> None:
         for n in live_ids:
             self.table[self._key(sub, n)] = None
 
@@ -176,7 +176,7 @@ class DictLiveLinks:
             if pu == removed or pv == removed:
                 self.table.pop((pu, pv))
 
-    def note_merge(self, new_id: str, members: List[str], live_ids: List[str]) -> None:
+    def note_merge(self, new_id: str, members: List[str], live_ids: Iterable[str]) -> None:
         for n in live_ids:
             key = self._key(new_id, n)
             self.table[key] = 0

@@ -2,7 +2,7 @@
 """GPU-side: wall time of the whole vstrains-compatible command on a configs[2]-shaped input
 (15-strain synthetic, ~4.5 k-node GFA) with M read pairs written as FASTQ text.
 
-    python tools/e2e_cli.py [M]        (default 2,000,000)
+    python tools/e2e_cli.py [M [n_strains genome_len]]        (default 2,000,000 15 10800)
 """
 import json
 import os
@@ -20,10 +20,12 @@ from vstrains_amd import cli, synth  # noqa: E402
 
 def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+    n_strains = int(sys.argv[2]) if len(sys.argv) > 3 else 15
+    genome_len = int(sys.argv[3]) if len(sys.argv) > 3 else 10800
     L = 150
     tmp = tempfile.mkdtemp(prefix="vstrains_e2e_")
     t0 = time.time()
-    pc = synth.make_pipeline_case(n_strains=15, genome_len=10800, snp_rate=0.09, k=55, n_pairs=0, read_len=L, seed=1003)
+    pc = synth.make_pipeline_case(n_strains=n_strains, genome_len=genome_len, snp_rate=0.09, k=55, n_pairs=0, read_len=L, seed=1003)
     st = pc.strains
     ab = np.array(st.abundance)
     cum = np.minimum(np.floor(np.cumsum(ab) / ab.sum() * 2 ** 32), 2 ** 32 - 1).astype(np.uint32)
@@ -46,9 +48,9 @@ def main():
     t1 = time.time()
     timings = cli.main(["-a", "spades", "-g", paths["gfa"], "-p", paths["paths"], "-o", out, "-fwd", paths["f"], "-rve", paths["r"]])
     wall = time.time() - t1
-    n_strains = open(os.path.join(out, "strain.paths")).read().count("NODE_")
+    n_out = open(os.path.join(out, "strain.paths")).read().count("NODE_")
     print(json.dumps({"pairs": M, "fastq_bytes": os.path.getsize(paths["f"]) + os.path.getsize(paths["r"]),
-                      "input_generation_s": prep_s, "cli_wall_s": wall, "stages": timings, "strains": n_strains,
+                      "input_generation_s": prep_s, "cli_wall_s": wall, "stages": timings, "strains": n_out,
                       "gfa_nodes": len(pc.graph.ids)}))
 
 

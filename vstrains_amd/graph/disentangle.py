@@ -271,7 +271,7 @@ def balance_split(stage: Stage, contigs: ContigDict, links: LiveLinks, logger, t
             _retire_edge(g, edges, no, w)
         _retire_vertex(g, nodes, no)
         by_node = contigs_by_node(contigs)
-        links.note_split(no, list(sub_of.values()), list(nodes.keys()))
+        links.note_split(no, list(sub_of.values()), nodes)
     links.end_pass()
     logger.debug("No of branch be removed: " + str(len(set(done))))
     logger.info("done")
@@ -311,7 +311,7 @@ def trivial_split(stage: Stage, links: LiveLinks, logger):
                     _add_edge(g, edges, src, sv, g.eovl[ine], g.eflow[ine])
                     _add_edge(g, edges, sv, ntv, g.eovl[g.edge(iv, ntv)], g.eflow[ine])
                     id_mapping[ino][g.vid[sv]] = None
-                    links.note_fork(g.vid[sv], list(nodes.keys()))
+                    links.note_fork(g.vid[sv], nodes)
                 forks += 1
                 links.note_drop(ino)
         for ov in set(g.out_neighbors(ntv)):
@@ -331,7 +331,7 @@ def trivial_split(stage: Stage, links: LiveLinks, logger):
                     _add_edge(g, edges, sv, tgt, g.eovl[oute], g.eflow[oute])
                     _add_edge(g, edges, ntv, sv, g.eovl[g.edge(ntv, ov)], g.eflow[oute])
                     id_mapping[ono][g.vid[sv]] = None
-                    links.note_fork(g.vid[sv], list(nodes.keys()))
+                    links.note_fork(g.vid[sv], nodes)
                 forks += 1
                 links.note_drop(ono)
     links.end_pass()
@@ -437,22 +437,27 @@ def contract_simple_paths(stage: Stage, contigs: Optional[ContigDict], links: Op
         cv = _add_vertex(g, nodes, new_id, cov, seq)
         built.append((first, last, cv, ins, outs))
         if links is not None:
-            links.note_merge(new_id, ids, list(nodes.keys()))
+            links.note_merge(new_id, ids, nodes)  # (the live ids: iterating the map gives them)
 
+    # a neighbour that was itself contracted is reached through its chain's new vertex (the
+    # reference scans every contracted path for "ends in u" / "starts with w", Utilities.py:
+    # 502-549; chains are disjoint, so there is at most one and a dictionary finds it)
+    by_last = {last: v for _, last, v, _, _ in built}
+    by_first = {first: v for first, _, v, _, _ in built}
     for _, _, cv, ins, outs in built:
         me = g.vid[cv]
         for u, _, ovl in ins:
             if u in nodes and (u, me) not in edges:
                 _add_edge(g, edges, nodes[u], cv, ovl)
-            for _, other_last, other_v, _, _ in built:
-                if other_last == u and (g.vid[other_v], me) not in edges:
-                    _add_edge(g, edges, other_v, cv, ovl)
+            other_v = by_last.get(u)
+            if other_v is not None and (g.vid[other_v], me) not in edges:
+                _add_edge(g, edges, other_v, cv, ovl)
         for _, w, ovl in outs:
             if w in nodes and (me, w) not in edges:
                 _add_edge(g, edges, cv, nodes[w], ovl)
-            for other_first, _, other_v, _, _ in built:
-                if other_first == w and (me, g.vid[other_v]) not in edges:
-                    _add_edge(g, edges, cv, other_v, ovl)
+            other_v = by_first.get(w)
+            if other_v is not None and (me, g.vid[other_v]) not in edges:
+                _add_edge(g, edges, cv, other_v, ovl)
 
     if contigs is not None:
         for cno, (ids, _, cov) in list(contigs.items()):

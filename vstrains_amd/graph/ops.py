@@ -138,17 +138,17 @@ class LiveLinks:
         if fresh:
             self._fresh[name] = None
 
-    def note_split(self, removed: str, subs: List[str], live_ids: List[str]) -> None:
+    def note_split(self, removed: str, subs: List[str], live_ids: Iterable[str]) -> None:
         for s in subs:
             self._born(s, [], True)
 
-    def note_fork(self, sub: str, live_ids: List[str]) -> None:
+    def note_fork(self, sub: str, live_ids: Iterable[str]) -> None:
         self._born(sub, [], True)
 
     def note_drop(self, removed: str) -> None:
         pass
 
-    def note_merge(self, new_id: str, members: List[str], live_ids: List[str]) -> None:
+    def note_merge(self, new_id: str, members: List[str], live_ids: Iterable[str]) -> None:
         support: List[int] = []
         for m in members:
             support.extend(self.rows(m))
