@@ -62,6 +62,7 @@ struct PeParams {
     uint32_t *out_lists;             // [n_tiles * ept * LC] accepted node ids per end, tile order
     uint32_t *out_counts;            // [n_tiles * ept] list lengths (0 for ends that add nothing)
     uint64_t n_pairs;
+    uint32_t no_xcd_map;             // VS_NO_XCD_MAP=1: workgroup b takes run b (experiments)
 };
 
 struct Mem {  // one credited maximal exact match
@@ -307,7 +308,12 @@ k_pe_tiles(PeParams P) {
 
     if (tid < 3) s_misc[8 + tid] = 0;  // workgroup-local stats
     // a workgroup takes a contiguous run of the locus-sorted tiles (node text stays in L1/L2)
-    const uint64_t tile_lo = (uint64_t)blockIdx.x * P.tiles_per_wg;
+    // Workgroups go to the 8 XCDs round-robin (blockIdx % 8).  The runs are handed out so that XCD x
+    // works through the x-th eighth of the locus order: what a locus touches (table slots, postings,
+    // node text) is then cached in one L2 instead of eight.
+    uint32_t wg = blockIdx.x;
+    if ((gridDim.x & 7u) == 0u && !P.no_xcd_map) wg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const uint64_t tile_lo = (uint64_t)wg * P.tiles_per_wg;
     const uint64_t tile_hi = tile_lo + P.tiles_per_wg < P.n_tiles ? tile_lo + P.tiles_per_wg : P.n_tiles;
     // The headers of a tile (pair order -> end index -> word offset, length) are two dependent
     // global loads; they are fetched one tile ahead into registers (one end per thread, ept <= TPB)
@@ -1082,6 +1088,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     P.dbg_counts = d_dbg_counts;
     P.dbg_cap = dbg_cap;
     P.accumulate = d_node_mat ? 1u : 0u;
+    P.no_xcd_map = (getenv("VS_NO_XCD_MAP") && atoi(getenv("VS_NO_XCD_MAP")) != 0) ? 1u : 0u;
 
     // straight-line extension when the whole block qualifies (see vs_extend_fast)
     const bool fast = !reads->d_mask && idx.s <= 32u && maxlen <= 128u + idx.w + 32u &&
@@ -1090,8 +1097,11 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     if (lds > 64u * 1024u)
         VS_HIP(ctx, hipFuncSetAttribute(tiles_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     uint64_t grid = P.n_tiles;
-    uint64_t max_grid = (uint64_t)ctx->n_cu * 8u;
-    if (const char *ev = getenv("VS_GRID_PER_CU")) max_grid = (uint64_t)ctx->n_cu * (uint64_t)(atoi(ev) > 0 ? atoi(ev) : 8);
+    // Many more workgroups than fit at once (4 per CU): loci differ a lot in postings per read, and
+    // short runs let the dispatcher even that out (runs of ~10 tiles at configs[2]: 8.4 ms, against
+    // 10.0 ms with 8 workgroups per CU and 9.0 ms with one tile per workgroup)
+    uint64_t max_grid = (uint64_t)ctx->n_cu * 128u;
+    if (const char *ev = getenv("VS_GRID_PER_CU")) max_grid = (uint64_t)ctx->n_cu * (uint64_t)(atoi(ev) > 0 ? atoi(ev) : 128);
     if (grid > max_grid) grid = max_grid;
     P.tiles_per_wg = (uint32_t)((P.n_tiles + grid - 1) / grid);
     grid = (P.n_tiles + P.tiles_per_wg - 1) / P.tiles_per_wg;
@@ -1138,7 +1148,10 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         if (list_ends > used_ends)
             VS_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->d_list_counts + used_ends, 0, sizeof(uint32_t) * (list_ends - used_ends), st));
         const uint64_t slots_pairs = list_ends / 2;
-        uint32_t acc_grid = (uint32_t)ctx->n_cu;
+        // one workgroup fits per CU (the cell table); 32 per CU queued, for the same reason as above
+        // (4.9 -> 3.9 ms), each at least one round of ACC_TPB pairs
+        uint32_t acc_grid = (uint32_t)ctx->n_cu * 32u;
+        if (const char *gv = getenv("VS_ACC_GRID_PER_CU")) acc_grid = (uint32_t)ctx->n_cu * (uint32_t)(atoi(gv) > 0 ? atoi(gv) : 32);
         uint32_t per_wg = (uint32_t)((slots_pairs + acc_grid - 1) / acc_grid);
         per_wg = (per_wg + ACC_TPB - 1) / ACC_TPB * ACC_TPB;
         acc_grid = (uint32_t)((slots_pairs + per_wg - 1) / per_wg);
