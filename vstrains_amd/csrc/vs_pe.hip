@@ -598,9 +598,11 @@ k_pe_tiles(PeParams P) {
 // the table is written out.  One wavefront expands 64 pairs at a time, one lane per run of at
 // most four increments.
 #define ACC_TPB 1024
+#ifndef ACC_BITS
 #define ACC_BITS 14
+#endif
 #define ACC_SLOTS (1u << ACC_BITS)
-#define ACC_LDS_BYTES ((2u * ACC_SLOTS + (ACC_TPB / 64) * 66u + (LC + 1u) + (LC + 1u) * 40u + 2u) * 4u)
+#define ACC_LDS_BYTES ((2u * ACC_SLOTS + (ACC_TPB / 64) * 66u + (LC + 1u) + (LC + 1u) * 40u + 4u) * 4u)
 // Work units: a list row is cut into runs of at most ACC_RUN partners, one lane per run, so that
 // every lane of a wavefront has about the same (small, fully unrolled) amount of work:
 //   node_mat : left node a against right positions [4c, 4c+4)           -> nl * ceil(nr/4) runs
@@ -673,7 +675,7 @@ template <typename KT>
 __global__ void __launch_bounds__(ACC_TPB)
 k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_slots_pairs,
                 uint32_t pairs_per_wg, uint32_t N, uint32_t use_table, uint32_t fill_limit,
-                uint32_t *__restrict__ node_mat, uint32_t *__restrict__ short_mat) {
+                uint32_t *__restrict__ node_mat, uint32_t *__restrict__ short_mat, uint32_t *__restrict__ queue) {
     constexpr uint32_t SLOTS = 1u << AccTable<KT>::BITS;
     KT *s_key = (KT *)vs_lds;                      // [SLOTS] keys: ACC_SLOTS words either way
     uint32_t *s_cnt = vs_lds + ACC_SLOTS;          // [SLOTS]
@@ -695,7 +697,19 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
     }
     if (tid == 0) { s_used = 0; s_lost = 0; }
     __syncthreads();
-    const uint64_t lo = (uint64_t)blockIdx.x * pairs_per_wg;
+    // chunks of pairs_per_wg pairs: chunk blockIdx.x, or (queue) whichever chunk is next when this
+    // workgroup is free -- the table then lives across chunks and is written out on fill only
+    uint32_t &s_chunk = s_ua[(LC + 1u) * ACC_GMAX + 2u];
+    for (;;) {
+    uint64_t chunk = blockIdx.x;
+    if (queue) {
+        __syncthreads();
+        if (tid == 0) s_chunk = atomicAdd(queue, 1u);
+        __syncthreads();
+        chunk = s_chunk;
+    }
+    const uint64_t lo = chunk * pairs_per_wg;
+    if (lo >= n_slots_pairs) break;
     const uint64_t hi = lo + pairs_per_wg < n_slots_pairs ? lo + pairs_per_wg : n_slots_pairs;
     for (uint64_t base = lo; base < hi; base += ACC_TPB) {  // ACC_TPB pairs per round, 64 per wavefront
         const uint64_t wbase = base + wv * 64u;             // wave-uniform
@@ -773,6 +787,8 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
             __syncthreads();
         }
     }
+    if (!queue) break;
+    }
     __syncthreads();
     for (uint32_t i = tid; i < SLOTS; i += ACC_TPB) {
         const KT key = s_key[i];
@@ -811,7 +827,9 @@ __device__ __forceinline__ uint32_t vs_locus_key(const VsIndexDev &idx, const Vs
 //                     (key, workgroup) run in the sorted order -- stable, deterministic
 //   k_locus_scatter : workgroup g loads its column as LDS cursors and places its pairs
 #define LOCUS_LDS_KEYS 36864u  // 144 KB of LDS counters
+#ifndef LOCUS_WGS
 #define LOCUS_WGS 1024u
+#endif
 __global__ void __launch_bounds__(TPB)
 k_locus_count(VsIndexDev idx, VsReadsDev rd, uint64_t n_pairs, uint32_t chunk, uint32_t n_wg, uint32_t *__restrict__ keys,
               uint32_t *__restrict__ cnt) {
@@ -1155,6 +1173,15 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         uint32_t per_wg = (uint32_t)((slots_pairs + acc_grid - 1) / acc_grid);
         per_wg = (per_wg + ACC_TPB - 1) / ACC_TPB * ACC_TPB;
         acc_grid = (uint32_t)((slots_pairs + per_wg - 1) / per_wg);
+        // the chunks are not bound to workgroups: two workgroups per CU take the next chunk off a
+        // counter whenever they are free, so a cell table lives across chunks and is written out on
+        // fill only (3.85 -> 3.6 ms against one workgroup per chunk; VS_ACC_QUEUE=0 for that)
+        uint32_t *acc_queue = nullptr;
+        if (!(getenv("VS_ACC_QUEUE") && atoi(getenv("VS_ACC_QUEUE")) == 0)) {
+            acc_queue = (uint32_t *)ctx->d_slow_count + 1;
+            const uint32_t wgs = (uint32_t)ctx->n_cu * 2u;
+            if (acc_grid > wgs) acc_grid = wgs;
+        }
         // 32-bit cell keys while 2*N*N fits, 64-bit keys (half the slots) above; VS_ACC_WIDE=1 forces
         // the wide table, VS_NO_AGG=1 turns the table off (every increment a global atomic)
         const bool wide = 2ull * idx.n_nodes * idx.n_nodes >= 0xFFFFFFFFull || (getenv("VS_ACC_WIDE") && atoi(getenv("VS_ACC_WIDE")) != 0);
@@ -1170,12 +1197,12 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
             VS_HIP(ctx, hipFuncSetAttribute((const void *)k_pe_accumulate<unsigned long long>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES));
             hipLaunchKernelGGL(k_pe_accumulate<unsigned long long>, dim3(acc_grid), dim3(ACC_TPB), ACC_LDS_BYTES, st,
                                (const uint32_t *)ctx->d_lists, (const uint32_t *)ctx->d_list_counts, slots_pairs, per_wg,
-                               idx.n_nodes, use_table, fill_limit, d_node_mat, d_short_mat);
+                               idx.n_nodes, use_table, fill_limit, d_node_mat, d_short_mat, acc_queue);
         } else {
             VS_HIP(ctx, hipFuncSetAttribute((const void *)k_pe_accumulate<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES));
             hipLaunchKernelGGL(k_pe_accumulate<uint32_t>, dim3(acc_grid), dim3(ACC_TPB), ACC_LDS_BYTES, st,
                                (const uint32_t *)ctx->d_lists, (const uint32_t *)ctx->d_list_counts, slots_pairs, per_wg,
-                               idx.n_nodes, use_table, fill_limit, d_node_mat, d_short_mat);
+                               idx.n_nodes, use_table, fill_limit, d_node_mat, d_short_mat, acc_queue);
         }
     }
     VS_HIP(ctx, hipEventRecord(ctx->ev[1], st));
