@@ -39,7 +39,10 @@
 #define LC 16u  // accepted nodes kept per read end in LDS (more -> slow path)
 #define EMPTY_NODE 0xFFFFFFFFu
 #ifndef PPT
-#define PPT 4u               // postings per thread and expansion chunk
+#define PPT 2u               // postings per thread and expansion chunk
+#endif
+#ifndef TILES_WAVES
+#define TILES_WAVES 5        // k_pe_tiles is compiled for 5 waves per SIMD (<= 96 VGPRs); its LDS tile fits 5 times too
 #endif
 #define CHUNK (TPB * PPT)
 
@@ -271,8 +274,9 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
     t.hminj = o; o += pool;
     t.ns = o;    o += ept;
     t.state = o; o += ept;
-    t.list = o;  o += ept * LC;
-    t.owner = o; o += CHUNK;          // probe owning each posting of the chunk being expanded
+    // the posting owners of P3 and the accepted lists of P4/P5 are never live together
+    t.list = o;
+    t.owner = o; o += (ept * LC > CHUNK ? ept * LC : CHUNK);
     t.misc = o;  o += 16u;
     t.total = o;
     return t;
@@ -280,6 +284,7 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
 
 template <bool FAST>
 __global__ void __launch_bounds__(TPB)
+__attribute__((amdgpu_waves_per_eu(TILES_WAVES, TILES_WAVES)))
 k_pe_tiles(PeParams P) {
     const uint32_t tid = threadIdx.x;
     const uint32_t ept = P.ept, pmax = P.pmax;
