@@ -742,16 +742,17 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
         uint32_t cur = 0;  // wave-uniform: first pair whose runs reach into the current window
         for (uint32_t t0 = 0; t0 < U; t0 += 64u) {
             while (s_pref[wv][cur + 1u] <= t0) cur++;
-            const uint32_t t = t0 + lane;
-            if (t >= U) break;
+            const uint32_t t_raw = t0 + lane;
+            const uint32_t t = t_raw < U ? t_raw : U - 1u;  // (lanes past the end ride along until the cross-lane read)
             uint32_t a0 = cur;  // last pair of this wavefront with pref <= t
             a0 += s_pref[wv][a0 + 1u] <= t ? 1u : 0u;
             a0 += s_pref[wv][a0 + 1u] <= t ? 1u : 0u;
             a0 += s_pref[wv][a0 + 1u] <= t ? 1u : 0u;
             while (s_pref[wv][a0 + 1u] <= t) a0++;
             uint32_t r = t - s_pref[wv][a0];
-            const uint2 c = *(const uint2 *)(wcounts + 2u * a0);
-            const uint32_t ql = c.x, qr = c.y;
+            // list lengths of pair a0: lane a0 holds them (cross-lane read, no memory round trip)
+            const uint32_t ql = __shfl(nl, (int)a0, 64), qr = __shfl(nr, (int)a0, 64);
+            if (t_raw >= U) break;
             const uint32_t row = 2u * a0 * LC;
             const uint32_t cq = (qr + ACC_RUN - 1u) / ACC_RUN;
             uint32_t x, mat, off, bi, be;
@@ -771,10 +772,38 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
             // past `be` stays inside the lists buffer, which carries padding, and is ignored)
             const uint32_t y0 = wlists[off + bi], y1 = wlists[off + bi + 1u], y2 = wlists[off + bi + 2u],
                            y3 = wlists[off + bi + 3u];
-            vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, use_table, mat, x, y0, N, node_mat, short_mat);  // bi < be always
-            if (bi + 1u < be) vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, use_table, mat, x, y1, N, node_mat, short_mat);
-            if (bi + 2u < be) vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, use_table, mat, x, y2, N, node_mat, short_mat);
-            if (bi + 3u < be) vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, use_table, mat, x, y3, N, node_mat, short_mat);
+            if (use_table) {
+                // the four cells' slots are read together (independent LDS loads), then counted; a
+                // slot that does not hold the cell yet goes the slow way (claim / probe / global)
+                const uint32_t ys[4] = {y0, y1, y2, y3};
+                KT key[4], seen[4];
+                uint32_t at[4];
+                bool live[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++) {
+                    live[j] = bi + j < be;  // j = 0 always
+                    const uint32_t yv = ys[j];
+                    const uint32_t cx = (mat && yv < x) ? yv : x, cy = (mat && yv < x) ? x : yv;
+                    key[j] = AccTable<KT>::key(mat, cx, cy, N);
+                    at[j] = AccTable<KT>::slot(key[j]);
+                    seen[j] = s_key[at[j]];
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++) {
+                    if (!live[j]) continue;
+                    if (seen[j] == key[j]) {
+                        atomicAdd(&s_cnt[at[j]], 1u);
+                    } else if (!vs_cell_claim<KT>(s_key, s_cnt, &s_used, key[j], at[j])) {
+                        atomicAdd(&s_lost, 1u);
+                        atomicAdd((mat ? short_mat : node_mat) + AccTable<KT>::cell_of(key[j], N), 1u);
+                    }
+                }
+            } else {
+                vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y0, N, node_mat, short_mat);  // bi < be always
+                if (bi + 1u < be) vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y1, N, node_mat, short_mat);
+                if (bi + 2u < be) vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y2, N, node_mat, short_mat);
+                if (bi + 3u < be) vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y3, N, node_mat, short_mat);
+            }
         }
         __syncthreads();
         const bool spill = s_used > fill_limit || s_lost > 4096u;
