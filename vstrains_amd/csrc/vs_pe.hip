@@ -770,8 +770,8 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
             }
             // up to ACC_RUN partners, loaded together (the row holds LC entries; reading a few words
             // past `be` stays inside the lists buffer, which carries padding, and is ignored)
-            const uint32_t y0 = wlists[off + bi], y1 = wlists[off + bi + 1u], y2 = wlists[off + bi + 2u],
-                           y3 = wlists[off + bi + 3u];
+            const VsQuad yq = *(const VsQuad *)(wlists + off + bi);  // one 16-byte load
+            const uint32_t y0 = yq.x, y1 = yq.y, y2 = yq.z, y3 = yq.w;
             if (use_table) {
                 // the four cells' slots are read together (independent LDS loads), then counted; a
                 // slot that does not hold the cell yet goes the slow way (claim / probe / global)
