@@ -1222,7 +1222,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         const uint32_t slots = wide ? ACC_SLOTS / 2u : ACC_SLOTS;
         // the table is written out once this many of its slots are taken: linear probing stays
         // short at a low fill, and cells of loci the run has left do not pile up (VS_ACC_FILL: percent)
-        uint32_t fill_limit = slots / 8u;
+        uint32_t fill_limit = slots / 16u;
         if (const char *fv = getenv("VS_ACC_FILL")) fill_limit = (uint32_t)((uint64_t)slots * (uint32_t)atoi(fv) / 100u);
         const char *ev = getenv("VS_NO_AGG");
         const uint32_t use_table = (ev && atoi(ev) != 0) ? 0u : 1u;
