@@ -97,6 +97,68 @@ def test_two_rank_read_sharding_and_allreduce_gloo():
                                  len(pe_oracle.fastq_sequences(os.path.join(d, "rve.fq"))))
 
 
+def _rank_overlap(rank, world, port, q):
+    """bench.py's step scheme on CPU tensors: two counter buffers, the all-reduce of step i is only
+    waited for when its buffer comes up again (step i+2) or at the end."""
+    import torch
+    import torch.distributed as dist
+
+    from vstrains_amd import dist as vdist
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    bufs = [(torch.zeros((2, 5, 5), dtype=torch.int32), torch.zeros(3, dtype=torch.int64)) for _ in range(2)]
+    pending = [[], []]
+    seen = []
+    for step in range(5):
+        b = step % 2
+        for wk in pending[b]:
+            wk.wait()
+        if step >= 2:
+            seen.append((step - 2, bufs[b][0].clone(), bufs[b][1].clone()))  # result of step-2, now final
+        mats, st = bufs[b]
+        mats.zero_()
+        st.zero_()
+        mats += (rank + 1) * (step + 1)
+        st += rank + 10 * step
+        pending[b] = vdist.all_reduce_counts_async(mats, st)
+    for b in range(2):
+        for wk in pending[b]:
+            wk.wait()
+    seen.append((3, bufs[1][0].clone(), bufs[1][1].clone()))
+    seen.append((4, bufs[0][0].clone(), bufs[0][1].clone()))
+    if rank == 0:
+        q.put([(i, m.numpy(), s_.numpy()) for i, m, s_ in seen])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_allreduce_with_two_buffers_gloo():
+    import torch.multiprocessing as mp
+
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29500 + ((os.getpid() + 17) % 500)
+    procs = [ctxm.Process(target=_rank_overlap, args=(rk, 2, port, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    seen = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(i for i, _, _ in seen) == [0, 1, 2, 3, 4]
+    for step, mats, st in seen:
+        assert (mats == (1 + 2) * (step + 1)).all()           # rank 0 + rank 1 contributions of that step
+        assert (st == (0 + 1) + 2 * 10 * step).all()
+
+
+def test_async_allreduce_without_process_group_is_a_no_op():
+    import torch
+
+    from vstrains_amd import dist as vdist
+
+    assert vdist.all_reduce_counts_async(torch.zeros((2, 2, 2), dtype=torch.int32), torch.zeros(3, dtype=torch.int64)) == []
+
+
 def test_shard_range_covers_everything_once():
     from vstrains_amd import dist as vdist
 

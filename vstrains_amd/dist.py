@@ -22,3 +22,15 @@ def all_reduce_counts(mats, stats):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(mats, op=dist.ReduceOp.SUM)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+
+
+def all_reduce_counts_async(mats, stats):
+    """Same sums, enqueued behind the work already on the current stream and NOT waited for: returns
+    the work handles (``w.wait()`` makes the then-current stream wait), or [] when there is no process
+    group.  The caller keeps counting into a second buffer meanwhile (bench.py)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return []
+    return [dist.all_reduce(mats, op=dist.ReduceOp.SUM, async_op=True),
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM, async_op=True)]

@@ -274,6 +274,11 @@ class PeCounter:
 
         all_reduce_counts(self.mats, self.stats)
 
+    def all_reduce_async(self):
+        from .dist import all_reduce_counts_async
+
+        return all_reduce_counts_async(self.mats, self.stats)
+
     def result(self):
         """-> (node_mat int64 [N,N], short_mat int64 [N,N], (n_reads, short_reads, used_reads))"""
         m = self.mats.cpu().numpy().astype(np.int64)
