@@ -532,7 +532,9 @@ k_pe_tiles(PeParams P) {
                     if (old == EMPTY_NODE || old == key) {
                         atomicAdd(&s_hcnt[at], add);
                         atomicMin(&s_hminp[at], minp);
-                        atomicMin(&s_hminj[at], a);
+                        // (straight-line instantiation: reads <= 191 bases, so the node length rides in
+                        // the upper 24 bits -- equal for every update of the slot -- and P4 needs no header)
+                        atomicMin(&s_hminj[at], FAST ? (nm.len << 8) | a : a);
                         placed = true;
                         break;
                     }
@@ -550,8 +552,10 @@ k_pe_tiles(PeParams P) {
             if (key != EMPTY_NODE) {
                 uint32_t e = key >> 25, node = key & 0x01FFFFFFu;
                 uint32_t rlen = s_meta[e] & VS_LEN_MASK;
-                uint32_t nlen = P.idx.meta[node].len;
-                if (vs_accept(s_hcnt[i], s_hminp[i], s_hminj[i], nlen, rlen, K)) {
+                const uint32_t hj = s_hminj[i];
+                const uint32_t nlen = FAST ? hj >> 8 : P.idx.meta[node].len;
+                const uint32_t minj = FAST ? hj & 0xFFu : hj;
+                if (vs_accept(s_hcnt[i], s_hminp[i], minj, nlen, rlen, K)) {
                     uint32_t k2 = atomicAdd(&s_ns[e], 1u);
                     if (k2 < LC) s_list[e * LC + k2] = node; else atomicOr(&s_state[e], 2u);
                 }
