@@ -321,21 +321,27 @@ k_pe_tiles(PeParams P) {
     const uint64_t tile_lo = (uint64_t)wg * P.tiles_per_wg;
     const uint64_t tile_hi = tile_lo + P.tiles_per_wg < P.n_tiles ? tile_lo + P.tiles_per_wg : P.n_tiles;
     // The headers of a tile (pair order -> end index -> word offset, length) are two dependent
-    // global loads; they are fetched one tile ahead into registers (one end per thread, ept <= TPB)
-    // so that their latency is covered by the previous tile's work.
-    uint32_t pf_gend = 0, pf_gwoff = 0, pf_meta = 0;
-    auto prefetch_headers = [&](uint64_t t) {
+    // global loads; they run ahead in registers, one link per tile (pair order two tiles ahead, word
+    // offset and length one tile ahead; one end per thread, ept <= TPB), so that neither waits for
+    // the other and both are covered by the previous tiles' work.
+    uint32_t pf_gend = 0, pf_gwoff = 0, pf_meta = 0, pf_pair = 0xFFFFFFFFu;
+    auto prefetch_pair = [&](uint64_t t) {  // pair (in input order) of this thread's end in tile t
+        pf_pair = 0xFFFFFFFFu;
         if (t < tile_hi && tid < ept) {
             const uint64_t p = t * ppt + (tid >> 1);
-            if (p < P.n_pairs) {
-                const uint32_t gp = P.perm ? P.perm[p] : (uint32_t)p;
-                pf_gend = 2u * gp + (tid & 1u);
-                pf_gwoff = P.rd.woff[pf_gend];
-                pf_meta = P.rd.meta[pf_gend];
-            }
+            if (p < P.n_pairs) pf_pair = P.perm ? P.perm[p] : (uint32_t)p;
         }
     };
-    prefetch_headers(tile_lo);
+    auto prefetch_headers = [&]() {  // of the tile whose pair order sits in pf_pair
+        if (pf_pair != 0xFFFFFFFFu) {
+            pf_gend = 2u * pf_pair + (tid & 1u);
+            pf_gwoff = P.rd.woff[pf_gend];
+            pf_meta = P.rd.meta[pf_gend];
+        }
+    };
+    prefetch_pair(tile_lo);
+    prefetch_headers();
+    prefetch_pair(tile_lo + 1u);
     for (uint64_t tile = tile_lo; tile < tile_hi; tile++) {
         const uint64_t p0 = tile * ppt;
         const uint32_t npair = (uint32_t)((P.n_pairs - p0) < ppt ? (P.n_pairs - p0) : ppt);
@@ -354,7 +360,8 @@ k_pe_tiles(PeParams P) {
             s_hminj[i] = 0xFFFFFFFFu;
         }
         __syncthreads();
-        prefetch_headers(tile + 1u);
+        prefetch_headers();            // tile + 1 (its pair order arrived during the previous tile)
+        prefetch_pair(tile + 2u);
         // packed reads: one end per wpe-word slot (gather; consecutive lanes read consecutive words)
         for (uint32_t i = tid; i < ne * wpe + 8u; i += TPB) {
             uint32_t v = 0u;
