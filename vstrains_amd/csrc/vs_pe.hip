@@ -261,10 +261,11 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
     TileLayout t;
     uint32_t o = 0;
     const uint32_t NI = ept * pmax;
-    t.woff = o;  o += (ept + 2u) & ~1u;  // global word offset of every end of the tile
-    t.gend = o;  o += ept;               // global end index
-    t.meta = o;  o += ept;
-    t.words = o; o += words_cap + 8u;
+    // headers and packed words exist twice: the next tile's are brought in while this one is worked on
+    t.woff = o;  o += 2u * ((ept + 2u) & ~1u);  // global word offset of every end of the tile
+    t.gend = o;  o += 2u * ept;                 // global end index
+    t.meta = o;  o += 2u * ept;
+    t.words = o; o += 2u * (words_cap + 8u);
     t.pcnt = o;  o += NI;
     t.pa = o;    o += NI;
     t.pb = o;    o += NI;
@@ -292,10 +293,12 @@ k_pe_tiles(PeParams P) {
     const uint32_t w = P.idx.w, s = P.idx.s, K = P.idx.K;
     const uint32_t pool = P.pool, pool_shift = 32u - P.pool_bits;
     const TileLayout T = tile_layout(ept, pmax, P.words_cap, pool);
+    // (these four point at the current tile's copy; see the top of the tile loop)
     uint32_t *s_gwoff = vs_lds + T.woff;   // global word offsets (mask reads, slow path)
     uint32_t *s_gend = vs_lds + T.gend;
     uint32_t *s_meta = vs_lds + T.meta;
     uint32_t *s_words = vs_lds + T.words;  // end e occupies words [e*wpe, (e+1)*wpe)
+    const uint32_t hw = (ept + 2u) & ~1u, wcap = P.words_cap + 8u;
     uint32_t *s_pcnt = vs_lds + T.pcnt;    // posting counts per probe, then their inclusive scan
     uint32_t *s_pa = vs_lds + T.pa;
     uint32_t *s_pb = vs_lds + T.pb;
@@ -339,19 +342,54 @@ k_pe_tiles(PeParams P) {
             pf_meta = P.rd.meta[pf_gend];
         }
     };
+    // The first tile's headers and words are fetched the plain way; from then on the headers of tile
+    // t+1 sit in registers during tile t, are put into the other LDS copy at its start, and the words
+    // of tile t+1 follow them there as LDS-direct loads (global_load_lds: no registers, nothing waits
+    // for them until just before P4) -- P0 of the next tile finds everything in place.
+    const uint32_t lane0 = tid & 63u, wv0 = tid >> 6;
     prefetch_pair(tile_lo);
     prefetch_headers();
+    {
+        const uint64_t np0 = P.n_pairs - tile_lo * ppt;
+        const uint32_t ne0 = 2u * (uint32_t)(np0 < ppt ? np0 : ppt);
+        if (tid < ne0) {
+            s_gend[tid] = pf_gend;
+            s_gwoff[tid] = pf_gwoff;
+            s_meta[tid] = pf_meta;
+        }
+        if (tid < 8u) { s_words[P.words_cap + tid] = 0u; s_words[wcap + P.words_cap + tid] = 0u; }  // pads of both copies
+        __syncthreads();
+        for (uint32_t i = tid; i < ne0 * wpe; i += TPB) {
+            const uint32_t e = vs_fastdiv(i, P.magic_wpe), k = i - e * wpe;
+            const uint32_t nw = ((s_meta[e] & VS_LEN_MASK) + 15u) >> 4;
+            s_words[i] = k < nw ? P.rd.words[s_gwoff[e] + k] : 0u;
+        }
+    }
     prefetch_pair(tile_lo + 1u);
+    prefetch_headers();
+    prefetch_pair(tile_lo + 2u);
     for (uint64_t tile = tile_lo; tile < tile_hi; tile++) {
         const uint64_t p0 = tile * ppt;
         const uint32_t npair = (uint32_t)((P.n_pairs - p0) < ppt ? (P.n_pairs - p0) : ppt);
         const uint32_t ne = 2u * npair;
-        __syncthreads();  // previous tile fully consumed
-        // ---- P0: which pairs (through the locus order when there is one), their headers
-        if (tid < ne) {
-            s_gend[tid] = pf_gend;
-            s_gwoff[tid] = pf_gwoff;
-            s_meta[tid] = pf_meta;
+        const uint32_t cur = (uint32_t)(tile - tile_lo) & 1u, nxt = cur ^ 1u;
+        s_gwoff = vs_lds + T.woff + cur * hw;
+        s_gend = vs_lds + T.gend + cur * ept;
+        s_meta = vs_lds + T.meta + cur * ept;
+        s_words = vs_lds + T.words + cur * wcap;
+        uint32_t *n_gwoff = vs_lds + T.woff + nxt * hw, *n_gend = vs_lds + T.gend + nxt * ept;
+        uint32_t *n_meta = vs_lds + T.meta + nxt * ept, *n_words = vs_lds + T.words + nxt * wcap;
+        uint32_t ne1 = 0;  // ends of the next tile of this run
+        if (tile + 1u < tile_hi) {
+            const uint64_t np1 = P.n_pairs - (tile + 1u) * ppt;
+            ne1 = 2u * (uint32_t)(np1 < ppt ? np1 : ppt);
+        }
+        __syncthreads();  // previous tile fully consumed; this tile's words have landed (see before P4)
+        // ---- P0: the next tile's headers go to the other copy, the (end, node) table is emptied
+        if (tid < ne1) {
+            n_gend[tid] = pf_gend;
+            n_gwoff[tid] = pf_gwoff;
+            n_meta[tid] = pf_meta;
         }
         for (uint32_t i = tid; i < pool; i += TPB) {
             s_hkey[i] = EMPTY_NODE;
@@ -360,17 +398,18 @@ k_pe_tiles(PeParams P) {
             s_hminj[i] = 0xFFFFFFFFu;
         }
         __syncthreads();
-        prefetch_headers();            // tile + 1 (its pair order arrived during the previous tile)
-        prefetch_pair(tile + 2u);
-        // packed reads: one end per wpe-word slot (gather; consecutive lanes read consecutive words)
-        for (uint32_t i = tid; i < ne * wpe + 8u; i += TPB) {
-            uint32_t v = 0u;
-            if (i < ne * wpe) {
+        prefetch_headers();            // tile + 2 (its pair order arrived during the previous tile)
+        prefetch_pair(tile + 3u);
+        // packed reads of the next tile: one end per wpe-word slot; a wavefront's load instruction
+        // fills 64 consecutive LDS words, every lane from its own global address
+        for (uint32_t b64 = wv0 * 64u; b64 < ne1 * wpe; b64 += TPB) {
+            const uint32_t i = b64 + lane0;
+            if (i < ne1 * wpe) {
                 const uint32_t e = vs_fastdiv(i, P.magic_wpe), k = i - e * wpe;
-                const uint32_t nw = ((s_meta[e] & VS_LEN_MASK) + 15u) >> 4;
-                if (k < nw) v = P.rd.words[s_gwoff[e] + k];
+                const uint32_t nw = ((n_meta[e] & VS_LEN_MASK) + 15u) >> 4;
+                // (words behind the read's last one are never looked at: they get a copy of the last)
+                if (nw) __builtin_amdgcn_global_load_lds(P.rd.words + n_gwoff[e] + (k < nw ? k : nw - 1u), n_words + b64, 4, 0, 0);
             }
-            s_words[i] = v;
         }
         // pair classification (PE_Inference.py:160-165): one thread per pair
         if (tid < npair) {
@@ -551,6 +590,7 @@ k_pe_tiles(PeParams P) {
             }
             __syncthreads();  // the owner array is reused by the next chunk
         }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wavefront's LDS-direct loads of the next tile's words are in
         __syncthreads();
         if (P.debug_stop == 4u) continue;
         // ---- P4: acceptance test per table slot; accepted nodes go to the end's list
