@@ -82,7 +82,9 @@ def test_stage_rebuild_in_memory_equals_reading_the_file(seed, tmp_path):
     path = str(tmp_path / "stage.gfa")
     write_stage_gfa(g, nodes, edges, path)
     a = read_stage_gfa(path)
-    b = stage_graph_from_state(g, nodes, edges)
+    path2 = str(tmp_path / "stage_one_pass.gfa")
+    b = stage_graph_from_state(g, nodes, edges, gfa_path=path2)  # rebuild + file in one pass (reinit)
+    assert open(path2).read() == open(path).read()
     for (ga, na, ea), (gb, nb, eb) in ((a, b),):
         assert list(na.items()) == list(nb.items())
         assert list(ea.items()) == list(eb.items())

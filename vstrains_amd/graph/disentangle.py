@@ -44,10 +44,10 @@ class Stage:
 def reinit(stage: Stage, ops: GraphOps, logger, filename: str) -> Stage:
     """``store_reinit_graph`` (IO.py:630-642): write the stage GFA, rebuild the graph from that
     file (drops gray objects, resets vertex order to map order), recompute every edge flow."""
-    write_stage_gfa(stage.g, stage.nodes, stage.edges, filename)
+    # one pass: the file write_stage_gfa would write, and the graph read_stage_gfa(filename) would
+    # give back (float(repr(dp)) == dp), without the parse
+    g, nodes, edges = stage_graph_from_state(stage.g, stage.nodes, stage.edges, gfa_path=filename)
     logger.info(filename + " is stored..")
-    # same graph read_stage_gfa(filename) would give (float(repr(dp)) == dp), without the parse
-    g, nodes, edges = stage_graph_from_state(stage.g, stage.nodes, stage.edges)
     return Stage(g, nodes, edges, ops.refresh(g))
 
 

@@ -61,22 +61,27 @@ def read_stage_gfa(filename: str) -> Tuple[AsmGraph, NodeMap, EdgeMap]:
     return g, nodes, edges
 
 
-def stage_graph_from_state(g: AsmGraph, nodes: NodeMap, edges: EdgeMap) -> Tuple[AsmGraph, NodeMap, EdgeMap]:
+def stage_graph_from_state(g: AsmGraph, nodes: NodeMap, edges: EdgeMap,
+                           gfa_path: Optional[str] = None) -> Tuple[AsmGraph, NodeMap, EdgeMap]:
     """The graph ``read_stage_gfa(write_stage_gfa(...))`` would give, without the file: same
     filtering and order; ``float(repr(x)) == x`` so dp survives exactly.  This runs once per
     re-initialisation (~100 times per run), so the rows are built in place instead of through
-    ``add_vertex`` / ``add_edge`` calls -- same placement rule as ``AsmGraph.add_edge``."""
+    ``add_vertex`` / ``add_edge`` calls -- same placement rule as ``AsmGraph.add_edge``.
+    With ``gfa_path`` the stage GFA (``write_stage_gfa``'s bytes) is written in the same pass."""
     ng = AsmGraph()
     nn: NodeMap = {}
     ne: EdgeMap = {}
     vblack, vid, vdp, vseq = g.vblack, g.vid, g.vdp, g.vseq
     n_vid, n_vdp, n_vseq = ng.vid, ng.vdp, ng.vseq
+    chunks: Optional[List[str]] = [] if gfa_path is not None else None
     for v in nodes.values():
         if vblack[v]:
             nn[vid[v]] = len(n_vid)
             n_vid.append(vid[v])
             n_vdp.append(vdp[v])
             n_vseq.append(vseq[v])
+            if chunks is not None:
+                chunks.append("S\t%s\t%s\tDP:f:%s\n" % (vid[v], vseq[v], repr(vdp[v])))
     nv = len(n_vid)
     ng.vblack = [BLACK] * nv
     adj = [[] for _ in range(nv)]
@@ -104,12 +109,17 @@ def stage_graph_from_state(g: AsmGraph, nodes: NodeMap, edges: EdgeMap) -> Tuple
         nout[s] = slot + 1
         adj[t].append((s, ei))
         ne[key] = ei
+        if chunks is not None:
+            chunks.append("L\t%s\t+\t%s\t+\t%dM\n" % (key[0], key[1], eovl_src[e]))
     ne_count = len(esrc)
     ng.adj = adj
     ng.nout = nout
     ng.eflow = [0.0] * ne_count
     ng.eblack = [BLACK] * ne_count
     ng._n_edges = ne_count
+    if chunks is not None:
+        with open(gfa_path, "w") as fh:
+            fh.write("".join(chunks))
     return ng, nn, ne
 
 
