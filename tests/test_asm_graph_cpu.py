@@ -92,3 +92,26 @@ def test_stage_rebuild_in_memory_equals_reading_the_file(seed, tmp_path):
         assert ga.adj == gb.adj and ga.nout == gb.nout
         assert ga.esrc == gb.esrc and ga.etgt == gb.etgt and ga.eovl == gb.eovl and ga.eblack == gb.eblack
         assert ga.num_edges() == gb.num_edges()
+
+
+def test_csr_arrays_are_the_adjacency_in_stored_order():
+    import numpy as np
+
+    rng = random.Random(5)
+    g = AsmGraph()
+    for i in range(40):
+        g.add_vertex(str(i), 1.0, "ACGT", True)
+    for _ in range(120):
+        a, b = rng.randrange(40), rng.randrange(40)
+        if g.edge(a, b) is None:
+            g.add_edge(a, b, 3, 0.0, True)
+    row_ptr, n_out, nbr, eidx = g.csr_arrays()
+    assert row_ptr.dtype == np.uint64 and n_out.dtype == nbr.dtype == eidx.dtype == np.uint32
+    assert row_ptr[0] == 0 and row_ptr[-1] == len(nbr) == len(eidx) == 2 * g.num_edges()
+    for v in range(40):
+        lo, hi = int(row_ptr[v]), int(row_ptr[v + 1])
+        assert list(zip(nbr[lo:hi].tolist(), eidx[lo:hi].tolist())) == [tuple(x) for x in g.adj[v]]
+        assert n_out[v] == g.nout[v]
+    empty = AsmGraph()
+    r, no, nb, ei = empty.csr_arrays()
+    assert r.tolist() == [0] and len(no) == len(nb) == len(ei) == 0

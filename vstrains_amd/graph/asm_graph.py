@@ -19,6 +19,7 @@ available here -- DESIGN.md "parity pins"):
 from __future__ import annotations
 
 from collections import deque
+from itertools import chain
 from typing import Deque, Dict, Iterator, List, Optional, Tuple
 
 BLACK = True
@@ -149,17 +150,23 @@ class AsmGraph:
 
     # ---- device view -------------------------------------------------------------------
     def csr_arrays(self):
-        """(row_ptr[V+1], n_out[V], nbr[sum deg], eidx[sum deg]) as Python lists: adjacency in the
-        stored order, out-entries before in-entries -- the layout the graph kernels read."""
-        row_ptr = [0]
-        nbr: List[int] = []
-        eidx: List[int] = []
-        for row in self.adj:
-            for n, e in row:
-                nbr.append(n)
-                eidx.append(e)
-            row_ptr.append(len(nbr))
-        return row_ptr, list(self.nout), nbr, eidx
+        """(row_ptr[V+1] u64, n_out[V] u32, nbr[sum deg] u32, eidx[sum deg] u32) as numpy arrays:
+        adjacency in the stored order, out-entries before in-entries -- the layout the graph
+        kernels read."""
+        import numpy as np
+
+        adj = self.adj
+        row_ptr = np.zeros(len(adj) + 1, dtype=np.uint64)
+        if adj:
+            np.cumsum(np.fromiter(map(len, adj), dtype=np.uint64, count=len(adj)), out=row_ptr[1:])
+        flat = list(chain.from_iterable(adj))
+        if flat:
+            pairs = np.array(flat, dtype=np.uint32)
+            nbr, eidx = np.ascontiguousarray(pairs[:, 0]), np.ascontiguousarray(pairs[:, 1])
+        else:
+            nbr = np.zeros(0, dtype=np.uint32)
+            eidx = np.zeros(0, dtype=np.uint32)
+        return row_ptr, np.asarray(self.nout, dtype=np.uint32), nbr, eidx
 
 
 NodeMap = Dict[str, int]
