@@ -176,6 +176,29 @@ def test_variable_lengths_and_empty_block(host, ctx):
     assert a.sum() == 0 and b.sum() == 0 and s == (0, 0, 0)
 
 
+@pytest.mark.parametrize("dirty", [False, True], ids=["straight_line_kernel", "generic_kernel_masked_bytes"])
+def test_ragged_block_through_sort_and_double_buffered_tiles(host, ctx, dirty):
+    """Many tiles of reads of every length 0..191 (sorted by locus, next tile's words arriving by
+    LDS-direct loads while a tile is worked on); with ``dirty`` some reads hold N / other bytes."""
+    g, f, r = _dense_case(55, 30000, 191, seed=777, snp=0.03, glen=6000, nrate=0.0)  # no N: the block qualifies for k_pe_tiles<true>
+    rng = np.random.default_rng(11)
+    f = [s[: int(rng.integers(0, 192))] for s in f]
+    r = [s[: int(rng.integers(40, 192))] for s in r]
+    if dirty:
+        for lst in (f, r):
+            for i in rng.choice(len(lst), size=600, replace=False):
+                s_ = lst[int(i)]
+                if len(s_) > 3:
+                    p_ = int(rng.integers(0, len(s_)))
+                    lst[int(i)] = s_[:p_] + ("N" if rng.random() < 0.3 else rng.choice(list("nRYacgt*"))) + s_[p_ + 1:]
+    (node_mat, short_mat, stats), _ = _gpu_matrices(host, ctx, g.seqs, f, r, 55)
+    orc = pe_oracle_c.Oracle(g.seqs, 55)
+    ref_node, ref_short, ref_stats = orc.count_pairs(f, r)
+    assert np.array_equal(node_mat, ref_node) and np.array_equal(short_mat, ref_short)
+    assert stats == tuple(int(x) for x in ref_stats)
+    assert int(ref_node.sum()) > 0
+
+
 def test_blocks_add_up_and_swapping_ends_transposes(host, ctx):
     g, f, r = _dense_case(55, 12000, 150, seed=601, snp=0.03, glen=5000)
     ctx.build_index(g.seqs, 55)
