@@ -111,11 +111,14 @@ __device__ __forceinline__ bool vs_extend_fast(const uint32_t *rw, RB rbase, uin
     const uint64_t x3 = vs_win(rw, rbase + rj + 96u) ^ tw64(q1.z, q1.w, q2.x);
     const uint64_t x4 = vs_win(rw, rbase + rj + 128u) ^ tw64(q2.x, q2.y, q2.z);
     const uint32_t left = xl ? n0 - 1u - (uint32_t)((63 - __clzll((long long)xl)) >> 1) : n0;
-    uint32_t ext = x4 ? 128u + ((uint32_t)(__ffsll((long long)x4) - 1) >> 1) : 160u;
-    ext = x3 ? 96u + ((uint32_t)(__ffsll((long long)x3) - 1) >> 1) : ext;
-    ext = x2 ? 64u + ((uint32_t)(__ffsll((long long)x2) - 1) >> 1) : ext;
-    ext = x1 ? 32u + ((uint32_t)(__ffsll((long long)x1) - 1) >> 1) : ext;
-    ext = x0 ? ((uint32_t)(__ffsll((long long)x0) - 1) >> 1) : ext;
+    // first window that differs (selects), then one find-first-set
+    uint64_t xs = x4;
+    uint32_t xb = 128u;
+    if (x3) { xs = x3; xb = 96u; }
+    if (x2) { xs = x2; xb = 64u; }
+    if (x1) { xs = x1; xb = 32u; }
+    if (x0) { xs = x0; xb = 0u; }
+    uint32_t ext = xs ? xb + ((uint32_t)(__ffsll((long long)xs) - 1) >> 1) : 160u;
     ext = ext < rem ? ext : rem;
     const uint32_t len = left + w + ext;
     *a_out = j - left;
