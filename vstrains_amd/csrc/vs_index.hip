@@ -150,7 +150,7 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
     woff[n_nodes] = (uint32_t)words;
     seed_off[n_nodes] = npos;
     if (npos > 0x3FFFFFF0ull) return vs_fail(ctx, VS_E_RANGE, "too many seed positions (%llu)", (unsigned long long)npos);
-    if (words >= (1ull << 28)) return vs_fail(ctx, VS_E_RANGE, "node text of %llu packed words exceeds 2^32 bases", (unsigned long long)words);
+    if (2 * (words + VS_PAD_WORDS) >= (1ull << 28)) return vs_fail(ctx, VS_E_RANGE, "node text of %llu packed words (both strands) exceeds 2^32 bases", (unsigned long long)words);
     uint32_t bits = 4;
     while ((1ull << bits) < 2 * npos + 2) bits++;
     const uint64_t n_slots = 1ull << bits;
@@ -162,8 +162,8 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
     size_t b_table = sizeof(VsSlot) * n_slots;
     size_t b_post = sizeof(uint2) * (npos ? npos : 1);
     VS_HIP(ctx, hipMalloc(&ctx->d_meta, b_meta));
-    VS_HIP(ctx, hipMalloc(&ctx->d_fwd, b_words));
-    VS_HIP(ctx, hipMalloc(&ctx->d_rc, b_words));
+    VS_HIP(ctx, hipMalloc(&ctx->d_fwd, 2 * b_words));  // forward text, then the reverse complements
+    ctx->d_rc = nullptr;
     VS_HIP(ctx, hipMalloc(&ctx->d_table, b_table));
     VS_HIP(ctx, hipMalloc(&ctx->d_post, b_post));
     ctx->index_bytes = b_meta + 2 * b_words + b_table + b_post;
@@ -199,8 +199,7 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
         TRY(hipMemcpyAsync(d_seed_off, seed_off.data(), sizeof(uint64_t) * (n_nodes + 1), hipMemcpyHostToDevice, st));
         TRY(hipMemcpyAsync(d_woff, woff.data(), sizeof(uint32_t) * (n_nodes + 1), hipMemcpyHostToDevice, st));
         TRY(hipMemcpyAsync(ctx->d_meta, meta.data(), b_meta, hipMemcpyHostToDevice, st));
-        TRY(hipMemsetAsync(ctx->d_fwd, 0, b_words, st));
-        TRY(hipMemsetAsync(ctx->d_rc, 0, b_words, st));
+        TRY(hipMemsetAsync(ctx->d_fwd, 0, 2 * b_words, st));
         TRY(hipMemsetAsync(d_keys, 0xFF, sizeof(unsigned long long) * n_slots, st));
         TRY(hipMemsetAsync(d_cnts, 0, sizeof(uint32_t) * n_slots, st));
         TRY(hipMemsetAsync(d_cursor, 0, sizeof(uint32_t) * n_slots, st));
@@ -211,13 +210,14 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
         d.n_nodes = n_nodes; d.K = K; d.w = w; d.s = s; d.table_bits = bits;
         d.meta = (const VsNodeMeta *)ctx->d_meta;
         d.fwd_words = (const uint32_t *)ctx->d_fwd;
-        d.rc_words = (const uint32_t *)ctx->d_rc;
+        d.rc_delta = (uint32_t)(words + VS_PAD_WORDS);
+        d.rc_words = d.fwd_words + d.rc_delta;
         d.table = (const VsSlot *)ctx->d_table;
         d.postings = (const uint2 *)ctx->d_post;
 
         if (words)
             hipLaunchKernelGGL(k_pack_nodes, dim3((unsigned)((words + TPB - 1) / TPB)), dim3(TPB), 0, st, d_ascii, d_aoff,
-                               d_woff, n_nodes, (uint32_t)words, K, (uint32_t *)ctx->d_fwd, (uint32_t *)ctx->d_rc, d_flags);
+                               d_woff, n_nodes, (uint32_t)words, K, (uint32_t *)ctx->d_fwd, (uint32_t *)ctx->d_fwd + (words + VS_PAD_WORDS), d_flags);
         uint32_t h_flags[4];
         TRY(hipMemcpyAsync(h_flags, d_flags, sizeof h_flags, hipMemcpyDeviceToHost, st));
         TRY(hipStreamSynchronize(st));

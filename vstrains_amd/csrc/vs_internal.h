@@ -41,7 +41,8 @@ struct VsIndexDev {
     uint32_t table_bits;
     const VsNodeMeta *meta;     // [n_nodes]
     const uint32_t *fwd_words;  // packed node texts
-    const uint32_t *rc_words;   // packed reverse complements, same offsets
+    const uint32_t *rc_words;   // packed reverse complements, same offsets; = fwd_words + rc_delta (one allocation,
+    uint32_t rc_delta;          // so that a kernel can address either strand off one uniform base)
     const VsSlot *table;        // [1 << table_bits]
     const uint2 *postings;      // (node, pos | strand << 31)
 };

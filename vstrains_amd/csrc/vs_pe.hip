@@ -560,15 +560,17 @@ k_pe_tiles(PeParams P) {
                 const VsNodeMeta nm = p_nm[k2];
                 const uint32_t meta = s_meta[e];
                 const uint32_t rlen = meta & VS_LEN_MASK;
-                const uint32_t *tw = opp ? P.idx.rc_words : P.idx.fwd_words;
+                // either strand off the one (wave-uniform) text base: the reverse complements lie rc_delta words on
+                const uint32_t *tw = P.idx.fwd_words;
+                const uint32_t tb = (nm.woff + (opp ? P.idx.rc_delta : 0u)) * 16u;
                 const uint32_t q = opp ? nm.len - p_pos[k2] - w : p_pos[k2];
                 const uint32_t *mk = ((meta >> 24) & VS_FLAG_INVALID) ? P.rd.mask : nullptr;
                 uint32_t a, qa, len;
                 bool credited;
                 if (FAST)
-                    credited = vs_extend_fast(s_words, e * wpe * 16u, rlen, tw, nm.woff * 16u, nm.len, j, q, w, s, K, &a, &qa, &len);
+                    credited = vs_extend_fast(s_words, e * wpe * 16u, rlen, tw, tb, nm.len, j, q, w, s, K, &a, &qa, &len);
                 else
-                    credited = vs_extend(s_words, e * wpe * 16u, rlen, tw, nm.woff * 16u, nm.len, j, q, w, s, K,
+                    credited = vs_extend(s_words, e * wpe * 16u, rlen, tw, tb, nm.len, j, q, w, s, K,
                                          mk, (uint64_t)s_gwoff[e] * 16u, &a, &qa, &len);
                 if (!credited) continue;
                 const uint32_t add = len - K + 1u;
