@@ -255,7 +255,7 @@ def test_device_read_generator_equals_cpu_twin(host, ctx):
 @pytest.mark.parametrize("env", [
     {"VS_NO_SORT": "1"}, {"VS_NO_AGG": "1"}, {"VS_LOCUS_GLOBAL": "1"}, {"VS_EPT": "32"}, {"VS_EPT": "128"},
     {"VS_EPT": "6", "VS_GRID_PER_CU": "1"}, {"VS_ACC_FILL": "1"}, {"VS_ACC_FILL": "100"}, {"VS_NO_FAST": "1"}, {"VS_ACC_WIDE": "1"},
-    {"VS_ACC_QUEUE": "0"}, {"VS_ACC_GRID_PER_CU": "1", "VS_ACC_QUEUE": "0"}, {"VS_NO_XCD_MAP": "1"}, {"VS_GRID_PER_CU": "8"},
+    {"VS_ACC_QUEUE": "0"}, {"VS_ACC_GRID_PER_CU": "1", "VS_ACC_QUEUE": "0"}, {"VS_NO_XCD_MAP": "1"}, {"VS_GRID_PER_CU": "8"}, {"VS_NO_STD": "1"},
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_every_kernel_variant_gives_the_same_counters(host, ctx, env, monkeypatch):
     """The tuning switches select other code paths (input order instead of locus order, global
@@ -263,14 +263,16 @@ def test_every_kernel_variant_gives_the_same_counters(host, ctx, env, monkeypatc
     flushed constantly / never): all of them must produce the oracle's counters."""
     from vstrains_amd import synth
 
+    # 2 x 150 bases at k = 55: the shape the compile-time-layout instantiation (k_pe_tiles<true, true>)
+    # is built for, so that VS_NO_STD / VS_NO_FAST / VS_EPT really switch between three kernels
     st = synth.make_strains(5, 4000, 0.04, seed=31)
-    g = synth.compact_dbg(st, 41)
-    fwd, rve = synth.sample_pairs(st, 12000, 120, seed=32, sub_rate=0.01, n_rate=0.01)
-    orc = pe_oracle_c.Oracle(g.seqs, 41)
+    g = synth.compact_dbg(st, 55)
+    fwd, rve = synth.sample_pairs(st, 12000, 150, seed=32, sub_rate=0.01, n_rate=0.01)
+    orc = pe_oracle_c.Oracle(g.seqs, 55)
     want = orc.count_pairs(fwd, rve)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    (node_mat, short_mat, stats), _ = _gpu_matrices(host, ctx, g.seqs, fwd, rve, 41)
+    (node_mat, short_mat, stats), _ = _gpu_matrices(host, ctx, g.seqs, fwd, rve, 55)
     assert np.array_equal(node_mat, want[0])
     assert np.array_equal(short_mat, want[1])
     assert stats == tuple(int(x) for x in want[2])

@@ -75,7 +75,7 @@ struct Mem {  // one credited maximal exact match
 // Straight-line form of vs_extend for the common block shape (no masked read bytes anywhere in
 // the block, probe stride <= 32, reads <= 191 bases with w = 31): one left window, five right
 // windows, everything loaded up front, the answer out of selects -- no data-dependent branch.
-// The host picks the kernel instantiation (k_pe_tiles<true>) when the whole block qualifies.
+// The host picks the kernel instantiation (k_pe_tiles<true, *>) when the whole block qualifies.
 struct __attribute__((packed, aligned(4))) VsQuad { uint32_t x, y, z, w; };  // 16-byte load at dword alignment
 
 template <typename RB>
@@ -286,22 +286,31 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
     return t;
 }
 
-template <bool FAST>
+// STD: the tile shape is the compile-time one of 2 x 150-base pairs at k = 55 (64 ends per tile, 5
+// probes and 10 packed words per end, 1024-slot table): every LDS array then sits at a constant
+// offset (folded into the LDS instructions) instead of costing a scalar register and an add, and
+// the divisions by pmax / wpe become constants.  The host picks it when the block has that shape.
+#define STD_EPT 64u
+#define STD_PMAX 5u
+#define STD_WPE 10u
+#define STD_POOL_BITS 10u
+template <bool FAST, bool STD>
 __global__ void __launch_bounds__(TPB)
 __attribute__((amdgpu_waves_per_eu(TILES_WAVES, TILES_WAVES)))
 k_pe_tiles(PeParams P) {
     const uint32_t tid = threadIdx.x;
-    const uint32_t ept = P.ept, pmax = P.pmax;
+    const uint32_t ept = STD ? STD_EPT : P.ept, pmax = STD ? STD_PMAX : P.pmax;
     const uint32_t NI = ept * pmax;
     const uint32_t w = P.idx.w, s = P.idx.s, K = P.idx.K;
-    const uint32_t pool = P.pool, pool_shift = 32u - P.pool_bits;
-    const TileLayout T = tile_layout(ept, pmax, P.words_cap, pool);
+    const uint32_t pool = STD ? (1u << STD_POOL_BITS) : P.pool, pool_shift = 32u - (STD ? STD_POOL_BITS : P.pool_bits);
+    const uint32_t words_cap = STD ? STD_EPT * STD_WPE : P.words_cap;
+    const TileLayout T = tile_layout(ept, pmax, words_cap, pool);
     // (these four point at the current tile's copy; see the top of the tile loop)
     uint32_t *s_gwoff = vs_lds + T.woff;   // global word offsets (mask reads, slow path)
     uint32_t *s_gend = vs_lds + T.gend;
     uint32_t *s_meta = vs_lds + T.meta;
     uint32_t *s_words = vs_lds + T.words;  // end e occupies words [e*wpe, (e+1)*wpe)
-    const uint32_t hw = (ept + 2u) & ~1u, wcap = P.words_cap + 8u;
+    const uint32_t hw = (ept + 2u) & ~1u, wcap = words_cap + 8u;
     uint32_t *s_pcnt = vs_lds + T.pcnt;    // posting counts per probe, then their inclusive scan
     uint32_t *s_pa = vs_lds + T.pa;
     uint32_t *s_pb = vs_lds + T.pb;
@@ -314,7 +323,7 @@ k_pe_tiles(PeParams P) {
     uint32_t *s_list = vs_lds + T.list;    // accepted node ids, LC per end
     uint32_t *s_misc = vs_lds + T.misc;
     uint32_t *s_owner = vs_lds + T.owner;
-    const uint32_t wpe = P.wpe;
+    const uint32_t wpe = STD ? STD_WPE : P.wpe;
     const uint32_t ppt = ept / 2u;
 
     if (tid < 3) s_misc[8 + tid] = 0;  // workgroup-local stats
@@ -360,10 +369,10 @@ k_pe_tiles(PeParams P) {
             s_gwoff[tid] = pf_gwoff;
             s_meta[tid] = pf_meta;
         }
-        if (tid < 8u) { s_words[P.words_cap + tid] = 0u; s_words[wcap + P.words_cap + tid] = 0u; }  // pads of both copies
+        if (tid < 8u) { s_words[words_cap + tid] = 0u; s_words[wcap + words_cap + tid] = 0u; }  // pads of both copies
         __syncthreads();
         for (uint32_t i = tid; i < ne0 * wpe; i += TPB) {
-            const uint32_t e = vs_fastdiv(i, P.magic_wpe), k = i - e * wpe;
+            const uint32_t e = STD ? i / STD_WPE : vs_fastdiv(i, P.magic_wpe), k = i - e * wpe;
             const uint32_t nw = ((s_meta[e] & VS_LEN_MASK) + 15u) >> 4;
             s_words[i] = k < nw ? P.rd.words[s_gwoff[e] + k] : 0u;
         }
@@ -408,7 +417,7 @@ k_pe_tiles(PeParams P) {
         for (uint32_t b64 = wv0 * 64u; b64 < ne1 * wpe; b64 += TPB) {
             const uint32_t i = b64 + lane0;
             if (i < ne1 * wpe) {
-                const uint32_t e = vs_fastdiv(i, P.magic_wpe), k = i - e * wpe;
+                const uint32_t e = STD ? i / STD_WPE : vs_fastdiv(i, P.magic_wpe), k = i - e * wpe;
                 const uint32_t nw = ((n_meta[e] & VS_LEN_MASK) + 15u) >> 4;
                 // (words behind the read's last one are never looked at: they get a copy of the last)
                 if (nw) __builtin_amdgcn_global_load_lds(P.rd.words + n_gwoff[e] + (k < nw ? k : nw - 1u), n_words + b64, 4, 0, 0);
@@ -429,7 +438,7 @@ k_pe_tiles(PeParams P) {
         if (P.debug_stop == 1u) continue;
         // ---- P1: probes
         for (uint32_t it = tid; it < NI; it += TPB) {
-            uint32_t e = vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
+            uint32_t e = STD ? it / STD_PMAX : vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
             uint32_t cnt = 0, pa = 0, pb = 0;
             if (e < ne && (s_state[e] & 1u)) {
                 uint32_t meta = s_meta[e];
@@ -527,7 +536,7 @@ k_pe_tiles(PeParams P) {
                 const uint32_t excl = it ? s_pcnt[it - 1u] : 0u;
                 const uint32_t cnt = s_pcnt[it] - excl;
                 const uint32_t pa = s_pa[it], pb = s_pb[it];
-                const uint32_t e = vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
+                const uint32_t e = STD ? it / STD_PMAX : vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
                 p_e[k2] = e;
                 p_j[k2] = pi * s;
                 uint32_t node = pa, pos = pb & 0x7FFFFFFFu, opp = pb >> 31;
@@ -1204,7 +1213,11 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     // straight-line extension when the whole block qualifies (see vs_extend_fast)
     const bool fast = !reads->d_mask && idx.s <= 32u && maxlen <= 128u + idx.w + 32u &&
                       !(getenv("VS_NO_FAST") && atoi(getenv("VS_NO_FAST")) != 0);
-    const void *tiles_fn = fast ? (const void *)k_pe_tiles<true> : (const void *)k_pe_tiles<false>;
+    const bool std_shape = fast && ept == STD_EPT && pmax == STD_PMAX && wpe == STD_WPE && P.pool_bits == STD_POOL_BITS &&
+                           !(getenv("VS_NO_STD") && atoi(getenv("VS_NO_STD")) != 0);
+    const void *tiles_fn = std_shape ? (const void *)k_pe_tiles<true, true>
+                           : fast    ? (const void *)k_pe_tiles<true, false>
+                                     : (const void *)k_pe_tiles<false, false>;
     if (lds > 64u * 1024u)
         VS_HIP(ctx, hipFuncSetAttribute(tiles_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     uint64_t grid = P.n_tiles;
@@ -1249,10 +1262,12 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     }
     VS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     if (!d_node_mat) VS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
-    if (fast)
-        hipLaunchKernelGGL(k_pe_tiles<true>, dim3((unsigned)grid), dim3(TPB), lds, st, P);
+    if (std_shape)
+        hipLaunchKernelGGL((k_pe_tiles<true, true>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
+    else if (fast)
+        hipLaunchKernelGGL((k_pe_tiles<true, false>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
     else
-        hipLaunchKernelGGL(k_pe_tiles<false>, dim3((unsigned)grid), dim3(TPB), lds, st, P);
+        hipLaunchKernelGGL((k_pe_tiles<false, false>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
     if (d_node_mat) {
         // the last tile may be partly empty: its unused rows must read as length 0
         const uint64_t used_ends = 2ull * n_pairs;
