@@ -299,6 +299,11 @@ __global__ void __launch_bounds__(TPB)
 __attribute__((amdgpu_waves_per_eu(TILES_WAVES, TILES_WAVES)))
 k_pe_tiles(PeParams P) {
     const uint32_t tid = threadIdx.x;
+    // (the compile-time-shape instantiation is also the one without diagnostics: the host only picks
+    // it for plain counting runs)
+    const uint32_t debug_stop = STD ? 0u : P.debug_stop;
+    const bool count_postings = !STD && P.count_postings, want_dbg = !STD && P.dbg_counts != nullptr;
+    const bool accumulate = STD || P.accumulate;
     const uint32_t ept = STD ? STD_EPT : P.ept, pmax = STD ? STD_PMAX : P.pmax;
     const uint32_t NI = ept * pmax;
     const uint32_t w = P.idx.w, s = P.idx.s, K = P.idx.K;
@@ -435,7 +440,7 @@ k_pe_tiles(PeParams P) {
             s_ns[2 * tid] = s_ns[2 * tid + 1] = 0;
         }
         __syncthreads();
-        if (P.debug_stop == 1u) continue;
+        if (debug_stop == 1u) continue;
         // ---- P1: probes
         for (uint32_t it = tid; it < NI; it += TPB) {
             uint32_t e = STD ? it / STD_PMAX : vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
@@ -457,7 +462,7 @@ k_pe_tiles(PeParams P) {
             s_pb[it] = pb;
         }
         __syncthreads();
-        if (P.debug_stop == 2u) continue;
+        if (debug_stop == 2u) continue;
         // ---- P2: inclusive scan of s_pcnt[0..NI)
         {
             const uint32_t chunk = (NI + TPB - 1u) / TPB;
@@ -483,9 +488,9 @@ k_pe_tiles(PeParams P) {
                 }
         }
         __syncthreads();
-        if (P.debug_stop == 3u) continue;
+        if (debug_stop == 3u) continue;
         const uint32_t total = s_pcnt[NI - 1u];
-        if (P.count_postings && tid == 0) atomicAdd((unsigned long long *)(P.slow_count + 2), (unsigned long long)total);
+        if (count_postings && tid == 0) atomicAdd((unsigned long long *)(P.slow_count + 2), (unsigned long long)total);
         // ---- P3: one thread per posting.  Expansion of the per-probe posting counts (CSR-style
         // frontier expansion) in chunks of CHUNK postings: every probe marks the first position it
         // owns in the chunk, a workgroup-wide running maximum fills the gaps, and each thread ends
@@ -606,7 +611,7 @@ k_pe_tiles(PeParams P) {
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wavefront's LDS-direct loads of the next tile's words are in
         __syncthreads();
-        if (P.debug_stop == 4u) continue;
+        if (debug_stop == 4u) continue;
         // ---- P4: acceptance test per table slot; accepted nodes go to the end's list
         for (uint32_t i = tid; i < pool; i += TPB) {
             uint32_t key = s_hkey[i];
@@ -634,16 +639,16 @@ k_pe_tiles(PeParams P) {
             }
         }
         __syncthreads();
-        if (P.debug_stop == 5u) continue;
+        if (debug_stop == 5u) continue;
         // ---- P5: hand the accepted lists to k_pe_accumulate (one LC-word row per end, tile order;
         // length 0 for ends of dropped pairs and of pairs the slow path takes)
-        if (P.accumulate) {
+        if (accumulate) {
             uint32_t *ol = P.out_lists + tile * ept * LC;
             for (uint32_t i = tid; i < ne * LC; i += TPB) ol[i] = s_list[i];
             for (uint32_t i = tid; i < ne; i += TPB)
                 P.out_counts[tile * ept + i] = (s_state[i] & 3u) == 1u ? s_ns[i] : 0u;
         }
-        if (P.dbg_counts) {
+        if (want_dbg) {
             for (uint32_t i = tid; i < ne; i += TPB) {
                 if (s_state[i] & 2u) continue;  // the slow kernel reports these
                 uint32_t n = s_ns[i];
@@ -1214,6 +1219,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     const bool fast = !reads->d_mask && idx.s <= 32u && maxlen <= 128u + idx.w + 32u &&
                       !(getenv("VS_NO_FAST") && atoi(getenv("VS_NO_FAST")) != 0);
     const bool std_shape = fast && ept == STD_EPT && pmax == STD_PMAX && wpe == STD_WPE && P.pool_bits == STD_POOL_BITS &&
+                           P.accumulate && !P.debug_stop && !P.count_postings && !P.dbg_counts &&
                            !(getenv("VS_NO_STD") && atoi(getenv("VS_NO_STD")) != 0);
     const void *tiles_fn = std_shape ? (const void *)k_pe_tiles<true, true>
                            : fast    ? (const void *)k_pe_tiles<true, false>
