@@ -294,6 +294,9 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
 #define STD_PMAX 5u
 #define STD_WPE 10u
 #define STD_POOL_BITS 10u
+#define STD_K 56u   // k + 1
+#define STD_W 31u   // seed length and probe stride that follow from it (seed_geometry)
+#define STD_S 26u
 template <bool FAST, bool STD>
 __global__ void __launch_bounds__(TPB)
 __attribute__((amdgpu_waves_per_eu(TILES_WAVES, TILES_WAVES)))
@@ -306,7 +309,7 @@ k_pe_tiles(PeParams P) {
     const bool accumulate = STD || P.accumulate;
     const uint32_t ept = STD ? STD_EPT : P.ept, pmax = STD ? STD_PMAX : P.pmax;
     const uint32_t NI = ept * pmax;
-    const uint32_t w = P.idx.w, s = P.idx.s, K = P.idx.K;
+    const uint32_t w = STD ? STD_W : P.idx.w, s = STD ? STD_S : P.idx.s, K = STD ? STD_K : P.idx.K;
     const uint32_t pool = STD ? (1u << STD_POOL_BITS) : P.pool, pool_shift = 32u - (STD ? STD_POOL_BITS : P.pool_bits);
     const uint32_t words_cap = STD ? STD_EPT * STD_WPE : P.words_cap;
     const TileLayout T = tile_layout(ept, pmax, words_cap, pool);
@@ -1219,6 +1222,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     const bool fast = !reads->d_mask && idx.s <= 32u && maxlen <= 128u + idx.w + 32u &&
                       !(getenv("VS_NO_FAST") && atoi(getenv("VS_NO_FAST")) != 0);
     const bool std_shape = fast && ept == STD_EPT && pmax == STD_PMAX && wpe == STD_WPE && P.pool_bits == STD_POOL_BITS &&
+                           idx.K == STD_K && idx.w == STD_W && idx.s == STD_S &&
                            P.accumulate && !P.debug_stop && !P.count_postings && !P.dbg_counts &&
                            !(getenv("VS_NO_STD") && atoi(getenv("VS_NO_STD")) != 0);
     const void *tiles_fn = std_shape ? (const void *)k_pe_tiles<true, true>
