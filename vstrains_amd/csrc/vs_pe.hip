@@ -104,12 +104,20 @@ __device__ __forceinline__ bool vs_extend_fast(const uint32_t *rw, RB rbase, uin
     auto tw64 = [&](uint32_t w0, uint32_t w1, uint32_t w2) {
         return (uint64_t)__builtin_amdgcn_alignbit(w1, w0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, sh) << 32);
     };
+    // the read's side of the same five windows: eleven consecutive LDS words, one shift
+    const uint32_t rr = (uint32_t)(rbase + rj), rsh = (rr & 15u) * 2u;
+    const uint32_t *rp = rw + (rr >> 4);
+    const uint32_t r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4], r5 = rp[5], r6 = rp[6], r7 = rp[7],
+                   r8 = rp[8], r9 = rp[9], r10 = rp[10];
+    auto rw64 = [&](uint32_t w0, uint32_t w1, uint32_t w2) {
+        return (uint64_t)__builtin_amdgcn_alignbit(w1, w0, rsh) | ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, rsh) << 32);
+    };
     const uint64_t xl = (vs_win(rw, rbase + j - n0) ^ vs_win(tw, tbase + q - n0)) & vs_lowmask(2u * n0);
-    const uint64_t x0 = vs_win(rw, rbase + rj) ^ tw64(q0.x, q0.y, q0.z);
-    const uint64_t x1 = vs_win(rw, rbase + rj + 32u) ^ tw64(q0.z, q0.w, q1.x);
-    const uint64_t x2 = vs_win(rw, rbase + rj + 64u) ^ tw64(q1.x, q1.y, q1.z);
-    const uint64_t x3 = vs_win(rw, rbase + rj + 96u) ^ tw64(q1.z, q1.w, q2.x);
-    const uint64_t x4 = vs_win(rw, rbase + rj + 128u) ^ tw64(q2.x, q2.y, q2.z);
+    const uint64_t x0 = rw64(r0, r1, r2) ^ tw64(q0.x, q0.y, q0.z);
+    const uint64_t x1 = rw64(r2, r3, r4) ^ tw64(q0.z, q0.w, q1.x);
+    const uint64_t x2 = rw64(r4, r5, r6) ^ tw64(q1.x, q1.y, q1.z);
+    const uint64_t x3 = rw64(r6, r7, r8) ^ tw64(q1.z, q1.w, q2.x);
+    const uint64_t x4 = rw64(r8, r9, r10) ^ tw64(q2.x, q2.y, q2.z);
     const uint32_t left = xl ? n0 - 1u - (uint32_t)((63 - __clzll((long long)xl)) >> 1) : n0;
     // first window that differs (selects), then one find-first-set
     uint64_t xs = x4;
