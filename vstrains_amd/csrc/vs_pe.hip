@@ -78,7 +78,7 @@ struct Mem {  // one credited maximal exact match
 // The host picks the kernel instantiation (k_pe_tiles<true, *>) when the whole block qualifies.
 struct __attribute__((packed, aligned(4))) VsQuad { uint32_t x, y, z, w; };  // 16-byte load at dword alignment
 
-template <typename RB>
+template <bool W4, typename RB>  // W4: four right windows are enough (reads <= 159 bases with w = 31)
 __device__ __forceinline__ bool vs_extend_fast(const uint32_t *rw, RB rbase, uint32_t rlen, const uint32_t *tw,
                                                uint32_t tbase, uint32_t tlen, uint32_t j, uint32_t q, uint32_t w,
                                                uint32_t s, uint32_t K, uint32_t *a_out, uint32_t *qa_out,
@@ -100,7 +100,8 @@ __device__ __forceinline__ bool vs_extend_fast(const uint32_t *rw, RB rbase, uin
     const VsQuad q0 = *(const VsQuad *)(tw + ti);
     VsQuad q1 = {0u, 0u, 0u, 0u}, q2 = {0u, 0u, 0u, 0u};
     if (rem > 48u) q1 = *(const VsQuad *)(tw + ti + 4u);
-    if (rem > 112u) q2 = *(const VsQuad *)(tw + ti + 8u);
+    if (!W4 && rem > 112u) q2 = *(const VsQuad *)(tw + ti + 8u);  // (the fourth window needs word 8 only)
+    if (W4 && rem > 112u) q2.x = tw[ti + 8u];
     auto tw64 = [&](uint32_t w0, uint32_t w1, uint32_t w2) {
         return (uint64_t)__builtin_amdgcn_alignbit(w1, w0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, sh) << 32);
     };
@@ -108,7 +109,7 @@ __device__ __forceinline__ bool vs_extend_fast(const uint32_t *rw, RB rbase, uin
     const uint32_t rr = (uint32_t)(rbase + rj), rsh = (rr & 15u) * 2u;
     const uint32_t *rp = rw + (rr >> 4);
     const uint32_t r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4], r5 = rp[5], r6 = rp[6], r7 = rp[7],
-                   r8 = rp[8], r9 = rp[9], r10 = rp[10];
+                   r8 = rp[8], r9 = W4 ? 0u : rp[9], r10 = W4 ? 0u : rp[10];
     auto rw64 = [&](uint32_t w0, uint32_t w1, uint32_t w2) {
         return (uint64_t)__builtin_amdgcn_alignbit(w1, w0, rsh) | ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, rsh) << 32);
     };
@@ -117,10 +118,10 @@ __device__ __forceinline__ bool vs_extend_fast(const uint32_t *rw, RB rbase, uin
     const uint64_t x1 = rw64(r2, r3, r4) ^ tw64(q0.z, q0.w, q1.x);
     const uint64_t x2 = rw64(r4, r5, r6) ^ tw64(q1.x, q1.y, q1.z);
     const uint64_t x3 = rw64(r6, r7, r8) ^ tw64(q1.z, q1.w, q2.x);
-    const uint64_t x4 = rw64(r8, r9, r10) ^ tw64(q2.x, q2.y, q2.z);
+    const uint64_t x4 = W4 ? 0ull : rw64(r8, r9, r10) ^ tw64(q2.x, q2.y, q2.z);
     const uint32_t left = xl ? n0 - 1u - (uint32_t)((63 - __clzll((long long)xl)) >> 1) : n0;
     // first window that differs (selects), then one find-first-set
-    uint64_t xs = x4;
+    uint64_t xs = x4;  // (W4: zero -- no difference found inside 128 bases means ext = 160, clipped by rem <= 128)
     uint32_t xb = 128u;
     if (x3) { xs = x3; xb = 96u; }
     if (x2) { xs = x2; xb = 64u; }
@@ -593,7 +594,7 @@ k_pe_tiles(PeParams P) {
                 uint32_t a, qa, len;
                 bool credited;
                 if (FAST)
-                    credited = vs_extend_fast(s_words, e * wpe * 16u, rlen, tw, tb, nm.len, j, q, w, s, K, &a, &qa, &len);
+                    credited = vs_extend_fast<STD>(s_words, e * wpe * 16u, rlen, tw, tb, nm.len, j, q, w, s, K, &a, &qa, &len);
                 else
                     credited = vs_extend(s_words, e * wpe * 16u, rlen, tw, tb, nm.len, j, q, w, s, K,
                                          mk, (uint64_t)s_gwoff[e] * 16u, &a, &qa, &len);
@@ -1229,7 +1230,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     // straight-line extension when the whole block qualifies (see vs_extend_fast)
     const bool fast = !reads->d_mask && idx.s <= 32u && maxlen <= 128u + idx.w + 32u &&
                       !(getenv("VS_NO_FAST") && atoi(getenv("VS_NO_FAST")) != 0);
-    const bool std_shape = fast && ept == STD_EPT && pmax == STD_PMAX && wpe == STD_WPE && P.pool_bits == STD_POOL_BITS &&
+    const bool std_shape = fast && ept == STD_EPT && pmax == STD_PMAX && wpe == STD_WPE && P.pool_bits == STD_POOL_BITS && maxlen <= 159u &&
                            idx.K == STD_K && idx.w == STD_W && idx.s == STD_S &&
                            P.accumulate && !P.debug_stop && !P.count_postings && !P.dbg_counts &&
                            !(getenv("VS_NO_STD") && atoi(getenv("VS_NO_STD")) != 0);
