@@ -66,6 +66,7 @@ struct PeParams {
     uint32_t *out_counts;            // [n_tiles * ept] list lengths (0 for ends that add nothing)
     uint64_t n_pairs;
     uint32_t no_xcd_map;             // VS_NO_XCD_MAP=1: workgroup b takes run b (experiments)
+    uint32_t shortcut;               // overlapping-seed ownership shortcut for single postings (P3 stage A)
 };
 
 struct Mem {  // one credited maximal exact match
@@ -560,7 +561,7 @@ k_pe_tiles(PeParams P) {
                 if (live[k2] && cnt != 1u) {
                     const uint2 po = P.idx.postings[pa + (t - excl)];
                     node = po.x; pos = po.y & 0x7FFFFFFFu; opp = (po.y >> 31) ^ (pb >> 31);
-                } else if (live[k2] && s <= w && pi) {
+                } else if (P.shortcut && live[k2] && s <= w && pi) {
                     // Overlapping seeds (s <= w): if the previous probe of this end holds the single
                     // posting one stride back on the same diagonal, the bases in between match too,
                     // so that probe (or an earlier one) owns this match -- no memory traffic needed.
@@ -1226,6 +1227,13 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     P.dbg_cap = dbg_cap;
     P.accumulate = d_node_mat ? 1u : 0u;
     P.no_xcd_map = (getenv("VS_NO_XCD_MAP") && atoi(getenv("VS_NO_XCD_MAP")) != 0) ? 1u : 0u;
+    // The shortcut spares a single posting its extension when the previous probe already owns the
+    // match; it pays on graphs whose seeds are mostly unique.  Where seeds repeat (a compacted de
+    // Bruijn graph of many strains: 3.5 postings per distinct seed at configs[2]) nearly every
+    // wavefront holds some single posting and all 64 lanes walk through the test for it: 6.0 ms with,
+    // 5.8 ms without.  VS_SHORTCUT=0/1 overrides.
+    P.shortcut = ctx->n_distinct && ctx->n_seed_pos < 2 * ctx->n_distinct ? 1u : 0u;
+    if (const char *sv = getenv("VS_SHORTCUT")) P.shortcut = atoi(sv) != 0 ? 1u : 0u;
 
     // straight-line extension when the whole block qualifies (see vs_extend_fast)
     const bool fast = !reads->d_mask && idx.s <= 32u && maxlen <= 128u + idx.w + 32u &&
