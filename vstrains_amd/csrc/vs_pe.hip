@@ -238,6 +238,18 @@ __device__ __forceinline__ bool vs_accept(uint32_t v, uint32_t coord, uint32_t k
     return ((long long)v >= saturate) || ((long long)v * rl >= span * (rl - k));
 }
 
+// The same test in 32-bit arithmetic for the straight-line kernels (reads <= 191 bases: v, the read
+// length and k+1 stay below 2^8, node offsets and lengths below 2^25, so nothing overflows int32).
+__device__ __forceinline__ bool vs_accept32(uint32_t v, uint32_t coord, uint32_t kidx, uint32_t nlen, uint32_t rlen, uint32_t K) {
+    const int c = (int)coord, ki = (int)kidx, nl = (int)nlen, rl = (int)rlen, k = (int)K;
+    int right = c + nl - 1;
+    const int alt = c - ki + rl - 1;
+    if (alt < right) right = alt;
+    const int saturate = right - c - k + 2;
+    const int span = (rl < nl ? rl : nl) - k + 1;
+    return ((int)v >= saturate) || ((int)v * rl >= span * (rl - k));
+}
+
 // Probe the table for the seed at read offset j.  Returns posting count (0 = miss) and payload.
 __device__ __forceinline__ uint32_t vs_probe(const VsIndexDev &idx, uint64_t f, uint32_t *pa, uint32_t *pb) {
     uint64_t r = vs_rc(f, idx.w);
@@ -634,7 +646,7 @@ k_pe_tiles(PeParams P) {
                 const uint32_t hj = s_hminj[i];
                 const uint32_t nlen = FAST ? hj >> 8 : P.idx.meta[node].len;
                 const uint32_t minj = FAST ? hj & 0xFFu : hj;
-                if (vs_accept(s_hcnt[i], s_hminp[i], minj, nlen, rlen, K)) {
+                if (FAST ? vs_accept32(s_hcnt[i], s_hminp[i], minj, nlen, rlen, K) : vs_accept(s_hcnt[i], s_hminp[i], minj, nlen, rlen, K)) {
                     uint32_t k2 = atomicAdd(&s_ns[e], 1u);
                     if (k2 < LC) s_list[e * LC + k2] = node; else atomicOr(&s_state[e], 2u);
                 }
