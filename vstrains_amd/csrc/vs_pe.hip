@@ -291,7 +291,7 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
     t.gend = o;  o += 2u * ept;                 // global end index
     t.meta = o;  o += 2u * ept;
     t.words = o; o += 2u * (words_cap + 8u);
-    t.pcnt = o;  o += NI;
+    t.pcnt = o;  o += NI + 1u;  // [0] stays zero: the scan is read as s_pcnt[it - 1] .. s_pcnt[it] without a test for it == 0
     t.pa = o;    o += NI;
     t.pb = o;    o += NI;
     t.hkey = o;  o += pool;
@@ -341,7 +341,7 @@ k_pe_tiles(PeParams P) {
     uint32_t *s_meta = vs_lds + T.meta;
     uint32_t *s_words = vs_lds + T.words;  // end e occupies words [e*wpe, (e+1)*wpe)
     const uint32_t hw = (ept + 2u) & ~1u, wcap = words_cap + 8u;
-    uint32_t *s_pcnt = vs_lds + T.pcnt;    // posting counts per probe, then their inclusive scan
+    uint32_t *s_pcnt = vs_lds + T.pcnt + 1u;  // posting counts per probe, then their inclusive scan; s_pcnt[-1] == 0
     uint32_t *s_pa = vs_lds + T.pa;
     uint32_t *s_pb = vs_lds + T.pb;
     uint32_t *s_hkey = vs_lds + T.hkey;    // tile-wide (end, node) table: key = end << 25 | node
@@ -357,6 +357,7 @@ k_pe_tiles(PeParams P) {
     const uint32_t ppt = ept / 2u;
 
     if (tid < 3) s_misc[8 + tid] = 0;  // workgroup-local stats
+    if (tid == 3) vs_lds[T.pcnt] = 0;
     // a workgroup takes a contiguous run of the locus-sorted tiles (node text stays in L1/L2)
     // Workgroups go to the 8 XCDs round-robin (blockIdx % 8).  The runs are handed out so that XCD x
     // works through the x-th eighth of the locus order: what a locus touches (table slots, postings,
@@ -524,7 +525,7 @@ k_pe_tiles(PeParams P) {
             for (uint32_t i = tid; i < CHUNK; i += TPB) s_owner[i] = 0;
             __syncthreads();
             for (uint32_t it = tid; it < NI; it += TPB) {
-                const uint32_t incl = s_pcnt[it], excl = it ? s_pcnt[it - 1u] : 0u;
+                const uint32_t incl = s_pcnt[it], excl = s_pcnt[(int)it - 1];
                 if (incl > excl) {
                     const uint32_t lo = excl > c0 ? excl : c0;
                     const uint32_t hi = incl < c0 + CHUNK ? incl : c0 + CHUNK;
@@ -551,7 +552,12 @@ k_pe_tiles(PeParams P) {
             uint32_t carry = __shfl_up(incl, 1, 64);
             if (lane == 0u) carry = 0;
             __syncthreads();
-            for (uint32_t wv = 0; wv < (tid >> 6); wv++) carry = s_misc[4u + wv] > carry ? s_misc[4u + wv] : carry;
+            {   // the wavefronts before this one (TPB = 256: at most three)
+                const uint32_t m0 = s_misc[4], m1 = s_misc[5], m2 = s_misc[6], wv = tid >> 6;
+                if (wv > 0u) carry = m0 > carry ? m0 : carry;
+                if (wv > 1u) carry = m1 > carry ? m1 : carry;
+                if (wv > 2u) carry = m2 > carry ? m2 : carry;
+            }
             // The thread's PPT postings go through three stages with every stage done for all of
             // them before the next one starts: A) which posting (LDS) and its node (one global load
             // for multi-posting seeds), B) node header, C) text windows + decision.  Stages hold no
@@ -563,7 +569,7 @@ k_pe_tiles(PeParams P) {
                 const uint32_t t = c0 + tid * PPT + k2;
                 live[k2] = t < total;
                 const uint32_t it = live[k2] ? (own[k2] > carry ? own[k2] : carry) - 1u : 0u;
-                const uint32_t excl = it ? s_pcnt[it - 1u] : 0u;
+                const uint32_t excl = s_pcnt[(int)it - 1];
                 const uint32_t cnt = s_pcnt[it] - excl;
                 const uint32_t pa = s_pa[it], pb = s_pb[it];
                 const uint32_t e = STD ? it / STD_PMAX : vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
@@ -577,7 +583,7 @@ k_pe_tiles(PeParams P) {
                     // Overlapping seeds (s <= w): if the previous probe of this end holds the single
                     // posting one stride back on the same diagonal, the bases in between match too,
                     // so that probe (or an earlier one) owns this match -- no memory traffic needed.
-                    const uint32_t excl2 = it > 1u ? s_pcnt[it - 2u] : 0u;
+                    const uint32_t excl2 = s_pcnt[(int)it - 2];  // (pi != 0, so it >= 1)
                     if (excl - excl2 == 1u && s_pa[it - 1u] == node) {
                         const uint32_t pbp = s_pb[it - 1u];
                         const uint32_t want = opp ? pos + s : pos - s;
