@@ -72,7 +72,7 @@ def pmc_traffic(pairs):
     """HBM bytes of one k_pe_tiles launch from the committed rocprofv3 PMC passes (profiles/,
     collected with tools/profile.sh on the default workload; counters cannot be read inside this
     process).  2 x FETCH_SIZE (the guide's gfx950 rule for wide reads) + WRITE_SIZE, both in KB."""
-    path = os.path.join(ROOT, "profiles", "r1", "pmc_summary_bench_10m_v5.json")
+    path = os.path.join(ROOT, "profiles", "r1", "pmc_summary_bench_10m_v6.json")
     if pairs != 10_000_000 or not os.path.exists(path):
         return {"traffic": None}
     try:
@@ -82,7 +82,7 @@ def pmc_traffic(pairs):
         fetch = k["FETCH_SIZE"]["per_dispatch_mean"] * 1024.0
         write = k["WRITE_SIZE"]["per_dispatch_mean"] * 1024.0
         return {"traffic": 2.0 * fetch + write, "traffic_unit": "B per k_pe_tiles launch",
-                "traffic_source": "profiles/r1/pmc_summary_bench_10m_v5.json (2*FETCH_SIZE + WRITE_SIZE; not live)"}
+                "traffic_source": "profiles/r1/pmc_summary_bench_10m_v6.json (2*FETCH_SIZE + WRITE_SIZE; not live)"}
     except Exception:
         return {"traffic": None}
 
