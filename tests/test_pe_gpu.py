@@ -159,6 +159,22 @@ def test_random_graphs_against_c_oracle(host, ctx, k, read_len, n_pairs, snp):
     assert int(ref_node.sum()) > 0
 
 
+@pytest.mark.parametrize("read_len", [100, 101, 125, 126, 150, 151, 159, 160])
+def test_read_lengths_around_the_compile_time_shapes(host, ctx, read_len, monkeypatch):
+    """k = 55 with the read lengths the shape-specialised instantiations of k_pe_tiles are picked
+    for (2x100/101, 2x125/126, 2x150/151; 159 = the longest that takes one, 160 = generic layout),
+    no N in the block so that the straight-line kernels apply; each also with VS_NO_STD=1."""
+    g, f, r = _dense_case(55, 9000, read_len, seed=900 + read_len, snp=0.03, glen=5000, nrate=0.0)
+    orc = pe_oracle_c.Oracle(g.seqs, 55)
+    ref_node, ref_short, ref_stats = orc.count_pairs(f, r)
+    for no_std in ("0", "1"):
+        monkeypatch.setenv("VS_NO_STD", no_std)
+        (node_mat, short_mat, stats), _ = _gpu_matrices(host, ctx, g.seqs, f, r, 55)
+        assert np.array_equal(node_mat, ref_node) and np.array_equal(short_mat, ref_short)
+        assert stats == tuple(int(x) for x in ref_stats)
+    assert int(ref_node.sum()) > 0
+
+
 def test_variable_lengths_and_empty_block(host, ctx):
     g, f, r = _dense_case(21, 3000, 90, seed=501, snp=0.03)
     rng = np.random.default_rng(5)

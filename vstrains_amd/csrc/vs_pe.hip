@@ -308,21 +308,22 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
     return t;
 }
 
-// STD: the tile shape is the compile-time one of 2 x 150-base pairs at k = 55 (64 ends per tile, 5
-// probes and 10 packed words per end, 1024-slot table): every LDS array then sits at a constant
-// offset (folded into the LDS instructions) instead of costing a scalar register and an add, and
-// the divisions by pmax / wpe become constants.  The host picks it when the block has that shape.
+// SW, SP != 0: the tile shape is a compile-time one for k = 55 -- 64 ends per tile, 1024-slot table,
+// SW packed words and SP probes per end: (10, 5) = 2 x 145..159 bases, (8, 4) = 2 x 113..128,
+// (7, 3) = 2 x 97..112.  Every LDS array then sits at a constant offset (folded into the LDS
+// instructions) instead of costing a scalar register and an add, the divisions by pmax / wpe and
+// k+1 / seed length / stride become constants.  The host picks one when the block has that shape.
 #define STD_EPT 64u
-#define STD_PMAX 5u
-#define STD_WPE 10u
 #define STD_POOL_BITS 10u
 #define STD_K 56u   // k + 1
 #define STD_W 31u   // seed length and probe stride that follow from it (seed_geometry)
 #define STD_S 26u
-template <bool FAST, bool STD>
+template <bool FAST, uint32_t SW, uint32_t SP>
 __global__ void __launch_bounds__(TPB)
 __attribute__((amdgpu_waves_per_eu(TILES_WAVES, TILES_WAVES)))
 k_pe_tiles(PeParams P) {
+    constexpr bool STD = SW != 0u;
+    constexpr uint32_t STD_WPE = SW, STD_PMAX = SP;
     const uint32_t tid = threadIdx.x;
     // (the compile-time-shape instantiation is also the one without diagnostics: the host only picks
     // it for plain counting runs)
@@ -1256,13 +1257,20 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     // straight-line extension when the whole block qualifies (see vs_extend_fast)
     const bool fast = !reads->d_mask && idx.s <= 32u && maxlen <= 128u + idx.w + 32u &&
                       !(getenv("VS_NO_FAST") && atoi(getenv("VS_NO_FAST")) != 0);
-    const bool std_shape = fast && ept == STD_EPT && pmax == STD_PMAX && wpe == STD_WPE && P.pool_bits == STD_POOL_BITS && maxlen <= 159u &&
-                           idx.K == STD_K && idx.w == STD_W && idx.s == STD_S &&
-                           P.accumulate && !P.debug_stop && !P.count_postings && !P.dbg_counts &&
-                           !(getenv("VS_NO_STD") && atoi(getenv("VS_NO_STD")) != 0);
-    const void *tiles_fn = std_shape ? (const void *)k_pe_tiles<true, true>
-                           : fast    ? (const void *)k_pe_tiles<true, false>
-                                     : (const void *)k_pe_tiles<false, false>;
+    // compile-time-shape instantiations (see k_pe_tiles): 1 = (10, 5), 2 = (8, 4), 3 = (7, 3)
+    int std_shape = 0;
+    if (fast && ept == STD_EPT && P.pool_bits == STD_POOL_BITS && maxlen <= 159u && idx.K == STD_K && idx.w == STD_W &&
+        idx.s == STD_S && P.accumulate && !P.debug_stop && !P.count_postings && !P.dbg_counts &&
+        !(getenv("VS_NO_STD") && atoi(getenv("VS_NO_STD")) != 0)) {
+        if (wpe == 10u && pmax == 5u) std_shape = 1;
+        else if (wpe == 8u && pmax == 4u) std_shape = 2;
+        else if (wpe == 7u && pmax == 3u) std_shape = 3;
+    }
+    const void *tiles_fn = std_shape == 1   ? (const void *)k_pe_tiles<true, 10u, 5u>
+                           : std_shape == 2 ? (const void *)k_pe_tiles<true, 8u, 4u>
+                           : std_shape == 3 ? (const void *)k_pe_tiles<true, 7u, 3u>
+                           : fast           ? (const void *)k_pe_tiles<true, 0u, 0u>
+                                            : (const void *)k_pe_tiles<false, 0u, 0u>;
     if (lds > 64u * 1024u)
         VS_HIP(ctx, hipFuncSetAttribute(tiles_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     uint64_t grid = P.n_tiles;
@@ -1307,12 +1315,16 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     }
     VS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     if (!d_node_mat) VS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
-    if (std_shape)
-        hipLaunchKernelGGL((k_pe_tiles<true, true>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
+    if (std_shape == 1)
+        hipLaunchKernelGGL((k_pe_tiles<true, 10u, 5u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
+    else if (std_shape == 2)
+        hipLaunchKernelGGL((k_pe_tiles<true, 8u, 4u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
+    else if (std_shape == 3)
+        hipLaunchKernelGGL((k_pe_tiles<true, 7u, 3u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
     else if (fast)
-        hipLaunchKernelGGL((k_pe_tiles<true, false>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
+        hipLaunchKernelGGL((k_pe_tiles<true, 0u, 0u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
     else
-        hipLaunchKernelGGL((k_pe_tiles<false, false>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
+        hipLaunchKernelGGL((k_pe_tiles<false, 0u, 0u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
     if (d_node_mat) {
         // the last tile may be partly empty: its unused rows must read as length 0
         const uint64_t used_ends = 2ull * n_pairs;
