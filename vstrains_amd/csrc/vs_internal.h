@@ -160,9 +160,10 @@ __device__ __forceinline__ uint64_t vs_lowmask(uint32_t bits) {  // bits in 0..6
 
 // Reverse complement of a w-mer held LSB-first in the low 2w bits.
 __device__ __forceinline__ uint64_t vs_rc(uint64_t x, uint32_t w) {
-    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
-    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
-    x = __builtin_bswap64(x);
+    // order of the 2-bit codes reversed = all 64 bits reversed (two v_bfrev_b32), then the two bits of
+    // every code swapped back; complement = bitwise not
+    x = __builtin_bitreverse64(x);
+    x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
     return (~x) >> (64u - 2u * w);
 }
 
