@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VS_ABI_VERSION 2
+#define VS_ABI_VERSION 3
 
 enum {
     VS_OK = 0,
@@ -119,9 +119,33 @@ int vs_synth_pairs(vs_ctx *ctx, const uint8_t *genomes, const uint64_t *goff,
  * d_node_mat, d_short_mat: DEVICE pointers to N*N row-major uint32 counters, d_stats: DEVICE
  * pointer to 3 uint64 {n_reads, short_reads, used_reads}.  Counts are ADDED (atomically), so
  * several blocks / ranks can accumulate and the caller all-reduces (RCCL) as it likes.
- * uint32 is exact while pairs counted into one buffer stay below 2^31. */
+ * A cell grows by at most 2 per pair (short_mat[i][i] is incremented once per end, :174-184), so
+ * uint32 is exact while 2 * (pairs counted into one buffer, over all ranks that will be summed
+ * into it) < 2^32; vs_counts_fold moves a buffer into int64 totals before that. */
 int vs_pe_count(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, uint32_t *d_short_mat,
                 uint64_t *d_stats);
+
+/* d_wide[i] += d_counts[i] (read as uint32); d_counts[i] = 0, for i < n.  DEVICE pointers.  The
+ * reference's matrices are numpy.zeros(..., dtype=int) = int64 (PE_Inference.py:139-140): a caller
+ * that counts more pairs than a uint32 cell can hold folds into int64 totals in between. */
+int vs_counts_fold(vs_ctx *ctx, uint32_t *d_counts, int64_t *d_wide, uint64_t n);
+
+/* ---- C1: sum of the counters over ranks (RCCL over xGMI) ---------------------------------------
+ * No counterpart in the reference (single process); read pairs are independent and the counters
+ * add (PE_Inference.py:174-188), so ranks count disjoint read blocks and sum.  One process per
+ * GPU.  The RCCL library is resolved at the first call (the copy already loaded into the process,
+ * else librccl.so.1); without it the calls fail with VS_E_HIP.
+ *   vs_comm_unique_id : rank 0 makes the 128-byte id and hands it to the other ranks out of band
+ *   vs_comm_init_rank : collective over the n_ranks processes; *comm receives an ncclComm_t
+ *   vs_pe_allreduce   : in-place ncclAllReduce(ncclSum) of node_mat[n*n], short_mat[n*n] (uint32,
+ *                       or int64 totals when `wide` != 0) and of the 3 uint64 stats, enqueued on the
+ *                       ctx stream.  `comm` is an ncclComm_t made by vs_comm_init_rank or by the
+ *                       caller's own RCCL calls in this process.  DEVICE pointers. */
+int vs_comm_unique_id(vs_ctx *ctx, uint8_t id[128]);
+int vs_comm_init_rank(vs_ctx *ctx, int n_ranks, const uint8_t id[128], int rank, void **comm);
+int vs_comm_destroy(vs_ctx *ctx, void *comm);
+int vs_pe_allreduce(vs_ctx *ctx, void *comm, void *d_node_mat, void *d_short_mat, uint64_t *d_stats,
+                    uint32_t n, int wide);
 
 /* Per-end result of single_end_read_mapping (PE_Inference.py:16-48) for testing: for each end
  * e, counts[e] = number of accepted nodes (0 for ends of pairs the filters drop), and up to
@@ -135,6 +159,9 @@ int vs_pe_map_ends(vs_ctx *ctx, const vs_reads *reads, uint32_t cap, uint32_t *l
  * kernel (k_pe_locus + scan + k_pe_permute), ms[4] = counter kernel (k_pe_accumulate).
  * Synchronises the stream. */
 int vs_pe_last_timing(vs_ctx *ctx, double ms[5]);
+/* Name of the mapping-kernel instantiation the most recent vs_pe_count launched, as a profiler
+ * prints it (e.g. "k_pe_tiles<true, 10u, 5u>"); "" before the first call. */
+const char *vs_pe_last_kernel(const vs_ctx *ctx);
 
 /* ---- graph stages: K5 PE-link table ---------------------------------------------------------
  * Replaces process_pe_info (utils/VStrains_IO.py:598-627) and every later read or rewrite of the
@@ -149,6 +176,9 @@ typedef struct vs_links vs_links;
 /* d_node_mat / d_short_mat: DEVICE pointers to the N*N uint32 counters vs_pe_count filled. */
 int vs_links_from_counts(vs_ctx *ctx, const uint32_t *d_node_mat, const uint32_t *d_short_mat,
                          uint32_t n, vs_links **out);
+/* Same from DEVICE int64 totals (vs_counts_fold). */
+int vs_links_from_wide(vs_ctx *ctx, const int64_t *d_node_mat, const int64_t *d_short_mat,
+                       uint32_t n, vs_links **out);
 /* Same from HOST int64 matrices (e.g. parsed back from pe_info / st_info text). */
 int vs_links_from_host(vs_ctx *ctx, const int64_t *node_mat, const int64_t *short_mat, uint32_t n,
                        vs_links **out);

@@ -256,6 +256,39 @@ void peo_count_pairs(peo *o, const uint8_t *fwd, const uint64_t *foff, const uin
     free(lefts); free(rights);
 }
 
+/* The same pair loop for graphs whose dense matrices do not fit the host (5e4 nodes = 2 x 20 GB of
+ * int64): every increment is emitted as a key instead -- bit 63 = matrix (0 node_mat, 1 short_mat),
+ * low bits = i * n + j -- and the caller sums equal keys.  At most `cap` keys are written; the
+ * number of increments is returned (call again with a larger buffer if it exceeds cap). */
+uint64_t peo_count_pairs_keys(peo *o, const uint8_t *fwd, const uint64_t *foff, const uint8_t *rve,
+                              const uint64_t *roff, uint64_t n_pairs, uint64_t *keys, uint64_t cap,
+                              uint64_t *stats) {
+    uint32_t n = o->n_nodes, K = o->split_len;
+    uint32_t *lefts = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
+    uint32_t *rights = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
+    uint64_t m = 0;
+    const uint64_t SHORT = 1ull << 63;
+#define EMIT(k) do { if (m < cap) keys[m] = (k); m++; } while (0)
+    for (uint64_t r = 0; r < n_pairs; r++) {
+        const uint8_t *fs = fwd + foff[r], *rs = rve + roff[r];
+        uint64_t fl = foff[r + 1] - foff[r], rl = roff[r + 1] - roff[r];
+        if (has_N(fs, fl) || has_N(rs, rl)) { stats[0]++; continue; }
+        if (fl < K || rl < K) { stats[1]++; continue; }
+        stats[2]++;
+        uint32_t nl = peo_map_end(o, fs, (uint32_t)fl, lefts, n);
+        uint32_t nr = peo_map_end(o, rs, (uint32_t)rl, rights, n);
+        for (uint32_t a = 0; a < nl; a++)
+            for (uint32_t b = a; b < nl; b++) EMIT(SHORT | ((uint64_t)lefts[a] * n + lefts[b]));
+        for (uint32_t a = 0; a < nr; a++)
+            for (uint32_t b = a; b < nr; b++) EMIT(SHORT | ((uint64_t)rights[a] * n + rights[b]));
+        for (uint32_t a = 0; a < nl; a++)
+            for (uint32_t b = 0; b < nr; b++) EMIT((uint64_t)lefts[a] * n + rights[b]);
+    }
+#undef EMIT
+    free(lefts); free(rights);
+    return m;
+}
+
 /* ------------------------------------------------------------------------------------------
  * CPU twin of the device read generator (vstrains_amd/csrc/vs_synth.hip).  Same integer
  * recipe, ASCII output.  See include/vstrains_hip.h: vs_synth_pairs for the parameter meaning.

@@ -34,6 +34,9 @@ def lib():
         L.peo_map_end.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         L.peo_count_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.peo_count_pairs_keys.restype = C.c_uint64
+        L.peo_count_pairs_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
         L.peo_synth_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
                                       C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.c_void_p, C.c_void_p]
@@ -99,6 +102,29 @@ class Oracle:
                               ro.ctypes.data, n_pairs, node_mat.ctypes.data,
                               short_mat.ctypes.data, stats.ctypes.data)
         return node_mat, short_mat, stats
+
+
+def _sparse(self, fd, fo, rd, ro, n_pairs):
+    """Sparse form of count_pairs_raw for graphs whose dense matrices do not fit the host:
+    -> (node cells, node counts, short cells, short counts, stats); a cell is i * n + j."""
+    stats = np.zeros(3, dtype=np.uint64)
+    cap = max(1 << 20, 96 * int(n_pairs))
+    while True:
+        keys = np.empty(cap, dtype=np.uint64)
+        st = np.zeros(3, dtype=np.uint64)
+        m = int(lib().peo_count_pairs_keys(self._h, fd.ctypes.data, fo.ctypes.data, rd.ctypes.data, ro.ctypes.data,
+                                           n_pairs, keys.ctypes.data, cap, st.ctypes.data))
+        if m <= cap:
+            stats = st
+            break
+        cap = m
+    cells, counts = np.unique(keys[:m], return_counts=True)
+    short = cells >= np.uint64(1 << 63)
+    return (cells[~short].astype(np.int64), counts[~short].astype(np.int64),
+            (cells[short] - np.uint64(1 << 63)).astype(np.int64), counts[short].astype(np.int64), stats)
+
+
+Oracle.count_pairs_sparse = _sparse
 
 
 def synth_pairs(genomes: Sequence[str], cum: np.ndarray, seed: int, first_pair: int, n: int,

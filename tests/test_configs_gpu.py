@@ -1,0 +1,116 @@
+"""BASELINE.json configs[3] and configs[4] at their real graph sizes (the generators bench.py
+--config uses): the code paths only these sizes take -- 64-bit cell keys in the counter kernel and
+the global-atomic locus sort above 46 k / 36 k nodes, 2 x 10 GB counters, the generic-loop mapping
+kernel for k = 127 / 2 x 250 -- against the C oracle on a prefix of the read stream, plus the
+size-independent partition property on the whole block.  Integer work: bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import pe_oracle_c
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def host():
+    from vstrains_amd import pe as host
+
+    return host
+
+
+@pytest.fixture(scope="module")
+def ctx(host):
+    c = host.Context(0)
+    yield c
+    c.close()
+
+
+def _count(host, ctx, st, cum, seed, L, pieces, sub, nth):
+    counter = host.PeCounter(ctx)
+    for first, n in pieces:
+        block = ctx.synth_pairs(st.genomes, cum, seed, first, n, L, sub, nth)
+        counter.add(block)
+        ctx.sync()
+        block.free()
+    return counter
+
+
+def _assert_equals_oracle(counter, orc, st, cum, seed, L, M, sub, nth):
+    import torch
+
+    fw, rv = pe_oracle_c.synth_pairs(st.genomes, cum, seed, 0, M, L, sub, nth)
+    off = np.arange(M + 1, dtype=np.uint64) * np.uint64(L)
+    node_cells, node_counts, short_cells, short_counts, ref_stats = orc.count_pairs_sparse(fw.reshape(-1), off, rv.reshape(-1), off, M)
+    assert tuple(int(x) for x in counter.stats.cpu().tolist()) == tuple(int(x) for x in ref_stats)
+    for mat, cells, counts in ((0, node_cells, node_counts), (1, short_cells, short_counts)):
+        flat = counter.mats[mat].reshape(-1)
+        got = flat[torch.from_numpy(cells).to(flat.device)].cpu().numpy().view(np.uint32).astype(np.int64)
+        assert np.array_equal(got, counts), "mat %d: %d cells differ" % (mat, int((got != counts).sum()))
+        # no count anywhere else: the totals agree
+        assert int(flat.sum(dtype=torch.int64).item()) == int(counts.sum())
+    assert int(node_counts.sum()) > M  # the sample says something
+
+
+def test_config4_50k_nodes_wide_cell_keys_and_global_sort(host, ctx, tmp_path):
+    import torch
+
+    from vstrains_amd.workloads import CONFIGS, workload_for
+
+    cfg = CONFIGS[4]
+    st, pre, names, seqs, cum, logger, n_in = workload_for(4, str(tmp_path))
+    n = len(seqs)
+    assert n >= 50000, n  # > 46340: 2*N*N no longer fits the 32-bit cell keys; > 36862: no LDS histogram for the sort
+    ctx.build_index(seqs, cfg["k"])
+    L, seed = cfg["read_len"], 4242
+    sub, nth = int(0.005 * 2 ** 32), int(0.001 * 2 ** 32)
+    R = 3_000_000
+    whole = _count(host, ctx, st, cum, seed, L, [(0, R)], sub, nth)
+    t = ctx.last_timing()
+    assert ctx.last_kernel.startswith("k_pe_tiles<true")  # the straight-line instantiation serves this config
+    parts = _count(host, ctx, st, cum, seed, L, [(0, 1), (1, 4999), (5000, 1_000_001), (1_005_001, R - 1_005_001)], sub, nth)
+    assert torch.equal(whole.mats, parts.mats) and torch.equal(whole.stats, parts.stats)
+    stats = whole.stats.cpu().tolist()
+    assert sum(stats) == R and stats[2] > 0.99 * R
+    del parts
+    torch.cuda.empty_cache()
+    # short_mat is upper triangular (PE_Inference.py:174-184): nothing below the diagonal
+    low = 0
+    rows = torch.arange(n, device=whole.mats.device)
+    for lo in range(0, n, 2048):
+        hi = min(n, lo + 2048)
+        blk = whole.mats[1, lo:hi, :hi]
+        below = rows[lo:hi, None] > rows[None, :hi]
+        low += int((blk * below).sum(dtype=torch.int64).item())
+    assert low == 0
+    del whole
+    torch.cuda.empty_cache()
+    M = 120_000
+    prefix = _count(host, ctx, st, cum, seed, L, [(0, M)], sub, nth)
+    orc = pe_oracle_c.Oracle(seqs, cfg["k"])
+    _assert_equals_oracle(prefix, orc, st, cum, seed, L, M, sub, nth)
+    assert t["slow_pairs"] >= 0
+
+
+def test_config3_10k_nodes_k127_reads_of_250(host, ctx, tmp_path):
+    import torch
+
+    from vstrains_amd.workloads import CONFIGS, workload_for
+
+    cfg = CONFIGS[3]
+    st, pre, names, seqs, cum, logger, n_in = workload_for(3, str(tmp_path))
+    assert len(seqs) >= 10000, len(seqs)
+    ctx.build_index(seqs, cfg["k"])
+    L, seed = cfg["read_len"], 4343
+    sub, nth = int(0.005 * 2 ** 32), int(0.001 * 2 ** 32)
+    R = 1_200_000
+    whole = _count(host, ctx, st, cum, seed, L, [(0, R)], sub, nth)
+    parts = _count(host, ctx, st, cum, seed, L, [(0, 300_001), (300_001, 7), (300_008, R - 300_008)], sub, nth)
+    assert torch.equal(whole.mats, parts.mats) and torch.equal(whole.stats, parts.stats)
+    stats = whole.stats.cpu().tolist()
+    assert sum(stats) == R and stats[2] > 0.99 * R
+    del parts, whole
+    torch.cuda.empty_cache()
+    M = 200_000
+    prefix = _count(host, ctx, st, cum, seed, L, [(0, M)], sub, nth)
+    orc = pe_oracle_c.Oracle(seqs, cfg["k"])
+    _assert_equals_oracle(prefix, orc, st, cum, seed, L, M, sub, nth)

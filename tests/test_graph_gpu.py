@@ -141,8 +141,9 @@ def test_link_table_from_device_counters(backend):
 
     n = 45
     rng = np.random.default_rng(2)
-    node = rng.integers(0, 2 ** 31 - 1, size=(n, n), dtype=np.int64)  # near the counter range
-    short = np.triu(rng.integers(0, 2 ** 31 - 1, size=(n, n), dtype=np.int64))
+    node = rng.integers(0, 2 ** 32, size=(n, n), dtype=np.int64)  # the whole uint32 range
+    short = np.triu(rng.integers(0, 2 ** 32, size=(n, n), dtype=np.int64))
+    node[0, 1], short[2, 2], short[3, 3] = 2 ** 31 + 5, 2 ** 32 - 1, 2 ** 31
 
     class Counter:
         pass

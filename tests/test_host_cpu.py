@@ -21,7 +21,7 @@ def test_library_exports_every_symbol_of_the_header():
     assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
     for name in declared:
         assert hasattr(L, name)
-    assert L.vs_abi_version() == 2
+    assert L.vs_abi_version() == 3
 
 
 def test_no_device_means_loud_failure_not_fallback():
@@ -149,6 +149,107 @@ def test_overlapped_allreduce_with_two_buffers_gloo():
     for step, mats, st in seen:
         assert (mats == (1 + 2) * (step + 1)).all()           # rank 0 + rank 1 contributions of that step
         assert (st == (0 + 1) + 2 * 10 * step).all()
+
+
+def _cpu_counter(n, pairs_in_buffer):
+    """PeCounter on CPU tensors with the device fold (vs_counts_fold) replaced by its definition:
+    what is under test is the range bookkeeping and the collective logic around it."""
+    import torch
+
+    from vstrains_amd import pe as host
+
+    class FakeCtx:
+        n_nodes = n
+        device = 0
+
+    class CpuCounter(host.PeCounter):
+        def fold(self):
+            if self.wide is None:
+                self.wide = torch.zeros(self.mats.shape, dtype=torch.int64)
+            self.wide += torch.from_numpy(self.mats.numpy().view(np.uint32).astype(np.int64))
+            self.mats.zero_()
+            self.pairs_in_buffer = 0
+
+    c = CpuCounter(FakeCtx(), device="cpu")
+    c.pairs_in_buffer = pairs_in_buffer
+    return c
+
+
+def _set_cell(counter, mat, i, j, value):
+    counter.mats[mat, i, j] = int(np.array([value], dtype=np.uint32).view(np.int32)[0])
+
+
+def test_counter_cells_above_2_31_come_back_positive():
+    """uint32 cells in int32 storage: values in [2^31, 2^32) must widen as unsigned (the diagonal of
+    short_mat takes two increments per pair, PE_Inference.py:174-184), and folded totals add on top."""
+    c = _cpu_counter(3, 2 ** 31 - 1)
+    _set_cell(c, 0, 1, 2, 2 ** 31 + 5)
+    _set_cell(c, 1, 1, 1, 2 ** 32 - 1)
+    node, short, _ = c.result()
+    assert node[1, 2] == 2 ** 31 + 5 and short[1, 1] == 2 ** 32 - 1 and node.min() >= 0 and short.min() >= 0
+    c.fold()
+    assert int(c.mats.abs().sum()) == 0 and c.pairs_in_buffer == 0
+    _set_cell(c, 1, 1, 1, 2 ** 32 - 1)
+    node, short, _ = c.result()
+    assert node[1, 2] == 2 ** 31 + 5 and short[1, 1] == 2 * (2 ** 32 - 1)
+
+
+def _rank_range(rank, world, port, q):
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    out = []
+    # (a) the uint32 buffers can hold the sum: summed as they are (int32 storage, unsigned meaning)
+    a = _cpu_counter(4, 2 ** 29)
+    _set_cell(a, 1, 2, 2, 2 ** 31 + 5 if rank == 0 else 2 ** 31 - 10)
+    _set_cell(a, 0, 0, 3, 7 + rank)
+    a.all_reduce()
+    out.append(("u32", a.wide is None, a.pairs_in_buffer, a.result()))
+    # (b) they cannot: every rank folds, the int64 totals are summed
+    b = _cpu_counter(4, 2 ** 31 - 1)
+    _set_cell(b, 1, 2, 2, 2 ** 32 - 1)
+    _set_cell(b, 0, 0, 3, 2 ** 31 + rank)
+    b.all_reduce()
+    out.append(("wide", b.wide is not None, b.pairs_in_buffer, b.result()))
+    # (c) one rank already holds int64 totals: all of them switch
+    c = _cpu_counter(4, 10)
+    _set_cell(c, 0, 1, 1, 5)
+    if rank == 1:
+        c.fold()
+        _set_cell(c, 0, 1, 1, 3)
+    c.all_reduce()
+    out.append(("mixed", c.wide is not None, c.pairs_in_buffer, c.result()))
+    # the overlapped form refuses what it cannot hold
+    d = _cpu_counter(4, 2 ** 30)
+    try:
+        d.all_reduce_async()
+        out.append(("async", False, 0, None))
+    except OverflowError:
+        out.append(("async", True, 0, None))
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_counter_range_across_two_ranks_gloo():
+    import torch.multiprocessing as mp
+
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29500 + ((os.getpid() + 41) % 500)
+    procs = [ctxm.Process(target=_rank_range, args=(rk, 2, port, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (ta, fa, pa, ra), (tb, fb, pb, rb), (tc, fc, pc, rc), (td, fd, _, _) = out
+    assert fa and pa == 2 ** 30 and ra[1][2, 2] == 2 ** 32 - 5 and ra[0][0, 3] == 15
+    assert fb and pb == 0 and rb[1][2, 2] == 2 * (2 ** 32 - 1) and rb[0][0, 3] == 2 ** 32 + 1
+    assert fc and rc[0][1, 1] == 5 + 5 + 3
+    assert fd
 
 
 def test_async_allreduce_without_process_group_is_a_no_op():

@@ -360,3 +360,74 @@ def test_many_nodes_sort_and_counters(host, ctx):
     assert np.array_equal(node_mat, want[0]) and np.array_equal(short_mat, want[1])
     assert stats == tuple(int(x) for x in want[2])
     assert node_mat.sum() > n
+
+
+def test_counter_range_fold_and_auto_fold(host, ctx):
+    """Cells in [2^31, 2^32) widen as unsigned; vs_counts_fold moves a buffer into int64 totals and
+    empties it; add() folds by itself before 2 * pairs can reach 2^32 (the reference counts in
+    int64, PE_Inference.py:139-140)."""
+    import torch
+
+    g, f, r = _dense_case(21, 400, 80, seed=61, snp=0.03)
+    ctx.build_index(g.seqs, 21)
+    base = host.PeCounter(ctx)
+    base.add(ctx.pack_pairs(f, r))
+    node0, short0, stats0 = base.result()
+    n = len(g.seqs)
+    c = host.PeCounter(ctx)
+    big = np.zeros((2, n, n), dtype=np.uint32)
+    big[0, 1, 2] = 2 ** 31 + 5
+    big[1, 1, 1] = 2 ** 32 - 1
+    big[1, 0, 0] = 2 ** 32 - 2
+    c.mats.copy_(torch.from_numpy(big.view(np.int32)))
+    c.pairs_in_buffer = 2 ** 31 - 1 - 100   # the next block of 400 pairs does not fit: add() must fold first
+    c.add(ctx.pack_pairs(f, r))
+    assert c.wide is not None and c.pairs_in_buffer == len(f)
+    node, short, stats = c.result()
+    assert np.array_equal(node, node0 + big[0].astype(np.int64))
+    assert np.array_equal(short, short0 + big[1].astype(np.int64))
+    assert stats == stats0
+    # the graph stages' link table from the same counter (int64 totals + live buffer)
+    from vstrains_amd.graph.hip_ops import HipPeLinks
+
+    links = HipPeLinks.from_counter(ctx, c, [str(i) for i in range(n)])
+    want = node + node.T + short + short.T
+    want[np.arange(n), np.arange(n)] = node.diagonal() + short.diagonal()
+    assert np.array_equal(links.to_numpy(), want)
+
+
+def test_rccl_allreduce_through_the_c_abi_one_rank(host, ctx):
+    """vs_comm_* / vs_pe_allreduce (ncclAllReduce on the ctx stream) with a one-rank communicator:
+    the sum over one rank is the identity, for the uint32 buffers and for int64 totals."""
+    import ctypes as C
+
+    import torch
+
+    from vstrains_amd import _native as nat
+
+    L = nat.lib()
+    uid = (C.c_uint8 * 128)()
+    nat.check(ctx._h, L.vs_comm_unique_id(ctx._h, uid))
+    comm = C.c_void_p()
+    nat.check(ctx._h, L.vs_comm_init_rank(ctx._h, 1, uid, 0, C.byref(comm)))
+    n = 37
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 2 ** 32, size=(2, n, n), dtype=np.uint64).astype(np.uint32)
+    mats = torch.from_numpy(a.view(np.int32)).cuda()
+    stats = torch.tensor([5, 6, 2 ** 40], dtype=torch.int64).cuda()
+    torch.cuda.synchronize()
+    nat.check(ctx._h, L.vs_pe_allreduce(ctx._h, comm, C.c_void_p(mats[0].data_ptr()), C.c_void_p(mats[1].data_ptr()),
+                                        C.c_void_p(stats.data_ptr()), n, 0))
+    ctx.sync()
+    assert np.array_equal(mats.cpu().numpy().view(np.uint32), a)
+    assert stats.cpu().tolist() == [5, 6, 2 ** 40]
+    wide = torch.from_numpy(rng.integers(0, 2 ** 62, size=(2, n, n), dtype=np.int64)).cuda()
+    keep = wide.clone()
+    torch.cuda.synchronize()
+    # two separate allocations take the two-call branch
+    w0, w1 = wide[0].clone(), wide[1].clone()
+    nat.check(ctx._h, L.vs_pe_allreduce(ctx._h, comm, C.c_void_p(w0.data_ptr()), C.c_void_p(w1.data_ptr()), None, n, 1))
+    nat.check(ctx._h, L.vs_pe_allreduce(ctx._h, comm, C.c_void_p(wide[0].data_ptr()), C.c_void_p(wide[1].data_ptr()), None, n, 1))
+    ctx.sync()
+    assert torch.equal(wide, keep) and torch.equal(w0, keep[0]) and torch.equal(w1, keep[1])
+    nat.check(ctx._h, L.vs_comm_destroy(ctx._h, comm))

@@ -2,7 +2,7 @@
 # GPU-side: SQ / TCP / TCC counter passes over the bench command (outputs under gpurun_out/pmc_$1)
 R="$GRAFT_REPO_ROOT"; TAG="${1:-x}"; OUT="$R/gpurun_out/pmc_$TAG"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-extract"
+B="python3 $R/bench.py --config ${CFG:-2} --steps 2 --warmup 1 --cpu-seconds 0 --no-extract"
 pass() { name=$1; shift; timeout 300 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- $B > "$OUT/$name.json" 2> "$OUT/$name.err"; }
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM
 pass sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT

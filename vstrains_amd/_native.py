@@ -40,9 +40,16 @@ SYMBOLS = {
                                  C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                  C.POINTER(C.c_void_p)]),
     "vs_pe_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vs_counts_fold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "vs_comm_unique_id": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vs_comm_init_rank": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "vs_comm_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vs_pe_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]),
     "vs_pe_map_ends": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "vs_pe_last_kernel": (C.c_char_p, [C.c_void_p]),
     "vs_pe_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "vs_links_from_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "vs_links_from_wide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "vs_links_from_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "vs_links_free": (None, [C.c_void_p, C.c_void_p]),
     "vs_links_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),

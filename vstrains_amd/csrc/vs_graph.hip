@@ -389,6 +389,12 @@ int vs_links_from_counts(vs_ctx *ctx, const uint32_t *d_node_mat, const uint32_t
     return links_build<uint32_t>(ctx, d_node_mat, d_short_mat, n, out);
 }
 
+int vs_links_from_wide(vs_ctx *ctx, const int64_t *d_node_mat, const int64_t *d_short_mat, uint32_t n, vs_links **out) {
+    if (!ctx || !out || (n && (!d_node_mat || !d_short_mat))) return vs_fail(ctx, VS_E_ARG, "vs_links_from_wide: bad argument");
+    VS_HIP(ctx, hipSetDevice(ctx->device));
+    return links_build<int64_t>(ctx, d_node_mat, d_short_mat, n, out);
+}
+
 int vs_links_from_host(vs_ctx *ctx, const int64_t *node_mat, const int64_t *short_mat, uint32_t n, vs_links **out) {
     if (!ctx || !out || (n && (!node_mat || !short_mat))) return vs_fail(ctx, VS_E_ARG, "vs_links_from_host: bad argument");
     VS_HIP(ctx, hipSetDevice(ctx->device));

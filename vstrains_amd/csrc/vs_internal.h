@@ -87,6 +87,7 @@ struct vs_ctx {
     size_t scratch_cap[32] = {};
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double last_ms[3] = {0, 0, 0};
+    const char *last_kernel = "";  // mapping-kernel instantiation of the last vs_pe_count
     int n_cu = 256;
 };
 

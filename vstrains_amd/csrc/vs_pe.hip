@@ -1315,6 +1315,11 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     }
     VS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     if (!d_node_mat) VS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
+    ctx->last_kernel = std_shape == 1   ? "k_pe_tiles<true, 10u, 5u>"
+                       : std_shape == 2 ? "k_pe_tiles<true, 8u, 4u>"
+                       : std_shape == 3 ? "k_pe_tiles<true, 7u, 3u>"
+                       : fast           ? "k_pe_tiles<true, 0u, 0u>"
+                                        : "k_pe_tiles<false, 0u, 0u>";
     if (std_shape == 1)
         hipLaunchKernelGGL((k_pe_tiles<true, 10u, 5u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
     else if (std_shape == 2)
@@ -1381,6 +1386,8 @@ extern "C" int vs_pe_count(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_
     if (!ctx || !reads || !d_node_mat || !d_short_mat || !d_stats) return VS_E_ARG;
     return pe_launch(ctx, reads, d_node_mat, d_short_mat, d_stats, nullptr, nullptr, 0);
 }
+
+extern "C" const char *vs_pe_last_kernel(const vs_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
 
 extern "C" int vs_pe_last_timing(vs_ctx *ctx, double ms[5]) {
     if (!ctx || !ms) return VS_E_ARG;

@@ -15,13 +15,24 @@ def shard_range(n_pairs: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, hi
 
 
+def group_size() -> int:
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size()
+    return 1
+
+
 def all_reduce_counts(mats, stats):
-    """In-place sum over ranks of the [2, N, N] counter tensor and the 3 stats."""
+    """In-place sum over ranks of the [2, N, N] counter tensor (int32 storage of uint32 cells, or
+    int64 totals; may be None) and of a small int64 tensor (the 3 stats, or PeCounter's flags)."""
     import torch.distributed as dist
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(mats, op=dist.ReduceOp.SUM)
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        if mats is not None:
+            dist.all_reduce(mats, op=dist.ReduceOp.SUM)
+        if stats is not None:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
 
 
 def all_reduce_counts_async(mats, stats):

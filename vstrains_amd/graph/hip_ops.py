@@ -99,8 +99,14 @@ class HipPeLinks(PeLinks):
         assert counter.n == n
         counter.torch.cuda.synchronize(counter.device)
         h = C.c_void_p()
-        nat.check(ctx._h, nat.lib().vs_links_from_counts(ctx._h, C.c_void_p(counter.mats[0].data_ptr()),
-                                                         C.c_void_p(counter.mats[1].data_ptr()), n, C.byref(h)))
+        if getattr(counter, "wide", None) is not None:  # int64 totals exist: everything goes there first
+            counter.fold()
+            counter.torch.cuda.synchronize(counter.device)
+            nat.check(ctx._h, nat.lib().vs_links_from_wide(ctx._h, C.c_void_p(counter.wide[0].data_ptr()),
+                                                           C.c_void_p(counter.wide[1].data_ptr()), n, C.byref(h)))
+        else:
+            nat.check(ctx._h, nat.lib().vs_links_from_counts(ctx._h, C.c_void_p(counter.mats[0].data_ptr()),
+                                                             C.c_void_p(counter.mats[1].data_ptr()), n, C.byref(h)))
         ctx.sync()
         return cls(ctx, h, names)
 

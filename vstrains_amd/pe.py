@@ -230,6 +230,11 @@ class Context:
         nat.check(self._h, nat.lib().vs_pe_last_timing(self._h, a))
         return dict(main_ms=a[0], slow_ms=a[1], slow_pairs=int(a[2]), sort_ms=a[3], accumulate_ms=a[4])
 
+    @property
+    def last_kernel(self) -> str:
+        """Name of the mapping-kernel instantiation the last ``pe_count`` launched."""
+        return (nat.lib().vs_pe_last_kernel(self._h) or b"").decode()
+
     def map_ends(self, reads: ReadBlock, cap: int = 64) -> List[List[int]]:
         n = reads.info["ends"]
         lists = np.zeros((max(n, 1), cap), dtype=np.uint32)
@@ -244,9 +249,18 @@ class Context:
         return out
 
 
+U32_LIMIT = 2 ** 32
+
+
 class PeCounter:
     """node_mat / short_mat accumulation on one device (PE_Inference.py:137-188), counters held
-    in torch tensors so that torch.distributed (RCCL) can all-reduce them in place."""
+    in torch tensors so that torch.distributed (RCCL) can all-reduce them in place.
+
+    The kernels count in uint32 cells (``mats``: int32 storage, the bits are what matters -- a
+    two's-complement sum IS the uint32 sum).  A cell grows by at most 2 per pair (``short_mat[i][i]``
+    takes one increment per end, :174-184), so a buffer is exact while ``2 * pairs < 2**32``; before
+    that bound is reached the buffer is folded into int64 totals on the device (``vs_counts_fold``),
+    the reference's own cell type (``numpy.zeros(..., dtype=int)``, :139-140)."""
 
     def __init__(self, ctx: Context, device: Optional[str] = None):
         import torch
@@ -258,30 +272,79 @@ class PeCounter:
         self.n = n
         self.mats = torch.zeros((2, max(n, 1), max(n, 1)), dtype=torch.int32, device=self.device)
         self.stats = torch.zeros(3, dtype=torch.int64, device=self.device)
+        self.wide = None          # int64 totals, allocated by the first fold
+        self.pairs_in_buffer = 0  # pairs counted into ``mats`` since it was last empty (all ranks, after a sum)
         self.pairs_seen = 0
+
+    def reset(self):
+        self.mats.zero_()
+        self.stats.zero_()
+        if self.wide is not None:
+            self.wide.zero_()
+        self.pairs_in_buffer = 0
+        self.pairs_seen = 0
+
+    def fold(self):
+        """uint32 buffer -> int64 totals (device), buffer left empty."""
+        torch = self.torch
+        if self.wide is None:
+            self.wide = torch.zeros(self.mats.shape, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            nat.check(self.ctx._h, nat.lib().vs_counts_fold(self.ctx._h, C.c_void_p(self.mats.data_ptr()),
+                                                            C.c_void_p(self.wide.data_ptr()), self.mats.numel()))
+        self.pairs_in_buffer = 0
 
     def add(self, reads: ReadBlock):
         torch = self.torch
-        self.pairs_seen += reads.info["ends"] // 2
-        if self.pairs_seen >= 2 ** 31:
-            raise OverflowError("uint32 PE counters hold < 2^31 pairs per buffer; all-reduce and fold earlier")
+        n_pairs = reads.info["ends"] // 2
+        if 2 * (self.pairs_in_buffer + n_pairs) >= U32_LIMIT:
+            self.fold()
+        if 2 * n_pairs >= U32_LIMIT:
+            raise OverflowError("one read block of %d pairs can overflow a uint32 cell; use blocks of < 2^31 pairs" % n_pairs)
+        self.pairs_in_buffer += n_pairs
+        self.pairs_seen += n_pairs
         with torch.cuda.device(self.device):
             self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
             self.ctx.pe_count(reads, self.mats[0].data_ptr(), self.mats[1].data_ptr(), self.stats.data_ptr())
 
     def all_reduce(self):
-        from .dist import all_reduce_counts
+        """Sum over the ranks of the process group, in place.  The ranks first agree (one small
+        all-reduce) on whether the uint32 buffers can hold the sum; if not, or if some rank already
+        holds int64 totals, every rank folds and the int64 totals are summed instead."""
+        from .dist import all_reduce_counts, group_size
 
-        all_reduce_counts(self.mats, self.stats)
+        if group_size() <= 1:
+            return
+        torch = self.torch
+        flags = torch.tensor([self.pairs_in_buffer, 1 if self.wide is not None else 0], dtype=torch.int64, device=self.device)
+        all_reduce_counts(None, flags)
+        total_in_buffers, any_wide = int(flags[0].item()), int(flags[1].item())
+        if any_wide or 2 * total_in_buffers >= U32_LIMIT:
+            self.fold()
+            all_reduce_counts(self.wide, self.stats)
+        else:
+            all_reduce_counts(self.mats, self.stats)
+            self.pairs_in_buffer = total_in_buffers
 
     def all_reduce_async(self):
-        from .dist import all_reduce_counts_async
+        """Overlapped form for fixed-size steps (bench.py): the caller keeps counting into a second
+        buffer meanwhile.  No agreement round, so the bound is checked statically."""
+        from .dist import all_reduce_counts_async, group_size
 
-        return all_reduce_counts_async(self.mats, self.stats)
+        world = max(group_size(), 1)
+        if self.wide is not None or 2 * self.pairs_in_buffer * world >= U32_LIMIT:
+            raise OverflowError("all_reduce_async sums uint32 buffers: 2 * %d pairs * %d ranks does not fit; use all_reduce()"
+                                % (self.pairs_in_buffer, world))
+        work = all_reduce_counts_async(self.mats, self.stats)
+        self.pairs_in_buffer *= world
+        return work
 
     def result(self):
         """-> (node_mat int64 [N,N], short_mat int64 [N,N], (n_reads, short_reads, used_reads))"""
-        m = self.mats.cpu().numpy().astype(np.int64)
+        m = self.mats.cpu().numpy().view(np.uint32).astype(np.int64)
+        if self.wide is not None:
+            m += self.wide.cpu().numpy()
         s = self.stats.cpu().numpy()
         n = self.n
         return m[0, :n, :n], m[1, :n, :n], (int(s[0]), int(s[1]), int(s[2]))

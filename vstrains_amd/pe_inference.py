@@ -70,15 +70,21 @@ def run(gfa: str, out_dir: str, fwd: str, rve: str, kmer_size: int, device: int 
     # PE_Inference.py:93-96: the output directory is wiped and recreated
     if out_dir[-1] == "/":
         out_dir = out_dir[:-1]
-    shutil.rmtree(out_dir, ignore_errors=True)
-    os.makedirs(out_dir, exist_ok=True)
+    rank, world = _rank_world()
+    if rank == 0:  # under torchrun only the writer touches the directory
+        shutil.rmtree(out_dir, ignore_errors=True)
+        os.makedirs(out_dir, exist_ok=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()  # nobody counts (or could fail half-way) before the directory is in its final state
 
     glb_start = time.time()
     if ctx is None:
         ctx = host.Context(device)
     ids, counter = count_links(ctx, gfa, fwd, rve, kmer_size)
     run.last = (ids, counter)
-    if _rank_world()[0] != 0:
+    if rank != 0:
         return None  # every rank holds the summed counters; rank 0 writes the files
     out_file, stats = write_info_files(out_dir, ids, counter)
     glb_elapsed = time.time() - glb_start
@@ -108,6 +114,9 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         args.device = local
+        # every rank indexes both FASTQ files on the host: share the cores between the local ranks
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        os.environ.setdefault("VS_HOST_THREADS", str(max(1, (os.cpu_count() or 1) // max(local_world, 1))))
     run(args.gfa, args.dir, args.fwd, args.rve, args.kmer_size, args.device)
     if world > 1:
         import torch.distributed as dist
