@@ -45,6 +45,7 @@
 #define TILES_WAVES 5        // k_pe_tiles is compiled for 5 waves per SIMD (<= 96 VGPRs); its LDS tile fits 5 times too
 #endif
 #define CHUNK (TPB * PPT)
+#define MCHUNK TPB           // straight-line kernels: postings looked at per round of stage M (one per thread)
 
 struct PeParams {
     VsIndexDev idx;
@@ -73,31 +74,28 @@ struct Mem {  // one credited maximal exact match
     uint32_t cnt, minp, minj;
 };
 
-// Straight-line form of vs_extend for the common block shape (no masked read bytes anywhere in
-// the block, probe stride <= 32, reads <= 191 bases with w = 31): one left window, five right
+// Straight-line agreement of a read with node text on either side of a seed, for the common block
+// shape (probe stride <= 32, reads <= 191 bases with w = 31): one left window, four / five right
 // windows, everything loaded up front, the answer out of selects -- no data-dependent branch.
-// The host picks the kernel instantiation (k_pe_tiles<true, *>) when the whole block qualifies.
+//   left : bases over which the read (going down from j) equals the text going down from tl, at
+//          most cl (<= 32)
+//   ext  : bases over which the read (going up from j + w) equals the text going up from tr, at most rem
+// tl / tr are base indices into the one array of node texts (forward, and rc_delta words on the
+// reverse complements); they may belong to different nodes (the reference postings of a seed's two
+// sides, see VsPosting) or to one.
 struct __attribute__((packed, aligned(4))) VsQuad { uint32_t x, y, z, w; };  // 16-byte load at dword alignment
 
-template <bool W4, typename RB>  // W4: four right windows are enough (reads <= 159 bases with w = 31)
-__device__ __forceinline__ bool vs_extend_fast(const uint32_t *rw, RB rbase, uint32_t rlen, const uint32_t *tw,
-                                               uint32_t tbase, uint32_t tlen, uint32_t j, uint32_t q, uint32_t w,
-                                               uint32_t s, uint32_t K, uint32_t *a_out, uint32_t *qa_out,
-                                               uint32_t *len_out) {
-    uint32_t c = s < j ? s : j;
-    c = c < q ? c : q;
-    const uint32_t n0 = c;  // s <= 32
-    const uint32_t rj = j + w, rq = q + w;
-    uint32_t rem = rlen - rj;
-    {
-        const uint32_t rem2 = tlen - rq;
-        rem = rem < rem2 ? rem : rem2;
-    }
+template <bool W4>  // W4: four right windows are enough (reads <= 159 bases with w = 31)
+__device__ __forceinline__ void vs_agree_fast(const uint32_t *rw, uint32_t rbase, const uint32_t *tw, uint32_t tl, uint32_t cl,
+                                              uint32_t tr, uint32_t rem, uint32_t j, uint32_t w, uint32_t *left_out,
+                                              uint32_t *ext_out) {
+    const uint32_t n0 = cl;
+    const uint32_t rj = j + w;
     // Node text to the right of the seed: eleven words cover the five windows; they come as 16-byte
     // loads, and the second / third only when the match can reach that far (rem) -- on a graph of
     // short nodes one load settles most postings.  Words not loaded read as zero: whatever they make
     // of the comparison lies beyond `rem` and is clipped.
-    const uint32_t tr = tbase + rq, ti = tr >> 4, sh = (tr & 15u) * 2u;
+    const uint32_t ti = tr >> 4, sh = (tr & 15u) * 2u;
     const VsQuad q0 = *(const VsQuad *)(tw + ti);
     VsQuad q1 = {0u, 0u, 0u, 0u}, q2 = {0u, 0u, 0u, 0u};
     if (rem > 48u) q1 = *(const VsQuad *)(tw + ti + 4u);
@@ -107,20 +105,20 @@ __device__ __forceinline__ bool vs_extend_fast(const uint32_t *rw, RB rbase, uin
         return (uint64_t)__builtin_amdgcn_alignbit(w1, w0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, sh) << 32);
     };
     // the read's side of the same five windows: eleven consecutive LDS words, one shift
-    const uint32_t rr = (uint32_t)(rbase + rj), rsh = (rr & 15u) * 2u;
+    const uint32_t rr = rbase + rj, rsh = (rr & 15u) * 2u;
     const uint32_t *rp = rw + (rr >> 4);
     const uint32_t r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4], r5 = rp[5], r6 = rp[6], r7 = rp[7],
                    r8 = rp[8], r9 = W4 ? 0u : rp[9], r10 = W4 ? 0u : rp[10];
     auto rw64 = [&](uint32_t w0, uint32_t w1, uint32_t w2) {
         return (uint64_t)__builtin_amdgcn_alignbit(w1, w0, rsh) | ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, rsh) << 32);
     };
-    const uint64_t xl = (vs_win(rw, rbase + j - n0) ^ vs_win(tw, tbase + q - n0)) & vs_lowmask(2u * n0);
+    const uint64_t xl = (vs_win(rw, rbase + j - n0) ^ vs_win(tw, tl - n0)) & vs_lowmask(2u * n0);
     const uint64_t x0 = rw64(r0, r1, r2) ^ tw64(q0.x, q0.y, q0.z);
     const uint64_t x1 = rw64(r2, r3, r4) ^ tw64(q0.z, q0.w, q1.x);
     const uint64_t x2 = rw64(r4, r5, r6) ^ tw64(q1.x, q1.y, q1.z);
     const uint64_t x3 = rw64(r6, r7, r8) ^ tw64(q1.z, q1.w, q2.x);
     const uint64_t x4 = W4 ? 0ull : rw64(r8, r9, r10) ^ tw64(q2.x, q2.y, q2.z);
-    const uint32_t left = xl ? n0 - 1u - (uint32_t)((63 - __clzll((long long)xl)) >> 1) : n0;
+    *left_out = xl ? n0 - 1u - (uint32_t)((63 - __clzll((long long)xl)) >> 1) : n0;
     // first window that differs (selects), then one find-first-set
     uint64_t xs = x4;  // (W4: zero -- no difference found inside 128 bases means ext = 160, clipped by rem <= 128)
     uint32_t xb = 128u;
@@ -128,13 +126,29 @@ __device__ __forceinline__ bool vs_extend_fast(const uint32_t *rw, RB rbase, uin
     if (x2) { xs = x2; xb = 64u; }
     if (x1) { xs = x1; xb = 32u; }
     if (x0) { xs = x0; xb = 0u; }
-    uint32_t ext = xs ? xb + ((uint32_t)(__ffsll((long long)xs) - 1) >> 1) : 160u;
-    ext = ext < rem ? ext : rem;
-    const uint32_t len = left + w + ext;
-    *a_out = j - left;
-    *qa_out = q - left;
-    *len_out = len;
-    return left < s && len >= K;
+    const uint32_t ext = xs ? xb + ((uint32_t)(__ffsll((long long)xs) - 1) >> 1) : 160u;
+    *ext_out = ext < rem ? ext : rem;
+}
+
+// Bytes outside ACGT cut a read into segments no match can cross (a dict lookup of a window over
+// such a byte misses, PE_Inference.py:25-26).  `inv4` lists up to four such positions of an end
+// (one byte each, 0xFF = none; ends with more go to the overflow path): is the seed at j clean, and
+// which stretch [lo, hi) of the read around it is.
+__device__ __forceinline__ bool vs_seed_limits(uint32_t inv4, uint32_t j, uint32_t w, uint32_t rlen, uint32_t *lo, uint32_t *hi) {
+    uint32_t l = 0u, h = rlen;
+    bool ok = true;
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; i++) {
+        const uint32_t p = (inv4 >> (8u * i)) & 0xFFu;
+        if (p != 0xFFu) {
+            if (p < j) l = l > p + 1u ? l : p + 1u;
+            else if (p >= j + w) h = h < p ? h : p;
+            else ok = false;
+        }
+    }
+    *lo = l;
+    *hi = h;
+    return ok;
 }
 
 // Extension of a seed hit.  rw/rbase: packed read (LDS or global) and its first base; tw/tbase:
@@ -263,10 +277,10 @@ __device__ __forceinline__ uint32_t vs_probe(const VsIndexDev &idx, uint64_t f, 
         uint64_t k = (uint64_t)raw.x | ((uint64_t)raw.y << 32);
         if (k == VS_EMPTY_KEY) return 0u;
         if ((k & ~VS_MULTI_BIT) == key) {
-            if (k & VS_MULTI_BIT) {
+            if (k & VS_MULTI_BIT) {  // *pb: count | VS_GROUP_SAME_REF | read strand << 31
                 *pa = raw.z;
                 *pb = raw.w | (sr << 31);
-                return raw.w;
+                return raw.w & VS_GROUP_COUNT_MASK;
             }
             *pa = raw.z;
             *pb = raw.w ^ (sr << 31);
@@ -280,7 +294,7 @@ extern __shared__ __attribute__((aligned(16))) uint32_t vs_lds[];
 
 // LDS carve shared by the kernel and the host-side size computation
 struct TileLayout {
-    uint32_t woff, gend, meta, words, pcnt, pa, pb, hkey, hcnt, hminp, hminj, ns, state, list, owner, misc, total;
+    uint32_t woff, gend, meta, inv, words, pcnt, pa, pb, hkey, hcnt, hminp, hminj, ns, state, list, owner, misc, total;
 };
 __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, uint32_t words_cap, uint32_t pool) {
     TileLayout t;
@@ -290,6 +304,7 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
     t.woff = o;  o += 2u * ((ept + 2u) & ~1u);  // global word offset of every end of the tile
     t.gend = o;  o += 2u * ept;                 // global end index
     t.meta = o;  o += 2u * ept;
+    t.inv = o;   o += 2u * ept;                 // positions of bytes outside ACGT (straight-line kernels)
     t.words = o; o += 2u * (words_cap + 8u);
     t.pcnt = o;  o += NI + 1u;  // [0] stays zero: the scan is read as s_pcnt[it - 1] .. s_pcnt[it] without a test for it == 0
     t.pa = o;    o += NI;
@@ -300,9 +315,10 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
     t.hminj = o; o += pool;
     t.ns = o;    o += ept;
     t.state = o; o += ept;
-    // the posting owners of P3 and the accepted lists of P4/P5 are never live together
+    // the posting owners (+ the worklist of the straight-line kernels: MCHUNK owners, 2 * MCHUNK
+    // entries) of P3 and the accepted lists of P4/P5 are never live together
     t.list = o;
-    t.owner = o; o += (ept * LC > CHUNK ? ept * LC : CHUNK);
+    t.owner = o; o += (ept * LC > 3u * MCHUNK ? ept * LC : 3u * MCHUNK);
     t.misc = o;  o += 16u;
     t.total = o;
     return t;
@@ -336,10 +352,11 @@ k_pe_tiles(PeParams P) {
     const uint32_t pool = STD ? (1u << STD_POOL_BITS) : P.pool, pool_shift = 32u - (STD ? STD_POOL_BITS : P.pool_bits);
     const uint32_t words_cap = STD ? STD_EPT * STD_WPE : P.words_cap;
     const TileLayout T = tile_layout(ept, pmax, words_cap, pool);
-    // (these four point at the current tile's copy; see the top of the tile loop)
+    // (these five point at the current tile's copy; see the top of the tile loop)
     uint32_t *s_gwoff = vs_lds + T.woff;   // global word offsets (mask reads, slow path)
     uint32_t *s_gend = vs_lds + T.gend;
     uint32_t *s_meta = vs_lds + T.meta;
+    uint32_t *s_inv = vs_lds + T.inv;      // up to four positions of bytes outside ACGT per end (vs_seed_limits)
     uint32_t *s_words = vs_lds + T.words;  // end e occupies words [e*wpe, (e+1)*wpe)
     const uint32_t hw = (ept + 2u) & ~1u, wcap = words_cap + 8u;
     uint32_t *s_pcnt = vs_lds + T.pcnt + 1u;  // posting counts per probe, then their inclusive scan; s_pcnt[-1] == 0
@@ -354,8 +371,10 @@ k_pe_tiles(PeParams P) {
     uint32_t *s_list = vs_lds + T.list;    // accepted node ids, LC per end
     uint32_t *s_misc = vs_lds + T.misc;
     uint32_t *s_owner = vs_lds + T.owner;
+    uint32_t *s_wl = vs_lds + T.owner + MCHUNK;  // FAST: postings that need a comparison of their own (probe << 20 | offset in its group)
     const uint32_t wpe = STD ? STD_WPE : P.wpe;
     const uint32_t ppt = ept / 2u;
+    const bool has_inv = FAST && P.rd.inv4 != nullptr;  // (the generic kernel reads the mask instead)
 
     if (tid < 3) s_misc[8 + tid] = 0;  // workgroup-local stats
     if (tid == 3) vs_lds[T.pcnt] = 0;
@@ -371,7 +390,7 @@ k_pe_tiles(PeParams P) {
     // global loads; they run ahead in registers, one link per tile (pair order two tiles ahead, word
     // offset and length one tile ahead; one end per thread, ept <= TPB), so that neither waits for
     // the other and both are covered by the previous tiles' work.
-    uint32_t pf_gend = 0, pf_gwoff = 0, pf_meta = 0, pf_pair = 0xFFFFFFFFu;
+    uint32_t pf_gend = 0, pf_gwoff = 0, pf_meta = 0, pf_inv = 0xFFFFFFFFu, pf_pair = 0xFFFFFFFFu;
     auto prefetch_pair = [&](uint64_t t) {  // pair (in input order) of this thread's end in tile t
         pf_pair = 0xFFFFFFFFu;
         if (t < tile_hi && tid < ept) {
@@ -384,7 +403,28 @@ k_pe_tiles(PeParams P) {
             pf_gend = 2u * pf_pair + (tid & 1u);
             pf_gwoff = P.rd.woff[pf_gend];
             pf_meta = P.rd.meta[pf_gend];
+            if (has_inv) pf_inv = P.rd.inv4[pf_gend];
         }
+    };
+    // One credited maximal exact match into the tile's (end, node) table.
+    auto credit = [&](uint32_t e, uint32_t node, uint32_t nlen, uint32_t add, uint32_t minp, uint32_t a) {
+        const uint32_t key = (e << 25) | node;
+        uint32_t at = (key * 0x9E3779B1u) >> pool_shift;
+        bool placed = false;
+        for (uint32_t pr = 0; pr < 64u; pr++) {
+            const uint32_t old = atomicCAS(&s_hkey[at], EMPTY_NODE, key);
+            if (old == EMPTY_NODE || old == key) {
+                atomicAdd(&s_hcnt[at], add);
+                atomicMin(&s_hminp[at], minp);
+                // (straight-line instantiations: reads <= 191 bases, so the node length rides in the
+                // upper 24 bits -- equal for every update of the slot -- and P4 needs no header)
+                atomicMin(&s_hminj[at], FAST ? (nlen << 8) | a : a);
+                placed = true;
+                break;
+            }
+            at = (at + 1u) & (pool - 1u);
+        }
+        if (!placed) atomicOr(&s_state[e], 2u);
     };
     // The first tile's headers and words are fetched the plain way; from then on the headers of tile
     // t+1 sit in registers during tile t, are put into the other LDS copy at its start, and the words
@@ -400,6 +440,7 @@ k_pe_tiles(PeParams P) {
             s_gend[tid] = pf_gend;
             s_gwoff[tid] = pf_gwoff;
             s_meta[tid] = pf_meta;
+            s_inv[tid] = pf_inv;
         }
         if (tid < 8u) { s_words[words_cap + tid] = 0u; s_words[wcap + words_cap + tid] = 0u; }  // pads of both copies
         __syncthreads();
@@ -420,9 +461,11 @@ k_pe_tiles(PeParams P) {
         s_gwoff = vs_lds + T.woff + cur * hw;
         s_gend = vs_lds + T.gend + cur * ept;
         s_meta = vs_lds + T.meta + cur * ept;
+        s_inv = vs_lds + T.inv + cur * ept;
         s_words = vs_lds + T.words + cur * wcap;
         uint32_t *n_gwoff = vs_lds + T.woff + nxt * hw, *n_gend = vs_lds + T.gend + nxt * ept;
         uint32_t *n_meta = vs_lds + T.meta + nxt * ept, *n_words = vs_lds + T.words + nxt * wcap;
+        uint32_t *n_inv = vs_lds + T.inv + nxt * ept;
         uint32_t ne1 = 0;  // ends of the next tile of this run
         if (tile + 1u < tile_hi) {
             const uint64_t np1 = P.n_pairs - (tile + 1u) * ppt;
@@ -434,6 +477,7 @@ k_pe_tiles(PeParams P) {
             n_gend[tid] = pf_gend;
             n_gwoff[tid] = pf_gwoff;
             n_meta[tid] = pf_meta;
+            n_inv[tid] = pf_inv;
         }
         for (uint32_t i = tid; i < pool; i += TPB) {
             s_hkey[i] = EMPTY_NODE;
@@ -441,6 +485,7 @@ k_pe_tiles(PeParams P) {
             s_hminp[i] = 0xFFFFFFFFu;
             s_hminj[i] = 0xFFFFFFFFu;
         }
+        if (tid == 0) { s_misc[12] = 0; s_misc[13] = 0; }  // worklist length, diagnostics
         __syncthreads();
         prefetch_headers();            // tile + 2 (its pair order arrived during the previous tile)
         prefetch_pair(tile + 3u);
@@ -463,7 +508,10 @@ k_pe_tiles(PeParams P) {
             else if ((mf & VS_LEN_MASK) < K || (mr & VS_LEN_MASK) < K) cls = 1;
             else cls = 2;
             atomicAdd(&s_misc[8 + cls], 1u);
-            s_state[2 * tid] = s_state[2 * tid + 1] = (cls == 2) ? 1u : 0u;
+            uint32_t st = (cls == 2) ? 1u : 0u;
+            // (an end with more bytes outside ACGT than vs_seed_limits can hold: the pair takes the overflow path)
+            if (FAST && st && (((mf | mr) >> 24) & VS_FLAG_MANY)) st = 3u;
+            s_state[2 * tid] = s_state[2 * tid + 1] = st;
             s_ns[2 * tid] = s_ns[2 * tid + 1] = 0;
         }
         __syncthreads();
@@ -472,16 +520,24 @@ k_pe_tiles(PeParams P) {
         for (uint32_t it = tid; it < NI; it += TPB) {
             uint32_t e = STD ? it / STD_PMAX : vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
             uint32_t cnt = 0, pa = 0, pb = 0;
-            if (e < ne && (s_state[e] & 1u)) {
+            if (e < ne && (s_state[e] & 3u) == 1u) {
                 uint32_t meta = s_meta[e];
                 uint32_t rlen = meta & VS_LEN_MASK;
                 uint32_t j = pi * s;
                 if (j + w <= rlen) {
                     uint64_t f = vs_win64_u32(s_words, e * wpe * 16u + j) & vs_lowmask(2u * w);
                     bool ok = true;
-                    if ((meta >> 24) & VS_FLAG_INVALID)
-                        ok = (vs_win64(P.rd.mask, (uint64_t)s_gwoff[e] * 16u + j) & vs_lowmask(2u * w)) == 0ull;
+                    if ((meta >> 24) & VS_FLAG_INVALID) {
+                        if (FAST) {
+                            uint32_t lo, hi;
+                            ok = vs_seed_limits(s_inv[e], j, w, rlen, &lo, &hi);
+                        } else {
+                            ok = (vs_win64(P.rd.mask, (uint64_t)s_gwoff[e] * 16u + j) & vs_lowmask(2u * w)) == 0ull;
+                        }
+                    }
                     if (ok) cnt = vs_probe(P.idx, f, &pa, &pb);
+                    // (a seed with more postings than the worklist can address: the overflow path takes the pair)
+                    if (FAST && cnt >= (1u << 20)) { atomicOr(&s_state[e], 2u); cnt = 0; }  // (cnt: flag bits already off)
                 }
             }
             s_pcnt[it] = cnt;
@@ -490,13 +546,87 @@ k_pe_tiles(PeParams P) {
         }
         __syncthreads();
         if (debug_stop == 2u) continue;
-        // ---- P2: inclusive scan of s_pcnt[0..NI)
+        if (FAST) {
+            // ---- R: one thread per probe.  A seed with one posting is settled here (agreement with
+            // its node, credit).  For a seed with several, the read is compared with the group's two
+            // reference postings -- the left side with the one that has the most text there, the right
+            // side likewise -- and the two agreement lengths are left in s_pb for stage M.
+            for (uint32_t it = tid; it < NI; it += TPB) {
+                const uint32_t cnt = s_pcnt[it];
+                if (cnt == 0u) continue;
+                const uint32_t e = STD ? it / STD_PMAX : vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
+                const uint32_t j = pi * s, pa = s_pa[it], pb = s_pb[it];
+                const uint32_t meta = s_meta[e], rlen = meta & VS_LEN_MASK;
+                uint32_t lo = 0u, hi = rlen;
+                if ((meta >> 24) & VS_FLAG_INVALID) vs_seed_limits(s_inv[e], j, w, rlen, &lo, &hi);
+                const uint32_t sr = pb >> 31;
+                uint32_t tl, tr, dl, dr;  // text positions of the seed start (left text) / seed end (right text), room on either side
+                uint32_t node = pa, nlen = 0, q = 0, opp = 0;
+                bool live = true;
+                if (cnt == 1u) {
+                    const uint32_t pos = pb & 0x7FFFFFFFu;
+                    opp = sr;  // (vs_probe folded the node strand into bit 31)
+                    if (P.shortcut && s <= w && pi) {
+                        // Overlapping seeds (s <= w): if the previous probe of this end holds the single
+                        // posting one stride back on the same diagonal, the bases in between match too,
+                        // so that probe (or an earlier one) owns this match -- no memory traffic needed.
+                        if (s_pcnt[it - 1u] == 1u && s_pa[it - 1u] == node) {
+                            const uint32_t pbp = s_pb[it - 1u];
+                            const uint32_t want = opp ? pos + s : pos - s;
+                            if ((pbp >> 31) == opp && (pbp & 0x7FFFFFFFu) == want && (opp || pos >= s) && j - s >= lo) live = false;
+                        }
+                    }
+                    if (live) {
+                        const VsNodeMeta nm = P.idx.meta[node];
+                        nlen = nm.len;
+                        q = opp ? nm.len - pos - w : pos;
+                        tl = (nm.woff + (opp ? P.idx.rc_delta : 0u)) * 16u + q;
+                        tr = tl + w;
+                        dl = q;
+                        dr = nm.len - q - w;
+                    }
+                } else {
+                    const VsPosting ra = vs_posting_unpack(P.idx.postings[pa]);
+                    const VsPosting rb = (pb & VS_GROUP_SAME_REF) ? ra : vs_posting_unpack(P.idx.postings[pa + 1u]);
+                    const VsPosting &pl = sr ? rb : ra, &pr = sr ? ra : rb;
+                    const uint32_t ol = pl.strand ^ sr, orr = pr.strand ^ sr;
+                    const uint32_t ql = ol ? pl.len - pl.pos - w : pl.pos, qr = orr ? pr.len - pr.pos - w : pr.pos;
+                    tl = (pl.woff + (ol ? P.idx.rc_delta : 0u)) * 16u + ql;
+                    tr = (pr.woff + (orr ? P.idx.rc_delta : 0u)) * 16u + qr + w;
+                    dl = ql;
+                    dr = pr.len - qr - w;
+                }
+                if (!live) continue;
+                uint32_t cl = s < j - lo ? s : j - lo;
+                cl = cl < dl ? cl : dl;
+                uint32_t rem = hi - j - w;
+                rem = rem < dr ? rem : dr;
+                uint32_t left, ext;
+                vs_agree_fast<STD>(s_words, e * wpe * 16u, P.idx.fwd_words, tl, cl, tr, rem, j, w, &left, &ext);
+                if (cnt == 1u) {
+                    const uint32_t len = left + w + ext;
+                    if (left < s && len >= K) {
+                        const uint32_t qa = q - left;
+                        credit(e, node, nlen, len - K + 1u, opp ? nlen - qa - len : qa, j - left);
+                    }
+                } else {
+                    s_pb[it] = (sr << 31) | (ext << 8) | left;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- P2: inclusive scan of the postings to expand per probe, s_pcnt[0..NI) (FAST: the members
+        // of seeds with several postings; seeds with one are done)
         {
             const uint32_t chunk = (NI + TPB - 1u) / TPB;
             const uint32_t b = tid * chunk;
             uint32_t local = 0;
             for (uint32_t i = 0; i < chunk; i++)
-                if (b + i < NI) local += s_pcnt[b + i];
+                if (b + i < NI) {
+                    uint32_t c = s_pcnt[b + i];
+                    if (FAST) c = c == 1u ? 0u : c;
+                    local += c;
+                }
             uint32_t incl = local;
             const uint32_t lane = tid & 63u;
 #pragma unroll
@@ -510,7 +640,9 @@ k_pe_tiles(PeParams P) {
             for (uint32_t wv = 0; wv < (tid >> 6); wv++) off += s_misc[wv];
             for (uint32_t i = 0; i < chunk; i++)
                 if (b + i < NI) {
-                    off += s_pcnt[b + i];
+                    uint32_t c = s_pcnt[b + i];
+                    if (FAST) c = c == 1u ? 0u : c;
+                    off += c;
                     s_pcnt[b + i] = off;
                 }
         }
@@ -519,9 +651,132 @@ k_pe_tiles(PeParams P) {
         const uint32_t total = s_pcnt[NI - 1u];
         if (count_postings && tid == 0) atomicAdd((unsigned long long *)(P.slow_count + 2), (unsigned long long)total);
         // ---- P3: one thread per posting.  Expansion of the per-probe posting counts (CSR-style
-        // frontier expansion) in chunks of CHUNK postings: every probe marks the first position it
-        // owns in the chunk, a workgroup-wide running maximum fills the gaps, and each thread ends
-        // up with the owners of its PPT consecutive postings in registers.
+        // frontier expansion) in chunks: every probe marks the first position it owns in the chunk, a
+        // workgroup-wide running maximum fills the gaps, and each thread ends up with the owners of
+        // its consecutive postings in registers.
+        if (FAST) {
+            // X: the agreement of a posting's own node text with the read (what every posting got
+            // before the groups had references), for the entries of the worklist
+            auto own_compare = [&](uint32_t entry) {
+                const uint32_t it = entry >> 20, off = entry & 0xFFFFFu;
+                const uint32_t e = STD ? it / STD_PMAX : vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
+                const uint32_t j = pi * s;
+                const VsPosting po = vs_posting_unpack(P.idx.postings[s_pa[it] + off]);
+                const uint32_t sr = s_pb[it] >> 31, opp = po.strand ^ sr;
+                const uint32_t meta = s_meta[e], rlen = meta & VS_LEN_MASK;
+                uint32_t lo = 0u, hi = rlen;
+                if ((meta >> 24) & VS_FLAG_INVALID) vs_seed_limits(s_inv[e], j, w, rlen, &lo, &hi);
+                const uint32_t q = opp ? po.len - po.pos - w : po.pos;
+                const uint32_t tl = (po.woff + (opp ? P.idx.rc_delta : 0u)) * 16u + q;
+                uint32_t cl = s < j - lo ? s : j - lo;
+                cl = cl < q ? cl : q;
+                uint32_t rem = hi - j - w;
+                const uint32_t dr = po.len - q - w;
+                rem = rem < dr ? rem : dr;
+                uint32_t left, ext;
+                vs_agree_fast<STD>(s_words, e * wpe * 16u, P.idx.fwd_words, tl, cl, tl + w, rem, j, w, &left, &ext);
+                const uint32_t len = left + w + ext;
+                if (left < s && len >= K) {
+                    const uint32_t qa = q - left;
+                    credit(e, po.node, po.len, len - K + 1u, opp ? po.len - qa - len : qa, j - left);
+                }
+            };
+            for (uint32_t c0 = 0; c0 < (debug_stop == 6u ? 0u : total); c0 += MCHUNK) {
+                s_owner[tid] = 0;
+                __syncthreads();
+                for (uint32_t it = tid; it < NI; it += TPB) {
+                    const uint32_t incl = s_pcnt[it], excl = s_pcnt[(int)it - 1];
+                    if (incl > excl) {
+                        const uint32_t lo = excl > c0 ? excl : c0;
+                        const uint32_t hi = incl < c0 + MCHUNK ? incl : c0 + MCHUNK;
+                        if (lo < hi) s_owner[lo - c0] = it + 1u;
+                    }
+                }
+                __syncthreads();
+                uint32_t own = s_owner[tid];
+                {
+                    const uint32_t lane = tid & 63u;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t t2 = __shfl_up(own, d, 64);
+                        if (lane >= (uint32_t)d && t2 > own) own = t2;
+                    }
+                    if (lane == 63u) s_misc[4u + (tid >> 6)] = own;
+                }
+                __syncthreads();
+                {   // the wavefronts before this one (TPB = 256: at most three)
+                    const uint32_t m0 = s_misc[4], m1 = s_misc[5], m2 = s_misc[6], wv = tid >> 6;
+                    if (wv > 0u) own = m0 > own ? m0 : own;
+                    if (wv > 1u) own = m1 > own ? m1 : own;
+                    if (wv > 2u) own = m2 > own ? m2 : own;
+                }
+                // ---- M: what the index knows about the posting (VsPosting: agreement with the group's
+                // reference of either side, next base) and the read's agreement with the references
+                // (stage R) settle most postings without touching their text.
+                const uint32_t t = c0 + tid;
+                if (t < total) {
+                    const uint32_t it = own - 1u;
+                    const uint32_t excl = s_pcnt[(int)it - 1];
+                    const uint32_t e = STD ? it / STD_PMAX : vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
+                    const uint32_t j = pi * s, pb = s_pb[it];
+                    const VsPosting po = vs_posting_unpack(P.idx.postings[s_pa[it] + (t - excl)]);
+                    const uint32_t sr = pb >> 31, r_l = pb & 0xFFu, r_r = (pb >> 8) & 0xFFu;
+                    const uint32_t opp = po.strand ^ sr;
+                    const uint32_t meta = s_meta[e], rlen = meta & VS_LEN_MASK;
+                    uint32_t lo = 0u, hi = rlen;
+                    if ((meta >> 24) & VS_FLAG_INVALID) vs_seed_limits(s_inv[e], j, w, rlen, &lo, &hi);
+                    const uint32_t q = opp ? po.len - po.pos - w : po.pos;
+                    const uint32_t dl = q, dr = po.len - q - w;
+                    const uint32_t l_l = sr ? po.lcp_b : po.lcp_a, l_r = sr ? po.lcp_a : po.lcp_b;
+                    const uint32_t nb_l = sr ? po.nb_b ^ 3u : po.nb_a, nb_r = sr ? po.nb_a ^ 3u : po.nb_b;
+                    uint32_t lim_l = s < j - lo ? s : j - lo;
+                    lim_l = lim_l < dl ? lim_l : dl;
+                    uint32_t lim_r = hi - j - w;
+                    lim_r = lim_r < dr ? lim_r : dr;
+                    const uint32_t rb0 = e * wpe * 16u;
+                    // left: r_l < l_l -> the read leaves the shared text first; r_l > l_l -> this posting
+                    // does; equal -> both leave it at the same base: the posting's next base decides
+                    uint32_t left = r_l < l_l ? r_l : l_l, ext = r_r < l_r ? r_r : l_r;
+                    bool lk = true, rk = true;
+                    if (r_l == l_l && l_l < lim_l) {
+                        const uint32_t bi = rb0 + j - 1u - l_l;
+                        lk = ((s_words[bi >> 4] >> ((bi & 15u) * 2u)) & 3u) != nb_l;
+                    }
+                    if (r_r == l_r && l_r < lim_r) {
+                        const uint32_t bi = rb0 + j + w + l_r;
+                        rk = ((s_words[bi >> 4] >> ((bi & 15u) * 2u)) & 3u) != nb_r;
+                    }
+                    if (l_l >= VS_LCP_CAP && r_l >= l_l) lk = false;  // (agreement longer than the field can say)
+                    if (l_r >= VS_LCP_CAP && r_r >= l_r) rk = false;
+                    if (!(lk && left >= s)) {
+                        if (lk && rk) {
+                            const uint32_t len = left + w + ext;
+                            if (len >= K) {
+                                const uint32_t qa = q - left;
+                                credit(e, po.node, po.len, len - K + 1u, opp ? po.len - qa - len : qa, j - left);
+                            }
+                        } else if ((lk ? left : lim_l) + w + (rk ? ext : lim_r) >= K) {
+                            s_wl[atomicAdd(&s_misc[12], 1u)] = (it << 20) | (t - excl);
+                            if (count_postings) atomicAdd(&s_misc[13], 1u);
+                        }
+                    }
+                }
+                __syncthreads();  // worklist complete for this chunk; the owner array is free again
+                const uint32_t n_wl = s_misc[12];
+                if (n_wl >= TPB && debug_stop == 7u) {  // (timing experiment: drop the entries)
+                    __syncthreads();
+                    if (tid == 0) s_misc[12] = n_wl - TPB;
+                } else if (n_wl >= TPB) {  // a full round of comparisons is waiting
+                    const uint32_t entry = s_wl[n_wl - TPB + tid];
+                    __syncthreads();
+                    if (tid == 0) s_misc[12] = n_wl - TPB;
+                    own_compare(entry);
+                }
+            }
+            __syncthreads();
+            if (debug_stop != 7u && tid < s_misc[12]) own_compare(s_wl[tid]);
+            if (count_postings && tid == 0) atomicAdd((unsigned long long *)(P.slow_count + 4), (unsigned long long)s_misc[13]);
+        } else {
         for (uint32_t c0 = 0; c0 < total; c0 += CHUNK) {
             for (uint32_t i = tid; i < CHUNK; i += TPB) s_owner[i] = 0;
             __syncthreads();
@@ -559,12 +814,12 @@ k_pe_tiles(PeParams P) {
                 if (wv > 1u) carry = m1 > carry ? m1 : carry;
                 if (wv > 2u) carry = m2 > carry ? m2 : carry;
             }
-            // The thread's PPT postings go through three stages with every stage done for all of
-            // them before the next one starts: A) which posting (LDS) and its node (one global load
-            // for multi-posting seeds), B) node header, C) text windows + decision.  Stages hold no
-            // early exits, so the loads of the PPT postings are in flight together.
+            // The thread's PPT postings go through stages with every stage done for all of them before
+            // the next one starts: A) which posting (LDS) and its record (one global load for
+            // multi-posting seeds; the node header for single ones), B) text windows + decision.
             bool live[PPT];
             uint32_t p_e[PPT], p_j[PPT], p_node[PPT], p_pos[PPT], p_opp[PPT];
+            VsNodeMeta p_nm[PPT];
 #pragma unroll
             for (uint32_t k2 = 0; k2 < PPT; k2++) {
                 const uint32_t t = c0 + tid * PPT + k2;
@@ -573,31 +828,19 @@ k_pe_tiles(PeParams P) {
                 const uint32_t excl = s_pcnt[(int)it - 1];
                 const uint32_t cnt = s_pcnt[it] - excl;
                 const uint32_t pa = s_pa[it], pb = s_pb[it];
-                const uint32_t e = STD ? it / STD_PMAX : vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
+                const uint32_t e = vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
                 p_e[k2] = e;
                 p_j[k2] = pi * s;
                 uint32_t node = pa, pos = pb & 0x7FFFFFFFu, opp = pb >> 31;
+                p_nm[k2].woff = 0; p_nm[k2].len = 0;
                 if (live[k2] && cnt != 1u) {
-                    const uint2 po = P.idx.postings[pa + (t - excl)];
-                    node = po.x; pos = po.y & 0x7FFFFFFFu; opp = (po.y >> 31) ^ (pb >> 31);
-                } else if (P.shortcut && live[k2] && s <= w && pi) {
-                    // Overlapping seeds (s <= w): if the previous probe of this end holds the single
-                    // posting one stride back on the same diagonal, the bases in between match too,
-                    // so that probe (or an earlier one) owns this match -- no memory traffic needed.
-                    const uint32_t excl2 = s_pcnt[(int)it - 2];  // (pi != 0, so it >= 1)
-                    if (excl - excl2 == 1u && s_pa[it - 1u] == node) {
-                        const uint32_t pbp = s_pb[it - 1u];
-                        const uint32_t want = opp ? pos + s : pos - s;
-                        if ((pbp >> 31) == opp && (pbp & 0x7FFFFFFFu) == want && (opp || pos >= s)) live[k2] = false;
-                    }
+                    const VsPosting po = vs_posting_unpack(P.idx.postings[pa + (t - excl)]);
+                    node = po.node; pos = po.pos; opp = po.strand ^ (pb >> 31);
+                    p_nm[k2].woff = po.woff; p_nm[k2].len = po.len;
+                } else if (live[k2]) {
+                    p_nm[k2] = P.idx.meta[node];
                 }
                 p_node[k2] = node; p_pos[k2] = pos; p_opp[k2] = opp;
-            }
-            VsNodeMeta p_nm[PPT];
-#pragma unroll
-            for (uint32_t k2 = 0; k2 < PPT; k2++) {
-                p_nm[k2].woff = 0; p_nm[k2].len = 0;
-                if (live[k2]) p_nm[k2] = P.idx.meta[p_node[k2]];
             }
 #pragma unroll
             for (uint32_t k2 = 0; k2 < PPT; k2++) {
@@ -612,34 +855,12 @@ k_pe_tiles(PeParams P) {
                 const uint32_t q = opp ? nm.len - p_pos[k2] - w : p_pos[k2];
                 const uint32_t *mk = ((meta >> 24) & VS_FLAG_INVALID) ? P.rd.mask : nullptr;
                 uint32_t a, qa, len;
-                bool credited;
-                if (FAST)
-                    credited = vs_extend_fast<STD>(s_words, e * wpe * 16u, rlen, tw, tb, nm.len, j, q, w, s, K, &a, &qa, &len);
-                else
-                    credited = vs_extend(s_words, e * wpe * 16u, rlen, tw, tb, nm.len, j, q, w, s, K,
-                                         mk, (uint64_t)s_gwoff[e] * 16u, &a, &qa, &len);
-                if (!credited) continue;
-                const uint32_t add = len - K + 1u;
-                const uint32_t minp = opp ? nm.len - qa - len : qa;
-                const uint32_t key = (e << 25) | node;
-                uint32_t at = (key * 0x9E3779B1u) >> pool_shift;
-                bool placed = false;
-                for (uint32_t pr = 0; pr < 64u; pr++) {
-                    uint32_t old = atomicCAS(&s_hkey[at], EMPTY_NODE, key);
-                    if (old == EMPTY_NODE || old == key) {
-                        atomicAdd(&s_hcnt[at], add);
-                        atomicMin(&s_hminp[at], minp);
-                        // (straight-line instantiation: reads <= 191 bases, so the node length rides in
-                        // the upper 24 bits -- equal for every update of the slot -- and P4 needs no header)
-                        atomicMin(&s_hminj[at], FAST ? (nm.len << 8) | a : a);
-                        placed = true;
-                        break;
-                    }
-                    at = (at + 1u) & (pool - 1u);
-                }
-                if (!placed) atomicOr(&s_state[e], 2u);
+                if (!vs_extend(s_words, e * wpe * 16u, rlen, tw, tb, nm.len, j, q, w, s, K, mk, (uint64_t)s_gwoff[e] * 16u, &a, &qa, &len))
+                    continue;
+                credit(e, node, nm.len, len - K + 1u, opp ? nm.len - qa - len : qa, a);
             }
             __syncthreads();  // the owner array is reused by the next chunk
+        }
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wavefront's LDS-direct loads of the next tile's words are in
         __syncthreads();
@@ -951,7 +1172,7 @@ __device__ __forceinline__ uint32_t vs_locus_key(const VsIndexDev &idx, const Vs
         if (inv && (vs_win64(rd.mask, base + j) & vs_lowmask(2u * w))) continue;
         uint32_t pa, pb;
         const uint32_t c = vs_probe(idx, vs_win64(rd.words, base + j) & vs_lowmask(2u * w), &pa, &pb);
-        if (c) return c == 1u ? pa : idx.postings[pa].x;
+        if (c) return c == 1u ? pa : (idx.postings[pa].x & 0x01FFFFFFu);
     }
     return N;
 }
@@ -1013,23 +1234,27 @@ k_pe_permute(uint64_t n_pairs, const uint32_t *__restrict__ keys, uint32_t *__re
     perm[atomicAdd(&cursor[keys[p]], 1u)] = (uint32_t)p;
 }
 
-// ---- slow path: any number of nodes per end ------------------------------------------------------
-// One workgroup per listed pair.  Node state is dense in HBM (three uint32 per node, the
-// reference's own layout, PE_Inference.py:19-21), updated with global atomics, swept and reset
-// after each end.  dense layout per workgroup: cnt[N] minp[N] minj[N] surv0[N] surv1[N].
+// ---- overflow path: any number of nodes per end, any read ------------------------------------------
+// One workgroup per listed pair (ends with more accepted nodes than an LDS row holds, ends with many
+// bytes outside ACGT, seeds with a huge posting list).  Node state is dense in HBM per workgroup --
+// the reference's own layout (PE_Inference.py:19-21) -- but only the nodes an end touches are ever
+// looked at: the first credit of a node appends it to a list, and the acceptance sweep walks that
+// list and restores the state.  Probes go through the workgroup 256 at a time; their postings are
+// spread over the threads (prefix sum of the counts in LDS, one posting per thread and round).
+// dense layout per workgroup: cnt[N] minp[N] minj[N] touched[N] surv0[N] surv1[N].
+#define SLOW_WORDS_PER_NODE 6u
 __global__ void __launch_bounds__(TPB)
 k_pe_slow(PeParams P, uint32_t *dense, uint32_t n_slow_cap) {
-    __shared__ uint32_t s_n[2];
+    __shared__ uint32_t s_n[2], s_nt, s_cnt[TPB + 1], s_pa[TPB], s_pb[TPB];
     const uint32_t tid = threadIdx.x;
     const uint32_t N = P.idx.n_nodes, w = P.idx.w, s = P.idx.s, K = P.idx.K;
     uint32_t n_slow = *P.slow_count;
     if (n_slow > n_slow_cap) n_slow = n_slow_cap;
-    uint32_t *cnt = dense + (uint64_t)blockIdx.x * 5u * N;
-    uint32_t *minp = cnt + N, *minj = minp + N, *surv0 = minj + N, *surv1 = surv0 + N;
+    uint32_t *cnt = dense + (uint64_t)blockIdx.x * SLOW_WORDS_PER_NODE * N;
+    uint32_t *minp = cnt + N, *minj = minp + N, *touched = minj + N, *surv0 = touched + N, *surv1 = surv0 + N;
     for (uint32_t li = blockIdx.x; li < n_slow; li += gridDim.x) {
         const uint32_t pair = P.slow_list[li];
         if (tid < 2) s_n[tid] = 0;
-        __syncthreads();
         for (uint32_t side = 0; side < 2; side++) {
             const uint64_t e = 2ull * pair + side;
             const uint32_t meta = P.rd.meta[e];
@@ -1038,44 +1263,76 @@ k_pe_slow(PeParams P, uint32_t *dense, uint32_t n_slow_cap) {
             const uint32_t *mk = ((meta >> 24) & VS_FLAG_INVALID) ? P.rd.mask : nullptr;
             uint32_t *surv = side ? surv1 : surv0;
             const uint32_t nprobe = rlen >= w ? (rlen - w) / s + 1u : 0u;
-            for (uint32_t pi = tid; pi < nprobe; pi += TPB) {
-                uint32_t j = pi * s;
-                uint64_t f = vs_win64(P.rd.words, rbase + j) & vs_lowmask(2u * w);
-                if (mk && (vs_win64(mk, rbase + j) & vs_lowmask(2u * w))) continue;
-                uint32_t pa, pb;
-                uint32_t c = vs_probe(P.idx, f, &pa, &pb);
-                for (uint32_t k2 = 0; k2 < c; k2++) {
+            if (tid == 0) s_nt = 0;
+            __syncthreads();
+            for (uint32_t p0 = 0; p0 < nprobe; p0 += TPB) {
+                // probes p0 .. p0 + 255: one per thread
+                uint32_t c = 0, pa = 0, pb = 0;
+                const uint32_t pi = p0 + tid;
+                if (pi < nprobe) {
+                    const uint32_t j = pi * s;
+                    if (!(mk && (vs_win64(mk, rbase + j) & vs_lowmask(2u * w))))
+                        c = vs_probe(P.idx, vs_win64(P.rd.words, rbase + j) & vs_lowmask(2u * w), &pa, &pb);
+                }
+                s_pa[tid] = pa;
+                s_pb[tid] = pb;
+                // inclusive scan of the posting counts over the workgroup -> s_cnt[1 .. 256], s_cnt[0] = 0
+                uint32_t incl = c;
+                const uint32_t lane = tid & 63u;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t t2 = __shfl_up(incl, d, 64);
+                    if (lane >= (uint32_t)d) incl += t2;
+                }
+                s_cnt[tid + 1u] = incl;
+                if (tid == 0) s_cnt[0] = 0;
+                __syncthreads();
+                uint32_t off = 0;
+                for (uint32_t wv = 0; wv < (tid >> 6); wv++) off += s_cnt[wv * 64u + 64u];
+                __syncthreads();
+                s_cnt[tid + 1u] = incl + off;
+                __syncthreads();
+                const uint32_t total = s_cnt[TPB];
+                for (uint32_t t = tid; t < total; t += TPB) {
+                    // the probe that owns posting t: last index with s_cnt[idx] <= t
+                    const uint32_t pr = vs_upper_idx(s_cnt, TPB + 1u, t);
+                    const uint32_t k2 = t - s_cnt[pr], j = (p0 + pr) * s;
+                    const uint32_t qa0 = s_pa[pr], qb0 = s_pb[pr];
                     uint32_t node, pos, opp;
-                    if (c == 1u) { node = pa; pos = pb & 0x7FFFFFFFu; opp = pb >> 31; }
-                    else {
-                        uint2 po = P.idx.postings[pa + k2];
-                        node = po.x; pos = po.y & 0x7FFFFFFFu; opp = (po.y >> 31) ^ (pb >> 31);
+                    VsNodeMeta nm;
+                    if (s_cnt[pr + 1u] - s_cnt[pr] == 1u) {
+                        node = qa0; pos = qb0 & 0x7FFFFFFFu; opp = qb0 >> 31;
+                        nm = P.idx.meta[node];
+                    } else {
+                        const VsPosting po = vs_posting_unpack(P.idx.postings[qa0 + k2]);
+                        node = po.node; pos = po.pos; opp = po.strand ^ (qb0 >> 31);
+                        nm.woff = po.woff; nm.len = po.len;
                     }
-                    const VsNodeMeta nm = P.idx.meta[node];
                     const uint32_t *tw = opp ? P.idx.rc_words : P.idx.fwd_words;
                     const uint32_t q = opp ? nm.len - pos - w : pos;
                     uint32_t a, qa, len;
                     if (!vs_extend(P.rd.words, rbase, rlen, tw, nm.woff * 16u, nm.len, j, q, w, s, K, mk, rbase, &a, &qa, &len))
                         continue;
-                    atomicAdd(&cnt[node], len - K + 1u);
+                    if (atomicAdd(&cnt[node], len - K + 1u) == 0u) touched[atomicAdd(&s_nt, 1u)] = node;
                     atomicMin(&minp[node], opp ? nm.len - qa - len : qa);
                     atomicMin(&minj[node], a);
                 }
+                __syncthreads();  // s_cnt / s_pa / s_pb are rewritten by the next batch of probes
             }
-            __threadfence();
+            // (all of it is this workgroup's own traffic, the loads below bypass L1: a workgroup barrier
+            // orders it; a device-wide fence would write back the whole L2 of the XCD each time)
             __syncthreads();
-            for (uint32_t nd = tid; nd < N; nd += TPB) {
-                uint32_t v = __hip_atomic_load(&cnt[nd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (v) {
-                    uint32_t c = __hip_atomic_load(&minp[nd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    uint32_t ki = __hip_atomic_load(&minj[nd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (vs_accept(v, c, ki, P.idx.meta[nd].len, rlen, K)) surv[atomicAdd(&s_n[side], 1u)] = nd;
-                    __hip_atomic_store(&cnt[nd], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&minp[nd], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&minj[nd], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+            const uint32_t nt = s_nt;
+            for (uint32_t i = tid; i < nt; i += TPB) {
+                const uint32_t nd = __hip_atomic_load(&touched[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t v = __hip_atomic_load(&cnt[nd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t c = __hip_atomic_load(&minp[nd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t ki = __hip_atomic_load(&minj[nd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (vs_accept(v, c, ki, P.idx.meta[nd].len, rlen, K)) surv[atomicAdd(&s_n[side], 1u)] = nd;
+                __hip_atomic_store(&cnt[nd], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&minp[nd], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&minj[nd], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            __threadfence();
             __syncthreads();
         }
         const uint32_t nl = s_n[0], nr = s_n[1];
@@ -1112,13 +1369,18 @@ k_pe_slow(PeParams P, uint32_t *dense, uint32_t n_slow_cap) {
 
 __global__ void __launch_bounds__(TPB) k_dense_zero_cnt(uint32_t *dense, uint64_t N, uint64_t groups) {
     uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
-    if (i < N * groups) dense[(i / N) * 5ull * N + (i % N)] = 0u;
+    if (i < N * groups) dense[(i / N) * (uint64_t)SLOW_WORDS_PER_NODE * N + (i % N)] = 0u;
 }
 
 // ---- host side ---------------------------------------------------------------------------------
 #define LDS_BUDGET_BYTES (64u * 1024u)
 #define NI_CAP 4096u
-#define SLOW_GRID 256u
+// workgroups of the overflow kernel: as many as 4 GB of dense per-workgroup node state allow, 64 .. 2048
+static uint32_t slow_grid_for(uint32_t n_nodes) {
+    const uint64_t per_wg = sizeof(uint32_t) * (uint64_t)SLOW_WORDS_PER_NODE * (n_nodes ? n_nodes : 1u);
+    uint64_t g = (4ull << 30) / per_wg;
+    return (uint32_t)(g < 64u ? 64u : g > 2048u ? 2048u : g);
+}
 
 static uint32_t pool_for(uint32_t ept, uint32_t *bits) {
     uint32_t b = 6;
@@ -1161,8 +1423,9 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         VS_HIP(ctx, hipMalloc(&ctx->d_slow_list, sizeof(uint32_t) * n_pairs));
         ctx->slow_cap = n_pairs;
     }
-    if (!ctx->d_slow_count) VS_HIP(ctx, hipMalloc(&ctx->d_slow_count, 16));
-    uint64_t need_dense = sizeof(uint32_t) * 5ull * (idx.n_nodes ? idx.n_nodes : 1) * SLOW_GRID;
+    if (!ctx->d_slow_count) VS_HIP(ctx, hipMalloc(&ctx->d_slow_count, 32));
+    const uint32_t SLOW_GRID = slow_grid_for(idx.n_nodes);
+    uint64_t need_dense = sizeof(uint32_t) * (uint64_t)SLOW_WORDS_PER_NODE * (idx.n_nodes ? idx.n_nodes : 1) * SLOW_GRID;
     if (ctx->dense_bytes < need_dense || ctx->dense_nodes != idx.n_nodes) {
         if (ctx->d_dense) VS_HIP(ctx, hipFree(ctx->d_dense));
         ctx->d_dense = nullptr;
@@ -1176,7 +1439,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         hipLaunchKernelGGL(k_dense_zero_cnt, dim3((unsigned)((N * SLOW_GRID + TPB - 1) / TPB)), dim3(TPB), 0, st,
                            (uint32_t *)ctx->d_dense, N, (uint64_t)SLOW_GRID);
     }
-    VS_HIP(ctx, hipMemsetAsync(ctx->d_slow_count, 0, 16, st));
+    VS_HIP(ctx, hipMemsetAsync(ctx->d_slow_count, 0, 32, st));
 
     // locus order of the pairs (see k_pe_locus); VS_NO_SORT=1 keeps the input order
     const bool use_sort = !(getenv("VS_NO_SORT") && atoi(getenv("VS_NO_SORT")) != 0) && n_pairs >= 4096 && n_pairs < 0xFFFFFFF0ull;
@@ -1255,7 +1518,8 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     if (const char *sv = getenv("VS_SHORTCUT")) P.shortcut = atoi(sv) != 0 ? 1u : 0u;
 
     // straight-line extension when the whole block qualifies (see vs_extend_fast)
-    const bool fast = !reads->d_mask && idx.s <= 32u && maxlen <= 128u + idx.w + 32u &&
+    // (reads with bytes outside ACGT qualify through their position lists, see k_inv4 / vs_seed_limits)
+    const bool fast = (!reads->d_mask || reads->d_inv4) && idx.s <= 32u && maxlen <= 128u + idx.w + 32u &&
                       !(getenv("VS_NO_FAST") && atoi(getenv("VS_NO_FAST")) != 0);
     // compile-time-shape instantiations (see k_pe_tiles): 1 = (10, 5), 2 = (8, 4), 3 = (7, 3)
     int std_shape = 0;
@@ -1405,9 +1669,9 @@ extern "C" int vs_pe_last_timing(vs_ctx *ctx, double ms[5]) {
     VS_HIP(ctx, hipMemcpy(&n_slow, ctx->d_slow_count, sizeof n_slow, hipMemcpyDeviceToHost));
     ms[0] = a; ms[1] = b; ms[2] = (double)n_slow; ms[3] = c; ms[4] = d;
     if (getenv("VS_DEBUG_POSTINGS")) {
-        unsigned long long np = 0;
-        VS_HIP(ctx, hipMemcpy(&np, (char *)ctx->d_slow_count + 8, sizeof np, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[vs] postings expanded by the last vs_pe_count: %llu\n", np);
+        unsigned long long np[2] = {0, 0};
+        VS_HIP(ctx, hipMemcpy(np, (char *)ctx->d_slow_count + 8, sizeof np, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[vs] postings expanded by the last vs_pe_count: %llu, compared with their own node text: %llu\n", np[0], np[1]);
     }
     ctx->last_ms[0] = a; ctx->last_ms[1] = b; ctx->last_ms[2] = n_slow;
     return VS_OK;

@@ -47,6 +47,38 @@ k_count_invalid(const uint32_t *__restrict__ meta, uint64_t n_ends, uint32_t *__
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, (uint32_t)__popcll(b));
 }
 
+// One thread per end: the positions of its bytes outside ACGT, read off the mask -- up to four of
+// them, one byte each (0xFF = none), for vs_seed_limits in the straight-line mapping kernels; an end
+// with more (or with one beyond position 254) is flagged VS_FLAG_MANY and takes the overflow path.
+__global__ void __launch_bounds__(TPB)
+k_inv4(const uint32_t *__restrict__ woff, const uint32_t *__restrict__ mask, uint64_t n_ends, uint32_t *__restrict__ meta,
+       uint32_t *__restrict__ inv4) {
+    const uint64_t e = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+    if (e >= n_ends) return;
+    const uint32_t m0 = meta[e];
+    uint32_t out = 0xFFFFFFFFu;
+    if ((m0 >> 24) & VS_FLAG_INVALID) {
+        const uint32_t len = m0 & VS_LEN_MASK, nw = (len + 15u) >> 4;
+        const uint32_t *mw = mask + woff[e];
+        uint32_t count = 0;
+        bool many = false;
+        for (uint32_t wi = 0; wi < nw && !many; wi++) {
+            uint32_t m = mw[wi];
+            while (m) {
+                const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;
+                const uint32_t pos = wi * 16u + (bit >> 1);
+                m &= ~(3u << (bit & ~1u));
+                if (pos >= len) continue;
+                if (count < 4u && pos < 255u) out = (out & ~(0xFFu << (8u * count))) | (pos << (8u * count));
+                else many = true;
+                count++;
+            }
+        }
+        if (many) meta[e] = m0 | (VS_FLAG_MANY << 24);
+    }
+    inv4[e] = out;
+}
+
 __global__ void __launch_bounds__(TPB)
 k_unpack_reads(VsReadsDev rd, const uint64_t *__restrict__ out_off, uint8_t *__restrict__ out) {
     uint64_t e = (uint64_t)blockIdx.x * TPB + threadIdx.x;
@@ -80,7 +112,7 @@ extern "C" void vs_reads_free(vs_ctx *ctx, vs_reads *r) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
-    void *ps[] = {r->d_woff, r->d_meta, r->d_words, r->d_mask};
+    void *ps[] = {r->d_woff, r->d_meta, r->d_words, r->d_mask, r->d_inv4};
     for (void *p : ps)
         if (p) (void)hipFree(p);
     delete r;
@@ -149,6 +181,10 @@ extern "C" int vs_reads_pack(vs_ctx *ctx, const uint8_t *ascii, const uint64_t *
                 r->bytes += b_words;
                 hipLaunchKernelGGL(k_pack_reads, dim3(nbw), dim3(TPB), 0, st, d_ascii, d_aoff, (const uint32_t *)r->d_woff, n_ends,
                                    (uint32_t)words, (uint32_t *)r->d_words, (uint32_t *)r->d_mask, (uint32_t *)r->d_meta);
+                if ((e1 = hipMalloc(&r->d_inv4, sizeof(uint32_t) * n_ends)) != hipSuccess) break;
+                r->bytes += sizeof(uint32_t) * n_ends;
+                hipLaunchKernelGGL(k_inv4, dim3((unsigned)((n_ends + TPB - 1) / TPB)), dim3(TPB), 0, st, (const uint32_t *)r->d_woff,
+                                   (const uint32_t *)r->d_mask, n_ends, (uint32_t *)r->d_meta, (uint32_t *)r->d_inv4);
             }
             if ((e1 = hipGetLastError()) != hipSuccess) break;
             e1 = hipStreamSynchronize(st);
