@@ -11,9 +11,7 @@
 // node text, which yields the whole run of K-windows on that diagonal at once (vs_pe.hip).
 // w odd => no seed equals its own reverse complement, so strand is always well defined.
 //
-// Build = pack_nodes -> seed_insert (atomicCAS claim + count) -> scan -> seed_fill -> group_refs
-//         (reference posting per seed and side) -> post_records (agreement of every posting with
-//         its group's references, see VsPosting) -> finalize.
+// Build = pack_nodes -> seed_insert (atomicCAS claim + count) -> scan -> seed_fill -> finalize.
 #include <vector>
 
 #include "vs_internal.h"
@@ -77,7 +75,7 @@ k_seed_insert(VsIndexDev idx, const uint64_t *__restrict__ seed_off, uint64_t n_
 __global__ void __launch_bounds__(TPB)
 k_seed_fill(VsIndexDev idx, const uint64_t *__restrict__ seed_off, uint64_t n_pos,
             const uint32_t *__restrict__ pos_slot, const uint32_t *__restrict__ offs,
-            uint32_t *__restrict__ cursor, uint2 *__restrict__ postings, uint32_t *__restrict__ post_slot) {
+            uint32_t *__restrict__ cursor, uint4 *__restrict__ postings) {
     uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
     if (g >= n_pos) return;
     uint32_t node = vs_upper_idx(seed_off, idx.n_nodes + 1, g);
@@ -88,131 +86,14 @@ k_seed_fill(VsIndexDev idx, const uint64_t *__restrict__ seed_off, uint64_t n_po
     uint32_t strand = r < f ? 1u : 0u;  // 1: the stored key is the reverse complement of the node text
     uint32_t sl = pos_slot[g];
     uint32_t at = offs[sl] + atomicAdd(&cursor[sl], 1u);
-    postings[at] = make_uint2(node, p | (strand << 31));
-    post_slot[at] = sl;
-}
-
-// ---- groups: the postings of one seed ------------------------------------------------------------
-// A posting in the orientation of the canonical seed: `b` = index (in bases, into the one array that
-// holds the forward texts and, rc_delta words on, the reverse complements) of the seed's first base;
-// da / db = bases of the node before / behind the seed there.
-struct CanonPosting {
-    uint32_t b, da, db;
-};
-__device__ __forceinline__ CanonPosting vs_canon(const VsIndexDev &idx, uint2 po) {
-    const VsNodeMeta m = idx.meta[po.x];
-    const uint32_t pos = po.y & 0x7FFFFFFFu, strand = po.y >> 31;
-    const uint32_t q = strand ? m.len - pos - idx.w : pos;
-    CanonPosting c;
-    c.b = (m.woff + (strand ? idx.rc_delta : 0u)) * 16u + q;
-    c.da = q;
-    c.db = m.len - q - idx.w;
-    return c;
-}
-
-// bases over which two texts agree going down from (not including) b1 / b2, at most `limit`
-__device__ __forceinline__ uint32_t vs_agree_down(const uint32_t *t, uint32_t b1, uint32_t b2, uint32_t limit) {
-    uint32_t done = 0;
-    while (done < limit) {
-        const uint32_t n = limit - done < 32u ? limit - done : 32u;
-        const uint64_t x = (vs_win(t, b1 - done - n) ^ vs_win(t, b2 - done - n)) & vs_lowmask(2u * n);
-        if (x) return done + n - 1u - (uint32_t)((63 - __clzll((long long)x)) >> 1);
-        done += n;
-    }
-    return done;
-}
-// ... going up from (and including) e1 / e2
-__device__ __forceinline__ uint32_t vs_agree_up(const uint32_t *t, uint32_t e1, uint32_t e2, uint32_t limit) {
-    uint32_t done = 0;
-    while (done < limit) {
-        const uint32_t n = limit - done < 32u ? limit - done : 32u;
-        const uint64_t x = (vs_win(t, e1 + done) ^ vs_win(t, e2 + done)) & vs_lowmask(2u * n);
-        if (x) return done + ((uint32_t)(__ffsll((long long)x) - 1) >> 1);
-        done += n;
-    }
-    return done;
-}
-__device__ __forceinline__ uint32_t vs_base_at(const uint32_t *t, uint32_t b) { return (t[b >> 4] >> ((b & 15u) * 2u)) & 3u; }
-
-// One thread per slot with several postings: the posting with the most text on side A goes to the
-// front of the group, the one with the most on side B behind it (ties: smaller (node, pos), so the
-// choice does not depend on the order the atomics of k_seed_fill happened to produce).
-__global__ void __launch_bounds__(TPB)
-k_group_refs(VsIndexDev idx, const uint32_t *__restrict__ cnts, const uint32_t *__restrict__ offs, uint32_t n_slots,
-             uint2 *__restrict__ postings, uint32_t *__restrict__ same_ref) {
-    const uint32_t sl = blockIdx.x * TPB + threadIdx.x;
-    if (sl >= n_slots) return;
-    const uint32_t c = cnts[sl];
-    if (c < 2u) return;
-    uint2 *g = postings + offs[sl];
-    auto better = [](uint32_t d, uint2 p, uint32_t bd, uint2 bp) {
-        if (d != bd) return d > bd;
-        if (p.x != bp.x) return p.x < bp.x;
-        return (p.y & 0x7FFFFFFFu) < (bp.y & 0x7FFFFFFFu);
-    };
-    uint32_t ia = 0, ib = 0;
-    CanonPosting c0 = vs_canon(idx, g[0]);
-    uint32_t best_a = c0.da, best_b = c0.db;
-    for (uint32_t i = 1; i < c; i++) {
-        const CanonPosting ci = vs_canon(idx, g[i]);
-        if (better(ci.da, g[i], best_a, g[ia])) { ia = i; best_a = ci.da; }
-        if (better(ci.db, g[i], best_b, g[ib])) { ib = i; best_b = ci.db; }
-    }
-    const uint2 pa = g[ia], pb = g[ib];
-    if (ia == ib) {
-        g[ia] = g[0];
-        g[0] = pa;
-        same_ref[sl] = 1u;
-    } else {
-        // place pa at 0 and pb at 1 (three cases keep every other posting in the group)
-        const uint2 g0 = g[0], g1 = g[1];
-        g[ia] = g0;                       // (no-op when ia == 0)
-        if (ib == 0u) ib = ia;            // g0 just moved there
-        g[0] = pa;
-        const uint2 cur1 = (ia == 1u) ? g0 : g1;  // what position 1 holds now
-        g[ib] = cur1;                     // (no-op when ib == 1)
-        g[1] = pb;
-        same_ref[sl] = 0u;
-    }
-}
-
-// One thread per posting: its record (VsPosting) -- for a seed with one posting just the plain
-// fields, otherwise also the agreement with the group's reference of either side.
-__global__ void __launch_bounds__(TPB)
-k_post_records(VsIndexDev idx, const uint2 *__restrict__ raw, const uint32_t *__restrict__ post_slot,
-               const uint32_t *__restrict__ cnts, const uint32_t *__restrict__ offs, const uint32_t *__restrict__ same_ref,
-               uint64_t n_pos, uint4 *__restrict__ out) {
-    const uint64_t at = (uint64_t)blockIdx.x * TPB + threadIdx.x;
-    if (at >= n_pos) return;
-    const uint2 po = raw[at];
-    const uint32_t sl = post_slot[at];
-    const VsNodeMeta m = idx.meta[po.x];
-    VsPosting r;
-    r.node = po.x; r.pos = po.y & 0x7FFFFFFFu; r.strand = po.y >> 31; r.len = m.len; r.woff = m.woff;
-    r.lcp_a = r.lcp_b = 0u; r.nb_a = r.nb_b = 0u;
-    if (cnts[sl] > 1u) {
-        const uint32_t first = offs[sl];
-        const CanonPosting me = vs_canon(idx, po);
-        const CanonPosting ra = vs_canon(idx, raw[first]);
-        const CanonPosting rb = same_ref[sl] ? ra : vs_canon(idx, raw[first + 1u]);
-        const uint32_t *t = idx.fwd_words;
-        uint32_t la = me.da < ra.da ? me.da : ra.da;
-        la = la < VS_LCP_CAP ? la : VS_LCP_CAP;
-        la = vs_agree_down(t, me.b, ra.b, la);
-        uint32_t lb = me.db < rb.db ? me.db : rb.db;
-        lb = lb < VS_LCP_CAP ? lb : VS_LCP_CAP;
-        lb = vs_agree_up(t, me.b + idx.w, rb.b + idx.w, lb);
-        r.lcp_a = la;
-        r.lcp_b = lb;
-        r.nb_a = la < me.da ? vs_base_at(t, me.b - 1u - la) : 0u;
-        r.nb_b = lb < me.db ? vs_base_at(t, me.b + idx.w + lb) : 0u;
-    }
-    out[at] = vs_posting_pack(r);
+    VsPosting rec;  // (carries the node header: the mapping kernel needs no second load for it)
+    rec.node = node; rec.pos = p; rec.strand = strand; rec.len = m.len; rec.woff = m.woff;
+    postings[at] = vs_posting_pack(rec);
 }
 
 __global__ void __launch_bounds__(TPB)
 k_table_finalize(const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ cnts,
-                 const uint32_t *__restrict__ offs, const uint2 *__restrict__ postings, const uint32_t *__restrict__ same_ref,
+                 const uint32_t *__restrict__ offs, const uint4 *__restrict__ postings,
                  uint32_t n_slots, VsSlot *__restrict__ table, uint32_t *__restrict__ n_distinct) {
     uint32_t sl = blockIdx.x * TPB + threadIdx.x;
     if (sl >= n_slots) return;
@@ -223,10 +104,10 @@ k_table_finalize(const unsigned long long *__restrict__ keys, const uint32_t *__
     } else {
         uint32_t c = cnts[sl];
         if (c == 1u) {
-            uint2 p = postings[offs[sl]];
+            const uint4 p = postings[offs[sl]];
             out.key = key; out.a = p.x; out.b = p.y;
         } else {
-            out.key = key | VS_MULTI_BIT; out.a = offs[sl]; out.b = c | (same_ref[sl] ? VS_GROUP_SAME_REF : 0u);
+            out.key = key | VS_MULTI_BIT; out.a = offs[sl]; out.b = c;
         }
         atomicAdd(n_distinct, 1u);
     }
@@ -292,8 +173,6 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
     uint8_t *d_ascii = nullptr;
     uint64_t *d_aoff = nullptr, *d_seed_off = nullptr, *d_tmp = nullptr;
     uint32_t *d_woff = nullptr, *d_cnts = nullptr, *d_offs = nullptr, *d_cursor = nullptr, *d_pos_slot = nullptr, *d_flags = nullptr;
-    uint32_t *d_post_slot = nullptr, *d_same = nullptr;
-    uint2 *d_raw = nullptr;
     unsigned long long *d_keys = nullptr;
     int rc = VS_OK;
     hipStream_t st = ctx->stream;
@@ -315,9 +194,6 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
         TRY(hipMalloc((void **)&d_offs, sizeof(uint32_t) * n_slots));
         TRY(hipMalloc((void **)&d_cursor, sizeof(uint32_t) * n_slots));
         TRY(hipMalloc((void **)&d_pos_slot, sizeof(uint32_t) * (npos ? npos : 1)));
-        TRY(hipMalloc((void **)&d_post_slot, sizeof(uint32_t) * (npos ? npos : 1)));
-        TRY(hipMalloc((void **)&d_raw, sizeof(uint2) * (npos ? npos : 1)));
-        TRY(hipMalloc((void **)&d_same, sizeof(uint32_t) * n_slots));
         TRY(hipMalloc((void **)&d_tmp, sizeof(uint64_t) * (n_slots / 2048 + 4)));
         TRY(hipMalloc((void **)&d_flags, sizeof(uint32_t) * 4));
         if (total_ascii) TRY(hipMemcpyAsync(d_ascii, node_ascii, total_ascii, hipMemcpyHostToDevice, st));
@@ -329,7 +205,6 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
         TRY(hipMemsetAsync(d_keys, 0xFF, sizeof(unsigned long long) * n_slots, st));
         TRY(hipMemsetAsync(d_cnts, 0, sizeof(uint32_t) * n_slots, st));
         TRY(hipMemsetAsync(d_cursor, 0, sizeof(uint32_t) * n_slots, st));
-        TRY(hipMemsetAsync(d_same, 0, sizeof(uint32_t) * n_slots, st));
         uint32_t init_flags[4] = {0xFFFFFFFFu, 0, 0, 0};
         TRY(hipMemcpyAsync(d_flags, init_flags, sizeof init_flags, hipMemcpyHostToDevice, st));
 
@@ -371,14 +246,10 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
             rc = vs_scan_u32(ctx, d_cnts, d_offs, n_slots, d_tmp, nullptr);
             if (rc) goto done;
             hipLaunchKernelGGL(k_seed_fill, dim3(nb), dim3(TPB), 0, st, d, d_seed_off, npos, d_pos_slot, d_offs, d_cursor,
-                               d_raw, d_post_slot);
-            hipLaunchKernelGGL(k_group_refs, dim3((unsigned)((n_slots + TPB - 1) / TPB)), dim3(TPB), 0, st, d,
-                               (const uint32_t *)d_cnts, (const uint32_t *)d_offs, (uint32_t)n_slots, d_raw, d_same);
-            hipLaunchKernelGGL(k_post_records, dim3(nb), dim3(TPB), 0, st, d, (const uint2 *)d_raw, (const uint32_t *)d_post_slot,
-                               (const uint32_t *)d_cnts, (const uint32_t *)d_offs, (const uint32_t *)d_same, npos, (uint4 *)ctx->d_post);
+                               (uint4 *)ctx->d_post);
         }
         hipLaunchKernelGGL(k_table_finalize, dim3((unsigned)((n_slots + TPB - 1) / TPB)), dim3(TPB), 0, st, d_keys, d_cnts,
-                           d_offs, (const uint2 *)d_raw, (const uint32_t *)d_same, (uint32_t)n_slots, (VsSlot *)ctx->d_table, d_flags + 1);
+                           d_offs, (const uint4 *)ctx->d_post, (uint32_t)n_slots, (VsSlot *)ctx->d_table, d_flags + 1);
         TRY(hipGetLastError());
         TRY(hipMemcpyAsync(h_flags, d_flags, sizeof h_flags, hipMemcpyDeviceToHost, st));
         TRY(hipStreamSynchronize(st));
@@ -391,8 +262,7 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
 done:
     (void)hipStreamSynchronize(st);
     {
-        void *tmps[] = {d_ascii, d_aoff, d_seed_off, d_woff, d_keys, d_cnts, d_offs, d_cursor, d_pos_slot, d_tmp, d_flags,
-                        d_post_slot, d_same, d_raw};
+        void *tmps[] = {d_ascii, d_aoff, d_seed_off, d_woff, d_keys, d_cnts, d_offs, d_cursor, d_pos_slot, d_tmp, d_flags};
         for (void *p : tmps)
             if (p) (void)hipFree(p);
     }

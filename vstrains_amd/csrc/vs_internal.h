@@ -24,7 +24,7 @@ struct VsNodeMeta {
 // One open-address slot of the seed table (16 B, read with one dwordx4 load).
 //  key  : canonical w-mer (2w <= 62 bits); bit 62 set = several postings; all ones = empty
 //  a, b : single -> a = node, b = pos | (node_strand << 31)
-//         multi  -> a = first posting index, b = number of postings | VS_GROUP_SAME_REF
+//         multi  -> a = first posting index, b = number of postings
 struct VsSlot {
     uint64_t key;
     uint32_t a;
@@ -33,45 +33,27 @@ struct VsSlot {
 #define VS_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 #define VS_MULTI_BIT (1ull << 62)
 
-// One posting of a seed with several postings (16 B, one dwordx4 load).  The postings of a seed
-// mostly describe the same stretch of sequence (the k-overlap a node shares with its neighbours),
-// so the index also records how each relates to the group's REFERENCE posting of either side (the
-// first / second record of the group: the postings with the most text on side A / side B of the
-// seed, in the orientation of the canonical seed; A = towards lower offsets there):
-//   lcp_a / lcp_b  bases on that side over which this posting's node text equals the reference's
-//                  (limited by either node's end; VS_LCP_CAP = "at least that many")
-//   nb_a / nb_b    this posting's base just beyond that agreement (undefined where its node ends)
-// k_pe_tiles compares a read with the two reference texts only and decides the other postings from
-// these fields; only a posting whose next base equals the read's needs a comparison of its own.
-//   x: node [0..24] | nb_a [25..26] | nb_b [27..28] | lcp_a bit 7 [29]
-//   y: pos [0..23] | lcp_a bits 0..6 [24..30] | strand [31]
-//   z: node length [0..23] | lcp_b [24..31]
-//   w: first word of the node text
-#define VS_LCP_CAP 255u
-#define VS_GROUP_SAME_REF (1u << 30)  // table slot .b of a multi slot: one posting is the reference of both sides
-#define VS_GROUP_COUNT_MASK 0x3FFFFFFFu
+// One posting of a seed with several postings (16 B, one dwordx4 load): where the seed lies and
+// the header of its node, so that the mapping kernel needs no second round trip for the header.
+//   x: node   y: pos [0..23] | strand [31]   z: node length   w: first word of the node text
 struct VsPosting {
-    uint32_t node, pos, strand, len, woff, lcp_a, lcp_b, nb_a, nb_b;
+    uint32_t node, pos, strand, len, woff;
 };
 #ifdef __HIPCC__
 __host__ __device__ inline uint4 vs_posting_pack(const VsPosting &p) {
     uint4 r;
-    r.x = p.node | (p.nb_a << 25) | (p.nb_b << 27) | ((p.lcp_a >> 7) << 29);
-    r.y = p.pos | ((p.lcp_a & 0x7Fu) << 24) | (p.strand << 31);
-    r.z = p.len | (p.lcp_b << 24);
+    r.x = p.node;
+    r.y = p.pos | (p.strand << 31);
+    r.z = p.len;
     r.w = p.woff;
     return r;
 }
 __host__ __device__ inline VsPosting vs_posting_unpack(const uint4 r) {
     VsPosting p;
-    p.node = r.x & 0x01FFFFFFu;
-    p.nb_a = (r.x >> 25) & 3u;
-    p.nb_b = (r.x >> 27) & 3u;
-    p.lcp_a = ((r.y >> 24) & 0x7Fu) | (((r.x >> 29) & 1u) << 7);
+    p.node = r.x;
     p.pos = r.y & 0x00FFFFFFu;
     p.strand = r.y >> 31;
-    p.len = r.z & 0x00FFFFFFu;
-    p.lcp_b = r.z >> 24;
+    p.len = r.z;
     p.woff = r.w;
     return p;
 }
@@ -88,7 +70,7 @@ struct VsIndexDev {
     const uint32_t *rc_words;   // packed reverse complements, same offsets; = fwd_words + rc_delta (one allocation,
     uint32_t rc_delta;          // so that a kernel can address either strand off one uniform base)
     const VsSlot *table;        // [1 << table_bits]
-    const uint4 *postings;      // VsPosting records, the postings of one seed contiguous, its reference(s) first
+    const uint4 *postings;      // VsPosting records, the postings of one seed contiguous
 };
 
 struct VsReadsDev {

@@ -45,7 +45,6 @@
 #define TILES_WAVES 5        // k_pe_tiles is compiled for 5 waves per SIMD (<= 96 VGPRs); its LDS tile fits 5 times too
 #endif
 #define CHUNK (TPB * PPT)
-#define MCHUNK TPB           // straight-line kernels: postings looked at per round of stage M (one per thread)
 
 struct PeParams {
     VsIndexDev idx;
@@ -81,8 +80,7 @@ struct Mem {  // one credited maximal exact match
 //          most cl (<= 32)
 //   ext  : bases over which the read (going up from j + w) equals the text going up from tr, at most rem
 // tl / tr are base indices into the one array of node texts (forward, and rc_delta words on the
-// reverse complements); they may belong to different nodes (the reference postings of a seed's two
-// sides, see VsPosting) or to one.
+// reverse complements).
 struct __attribute__((packed, aligned(4))) VsQuad { uint32_t x, y, z, w; };  // 16-byte load at dword alignment
 
 template <bool W4>  // W4: four right windows are enough (reads <= 159 bases with w = 31)
@@ -277,10 +275,10 @@ __device__ __forceinline__ uint32_t vs_probe(const VsIndexDev &idx, uint64_t f, 
         uint64_t k = (uint64_t)raw.x | ((uint64_t)raw.y << 32);
         if (k == VS_EMPTY_KEY) return 0u;
         if ((k & ~VS_MULTI_BIT) == key) {
-            if (k & VS_MULTI_BIT) {  // *pb: count | VS_GROUP_SAME_REF | read strand << 31
+            if (k & VS_MULTI_BIT) {
                 *pa = raw.z;
                 *pb = raw.w | (sr << 31);
-                return raw.w & VS_GROUP_COUNT_MASK;
+                return raw.w;
             }
             *pa = raw.z;
             *pb = raw.w ^ (sr << 31);
@@ -304,7 +302,7 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
     t.woff = o;  o += 2u * ((ept + 2u) & ~1u);  // global word offset of every end of the tile
     t.gend = o;  o += 2u * ept;                 // global end index
     t.meta = o;  o += 2u * ept;
-    t.inv = o;   o += 2u * ept;                 // positions of bytes outside ACGT (straight-line kernels)
+    t.inv = o;   o += ept;                      // positions of bytes outside ACGT (straight-line kernels; current tile only)
     t.words = o; o += 2u * (words_cap + 8u);
     t.pcnt = o;  o += NI + 1u;  // [0] stays zero: the scan is read as s_pcnt[it - 1] .. s_pcnt[it] without a test for it == 0
     t.pa = o;    o += NI;
@@ -315,10 +313,9 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
     t.hminj = o; o += pool;
     t.ns = o;    o += ept;
     t.state = o; o += ept;
-    // the posting owners (+ the worklist of the straight-line kernels: MCHUNK owners, 2 * MCHUNK
-    // entries) of P3 and the accepted lists of P4/P5 are never live together
+    // the posting owners of P3 and the accepted lists of P4/P5 are never live together
     t.list = o;
-    t.owner = o; o += (ept * LC > 3u * MCHUNK ? ept * LC : 3u * MCHUNK);
+    t.owner = o; o += (ept * LC > CHUNK ? ept * LC : CHUNK);
     t.misc = o;  o += 16u;
     t.total = o;
     return t;
@@ -371,7 +368,6 @@ k_pe_tiles(PeParams P) {
     uint32_t *s_list = vs_lds + T.list;    // accepted node ids, LC per end
     uint32_t *s_misc = vs_lds + T.misc;
     uint32_t *s_owner = vs_lds + T.owner;
-    uint32_t *s_wl = vs_lds + T.owner + MCHUNK;  // FAST: postings that need a comparison of their own (probe << 20 | offset in its group)
     const uint32_t wpe = STD ? STD_WPE : P.wpe;
     const uint32_t ppt = ept / 2u;
     const bool has_inv = FAST && P.rd.inv4 != nullptr;  // (the generic kernel reads the mask instead)
@@ -391,6 +387,7 @@ k_pe_tiles(PeParams P) {
     // offset and length one tile ahead; one end per thread, ept <= TPB), so that neither waits for
     // the other and both are covered by the previous tiles' work.
     uint32_t pf_gend = 0, pf_gwoff = 0, pf_meta = 0, pf_inv = 0xFFFFFFFFu, pf_pair = 0xFFFFFFFFu;
+    uint32_t cur_inv = 0xFFFFFFFFu;  // this thread's end of the CURRENT tile (goes to LDS at the top of the tile)
     auto prefetch_pair = [&](uint64_t t) {  // pair (in input order) of this thread's end in tile t
         pf_pair = 0xFFFFFFFFu;
         if (t < tile_hi && tid < ept) {
@@ -440,8 +437,8 @@ k_pe_tiles(PeParams P) {
             s_gend[tid] = pf_gend;
             s_gwoff[tid] = pf_gwoff;
             s_meta[tid] = pf_meta;
-            s_inv[tid] = pf_inv;
         }
+        cur_inv = pf_inv;
         if (tid < 8u) { s_words[words_cap + tid] = 0u; s_words[wcap + words_cap + tid] = 0u; }  // pads of both copies
         __syncthreads();
         for (uint32_t i = tid; i < ne0 * wpe; i += TPB) {
@@ -461,11 +458,9 @@ k_pe_tiles(PeParams P) {
         s_gwoff = vs_lds + T.woff + cur * hw;
         s_gend = vs_lds + T.gend + cur * ept;
         s_meta = vs_lds + T.meta + cur * ept;
-        s_inv = vs_lds + T.inv + cur * ept;
         s_words = vs_lds + T.words + cur * wcap;
         uint32_t *n_gwoff = vs_lds + T.woff + nxt * hw, *n_gend = vs_lds + T.gend + nxt * ept;
         uint32_t *n_meta = vs_lds + T.meta + nxt * ept, *n_words = vs_lds + T.words + nxt * wcap;
-        uint32_t *n_inv = vs_lds + T.inv + nxt * ept;
         uint32_t ne1 = 0;  // ends of the next tile of this run
         if (tile + 1u < tile_hi) {
             const uint64_t np1 = P.n_pairs - (tile + 1u) * ppt;
@@ -477,7 +472,10 @@ k_pe_tiles(PeParams P) {
             n_gend[tid] = pf_gend;
             n_gwoff[tid] = pf_gwoff;
             n_meta[tid] = pf_meta;
-            n_inv[tid] = pf_inv;
+        }
+        if (has_inv && tid < ept) {  // (one copy is enough: nothing reads it before the barrier below)
+            s_inv[tid] = cur_inv;
+            cur_inv = pf_inv;
         }
         for (uint32_t i = tid; i < pool; i += TPB) {
             s_hkey[i] = EMPTY_NODE;
@@ -485,7 +483,6 @@ k_pe_tiles(PeParams P) {
             s_hminp[i] = 0xFFFFFFFFu;
             s_hminj[i] = 0xFFFFFFFFu;
         }
-        if (tid == 0) { s_misc[12] = 0; s_misc[13] = 0; }  // worklist length, diagnostics
         __syncthreads();
         prefetch_headers();            // tile + 2 (its pair order arrived during the previous tile)
         prefetch_pair(tile + 3u);
@@ -536,8 +533,6 @@ k_pe_tiles(PeParams P) {
                         }
                     }
                     if (ok) cnt = vs_probe(P.idx, f, &pa, &pb);
-                    // (a seed with more postings than the worklist can address: the overflow path takes the pair)
-                    if (FAST && cnt >= (1u << 20)) { atomicOr(&s_state[e], 2u); cnt = 0; }  // (cnt: flag bits already off)
                 }
             }
             s_pcnt[it] = cnt;
@@ -546,87 +541,13 @@ k_pe_tiles(PeParams P) {
         }
         __syncthreads();
         if (debug_stop == 2u) continue;
-        if (FAST) {
-            // ---- R: one thread per probe.  A seed with one posting is settled here (agreement with
-            // its node, credit).  For a seed with several, the read is compared with the group's two
-            // reference postings -- the left side with the one that has the most text there, the right
-            // side likewise -- and the two agreement lengths are left in s_pb for stage M.
-            for (uint32_t it = tid; it < NI; it += TPB) {
-                const uint32_t cnt = s_pcnt[it];
-                if (cnt == 0u) continue;
-                const uint32_t e = STD ? it / STD_PMAX : vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
-                const uint32_t j = pi * s, pa = s_pa[it], pb = s_pb[it];
-                const uint32_t meta = s_meta[e], rlen = meta & VS_LEN_MASK;
-                uint32_t lo = 0u, hi = rlen;
-                if ((meta >> 24) & VS_FLAG_INVALID) vs_seed_limits(s_inv[e], j, w, rlen, &lo, &hi);
-                const uint32_t sr = pb >> 31;
-                uint32_t tl, tr, dl, dr;  // text positions of the seed start (left text) / seed end (right text), room on either side
-                uint32_t node = pa, nlen = 0, q = 0, opp = 0;
-                bool live = true;
-                if (cnt == 1u) {
-                    const uint32_t pos = pb & 0x7FFFFFFFu;
-                    opp = sr;  // (vs_probe folded the node strand into bit 31)
-                    if (P.shortcut && s <= w && pi) {
-                        // Overlapping seeds (s <= w): if the previous probe of this end holds the single
-                        // posting one stride back on the same diagonal, the bases in between match too,
-                        // so that probe (or an earlier one) owns this match -- no memory traffic needed.
-                        if (s_pcnt[it - 1u] == 1u && s_pa[it - 1u] == node) {
-                            const uint32_t pbp = s_pb[it - 1u];
-                            const uint32_t want = opp ? pos + s : pos - s;
-                            if ((pbp >> 31) == opp && (pbp & 0x7FFFFFFFu) == want && (opp || pos >= s) && j - s >= lo) live = false;
-                        }
-                    }
-                    if (live) {
-                        const VsNodeMeta nm = P.idx.meta[node];
-                        nlen = nm.len;
-                        q = opp ? nm.len - pos - w : pos;
-                        tl = (nm.woff + (opp ? P.idx.rc_delta : 0u)) * 16u + q;
-                        tr = tl + w;
-                        dl = q;
-                        dr = nm.len - q - w;
-                    }
-                } else {
-                    const VsPosting ra = vs_posting_unpack(P.idx.postings[pa]);
-                    const VsPosting rb = (pb & VS_GROUP_SAME_REF) ? ra : vs_posting_unpack(P.idx.postings[pa + 1u]);
-                    const VsPosting &pl = sr ? rb : ra, &pr = sr ? ra : rb;
-                    const uint32_t ol = pl.strand ^ sr, orr = pr.strand ^ sr;
-                    const uint32_t ql = ol ? pl.len - pl.pos - w : pl.pos, qr = orr ? pr.len - pr.pos - w : pr.pos;
-                    tl = (pl.woff + (ol ? P.idx.rc_delta : 0u)) * 16u + ql;
-                    tr = (pr.woff + (orr ? P.idx.rc_delta : 0u)) * 16u + qr + w;
-                    dl = ql;
-                    dr = pr.len - qr - w;
-                }
-                if (!live) continue;
-                uint32_t cl = s < j - lo ? s : j - lo;
-                cl = cl < dl ? cl : dl;
-                uint32_t rem = hi - j - w;
-                rem = rem < dr ? rem : dr;
-                uint32_t left, ext;
-                vs_agree_fast<STD>(s_words, e * wpe * 16u, P.idx.fwd_words, tl, cl, tr, rem, j, w, &left, &ext);
-                if (cnt == 1u) {
-                    const uint32_t len = left + w + ext;
-                    if (left < s && len >= K) {
-                        const uint32_t qa = q - left;
-                        credit(e, node, nlen, len - K + 1u, opp ? nlen - qa - len : qa, j - left);
-                    }
-                } else {
-                    s_pb[it] = (sr << 31) | (ext << 8) | left;
-                }
-            }
-            __syncthreads();
-        }
-        // ---- P2: inclusive scan of the postings to expand per probe, s_pcnt[0..NI) (FAST: the members
-        // of seeds with several postings; seeds with one are done)
+        // ---- P2: inclusive scan of the postings per probe, s_pcnt[0..NI)
         {
             const uint32_t chunk = (NI + TPB - 1u) / TPB;
             const uint32_t b = tid * chunk;
             uint32_t local = 0;
             for (uint32_t i = 0; i < chunk; i++)
-                if (b + i < NI) {
-                    uint32_t c = s_pcnt[b + i];
-                    if (FAST) c = c == 1u ? 0u : c;
-                    local += c;
-                }
+                if (b + i < NI) local += s_pcnt[b + i];
             uint32_t incl = local;
             const uint32_t lane = tid & 63u;
 #pragma unroll
@@ -640,143 +561,19 @@ k_pe_tiles(PeParams P) {
             for (uint32_t wv = 0; wv < (tid >> 6); wv++) off += s_misc[wv];
             for (uint32_t i = 0; i < chunk; i++)
                 if (b + i < NI) {
-                    uint32_t c = s_pcnt[b + i];
-                    if (FAST) c = c == 1u ? 0u : c;
-                    off += c;
+                    off += s_pcnt[b + i];
                     s_pcnt[b + i] = off;
                 }
         }
         __syncthreads();
         if (debug_stop == 3u) continue;
+        // ---- P3: one thread per posting.  Expansion of the per-probe posting counts (CSR-style
+        // frontier expansion) in chunks of CHUNK postings: every probe marks the first position it
+        // owns in the chunk, a workgroup-wide running maximum fills the gaps, and each thread ends
+        // up with the owners of its PPT consecutive postings in registers.
+        {
         const uint32_t total = s_pcnt[NI - 1u];
         if (count_postings && tid == 0) atomicAdd((unsigned long long *)(P.slow_count + 2), (unsigned long long)total);
-        // ---- P3: one thread per posting.  Expansion of the per-probe posting counts (CSR-style
-        // frontier expansion) in chunks: every probe marks the first position it owns in the chunk, a
-        // workgroup-wide running maximum fills the gaps, and each thread ends up with the owners of
-        // its consecutive postings in registers.
-        if (FAST) {
-            // X: the agreement of a posting's own node text with the read (what every posting got
-            // before the groups had references), for the entries of the worklist
-            auto own_compare = [&](uint32_t entry) {
-                const uint32_t it = entry >> 20, off = entry & 0xFFFFFu;
-                const uint32_t e = STD ? it / STD_PMAX : vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
-                const uint32_t j = pi * s;
-                const VsPosting po = vs_posting_unpack(P.idx.postings[s_pa[it] + off]);
-                const uint32_t sr = s_pb[it] >> 31, opp = po.strand ^ sr;
-                const uint32_t meta = s_meta[e], rlen = meta & VS_LEN_MASK;
-                uint32_t lo = 0u, hi = rlen;
-                if ((meta >> 24) & VS_FLAG_INVALID) vs_seed_limits(s_inv[e], j, w, rlen, &lo, &hi);
-                const uint32_t q = opp ? po.len - po.pos - w : po.pos;
-                const uint32_t tl = (po.woff + (opp ? P.idx.rc_delta : 0u)) * 16u + q;
-                uint32_t cl = s < j - lo ? s : j - lo;
-                cl = cl < q ? cl : q;
-                uint32_t rem = hi - j - w;
-                const uint32_t dr = po.len - q - w;
-                rem = rem < dr ? rem : dr;
-                uint32_t left, ext;
-                vs_agree_fast<STD>(s_words, e * wpe * 16u, P.idx.fwd_words, tl, cl, tl + w, rem, j, w, &left, &ext);
-                const uint32_t len = left + w + ext;
-                if (left < s && len >= K) {
-                    const uint32_t qa = q - left;
-                    credit(e, po.node, po.len, len - K + 1u, opp ? po.len - qa - len : qa, j - left);
-                }
-            };
-            for (uint32_t c0 = 0; c0 < (debug_stop == 6u ? 0u : total); c0 += MCHUNK) {
-                s_owner[tid] = 0;
-                __syncthreads();
-                for (uint32_t it = tid; it < NI; it += TPB) {
-                    const uint32_t incl = s_pcnt[it], excl = s_pcnt[(int)it - 1];
-                    if (incl > excl) {
-                        const uint32_t lo = excl > c0 ? excl : c0;
-                        const uint32_t hi = incl < c0 + MCHUNK ? incl : c0 + MCHUNK;
-                        if (lo < hi) s_owner[lo - c0] = it + 1u;
-                    }
-                }
-                __syncthreads();
-                uint32_t own = s_owner[tid];
-                {
-                    const uint32_t lane = tid & 63u;
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        const uint32_t t2 = __shfl_up(own, d, 64);
-                        if (lane >= (uint32_t)d && t2 > own) own = t2;
-                    }
-                    if (lane == 63u) s_misc[4u + (tid >> 6)] = own;
-                }
-                __syncthreads();
-                {   // the wavefronts before this one (TPB = 256: at most three)
-                    const uint32_t m0 = s_misc[4], m1 = s_misc[5], m2 = s_misc[6], wv = tid >> 6;
-                    if (wv > 0u) own = m0 > own ? m0 : own;
-                    if (wv > 1u) own = m1 > own ? m1 : own;
-                    if (wv > 2u) own = m2 > own ? m2 : own;
-                }
-                // ---- M: what the index knows about the posting (VsPosting: agreement with the group's
-                // reference of either side, next base) and the read's agreement with the references
-                // (stage R) settle most postings without touching their text.
-                const uint32_t t = c0 + tid;
-                if (t < total) {
-                    const uint32_t it = own - 1u;
-                    const uint32_t excl = s_pcnt[(int)it - 1];
-                    const uint32_t e = STD ? it / STD_PMAX : vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
-                    const uint32_t j = pi * s, pb = s_pb[it];
-                    const VsPosting po = vs_posting_unpack(P.idx.postings[s_pa[it] + (t - excl)]);
-                    const uint32_t sr = pb >> 31, r_l = pb & 0xFFu, r_r = (pb >> 8) & 0xFFu;
-                    const uint32_t opp = po.strand ^ sr;
-                    const uint32_t meta = s_meta[e], rlen = meta & VS_LEN_MASK;
-                    uint32_t lo = 0u, hi = rlen;
-                    if ((meta >> 24) & VS_FLAG_INVALID) vs_seed_limits(s_inv[e], j, w, rlen, &lo, &hi);
-                    const uint32_t q = opp ? po.len - po.pos - w : po.pos;
-                    const uint32_t dl = q, dr = po.len - q - w;
-                    const uint32_t l_l = sr ? po.lcp_b : po.lcp_a, l_r = sr ? po.lcp_a : po.lcp_b;
-                    const uint32_t nb_l = sr ? po.nb_b ^ 3u : po.nb_a, nb_r = sr ? po.nb_a ^ 3u : po.nb_b;
-                    uint32_t lim_l = s < j - lo ? s : j - lo;
-                    lim_l = lim_l < dl ? lim_l : dl;
-                    uint32_t lim_r = hi - j - w;
-                    lim_r = lim_r < dr ? lim_r : dr;
-                    const uint32_t rb0 = e * wpe * 16u;
-                    // left: r_l < l_l -> the read leaves the shared text first; r_l > l_l -> this posting
-                    // does; equal -> both leave it at the same base: the posting's next base decides
-                    uint32_t left = r_l < l_l ? r_l : l_l, ext = r_r < l_r ? r_r : l_r;
-                    bool lk = true, rk = true;
-                    if (r_l == l_l && l_l < lim_l) {
-                        const uint32_t bi = rb0 + j - 1u - l_l;
-                        lk = ((s_words[bi >> 4] >> ((bi & 15u) * 2u)) & 3u) != nb_l;
-                    }
-                    if (r_r == l_r && l_r < lim_r) {
-                        const uint32_t bi = rb0 + j + w + l_r;
-                        rk = ((s_words[bi >> 4] >> ((bi & 15u) * 2u)) & 3u) != nb_r;
-                    }
-                    if (l_l >= VS_LCP_CAP && r_l >= l_l) lk = false;  // (agreement longer than the field can say)
-                    if (l_r >= VS_LCP_CAP && r_r >= l_r) rk = false;
-                    if (!(lk && left >= s)) {
-                        if (lk && rk) {
-                            const uint32_t len = left + w + ext;
-                            if (len >= K) {
-                                const uint32_t qa = q - left;
-                                credit(e, po.node, po.len, len - K + 1u, opp ? po.len - qa - len : qa, j - left);
-                            }
-                        } else if ((lk ? left : lim_l) + w + (rk ? ext : lim_r) >= K) {
-                            s_wl[atomicAdd(&s_misc[12], 1u)] = (it << 20) | (t - excl);
-                            if (count_postings) atomicAdd(&s_misc[13], 1u);
-                        }
-                    }
-                }
-                __syncthreads();  // worklist complete for this chunk; the owner array is free again
-                const uint32_t n_wl = s_misc[12];
-                if (n_wl >= TPB && debug_stop == 7u) {  // (timing experiment: drop the entries)
-                    __syncthreads();
-                    if (tid == 0) s_misc[12] = n_wl - TPB;
-                } else if (n_wl >= TPB) {  // a full round of comparisons is waiting
-                    const uint32_t entry = s_wl[n_wl - TPB + tid];
-                    __syncthreads();
-                    if (tid == 0) s_misc[12] = n_wl - TPB;
-                    own_compare(entry);
-                }
-            }
-            __syncthreads();
-            if (debug_stop != 7u && tid < s_misc[12]) own_compare(s_wl[tid]);
-            if (count_postings && tid == 0) atomicAdd((unsigned long long *)(P.slow_count + 4), (unsigned long long)s_misc[13]);
-        } else {
         for (uint32_t c0 = 0; c0 < total; c0 += CHUNK) {
             for (uint32_t i = tid; i < CHUNK; i += TPB) s_owner[i] = 0;
             __syncthreads();
@@ -828,17 +625,28 @@ k_pe_tiles(PeParams P) {
                 const uint32_t excl = s_pcnt[(int)it - 1];
                 const uint32_t cnt = s_pcnt[it] - excl;
                 const uint32_t pa = s_pa[it], pb = s_pb[it];
-                const uint32_t e = vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
+                const uint32_t e = STD ? it / STD_PMAX : vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
                 p_e[k2] = e;
                 p_j[k2] = pi * s;
                 uint32_t node = pa, pos = pb & 0x7FFFFFFFu, opp = pb >> 31;
                 p_nm[k2].woff = 0; p_nm[k2].len = 0;
-                if (live[k2] && cnt != 1u) {
+                if (live[k2] && cnt != 1u) {  // (the record carries the node header: no second round trip)
                     const VsPosting po = vs_posting_unpack(P.idx.postings[pa + (t - excl)]);
                     node = po.node; pos = po.pos; opp = po.strand ^ (pb >> 31);
                     p_nm[k2].woff = po.woff; p_nm[k2].len = po.len;
                 } else if (live[k2]) {
-                    p_nm[k2] = P.idx.meta[node];
+                    if (P.shortcut && s <= w && pi) {
+                        // Overlapping seeds (s <= w): if the previous probe of this end holds the single
+                        // posting one stride back on the same diagonal, the bases in between match too,
+                        // so that probe (or an earlier one) owns this match -- no memory traffic needed.
+                        const uint32_t excl2 = s_pcnt[(int)it - 2];  // (pi != 0, so it >= 1)
+                        if (excl - excl2 == 1u && s_pa[it - 1u] == node) {
+                            const uint32_t pbp = s_pb[it - 1u];
+                            const uint32_t want = opp ? pos + s : pos - s;
+                            if ((pbp >> 31) == opp && (pbp & 0x7FFFFFFFu) == want && (opp || pos >= s)) live[k2] = false;
+                        }
+                    }
+                    if (live[k2]) p_nm[k2] = P.idx.meta[node];
                 }
                 p_node[k2] = node; p_pos[k2] = pos; p_opp[k2] = opp;
             }
@@ -853,10 +661,27 @@ k_pe_tiles(PeParams P) {
                 const uint32_t *tw = P.idx.fwd_words;
                 const uint32_t tb = (nm.woff + (opp ? P.idx.rc_delta : 0u)) * 16u;
                 const uint32_t q = opp ? nm.len - p_pos[k2] - w : p_pos[k2];
-                const uint32_t *mk = ((meta >> 24) & VS_FLAG_INVALID) ? P.rd.mask : nullptr;
                 uint32_t a, qa, len;
-                if (!vs_extend(s_words, e * wpe * 16u, rlen, tw, tb, nm.len, j, q, w, s, K, mk, (uint64_t)s_gwoff[e] * 16u, &a, &qa, &len))
-                    continue;
+                if (FAST) {
+                    // the clean stretch [lo, hi) of the read around the seed bounds the match
+                    uint32_t lo = 0u, hi = rlen;
+                    if ((meta >> 24) & VS_FLAG_INVALID) vs_seed_limits(s_inv[e], j, w, rlen, &lo, &hi);
+                    uint32_t cl = s < j - lo ? s : j - lo;
+                    cl = cl < q ? cl : q;
+                    uint32_t rem = hi - j - w;
+                    const uint32_t dr = nm.len - q - w;
+                    rem = rem < dr ? rem : dr;
+                    uint32_t left, ext;
+                    vs_agree_fast<STD>(s_words, e * wpe * 16u, tw, tb + q, cl, tb + q + w, rem, j, w, &left, &ext);
+                    len = left + w + ext;
+                    if (left >= s || len < K) continue;  // an earlier probe lies inside this match and owns it / too short
+                    a = j - left;
+                    qa = q - left;
+                } else {
+                    const uint32_t *mk = ((meta >> 24) & VS_FLAG_INVALID) ? P.rd.mask : nullptr;
+                    if (!vs_extend(s_words, e * wpe * 16u, rlen, tw, tb, nm.len, j, q, w, s, K, mk, (uint64_t)s_gwoff[e] * 16u, &a, &qa, &len))
+                        continue;
+                }
                 credit(e, node, nm.len, len - K + 1u, opp ? nm.len - qa - len : qa, a);
             }
             __syncthreads();  // the owner array is reused by the next chunk
@@ -1537,6 +1362,11 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
                                             : (const void *)k_pe_tiles<false, 0u, 0u>;
     if (lds > 64u * 1024u)
         VS_HIP(ctx, hipFuncSetAttribute(tiles_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (getenv("VS_DEBUG_OCC")) {
+        int nb = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tiles_fn, TPB, lds);
+        fprintf(stderr, "[vs] k_pe_tiles: %zu B of LDS per workgroup, %d workgroups per CU\n", lds, nb);
+    }
     uint64_t grid = P.n_tiles;
     // Many more workgroups than fit at once (4 per CU): loci differ a lot in postings per read, and
     // short runs let the dispatcher even that out (runs of ~10 tiles at configs[2]: 8.4 ms, against
@@ -1669,9 +1499,9 @@ extern "C" int vs_pe_last_timing(vs_ctx *ctx, double ms[5]) {
     VS_HIP(ctx, hipMemcpy(&n_slow, ctx->d_slow_count, sizeof n_slow, hipMemcpyDeviceToHost));
     ms[0] = a; ms[1] = b; ms[2] = (double)n_slow; ms[3] = c; ms[4] = d;
     if (getenv("VS_DEBUG_POSTINGS")) {
-        unsigned long long np[2] = {0, 0};
-        VS_HIP(ctx, hipMemcpy(np, (char *)ctx->d_slow_count + 8, sizeof np, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[vs] postings expanded by the last vs_pe_count: %llu, compared with their own node text: %llu\n", np[0], np[1]);
+        unsigned long long np = 0;
+        VS_HIP(ctx, hipMemcpy(&np, (char *)ctx->d_slow_count + 8, sizeof np, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[vs] postings expanded by the last vs_pe_count: %llu\n", np);
     }
     ctx->last_ms[0] = a; ctx->last_ms[1] = b; ctx->last_ms[2] = n_slow;
     return VS_OK;
