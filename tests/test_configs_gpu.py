@@ -66,7 +66,7 @@ def test_config4_50k_nodes_wide_cell_keys_and_global_sort(host, ctx, tmp_path):
     R = 3_000_000
     whole = _count(host, ctx, st, cum, seed, L, [(0, R)], sub, nth)
     t = ctx.last_timing()
-    assert ctx.last_kernel.startswith("k_pe_tiles<true")  # the straight-line instantiation serves this config
+    assert ctx.last_kernel.startswith("k_pe_tiles<1")  # the straight-line instantiation serves this config
     parts = _count(host, ctx, st, cum, seed, L, [(0, 1), (1, 4999), (5000, 1_000_001), (1_005_001, R - 1_005_001)], sub, nth)
     assert torch.equal(whole.mats, parts.mats) and torch.equal(whole.stats, parts.stats)
     stats = whole.stats.cpu().tolist()
@@ -104,6 +104,7 @@ def test_config3_10k_nodes_k127_reads_of_250(host, ctx, tmp_path):
     sub, nth = int(0.005 * 2 ** 32), int(0.001 * 2 ** 32)
     R = 1_200_000
     whole = _count(host, ctx, st, cum, seed, L, [(0, R)], sub, nth)
+    assert ctx.last_kernel.startswith("k_pe_tiles<2")  # straight-line comparison with the long windows (stride 98, 2 x 250)
     parts = _count(host, ctx, st, cum, seed, L, [(0, 300_001), (300_001, 7), (300_008, R - 300_008)], sub, nth)
     assert torch.equal(whole.mats, parts.mats) and torch.equal(whole.stats, parts.stats)
     stats = whole.stats.cpu().tolist()

@@ -215,6 +215,34 @@ def test_ragged_block_through_sort_and_double_buffered_tiles(host, ctx, dirty):
     assert int(ref_node.sum()) > 0
 
 
+@pytest.mark.parametrize("k,max_len", [(127, 287), (99, 250), (86, 200)])
+def test_long_stride_kernel_with_ragged_dirty_reads(host, ctx, k, max_len, monkeypatch):
+    """k > 85 (probe stride > 32) / reads beyond 191 bases take the long-window straight-line kernel
+    (k_pe_tiles<2>): reads of every length up to its limit, some with N or other bytes outside
+    ACGT; the generic kernel (VS_NO_FAST=1) must agree with it and with the oracle."""
+    g, f, r = _dense_case(k, 9000, max_len, seed=1200 + k, snp=0.02, glen=6000, nrate=0.0)
+    rng = np.random.default_rng(k)
+    f = [s[: int(rng.integers(0, max_len + 1))] for s in f]
+    r = [s[: int(rng.integers(k - 5, max_len + 1))] for s in r]
+    for lst in (f, r):
+        for i in rng.choice(len(lst), size=500, replace=False):
+            s_ = lst[int(i)]
+            for _ in range(int(rng.integers(1, 7))):
+                if len(s_) > 3:
+                    p_ = int(rng.integers(0, len(s_)))
+                    s_ = s_[:p_] + ("N" if rng.random() < 0.1 else str(rng.choice(list("nRYacgt*")))) + s_[p_ + 1:]
+            lst[int(i)] = s_
+    orc = pe_oracle_c.Oracle(g.seqs, k)
+    ref_node, ref_short, ref_stats = orc.count_pairs(f, r)
+    assert int(ref_node.sum()) > 0
+    for no_fast in ("0", "1"):
+        monkeypatch.setenv("VS_NO_FAST", no_fast)
+        (node_mat, short_mat, stats), _ = _gpu_matrices(host, ctx, g.seqs, f, r, k)
+        assert ctx.last_kernel.startswith("k_pe_tiles<0" if no_fast == "1" else "k_pe_tiles<2")
+        assert np.array_equal(node_mat, ref_node) and np.array_equal(short_mat, ref_short)
+        assert stats == tuple(int(x) for x in ref_stats)
+
+
 def test_blocks_add_up_and_swapping_ends_transposes(host, ctx):
     g, f, r = _dense_case(55, 12000, 150, seed=601, snp=0.03, glen=5000)
     ctx.build_index(g.seqs, 55)

@@ -255,6 +255,8 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
         TRY(hipStreamSynchronize(st));
         ctx->idx = d;
         ctx->n_seed_pos = npos;
+        ctx->max_node_len = 0;
+        for (uint32_t i = 0; i < n_nodes; i++) ctx->max_node_len = meta[i].len > ctx->max_node_len ? meta[i].len : ctx->max_node_len;
         ctx->n_slots = n_slots;
         ctx->n_distinct = h_flags[1];
         ctx->has_index = true;

@@ -96,6 +96,7 @@ struct vs_ctx {
     // owned device allocations of the index
     void *d_meta = nullptr, *d_fwd = nullptr, *d_rc = nullptr, *d_table = nullptr, *d_post = nullptr;
     uint64_t n_seed_pos = 0, n_slots = 0, n_distinct = 0, index_bytes = 0;
+    uint32_t max_node_len = 0;
     // scratch for vs_pe_count
     void *d_slow_list = nullptr;   // pair indices sent to the slow path
     uint64_t slow_cap = 0;

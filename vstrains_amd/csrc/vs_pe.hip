@@ -128,6 +128,71 @@ __device__ __forceinline__ void vs_agree_fast(const uint32_t *rw, uint32_t rbase
     *ext_out = ext < rem ? ext : rem;
 }
 
+// The same for longer strides and reads (k up to 158: stride <= 128; reads <= w + 256 bases): four
+// left windows, eight right windows, still without a data-dependent branch.  Text words come as
+// 16-byte loads that are skipped where the match cannot reach (cl / rem).
+__device__ __forceinline__ void vs_agree_long(const uint32_t *rw, uint32_t rbase, const uint32_t *tw, uint32_t tl, uint32_t cl,
+                                              uint32_t tr, uint32_t rem, uint32_t j, uint32_t w, uint32_t *left_out,
+                                              uint32_t *ext_out) {
+    // ---- left: window i holds the n_i = clamp(cl - 32 i, 0, 32) bases just below the previous one,
+    // lowest base first, so a difference nearest the seed is the highest set bit
+    uint32_t left = cl;
+    {
+        uint64_t xs = 0ull;
+        uint32_t at = 0u, nn = 0u;
+#pragma unroll
+        for (int i = 3; i >= 0; i--) {  // (from the far window to the near one: the nearest difference wins)
+            const uint32_t lo = 32u * (uint32_t)i;
+            const uint32_t n = cl > lo ? (cl - lo < 32u ? cl - lo : 32u) : 0u;
+            uint64_t x = 0ull;
+            if (n) x = (vs_win(rw, rbase + j - lo - n) ^ vs_win(tw, tl - lo - n)) & vs_lowmask(2u * n);
+            if (x) { xs = x; at = lo; nn = n; }
+        }
+        if (xs) left = at + nn - 1u - (uint32_t)((63 - __clzll((long long)xs)) >> 1);
+    }
+    // ---- right: seventeen words either side cover eight windows
+    const uint32_t rj = j + w;
+    const uint32_t ti = tr >> 4, sh = (tr & 15u) * 2u;
+    const VsQuad q0 = *(const VsQuad *)(tw + ti);
+    VsQuad q1 = {0u, 0u, 0u, 0u}, q2 = q1, q3 = q1;
+    uint32_t t16 = 0u;
+    if (rem > 48u) q1 = *(const VsQuad *)(tw + ti + 4u);
+    if (rem > 112u) q2 = *(const VsQuad *)(tw + ti + 8u);
+    if (rem > 176u) q3 = *(const VsQuad *)(tw + ti + 12u);
+    if (rem > 240u) t16 = tw[ti + 16u];
+    auto tw64 = [&](uint32_t w0, uint32_t w1, uint32_t w2) {
+        return (uint64_t)__builtin_amdgcn_alignbit(w1, w0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, sh) << 32);
+    };
+    const uint32_t rr = rbase + rj, rsh = (rr & 15u) * 2u;
+    const uint32_t *rp = rw + (rr >> 4);
+    uint32_t r[17];
+#pragma unroll
+    for (int i = 0; i < 17; i++) r[i] = rp[i];
+    auto rw64 = [&](uint32_t w0, uint32_t w1, uint32_t w2) {
+        return (uint64_t)__builtin_amdgcn_alignbit(w1, w0, rsh) | ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, rsh) << 32);
+    };
+    const uint64_t x0 = rw64(r[0], r[1], r[2]) ^ tw64(q0.x, q0.y, q0.z);
+    const uint64_t x1 = rw64(r[2], r[3], r[4]) ^ tw64(q0.z, q0.w, q1.x);
+    const uint64_t x2 = rw64(r[4], r[5], r[6]) ^ tw64(q1.x, q1.y, q1.z);
+    const uint64_t x3 = rw64(r[6], r[7], r[8]) ^ tw64(q1.z, q1.w, q2.x);
+    const uint64_t x4 = rw64(r[8], r[9], r[10]) ^ tw64(q2.x, q2.y, q2.z);
+    const uint64_t x5 = rw64(r[10], r[11], r[12]) ^ tw64(q2.z, q2.w, q3.x);
+    const uint64_t x6 = rw64(r[12], r[13], r[14]) ^ tw64(q3.x, q3.y, q3.z);
+    const uint64_t x7 = rw64(r[14], r[15], r[16]) ^ tw64(q3.z, q3.w, t16);
+    uint64_t xs = x7;
+    uint32_t xb = 224u;
+    if (x6) { xs = x6; xb = 192u; }
+    if (x5) { xs = x5; xb = 160u; }
+    if (x4) { xs = x4; xb = 128u; }
+    if (x3) { xs = x3; xb = 96u; }
+    if (x2) { xs = x2; xb = 64u; }
+    if (x1) { xs = x1; xb = 32u; }
+    if (x0) { xs = x0; xb = 0u; }
+    const uint32_t ext = xs ? xb + ((uint32_t)(__ffsll((long long)xs) - 1) >> 1) : 256u;
+    *left_out = left;
+    *ext_out = ext < rem ? ext : rem;
+}
+
 // Bytes outside ACGT cut a read into segments no match can cross (a dict lookup of a window over
 // such a byte misses, PE_Inference.py:25-26).  `inv4` lists up to four such positions of an end
 // (one byte each, 0xFF = none; ends with more go to the overflow path): is the seed at j clean, and
@@ -331,10 +396,14 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
 #define STD_K 56u   // k + 1
 #define STD_W 31u   // seed length and probe stride that follow from it (seed_geometry)
 #define STD_S 26u
-template <bool FAST, uint32_t SW, uint32_t SP>
+// MODE 0: generic loops (masked reads through the validity mask, any stride / read length);
+//      1: straight-line comparison, stride <= 32, reads <= w + 160; 2: the same for stride <= 128, reads <= w + 256.
+template <int MODE, uint32_t SW, uint32_t SP>
 __global__ void __launch_bounds__(TPB)
-__attribute__((amdgpu_waves_per_eu(TILES_WAVES, TILES_WAVES)))
+__attribute__((amdgpu_waves_per_eu(MODE == 2 ? TILES_WAVES - 1 : TILES_WAVES, MODE == 2 ? TILES_WAVES - 1 : TILES_WAVES)))
 k_pe_tiles(PeParams P) {
+    constexpr bool FAST = MODE != 0;
+    constexpr uint32_t AB = MODE == 2 ? 9u : 8u;  // bits of the read offset packed under the node length (credit / P4)
     constexpr bool STD = SW != 0u;
     constexpr uint32_t STD_WPE = SW, STD_PMAX = SP;
     const uint32_t tid = threadIdx.x;
@@ -415,7 +484,7 @@ k_pe_tiles(PeParams P) {
                 atomicMin(&s_hminp[at], minp);
                 // (straight-line instantiations: reads <= 191 bases, so the node length rides in the
                 // upper 24 bits -- equal for every update of the slot -- and P4 needs no header)
-                atomicMin(&s_hminj[at], FAST ? (nlen << 8) | a : a);
+                atomicMin(&s_hminj[at], FAST ? (nlen << AB) | a : a);
                 placed = true;
                 break;
             }
@@ -672,7 +741,8 @@ k_pe_tiles(PeParams P) {
                     const uint32_t dr = nm.len - q - w;
                     rem = rem < dr ? rem : dr;
                     uint32_t left, ext;
-                    vs_agree_fast<STD>(s_words, e * wpe * 16u, tw, tb + q, cl, tb + q + w, rem, j, w, &left, &ext);
+                    if (MODE == 2) vs_agree_long(s_words, e * wpe * 16u, tw, tb + q, cl, tb + q + w, rem, j, w, &left, &ext);
+                    else vs_agree_fast<STD>(s_words, e * wpe * 16u, tw, tb + q, cl, tb + q + w, rem, j, w, &left, &ext);
                     len = left + w + ext;
                     if (left >= s || len < K) continue;  // an earlier probe lies inside this match and owns it / too short
                     a = j - left;
@@ -697,8 +767,8 @@ k_pe_tiles(PeParams P) {
                 uint32_t e = key >> 25, node = key & 0x01FFFFFFu;
                 uint32_t rlen = s_meta[e] & VS_LEN_MASK;
                 const uint32_t hj = s_hminj[i];
-                const uint32_t nlen = FAST ? hj >> 8 : P.idx.meta[node].len;
-                const uint32_t minj = FAST ? hj & 0xFFu : hj;
+                const uint32_t nlen = FAST ? hj >> AB : P.idx.meta[node].len;
+                const uint32_t minj = FAST ? hj & ((1u << AB) - 1u) : hj;
                 if (FAST ? vs_accept32(s_hcnt[i], s_hminp[i], minj, nlen, rlen, K) : vs_accept(s_hcnt[i], s_hminp[i], minj, nlen, rlen, K)) {
                     uint32_t k2 = atomicAdd(&s_ns[e], 1u);
                     if (k2 < LC) s_list[e * LC + k2] = node; else atomicOr(&s_state[e], 2u);
@@ -1237,6 +1307,15 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     if (const char *ev = getenv("VS_EPT")) ept = (uint32_t)atoi(ev) & ~1u;
     if (ept < 2 || ept > 128) ept = 64;
     while (ept > 2 && (ept * pmax > NI_CAP || lds_bytes(ept, pmax, ept * wpe) > LDS_BUDGET_BYTES)) ept -= 2;
+    // (LDS is handed out in 1280-byte pieces: 32 000 B per workgroup lets five share a CU, 40 000 four.  A tile of
+    // at least 32 ends that fits one of these is taken over a larger one that wastes the rest.)
+    if (!getenv("VS_EPT")) {
+        for (size_t fit : {(size_t)32000, (size_t)40000}) {
+            uint32_t e2 = ept;
+            while (e2 > 32 && lds_bytes(e2, pmax, e2 * wpe) > fit) e2 -= 2;
+            if (lds_bytes(e2, pmax, e2 * wpe) <= fit) { ept = e2; break; }
+        }
+    }
     size_t lds = lds_bytes(ept, pmax, ept * wpe);
     if (lds > 160u * 1024u)
         return vs_fail(ctx, VS_E_RANGE, "reads of %u bases with k+1=%u need %zu B of LDS per pair (limit 160 KiB)", maxlen, idx.K, lds);
@@ -1355,11 +1434,15 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         else if (wpe == 8u && pmax == 4u) std_shape = 2;
         else if (wpe == 7u && pmax == 3u) std_shape = 3;
     }
-    const void *tiles_fn = std_shape == 1   ? (const void *)k_pe_tiles<true, 10u, 5u>
-                           : std_shape == 2 ? (const void *)k_pe_tiles<true, 8u, 4u>
-                           : std_shape == 3 ? (const void *)k_pe_tiles<true, 7u, 3u>
-                           : fast           ? (const void *)k_pe_tiles<true, 0u, 0u>
-                                            : (const void *)k_pe_tiles<false, 0u, 0u>;
+    // longer strides and reads (k = 127 with 2 x 250 bases): the straight-line kernel with more windows
+    const bool fast_long = !fast && (!reads->d_mask || reads->d_inv4) && idx.s <= 128u && maxlen <= idx.w + 256u &&
+                           ctx->max_node_len < (1u << 23) && !(getenv("VS_NO_FAST") && atoi(getenv("VS_NO_FAST")) != 0);
+    const void *tiles_fn = std_shape == 1   ? (const void *)k_pe_tiles<1, 10u, 5u>
+                           : std_shape == 2 ? (const void *)k_pe_tiles<1, 8u, 4u>
+                           : std_shape == 3 ? (const void *)k_pe_tiles<1, 7u, 3u>
+                           : fast           ? (const void *)k_pe_tiles<1, 0u, 0u>
+                           : fast_long      ? (const void *)k_pe_tiles<2, 0u, 0u>
+                                            : (const void *)k_pe_tiles<0, 0u, 0u>;
     if (lds > 64u * 1024u)
         VS_HIP(ctx, hipFuncSetAttribute(tiles_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (getenv("VS_DEBUG_OCC")) {
@@ -1409,21 +1492,24 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     }
     VS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     if (!d_node_mat) VS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
-    ctx->last_kernel = std_shape == 1   ? "k_pe_tiles<true, 10u, 5u>"
-                       : std_shape == 2 ? "k_pe_tiles<true, 8u, 4u>"
-                       : std_shape == 3 ? "k_pe_tiles<true, 7u, 3u>"
-                       : fast           ? "k_pe_tiles<true, 0u, 0u>"
-                                        : "k_pe_tiles<false, 0u, 0u>";
+    ctx->last_kernel = std_shape == 1   ? "k_pe_tiles<1, 10u, 5u>"
+                       : std_shape == 2 ? "k_pe_tiles<1, 8u, 4u>"
+                       : std_shape == 3 ? "k_pe_tiles<1, 7u, 3u>"
+                       : fast           ? "k_pe_tiles<1, 0u, 0u>"
+                       : fast_long      ? "k_pe_tiles<2, 0u, 0u>"
+                                        : "k_pe_tiles<0, 0u, 0u>";
     if (std_shape == 1)
-        hipLaunchKernelGGL((k_pe_tiles<true, 10u, 5u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
+        hipLaunchKernelGGL((k_pe_tiles<1, 10u, 5u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
     else if (std_shape == 2)
-        hipLaunchKernelGGL((k_pe_tiles<true, 8u, 4u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
+        hipLaunchKernelGGL((k_pe_tiles<1, 8u, 4u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
     else if (std_shape == 3)
-        hipLaunchKernelGGL((k_pe_tiles<true, 7u, 3u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
+        hipLaunchKernelGGL((k_pe_tiles<1, 7u, 3u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
     else if (fast)
-        hipLaunchKernelGGL((k_pe_tiles<true, 0u, 0u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
+        hipLaunchKernelGGL((k_pe_tiles<1, 0u, 0u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
+    else if (fast_long)
+        hipLaunchKernelGGL((k_pe_tiles<2, 0u, 0u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
     else
-        hipLaunchKernelGGL((k_pe_tiles<false, 0u, 0u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
+        hipLaunchKernelGGL((k_pe_tiles<0, 0u, 0u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
     if (d_node_mat) {
         // the last tile may be partly empty: its unused rows must read as length 0
         const uint64_t used_ends = 2ull * n_pairs;
