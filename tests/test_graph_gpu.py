@@ -323,3 +323,25 @@ def test_cli_without_pe_text_gives_the_same_strains(tmp_path):
     assert not os.path.exists(os.path.join(out, "aln", "pe_info"))
     problems, _ = compare(case, out, skip=("aln/pe_info", "aln/st_info"))
     assert not problems, problems
+
+
+@pytest.mark.parametrize("name", ["hiv_like_k55", "ten_strain_k31"])
+def test_reference_shaped_driver_on_the_device(backend, name, tmp_path):
+    """The reference's own call sequence and argument lists (vstrains_amd/graph/reference_api.py)
+    with the HIP backend behind them: process_pe_info builds the link table on the device from the
+    two text files, every stage runs its kernels, and the outputs equal the reference's."""
+    from graph_case import Case, compare, quiet_logger
+    from test_reference_api_cpu import reference_shaped_driver
+    from vstrains_amd.graph import reference_api as api
+
+    case = Case(name)
+    api.set_backend(backend)
+    try:
+        inp = case.inputs(str(tmp_path))
+        out = str(tmp_path / "out")
+        reference_shaped_driver(case.args(inp, out), quiet_logger(), case)
+    finally:
+        api.set_backend(None)
+    problems, _ = compare(case, out)
+    binding = [p for p in problems if p.split(" ", 1)[1] not in case.meta["differs_under_other_hashseeds"]]
+    assert not binding, binding

@@ -233,5 +233,9 @@ class HipBackend:
             raise RuntimeError("node order of %s differs from the stage graph" % gfa)
         return HipPeLinks.from_counter(self.ctx, counter, names)
 
+    def links_from_files(self, names: Sequence[str], pe_file: str, st_file: str) -> HipPeLinks:
+        """``process_pe_info`` (IO.py:598-627) from the two text files, table resident on the device."""
+        return HipPeLinks.from_files(self.ctx, list(names), pe_file, st_file)
+
     def live_links(self, table: PeLinks) -> LiveLinks:
         return LiveLinks(table)
