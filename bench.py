@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time (0 = skip)")
     ap.add_argument("--no-extract", action="store_true", help="skip the strain-extract leg (kernel experiments)")
     ap.add_argument("--extract", action="store_true", help="run the strain-extract leg also for configs 3 / 4")
-    ap.add_argument("--ingest-pairs", type=int, default=1_000_000,
+    ap.add_argument("--ingest-pairs", type=int, default=4_000_000,
                     help="pairs written as FASTQ text and timed through the native ingest (0 = skip)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -320,29 +320,42 @@ def fastq_ingest(ctx, host, st, cum, seed, L, k, sub_thresh, n_thresh, M, work_d
     text = text.reshape(M, 2, L).copy()
     text[(flags.reshape(M, 2) & 1).astype(bool), 0] = ord("N")
     paths = []
-    qual = b"I" * L
+    digits = (np.arange(M, dtype=np.int64)[:, None] // 10 ** np.arange(8, -1, -1, dtype=np.int64)[None, :]) % 10
     for w, tag in enumerate(("f", "r")):
+        # fixed-width records "@f000000123\n<seq>\n+\n<qual>\n", assembled as one byte matrix
+        rec = np.empty((M, 2 + 9 + 1 + L + 3 + L + 1), dtype=np.uint8)
+        rec[:, 0] = ord("@")
+        rec[:, 1] = ord(tag)
+        rec[:, 2:11] = digits + ord("0")
+        rec[:, 11] = ord("\n")
+        rec[:, 12:12 + L] = text[:, w]
+        rec[:, 12 + L:15 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+        rec[:, 15 + L:15 + 2 * L] = ord("I")
+        rec[:, 15 + 2 * L] = ord("\n")
         path = os.path.join(work_dir, "ingest_%s.fq" % tag)
-        with open(path, "wb") as fh:
-            rows = [b"@%s%d\n%s\n+\n%s\n" % (tag.encode(), i, text[i, w].tobytes(), qual) for i in range(M)]
-            fh.write(b"".join(rows))
+        rec.tofile(path)
         paths.append(path)
     size = sum(os.path.getsize(p) for p in paths)
+    from vstrains_amd import pe_inference
+
+    counter = host.PeCounter(ctx)
+    warm = host.FastqPair(paths[0], paths[1], ctx)  # (first use: pinned staging and device buffers get allocated)
+    pe_inference.count_fastq(ctx, warm, counter, 0, min(len(warm), 2 * pe_inference.BATCH_PAIRS))
+    warm.close()
+    counter.reset()
     t0 = time.perf_counter()
     fq = host.FastqPair(paths[0], paths[1], ctx)
     t1 = time.perf_counter()
-    counter = host.PeCounter(ctx)
-    block = fq.block(0, len(fq))
-    ctx.sync()
-    t2 = time.perf_counter()
-    counter.add(block)
-    ctx.sync()
+    pe_inference.count_fastq(ctx, fq, counter, 0, len(fq))
     torch.cuda.synchronize()
-    t3 = time.perf_counter()
+    t2 = time.perf_counter()
+    n = len(fq)
     fq.close()
-    return {"pairs": len(fq), "fastq_bytes": size, "host_threads": os.cpu_count(),
-            "open_index_s": t1 - t0, "gather_upload_pack_s": t2 - t1, "count_s": t3 - t2,
-            "pairs_per_s": len(fq) / (t3 - t0), "note": "files in page cache; PCIe-inclusive; never reported as value"}
+    return {"pairs": n, "fastq_bytes": size, "host_threads": os.cpu_count(),
+            "open_index_s": t1 - t0, "pack_upload_count_s": t2 - t1,
+            "pairs_per_s": n / (t2 - t0), "pairs_per_s_after_open": n / (t2 - t1),
+            "note": "files in page cache; blocks of %d pairs, host packing of block i+1 overlapped with the device counting block i; "
+                    "PCIe-inclusive; never reported as value" % pe_inference.BATCH_PAIRS}
 
 
 def cpu_baseline(ctx, host, st, g, cum, seed, L, k, sub_thresh, n_thresh, R, target_s):

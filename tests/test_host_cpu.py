@@ -317,9 +317,20 @@ def test_native_fastq_ingest_odd_inputs(tmp_path):
         assert len(fq) == len(want), name
         assert [fq.sequence(0, i) for i in range(len(want))] == want, name
         fq.close()
+    # non-ASCII bytes: fine in header / quality lines (text mode decodes them, nothing uses them),
+    # refused in a sequence line -- where the bytes are first read
+    ok = tmp_path / "utf8_header.fq"
+    ok.write_bytes("@r\u00e9ad 1\nACGT\n+\nII\u00e9I\n".encode("utf-8"))
+    fq = host.FastqPair(str(ok), str(ok))
+    assert len(fq) == 1 and fq.sequence(0, 0) == "ACGT"
+    fq.close()
     bad = tmp_path / "bad.fq"
     bad.write_bytes(b"@a\nAC\xc3\xa9T\n+\nIIII\n")
+    fq = host.FastqPair(str(bad), str(bad))
     with pytest.raises(ValueError):
-        host.FastqPair(str(bad), str(bad))
+        fq.sequence(0, 0)
+    with pytest.raises(ValueError):
+        fq.gather(0, 1)
+    fq.close()
     with pytest.raises(FileNotFoundError):
         host.FastqPair(str(tmp_path / "nope.fq"), str(bad))

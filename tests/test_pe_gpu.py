@@ -459,3 +459,37 @@ def test_rccl_allreduce_through_the_c_abi_one_rank(host, ctx):
     ctx.sync()
     assert torch.equal(wide, keep) and torch.equal(w0, keep[0]) and torch.equal(w1, keep[1])
     nat.check(ctx._h, L.vs_comm_destroy(ctx._h, comm))
+
+
+def test_fastq_block_refuses_non_ascii_sequence_bytes_and_takes_dirty_reads(host, ctx, tmp_path):
+    """vs_fastq_block packs on the host cores: a byte >= 0x80 in a sequence line is refused there
+    (ValueError; a header may hold UTF-8), a block with lower-case / IUPAC bytes falls back to the
+    device packer (mask + position lists) and counts like the oracle."""
+    bad = tmp_path / "bad.fq"
+    bad.write_bytes("@r\u00e9ad\nACGTACGTAC\n+\nIIIIIIIIII\n@b\nAC\u00e9TACGTAC\n+\nIIIIIIIIII\n".encode("utf-8"))
+    fq = host.FastqPair(str(bad), str(bad), ctx)
+    with pytest.raises(ValueError):
+        fq.block(0, len(fq))
+    fq.close()
+    g, f, r = _dense_case(21, 700, 90, seed=99, snp=0.03)
+    rng = np.random.default_rng(1)
+    for lst in (f, r):
+        for i in rng.choice(len(lst), size=80, replace=False):
+            s_ = lst[int(i)]
+            p_ = int(rng.integers(0, len(s_)))
+            lst[int(i)] = s_[:p_] + str(rng.choice(list("nRYacgt*N"))) + s_[p_ + 1:]
+    from vstrains_amd import synth
+
+    (tmp_path / "f.fq").write_text(synth.fastq_text(f, "f"))
+    (tmp_path / "r.fq").write_text(synth.fastq_text(r, "r"))
+    ctx.build_index(g.seqs, 21)
+    counter = host.PeCounter(ctx)
+    fq = host.FastqPair(str(tmp_path / "f.fq"), str(tmp_path / "r.fq"), ctx)
+    from vstrains_amd import pe_inference
+
+    pe_inference.count_fastq(ctx, fq, counter, 0, len(fq), batch=256)  # several blocks, staging sets alternate
+    fq.close()
+    node_mat, short_mat, stats = counter.result()
+    ref = pe_oracle_c.Oracle(g.seqs, 21).count_pairs(f, r)
+    assert np.array_equal(node_mat, ref[0]) and np.array_equal(short_mat, ref[1])
+    assert stats == tuple(int(x) for x in ref[2])

@@ -16,6 +16,37 @@ int vs_fail(vs_ctx *ctx, int code, const char *fmt, ...) {
     return code;
 }
 
+void *vs_cache_alloc(vs_ctx *ctx, size_t bytes) {
+    if (!bytes) bytes = 16;
+    for (auto &b : ctx->cache)
+        if (!b.used && b.cap >= bytes && b.cap <= 2 * bytes + (1u << 20)) {
+            b.used = true;
+            return b.p;
+        }
+    void *p = nullptr;
+    const size_t cap = bytes + bytes / 8;  // (blocks of one file differ a little in size)
+    if (hipMalloc(&p, cap) != hipSuccess) return nullptr;
+    ctx->cache.push_back({p, cap, true});
+    return p;
+}
+
+void vs_cache_release(vs_ctx *ctx, void *p) {
+    if (!p) return;
+    size_t idle = 0;
+    for (auto &b : ctx->cache)
+        if (b.p == p) b.used = false;
+    for (auto &b : ctx->cache)
+        if (!b.used) idle++;
+    if (idle > 24) {  // do not hoard: drop the idle ones
+        std::vector<vs_ctx::CachedBuf> keep;
+        for (auto &b : ctx->cache) {
+            if (b.used) keep.push_back(b);
+            else (void)hipFree(b.p);
+        }
+        ctx->cache.swap(keep);
+    }
+}
+
 extern "C" {
 
 int vs_abi_version(void) { return VS_ABI_VERSION; }
@@ -79,6 +110,7 @@ void vs_ctx_destroy(vs_ctx *ctx) {
         if (q) (void)hipFree(q);
     for (void *q : ctx->scratch)
         if (q) (void)hipFree(q);
+    for (auto &b : ctx->cache) (void)hipFree(b.p);
     for (int i = 0; i < 5; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     delete ctx;

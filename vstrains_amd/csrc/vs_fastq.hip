@@ -4,10 +4,13 @@
 // and a lone "\r" both end a line.  A final line without a newline still loses its last (real)
 // character.  total = min(len_f // 4, len_r // 4).
 //
-// vs_fastq_open maps both files and indexes the sequence lines (newline counting and line
-// location split over the host cores); vs_fastq_block gathers the sequences of a record range
-// into one interleaved ASCII buffer (forward, reverse, forward, ...) on all cores and hands it to
-// vs_reads_pack, which packs on the device.  No Python objects, no per-record allocation.
+// vs_fastq_open maps both files and indexes the sequence lines in ONE pass over the text (every
+// host core takes a byte range and notes where its newlines are; line numbers follow from the
+// per-range counts).  vs_fastq_block packs the sequences of a record range to 2 bits per base ON
+// THE HOST CORES, straight into pinned staging (a quarter of the ASCII bytes cross PCIe, no device
+// packing pass), and enqueues the upload into device buffers recycled from earlier blocks; two
+// staging sets alternate, so the cores can pack block i+1 while block i is uploaded and counted.
+// No Python objects, no per-record allocation.
 #include <errno.h>
 #include <fcntl.h>
 #include <string.h>
@@ -67,22 +70,38 @@ int map_file(vs_ctx *ctx, const char *path, FqFile &f) {
 // Index the sequence lines of one file.
 int index_file(vs_ctx *ctx, const char *path, FqFile &f) {
     const unsigned T = n_threads();
-    // bytes >= 0x80 would be decoded (or rejected) by Python's text mode; not reproduced
-    {
-        std::vector<int> bad(T, 0), cr(T, 0);
+    std::vector<std::vector<uint64_t>> pos(T);
+    std::vector<uint64_t> nl(T + 1, 0);
+    // One pass: every part notes the positions of its newlines, a piece at a time (a piece is first
+    // searched for '\r', then for '\n', while it is still in cache).
+    auto scan = [&](const uint8_t *txt, size_t n, bool look_for_cr) {
+        std::vector<int> cr(T, 0);
         parallel_for(T, [&](unsigned p) {
-            size_t lo = f.size * p / T, hi = f.size * (p + 1) / T;
-            for (size_t i = lo; i < hi; i++) {
-                uint8_t c = f.data[i];
-                if (c >= 0x80) { bad[p] = 1; break; }
-                if (c == '\r') cr[p] = 1;
+            size_t lo = n * p / T, hi = n * (p + 1) / T;
+            std::vector<uint64_t> &v = pos[p];
+            v.clear();
+            v.reserve((hi - lo) / 64 + 16);
+            for (size_t c0 = lo; c0 < hi; c0 += (256u << 10)) {
+                const size_t c1 = c0 + (256u << 10) < hi ? c0 + (256u << 10) : hi;
+                if (look_for_cr && !cr[p] && memchr(txt + c0, '\r', c1 - c0)) cr[p] = 1;
+                const uint8_t *q = txt + c0, *end = txt + c1;
+                while (q < end) {
+                    const uint8_t *r = (const uint8_t *)memchr(q, '\n', (size_t)(end - q));
+                    if (!r) break;
+                    v.push_back((uint64_t)(r - txt));
+                    q = r + 1;
+                }
             }
+            nl[p + 1] = v.size();
         });
-        for (unsigned p = 0; p < T; p++)
-            if (bad[p]) return vs_fail(ctx, VS_E_ARG, "%s holds non-ASCII bytes; the reference's text-mode decoding is not reproduced", path);
-        bool any_cr = false;
-        for (unsigned p = 0; p < T; p++) any_cr |= cr[p] != 0;
-        if (any_cr) {  // rare: make the universal-newline view once, then index that
+        bool any = false;
+        for (unsigned p = 0; p < T; p++) any |= cr[p] != 0;
+        return any;
+    };
+    // '\r' anywhere means universal-newline translation (rare): make that view once, then index it
+    {
+        const bool any_cr = scan(f.data, f.size, true);
+        if (any_cr) {
             f.translated.reserve(f.size);
             for (size_t i = 0; i < f.size; i++) {
                 uint8_t c = f.data[i];
@@ -94,24 +113,11 @@ int index_file(vs_ctx *ctx, const char *path, FqFile &f) {
                 }
             }
             if (f.translated.empty() && f.size) f.translated.push_back('\n');
+            scan(f.translated.data(), f.translated.size(), false);
         }
     }
     const uint8_t *txt = f.text();
     const size_t n = f.text_size();
-    // pass 1: newlines per part
-    std::vector<uint64_t> nl(T + 1, 0);
-    parallel_for(T, [&](unsigned p) {
-        size_t lo = n * p / T, hi = n * (p + 1) / T;
-        uint64_t c = 0;
-        const uint8_t *q = txt + lo, *end = txt + hi;
-        while (q < end) {
-            const uint8_t *r = (const uint8_t *)memchr(q, '\n', (size_t)(end - q));
-            if (!r) break;
-            c++;
-            q = r + 1;
-        }
-        nl[p + 1] = c;
-    });
     for (unsigned p = 0; p < T; p++) nl[p + 1] += nl[p];
     const uint64_t n_newlines = nl[T];
     const bool open_tail = n > 0 && txt[n - 1] != '\n';
@@ -119,35 +125,32 @@ int index_file(vs_ctx *ctx, const char *path, FqFile &f) {
     const uint64_t n_rec = f.n_lines / 4;
     f.seq_start.assign(n_rec, 0);
     f.seq_len.assign(n_rec, 0);
-    // pass 2: the newline that ends line L (0-based) is newline number L; a sequence line has
-    // L % 4 == 1; it starts right after newline L-1
+    // the newline that ends line L (0-based) is newline number L; a sequence line has L % 4 == 1; it
+    // starts right after newline L-1 (possibly the last one of an earlier part)
     parallel_for(T, [&](unsigned p) {
-        size_t lo = n * p / T, hi = n * (p + 1) / T;
-        uint64_t line = nl[p];  // index of the line that the next newline in this part ends
-        // start of that line: after the previous newline (possibly in an earlier part)
-        size_t start = 0;
-        if (lo > 0) {
-            const uint8_t *r = (const uint8_t *)memrchr(txt, '\n', lo);
-            start = r ? (size_t)(r - txt) + 1 : 0;
-        }
-        const uint8_t *q = txt + lo, *end = txt + hi;
-        while (q < end) {
-            const uint8_t *r = (const uint8_t *)memchr(q, '\n', (size_t)(end - q));
-            if (!r) break;
+        const std::vector<uint64_t> &v = pos[p];
+        if (v.empty()) return;
+        uint64_t prev_end = 0;  // one past the newline before this part's first one
+        bool have_prev = false;
+        for (unsigned pp = p; pp-- > 0;)
+            if (!pos[pp].empty()) { prev_end = pos[pp].back() + 1; have_prev = true; break; }
+        (void)have_prev;
+        uint64_t line = nl[p];
+        uint64_t start = prev_end;
+        for (size_t i = 0; i < v.size(); i++, line++) {
             if ((line & 3u) == 1u && (line >> 2) < n_rec) {
                 f.seq_start[line >> 2] = start;
-                f.seq_len[line >> 2] = (uint32_t)((size_t)(r - txt) - start);  // the dropped char is the newline
+                f.seq_len[line >> 2] = (uint32_t)(v[i] - start);  // the dropped char is the newline
             }
-            start = (size_t)(r - txt) + 1;
-            line++;
-            q = r + 1;
+            start = v[i] + 1;
         }
     });
     if (open_tail) {  // last line without newline: it loses a real character
         const uint64_t line = n_newlines;
         if ((line & 3u) == 1u && (line >> 2) < n_rec) {
-            const uint8_t *r = n ? (const uint8_t *)memrchr(txt, '\n', n) : nullptr;
-            size_t start = r ? (size_t)(r - txt) + 1 : 0;
+            uint64_t start = 0;
+            for (unsigned pp = T; pp-- > 0;)
+                if (!pos[pp].empty()) { start = pos[pp].back() + 1; break; }
             f.seq_start[line >> 2] = start;
             f.seq_len[line >> 2] = (uint32_t)(n - start - 1);
         }
@@ -166,15 +169,71 @@ void close_file(FqFile &f) {
 
 }  // namespace
 
+// pinned staging of one block in flight: packed words (+ pad), word offsets, lengths | flags
+struct FqStage {
+    uint32_t *words = nullptr, *woff = nullptr, *meta = nullptr;
+    size_t words_cap = 0, ends_cap = 0;
+    hipEvent_t done = nullptr;  // the uploads out of this set have finished
+    bool in_flight = false;
+};
+
 struct vs_fastq {
     FqFile f[2];
     uint64_t n_pairs = 0;
-    // pinned staging for vs_fastq_block (grow-only): the gather writes here, the upload reads here
-    uint8_t *stage = nullptr;
-    size_t stage_cap = 0;
-    uint64_t *stage_off = nullptr;
-    size_t stage_off_cap = 0;
+    FqStage stage[2];  // alternate: the cores fill one while the other is still being uploaded
+    unsigned next_stage = 0;
 };
+
+namespace {
+// 2-bit code of a sequence byte: 0..3 = ACGT, 4 = 'N', 5 = any other byte
+struct CodeLut {
+    uint8_t v[256];
+    CodeLut() {
+        for (int i = 0; i < 256; i++) v[i] = i < 128 ? 5 : 8;  // (8: non-ASCII, refused)
+        v['A'] = 0; v['C'] = 1; v['G'] = 2; v['T'] = 3; v['N'] = 4;
+    }
+};
+const CodeLut g_code;
+// Python's text mode decodes the file; header and quality lines may hold any valid UTF-8, but a
+// byte >= 0x80 inside a sequence line would count as a character of its own there, which packing by
+// bytes cannot mirror: such a file is refused where its sequence bytes are first read.
+const char *const NON_ASCII_MSG = "a sequence line holds non-ASCII bytes; the reference's text-mode decoding is not reproduced";
+inline bool has_high_bit(const uint8_t *q, uint32_t len) {
+    uint8_t acc = 0;
+    for (uint32_t i = 0; i < len; i++) acc |= q[i];
+    return (acc & 0x80u) != 0;
+}
+
+// pack one sequence; returns the flags (VS_FLAG_N / VS_FLAG_INVALID)
+inline uint32_t pack_sequence(const uint8_t *q, uint32_t len, uint32_t *out) {
+    uint32_t flags = 0;
+    const uint32_t nw = (len + 15u) >> 4;
+    for (uint32_t wi = 0; wi < nw; wi++) {
+        const uint32_t b0 = wi * 16u, m = len - b0 < 16u ? len - b0 : 16u;
+        uint32_t v = 0, odd = 0;
+        for (uint32_t i = 0; i < m; i++) {
+            const uint32_t c = g_code.v[q[b0 + i]];
+            v |= (c & 3u) << (2u * i);
+            odd |= c;
+        }
+        out[wi] = v;
+        if (odd > 3u) {  // rare: look again for which kind
+            for (uint32_t i = 0; i < m; i++) {
+                const uint32_t c = g_code.v[q[b0 + i]];
+                if (c == 4u) flags |= VS_FLAG_N; else if (c == 5u) flags |= VS_FLAG_INVALID; else if (c == 8u) flags |= 0x80u;
+            }
+            // (the code of such a byte is whatever its low bits say: masked out / never matched)
+            uint32_t v2 = 0;
+            for (uint32_t i = 0; i < m; i++) {
+                const uint32_t c = g_code.v[q[b0 + i]];
+                v2 |= (c > 3u ? 0u : c) << (2u * i);
+            }
+            out[wi] = v2;
+        }
+    }
+    return flags;
+}
+}  // namespace
 
 extern "C" {
 
@@ -200,8 +259,13 @@ int vs_fastq_open(vs_ctx *ctx, const char *fwd_path, const char *rve_path, vs_fa
 
 void vs_fastq_close(vs_fastq *fq) {
     if (!fq) return;
-    if (fq->stage) (void)hipHostFree(fq->stage);
-    if (fq->stage_off) (void)hipHostFree(fq->stage_off);
+    for (FqStage &st : fq->stage) {
+        if (st.in_flight && st.done) (void)hipEventSynchronize(st.done);
+        if (st.words) (void)hipHostFree(st.words);
+        if (st.woff) (void)hipHostFree(st.woff);
+        if (st.meta) (void)hipHostFree(st.meta);
+        if (st.done) (void)hipEventDestroy(st.done);
+    }
     close_file(fq->f[0]);
     close_file(fq->f[1]);
     delete fq;
@@ -222,6 +286,7 @@ int vs_fastq_sequence(const vs_fastq *fq, int which, uint64_t record, uint8_t *b
     const FqFile &f = fq->f[which];
     if (record >= f.seq_start.size()) return VS_E_RANGE;
     *len = f.seq_len[record];
+    if (has_high_bit(f.text() + f.seq_start[record], *len)) return vs_fail(nullptr, VS_E_ARG, "%s", NON_ASCII_MSG);
     if (buf && cap >= *len && *len) memcpy(buf, f.text() + f.seq_start[record], *len);
     return VS_OK;
 }
@@ -237,6 +302,7 @@ int vs_fastq_gather(const vs_fastq *fq, uint64_t first, uint64_t count, uint64_t
     }
     if (!ascii) return VS_OK;
     const unsigned T = n_threads();
+    std::vector<int> bad(T, 0);
     parallel_for(T, [&](unsigned p) {
         uint64_t lo = count * p / T, hi = count * (p + 1) / T;
         for (uint64_t r = lo; r < hi; r++) {
@@ -244,39 +310,128 @@ int vs_fastq_gather(const vs_fastq *fq, uint64_t first, uint64_t count, uint64_t
                 const FqFile &f = fq->f[w];
                 const uint32_t l = f.seq_len[first + r];
                 if (l) memcpy(ascii + off[2 * r + w], f.text() + f.seq_start[first + r], l);
+                if (has_high_bit(f.text() + f.seq_start[first + r], l)) bad[p] = 1;
             }
         }
     });
+    for (unsigned p = 0; p < T; p++)
+        if (bad[p]) return vs_fail(nullptr, VS_E_ARG, "%s", NON_ASCII_MSG);
     return VS_OK;
 }
 
 // Pairs [first, first+count) of the two files as a device read block (replaces
-// PE_Inference.py:158-159 for that range).
+// PE_Inference.py:158-159 for that range).  The uploads are enqueued on the ctx stream and not
+// waited for: the block is ready for anything enqueued behind them (vs_pe_count does).
 int vs_fastq_block(vs_ctx *ctx, vs_fastq *fq, uint64_t first, uint64_t count, vs_reads **out) {
     if (!ctx || !fq || !out) return vs_fail(ctx, VS_E_ARG, "vs_fastq_block: bad argument");
     if (first + count > fq->n_pairs) return vs_fail(ctx, VS_E_RANGE, "vs_fastq_block: pairs %llu..%llu of %llu", (unsigned long long)first, (unsigned long long)(first + count), (unsigned long long)fq->n_pairs);
+    *out = nullptr;
+    const uint64_t n_ends = 2 * count;
+    if (n_ends > 0xFFFFFFF0ull) return vs_fail(ctx, VS_E_RANGE, "vs_fastq_block: split the input into blocks of < 2^31 pairs");
     VS_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t need_off = sizeof(uint64_t) * (2 * count + 1);
-    if (fq->stage_off_cap < need_off) {
-        if (fq->stage_off) VS_HIP(ctx, hipHostFree(fq->stage_off));
-        fq->stage_off = nullptr;
-        fq->stage_off_cap = 0;
-        VS_HIP(ctx, hipHostMalloc((void **)&fq->stage_off, need_off + need_off / 4, hipHostMallocDefault));
-        fq->stage_off_cap = need_off + need_off / 4;
+    FqStage &st = fq->stage[fq->next_stage];
+    fq->next_stage ^= 1u;
+    if (!st.done) VS_HIP(ctx, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+    if (st.in_flight) {  // the block that used this set two calls ago
+        VS_HIP(ctx, hipEventSynchronize(st.done));
+        st.in_flight = false;
     }
-    int rc = vs_fastq_gather(fq, first, count, fq->stage_off, nullptr);
-    if (rc) return vs_fail(ctx, rc, "vs_fastq_block: gather failed");
-    const size_t need = fq->stage_off[2 * count] ? fq->stage_off[2 * count] : 1;
-    if (fq->stage_cap < need) {
-        if (fq->stage) VS_HIP(ctx, hipHostFree(fq->stage));
-        fq->stage = nullptr;
-        fq->stage_cap = 0;
-        VS_HIP(ctx, hipHostMalloc((void **)&fq->stage, need + need / 4, hipHostMallocDefault));
-        fq->stage_cap = need + need / 4;
+    const unsigned T = n_threads();
+    // words per thread range -> word offset of every end
+    if (st.ends_cap < n_ends + 1) {
+        if (st.woff) VS_HIP(ctx, hipHostFree(st.woff));
+        if (st.meta) VS_HIP(ctx, hipHostFree(st.meta));
+        st.woff = st.meta = nullptr;
+        st.ends_cap = 0;
+        const size_t cap = n_ends + n_ends / 8 + 16;
+        VS_HIP(ctx, hipHostMalloc((void **)&st.woff, sizeof(uint32_t) * cap, hipHostMallocDefault));
+        VS_HIP(ctx, hipHostMalloc((void **)&st.meta, sizeof(uint32_t) * cap, hipHostMallocDefault));
+        st.ends_cap = cap;
     }
-    rc = vs_fastq_gather(fq, first, count, fq->stage_off, fq->stage);
-    if (rc) return vs_fail(ctx, rc, "vs_fastq_block: gather failed");
-    return vs_reads_pack(ctx, fq->stage, fq->stage_off, 2 * count, out);
+    std::vector<uint64_t> part_words(T + 1, 0);
+    std::vector<uint32_t> part_max(T, 0);
+    parallel_for(T, [&](unsigned p) {
+        uint64_t lo = count * p / T, hi = count * (p + 1) / T, wsum = 0;
+        uint32_t mx = 0;
+        for (uint64_t r = lo; r < hi; r++)
+            for (int w2 = 0; w2 < 2; w2++) {
+                const uint32_t l = fq->f[w2].seq_len[first + r];
+                wsum += (l + 15u) >> 4;
+                mx = l > mx ? l : mx;
+            }
+        part_words[p + 1] = wsum;
+        part_max[p] = mx;
+    });
+    for (unsigned p = 0; p < T; p++) part_words[p + 1] += part_words[p];
+    const uint64_t words = part_words[T];
+    if (words > 0xFFFFFFF0ull) return vs_fail(ctx, VS_E_RANGE, "vs_fastq_block: block exceeds 2^32 packed words");
+    if (st.words_cap < words + VS_PAD_WORDS) {
+        if (st.words) VS_HIP(ctx, hipHostFree(st.words));
+        st.words = nullptr;
+        st.words_cap = 0;
+        const size_t cap = words + words / 8 + VS_PAD_WORDS;
+        VS_HIP(ctx, hipHostMalloc((void **)&st.words, sizeof(uint32_t) * cap, hipHostMallocDefault));
+        st.words_cap = cap;
+    }
+    std::vector<uint32_t> part_flags(T, 0);
+    parallel_for(T, [&](unsigned p) {
+        uint64_t lo = count * p / T, hi = count * (p + 1) / T;
+        uint64_t wat = part_words[p];
+        uint32_t any = 0;
+        for (uint64_t r = lo; r < hi; r++)
+            for (int w2 = 0; w2 < 2; w2++) {
+                const FqFile &f = fq->f[w2];
+                const uint32_t l = f.seq_len[first + r];
+                const uint32_t fl = pack_sequence(f.text() + f.seq_start[first + r], l, st.words + wat);
+                st.woff[2 * r + w2] = (uint32_t)wat;
+                st.meta[2 * r + w2] = l | (fl << 24);
+                any |= fl;
+                wat += (l + 15u) >> 4;
+            }
+        part_flags[p] = any;
+    });
+    st.woff[n_ends] = (uint32_t)words;
+    for (uint32_t i = 0; i < VS_PAD_WORDS; i++) st.words[words + i] = 0u;
+    uint32_t any = 0, maxlen = 0;
+    for (unsigned p = 0; p < T; p++) { any |= part_flags[p]; maxlen = part_max[p] > maxlen ? part_max[p] : maxlen; }
+    if (any & 0x80u) return vs_fail(ctx, VS_E_ARG, "%s", NON_ASCII_MSG);
+    if (any & VS_FLAG_INVALID) {
+        // some read holds a byte outside ACGTN (rare): the device packer also builds the validity
+        // mask and the position lists -- take that path with the plain bytes of this block
+        std::vector<uint64_t> off(n_ends + 1);
+        int rc = vs_fastq_gather(fq, first, count, off.data(), nullptr);
+        if (rc) return vs_fail(ctx, rc, "vs_fastq_block: gather failed");
+        std::vector<uint8_t> bytes(off[n_ends] ? off[n_ends] : 1);
+        rc = vs_fastq_gather(fq, first, count, off.data(), bytes.data());
+        if (rc) return vs_fail(ctx, rc, "vs_fastq_block: gather failed");
+        return vs_reads_pack(ctx, bytes.data(), off.data(), n_ends, out);
+    }
+    vs_reads *r = new vs_reads();
+    r->n_ends = n_ends;
+    r->n_words = words;
+    r->max_len = maxlen;
+    r->cached = true;
+    const size_t b_woff = sizeof(uint32_t) * (n_ends + 1), b_meta = sizeof(uint32_t) * (n_ends ? n_ends : 1);
+    const size_t b_words = sizeof(uint32_t) * (words + VS_PAD_WORDS);
+    r->d_woff = vs_cache_alloc(ctx, b_woff);
+    r->d_meta = vs_cache_alloc(ctx, b_meta);
+    r->d_words = vs_cache_alloc(ctx, b_words);
+    r->bytes = b_woff + b_meta + b_words;
+    if (!r->d_woff || !r->d_meta || !r->d_words) {
+        vs_reads_free(ctx, r);
+        return vs_fail(ctx, VS_E_OOM, "vs_fastq_block: device buffers for %llu ends", (unsigned long long)n_ends);
+    }
+    hipError_t e1 = hipMemcpyAsync(r->d_woff, st.woff, b_woff, hipMemcpyHostToDevice, ctx->stream);
+    if (e1 == hipSuccess && n_ends) e1 = hipMemcpyAsync(r->d_meta, st.meta, sizeof(uint32_t) * n_ends, hipMemcpyHostToDevice, ctx->stream);
+    if (e1 == hipSuccess) e1 = hipMemcpyAsync(r->d_words, st.words, b_words, hipMemcpyHostToDevice, ctx->stream);
+    if (e1 == hipSuccess) e1 = hipEventRecord(st.done, ctx->stream);
+    if (e1 != hipSuccess) {
+        vs_reads_free(ctx, r);
+        return vs_fail(ctx, VS_E_HIP, "vs_fastq_block: %s", hipGetErrorString(e1));
+    }
+    st.in_flight = true;
+    *out = r;
+    return VS_OK;
 }
 
 }  // extern "C"
@@ -348,6 +503,7 @@ extern "C" int vs_write_matrix_text(vs_ctx *ctx, const char *path, const uint8_t
     uint64_t done = 0;
     while (done < total) {
         ssize_t w = write(fd, buf + done, (size_t)std::min<uint64_t>(total - done, 1u << 30));
+        if (w < 0 && errno == EINTR) continue;
         if (w < 0) {
             int e = errno;
             close(fd);

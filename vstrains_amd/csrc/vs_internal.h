@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #include "../../include/vstrains_hip.h"
 
@@ -114,6 +115,10 @@ struct vs_ctx {
     // grow-only device scratch slots of the graph-stage entry points (no hipMalloc per call)
     void *scratch[32] = {};
     size_t scratch_cap[32] = {};
+    // device buffers of freed read blocks, kept for the next block of about the same size (the
+    // FASTQ ingest makes and frees one block per million pairs)
+    struct CachedBuf { void *p; size_t cap; bool used; };
+    std::vector<CachedBuf> cache;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double last_ms[3] = {0, 0, 0};
     const char *last_kernel = "";  // mapping-kernel instantiation of the last vs_pe_count
@@ -123,6 +128,7 @@ struct vs_ctx {
 struct vs_reads {
     uint64_t n_ends = 0, n_words = 0, max_len = 0, n_invalid = 0, bytes = 0;
     void *d_woff = nullptr, *d_meta = nullptr, *d_words = nullptr, *d_mask = nullptr, *d_inv4 = nullptr;
+    bool cached = false;  // buffers came from vs_cache_alloc
     VsReadsDev dev() const {
         VsReadsDev r;
         r.n_ends = n_ends;
@@ -136,6 +142,9 @@ struct vs_reads {
 };
 
 int vs_fail(vs_ctx *ctx, int code, const char *fmt, ...);
+// grow-only cache of device buffers (see vs_ctx::cache); NULL on allocation failure
+void *vs_cache_alloc(vs_ctx *ctx, size_t bytes);
+void vs_cache_release(vs_ctx *ctx, void *p);
 extern "C" void vs_ctx_free_index(vs_ctx *ctx);
 #define VS_HIP(ctx, call)                                                                  \
     do {                                                                                   \

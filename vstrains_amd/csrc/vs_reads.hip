@@ -113,8 +113,11 @@ extern "C" void vs_reads_free(vs_ctx *ctx, vs_reads *r) {
         (void)hipStreamSynchronize(ctx->stream);
     }
     void *ps[] = {r->d_woff, r->d_meta, r->d_words, r->d_mask, r->d_inv4};
-    for (void *p : ps)
-        if (p) (void)hipFree(p);
+    for (void *p : ps) {
+        if (!p) continue;
+        if (r->cached && ctx) vs_cache_release(ctx, p);
+        else (void)hipFree(p);
+    }
     delete r;
 }
 

@@ -75,9 +75,18 @@ class FastqPair:
         except Exception:
             pass
 
+    @staticmethod
+    def _raise(ctx_h, rc):
+        msg = nat.lib().vs_last_error(ctx_h).decode("utf-8", "replace")
+        if "non-ASCII" in msg:
+            raise ValueError(msg)
+        raise nat.NativeError(rc, msg)
+
     def sequence(self, which: int, record: int) -> str:
         n = C.c_uint32(0)
         rc = nat.lib().vs_fastq_sequence(self._h, which, record, None, 0, C.byref(n))
+        if rc == nat.VS_E_ARG and "non-ASCII" in nat.lib().vs_last_error(None).decode("utf-8", "replace"):
+            self._raise(None, rc)
         if rc != nat.VS_OK:
             raise IndexError(record)
         buf = np.zeros(max(n.value, 1), dtype=np.uint8)
@@ -88,12 +97,16 @@ class FastqPair:
         off = np.zeros(2 * count + 1, dtype=np.uint64)
         assert nat.lib().vs_fastq_gather(self._h, first, count, off.ctypes.data, None) == nat.VS_OK
         data = np.zeros(max(int(off[-1]), 1), dtype=np.uint8)
-        assert nat.lib().vs_fastq_gather(self._h, first, count, off.ctypes.data, data.ctypes.data) == nat.VS_OK
+        rc = nat.lib().vs_fastq_gather(self._h, first, count, off.ctypes.data, data.ctypes.data)
+        if rc != nat.VS_OK:
+            self._raise(None, rc)
         return data, off
 
     def block(self, first: int, count: int) -> "ReadBlock":
         h = C.c_void_p()
-        nat.check(self._ctx._h, nat.lib().vs_fastq_block(self._ctx._h, self._h, first, count, C.byref(h)))
+        rc = nat.lib().vs_fastq_block(self._ctx._h, self._h, first, count, C.byref(h))
+        if rc != nat.VS_OK:
+            self._raise(self._ctx._h, rc)  # ValueError for non-ASCII sequence bytes (a text-mode open would decode them)
         return ReadBlock(self._ctx, h)
 
 

@@ -41,19 +41,28 @@ def count_links(ctx, gfa: str, fwd: str, rve: str, kmer_size: int):
     # counters are summed over ranks afterwards (RCCL all-reduce); a single process takes everything
     rank, world = _rank_world()
     first, last = shard_range(total, rank, world)
-    for lo in range(first, last, BATCH_PAIRS):
-        hi = min(last, lo + BATCH_PAIRS)
-        if rank == 0:
-            for mark in range(((lo + 99999) // 100000) * 100000, hi, 100000):
-                print("Number of processed reads: ", mark)  # :156-157 (rank 0's own block under torchrun)
-        block = fq.block(lo, hi - lo)
-        counter.add(block)
-        ctx.sync()
-        block.free()
+    count_fastq(ctx, fq, counter, first, last, progress=(rank == 0))
     fq.close()
     if world > 1:
         counter.all_reduce()
     return ids, counter
+
+
+def count_fastq(ctx, fq, counter, first: int, last: int, batch: int = BATCH_PAIRS, progress: bool = False):
+    """Pairs [first, last) of an indexed FASTQ pair through the counters, one block of ``batch``
+    pairs at a time.  The host cores pack block i+1 (``vs_fastq_block``: 2 bits per base into
+    pinned staging, upload enqueued) while the device still counts block i."""
+    spans = [(lo, min(last, lo + batch)) for lo in range(first, last, batch)]
+    nxt = fq.block(spans[0][0], spans[0][1] - spans[0][0]) if spans else None
+    for i, (lo, hi) in enumerate(spans):
+        if progress:
+            for mark in range(((lo + 99999) // 100000) * 100000, hi, 100000):
+                print("Number of processed reads: ", mark)  # :156-157 (rank 0's own block under torchrun)
+        block = nxt
+        counter.add(block)  # enqueued behind the block's uploads
+        nxt = fq.block(spans[i + 1][0], spans[i + 1][1] - spans[i + 1][0]) if i + 1 < len(spans) else None
+        ctx.sync()
+        block.free()
 
 
 def write_info_files(out_dir: str, ids, counter):

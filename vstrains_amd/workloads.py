@@ -11,6 +11,9 @@ import numpy as np
 # has the node count BASELINE names; the 10.8 kb genome of SURVEY's config 3 tops out at 4.5 k
 # nodes with 15 strains, so configs[2] uses 13.2 kb to reach the "5k-node GFA" of the metric.
 CONFIGS = {
+    0: dict(tag="configs[0]: 6-strain HIV-like quasispecies, 200-node GFA (the reference's own CPU-runnable case)", n_strains=6,
+            genome_len=9700, snp_rate=0.007, abundance_ratio=0.8, read_len=150, k=55, total_pairs=100_000, gpus=1, seed=1001,
+            extract=True),
     1: dict(tag="configs[1]: 5-strain HCV-like mix, 1k-node GFA", n_strains=5, genome_len=9600, snp_rate=0.055,
             abundance_ratio=0.8, read_len=150, k=55, total_pairs=1_000_000, gpus=1, seed=1002, extract=True),
     2: dict(tag="configs[2]: 15-strain ZIKV-like synthetic, 5k-node GFA", n_strains=15, genome_len=13200, snp_rate=0.085,
