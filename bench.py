@@ -281,7 +281,7 @@ def main():
         if world == 1 and args.ingest_pairs > 0 and not args.no_extract:
             out["fastq_ingest"] = fastq_ingest(ctx, host, st, cum, seed, L, k, sub_thresh, n_thresh, min(args.ingest_pairs, R), work_dir)
         if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(ctx, host, st, g, cum, seed, L, k, sub_thresh, n_thresh, R, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(ctx, host, st, g, cum, seed, L, k, sub_thresh, n_thresh, R, args.cpu_seconds, args.config)
         print(json.dumps(out))
     if use_dist:
         import torch.distributed as dist
@@ -358,7 +358,7 @@ def fastq_ingest(ctx, host, st, cum, seed, L, k, sub_thresh, n_thresh, M, work_d
                     "PCIe-inclusive; never reported as value" % pe_inference.BATCH_PAIRS}
 
 
-def cpu_baseline(ctx, host, st, g, cum, seed, L, k, sub_thresh, n_thresh, R, target_s):
+def cpu_baseline(ctx, host, st, g, cum, seed, L, k, sub_thresh, n_thresh, R, target_s, config=2):
     """oracle/pe_oracle.c (1 thread) on the first M pairs of rank 0's stream; M sized from a
     short calibration so the whole leg stays near target_s.  Also the checker: the GPU counters
     for the same M pairs must be identical (compared cell by cell through the oracle's sparse
@@ -389,11 +389,45 @@ def cpu_baseline(ctx, host, st, g, cum, seed, L, k, sub_thresh, n_thresh, R, tar
         flat = chk.mats[mat].reshape(-1)
         got = flat[torch.from_numpy(cells).to(flat.device)].cpu().numpy().view(np.uint32).astype(np.int64)
         same = same and bool(np.array_equal(got, counts)) and int(flat.sum(dtype=torch.int64).item()) == int(counts.sum())
-    return {
+    out = {
         "value": M / secs, "unit": "pairs/s", "cores": 1, "kind": "port",
         "sample": "first %d pairs of the same seeded stream (%.1f s; table build %.2f s not included)" % (M, secs, build_s),
         "gpu_matches_on_sample": bool(same),
     }
+    # every host core (information only; the reference itself is single-threaded): a child process forks
+    # one worker per core, each with its own table and its own slice of the stream
+    try:
+        import pickle
+        import subprocess
+        import tempfile
+
+        cores = os.cpu_count() or 1
+        with tempfile.NamedTemporaryFile(suffix=".pkl", delete=False) as fh:
+            pickle.dump(dict(seqs=list(g.seqs), k=k, genomes=list(st.genomes), cum=np.asarray(cum), seed=seed, first_pair=R,
+                             L=L, sub_thresh=sub_thresh, n_thresh=n_thresh, rate_hint=0.6 * M / secs), fh)
+        proc = subprocess.run([sys.executable, "-m", "oracle.cpu_all_cores", fh.name, str(cores), str(min(target_s, 8.0))],
+                              cwd=ROOT, capture_output=True, text=True, timeout=600)
+        os.unlink(fh.name)
+        allc = json.loads(proc.stdout.strip().splitlines()[-1])
+        out["all_cores"] = {"value": allc["pairs_per_s"], "unit": "pairs/s", "cores": allc["workers"],
+                            "sample": "%d pairs in %.1f s (slowest worker)" % (allc["pairs"], allc["seconds"])}
+    except Exception as err:
+        out["all_cores"] = {"error": repr(err)}
+    # how this box's port relates to the reference script itself (which cannot travel here): measured
+    # in the build container by tools/time_reference.py on the same workload
+    try:
+        with open(os.path.join(ROOT, "profiles", "r2", "cpu_reference.json")) as fh:
+            ref = json.load(fh)["configs"].get("configs[%d]" % config)
+        if ref:
+            out["reference_ratio"] = ref["port_over_reference"]
+            out["reference"] = {"pairs_per_s_build_container": ref["reference"]["pairs_per_s"],
+                                "port_pairs_per_s_build_container": ref["port"]["pairs_per_s"],
+                                "estimated_pairs_per_s_on_this_host": out["value"] / ref["port_over_reference"],
+                                "source": "profiles/r2/cpu_reference.json: real VStrains_PE_Inference.py vs the port on the same "
+                                          "%d pairs, same box, 1 core each" % ref["pairs"]}
+    except Exception:
+        pass
+    return out
 
 
 if __name__ == "__main__":

@@ -16,6 +16,7 @@ the seed and pinned by digest), and the reference's outputs in digest form (sequ
 by ``len:md5[:12]``; pe_info/st_info as their non-zero lines).  No reference source is copied.
 
     python tests/golden/make_graph_golden.py [case ...]
+    python tests/golden/make_graph_golden.py --search-invariant [n_seeds]   (prints candidate case entries)
 """
 import hashlib
 import json
@@ -74,6 +75,26 @@ CASES = {
                              read_len=100, seed=81, abundance_ratio=0.55, sub_rate=0.004,
                              scramble=True), []),
 }
+
+
+# Cases found by ``--search-invariant`` (below): the reference's outputs are the same under both
+# in-edge-order models of the stand-in although its log shows branch splits by links, coverage
+# matching and trivial splits -- what they pin does not hinge on the recalled adjacency order.
+INVARIANT_CASES = {
+    "inv3_k21_s200": (dict(n_strains=3, genome_len=2600, snp_rate=0.009, k=21, n_pairs=5000, read_len=100,
+                           abundance_ratio=0.55, seed=200), []),
+    "inv4_k21_s200": (dict(n_strains=4, genome_len=3000, snp_rate=0.01, k=21, n_pairs=7000, read_len=100,
+                           abundance_ratio=0.6, seed=200), []),
+    "inv4_k21_s201": (dict(n_strains=4, genome_len=3000, snp_rate=0.01, k=21, n_pairs=7000, read_len=100,
+                           abundance_ratio=0.6, seed=201), []),
+    "inv5_k21_s201": (dict(n_strains=5, genome_len=3200, snp_rate=0.012, k=21, n_pairs=9000, read_len=100,
+                           abundance_ratio=0.7, seed=201), []),
+}
+CASES.update(INVARIANT_CASES)
+
+
+PHRASES = {"link_split": "->perform split, all kept links", "coverage_match": "obtain best match via coverage similarity",
+           "trivial_split": ("split left", "split right")}
 
 
 def md5(text):
@@ -166,7 +187,14 @@ def emit(case):
                 fh.write(text)
         log_dir = os.environ.get("VS_GOLDEN_LOGS")
         log_to = os.path.join(log_dir, case + ".log") if log_dir else None
-        rc, files, err = run_reference(inp, extra, "rotate", 0, log_to)
+        own_log = os.path.join(tmp, "reference_debug.log")
+        rc, files, err = run_reference(inp, extra, "rotate", 0, own_log)
+        ops_seen = {}
+        if os.path.exists(own_log):
+            text = open(own_log).read()
+            ops_seen = {k: (sum(text.count(x) for x in v) if isinstance(v, tuple) else text.count(v)) for k, v in PHRASES.items()}
+            if log_to:
+                shutil.copy(own_log, log_to)
         rc2, files2, _ = run_reference(inp, extra, "plain", 0)
         seed_variant = set()
         for hs in (1, 2, 3):
@@ -181,6 +209,7 @@ def emit(case):
         "files": sorted(files),
         "hashseed": 0,
         "hashseed_invariant": not seed_variant,
+        "operations_in_reference_log": ops_seen,
         "differs_under_other_hashseeds": sorted(seed_variant),
     }
     if rc != 0:
@@ -200,7 +229,49 @@ def emit(case):
         print(err)
 
 
+def search_invariant(n_seeds):
+    """Look for seeded cases whose reference outputs do not depend on the in-edge-order model AND
+    whose debug log shows the operations the model could influence (branch split, coverage
+    matching, trivial split).  Prints entries for INVARIANT_CASES."""
+    templates = [
+        ("inv3_k21", dict(n_strains=3, genome_len=2600, snp_rate=0.009, k=21, n_pairs=5000, read_len=100, abundance_ratio=0.55)),
+        ("inv4_k21", dict(n_strains=4, genome_len=3000, snp_rate=0.01, k=21, n_pairs=7000, read_len=100, abundance_ratio=0.6)),
+        ("inv4_k31", dict(n_strains=4, genome_len=3600, snp_rate=0.012, k=31, n_pairs=8000, read_len=120, abundance_ratio=0.65)),
+        ("inv5_k21", dict(n_strains=5, genome_len=3200, snp_rate=0.012, k=21, n_pairs=9000, read_len=100, abundance_ratio=0.7)),
+    ]
+    found = 0
+    for seed in range(200, 200 + n_seeds):
+        for tname, base in templates:
+            kwargs = dict(base, seed=seed)
+            pc = synth.make_pipeline_case(**kwargs)
+            with tempfile.TemporaryDirectory() as tmp:
+                inp = {"gfa": os.path.join(tmp, "graph.gfa"), "paths": os.path.join(tmp, "contigs.paths"),
+                       "fwd": os.path.join(tmp, "fwd.fq"), "rve": os.path.join(tmp, "rve.fq")}
+                for key, text in (("gfa", pc.gfa_text), ("paths", pc.paths_text), ("fwd", synth.fastq_text(pc.fwd, "f")),
+                                  ("rve", synth.fastq_text(pc.rve, "r"))):
+                    with open(inp[key], "w") as fh:
+                        fh.write(text)
+                log = os.path.join(tmp, "run.log")
+                rc, files, _ = run_reference(inp, [], "rotate", 0, log)
+                if rc != 0 or not os.path.exists(log):
+                    continue
+                text = open(log).read()
+                ops = {k: (sum(text.count(x) for x in v) if isinstance(v, tuple) else text.count(v)) for k, v in PHRASES.items()}
+                if not all(ops.values()):
+                    continue
+                rc2, files2, _ = run_reference(inp, [], "plain", 0)
+                if rc2 != 0 or files2 != files:
+                    continue
+            found += 1
+            print('    "%s_s%d": (%r, []),  # %s, %d strains out' % (tname, seed, kwargs, ops, files.get("strain.paths", "").count("NODE_")),
+                  flush=True)
+    print("found", found)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--search-invariant":
+        search_invariant(int(sys.argv[2]) if len(sys.argv) > 2 else 30)
+        sys.exit(0)
     names = sys.argv[1:] or list(CASES)
     os.makedirs(OUT, exist_ok=True)
     for name in names:
