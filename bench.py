@@ -401,16 +401,24 @@ def cpu_baseline(ctx, host, st, g, cum, seed, L, k, sub_thresh, n_thresh, R, tar
         import subprocess
         import tempfile
 
-        cores = os.cpu_count() or 1
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         with tempfile.NamedTemporaryFile(suffix=".pkl", delete=False) as fh:
             pickle.dump(dict(seqs=list(g.seqs), k=k, genomes=list(st.genomes), cum=np.asarray(cum), seed=seed, first_pair=R,
-                             L=L, sub_thresh=sub_thresh, n_thresh=n_thresh, rate_hint=0.6 * M / secs), fh)
-        proc = subprocess.run([sys.executable, "-m", "oracle.cpu_all_cores", fh.name, str(cores), str(min(target_s, 8.0))],
-                              cwd=ROOT, capture_output=True, text=True, timeout=600)
+                             L=L, sub_thresh=sub_thresh, n_thresh=n_thresh), fh)
+        proc = subprocess.run([sys.executable, "-m", "oracle.cpu_all_cores", fh.name, str(cores), str(min(target_s, 5.0))],
+                              cwd=ROOT, capture_output=True, text=True, timeout=300)
         os.unlink(fh.name)
         allc = json.loads(proc.stdout.strip().splitlines()[-1])
+        quota = None
+        try:
+            with open("/sys/fs/cgroup/cpu.max") as qf:
+                a, b = qf.read().split()
+                quota = None if a == "max" else float(a) / float(b)
+        except Exception:
+            pass
         out["all_cores"] = {"value": allc["pairs_per_s"], "unit": "pairs/s", "cores": allc["workers"],
-                            "sample": "%d pairs in %.1f s (slowest worker)" % (allc["pairs"], allc["seconds"])}
+                            "cgroup_cpu_quota_cores": quota,
+                            "sample": "%d pairs, %.1f s of counting per worker, %.1f s wall" % (allc["pairs"], allc["seconds"], allc["wall_s"])}
     except Exception as err:
         out["all_cores"] = {"error": repr(err)}
     # how this box's port relates to the reference script itself (which cannot travel here): measured
