@@ -218,6 +218,18 @@ int vs_graph_refresh(vs_ctx *ctx, uint32_t n_vertices, uint32_t n_edge_slots,
                      uint8_t *fork_kind, int32_t *chain_next, int32_t *chain_top,
                      int32_t *chain_rank, uint32_t *zero_sum_edge);
 
+/* One re-initialised stage graph in one call (store_reinit_graph, VStrains_IO.py:630-642, from the
+ * point where the surviving vertices and edges are known): src/tgt[n_edges] = the edges in the
+ * order they are re-inserted (file order of the stage GFA); the adjacency comes back in the order
+ * rules of the graph container (row_ptr[n_vertices+1], n_out[n_vertices], nbr/eidx[2*n_edges]:
+ * out-entries, then in-entries, see vstrains_amd/graph/asm_graph.py), followed by everything
+ * vs_graph_refresh computes on it (all vertices and edges live).  Host pointers. */
+int vs_stage_rebuild(vs_ctx *ctx, uint32_t n_vertices, uint32_t n_edges, const uint32_t *src,
+                     const uint32_t *tgt, const double *dp, uint64_t *row_ptr, uint32_t *n_out,
+                     uint32_t *nbr, uint32_t *eidx, double *flow, uint8_t *nontrivial,
+                     uint8_t *fork_kind, int32_t *chain_next, int32_t *chain_top,
+                     int32_t *chain_rank, uint32_t *zero_sum_edge);
+
 /* ---- device memory helpers for C callers without another allocator ----------------------- */
 int vs_dev_alloc(vs_ctx *ctx, size_t bytes, void **out); /* zero-filled */
 int vs_dev_free(vs_ctx *ctx, void *ptr);

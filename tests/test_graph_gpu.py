@@ -345,3 +345,51 @@ def test_reference_shaped_driver_on_the_device(backend, name, tmp_path):
     problems, _ = compare(case, out)
     binding = [p for p in problems if p.split(" ", 1)[1] not in case.meta["differs_under_other_hashseeds"]]
     assert not binding, binding
+
+
+def test_native_reinit_equals_the_python_rebuild(backend, tmp_path):
+    """HipGraphOps.reinit (vs_stage_rebuild: adjacency by the container's placement rule + flows +
+    scan in one library call) against formats.stage_graph_from_state + refresh on random graphs with
+    gray vertices / edges, unmapped names and multi-edges: same maps, same adjacency rows in the same
+    order, same flows, same scan, same GFA bytes."""
+    from vstrains_amd.graph.formats import stage_graph_from_state
+
+    import random
+
+    rng = np.random.default_rng(77)
+    for trial in range(6):
+        nv, ne = int(rng.integers(2, 400)), int(rng.integers(1, 900))
+        g = random_graph(random.Random(trial), nv, ne, gray_frac=0.15, hub=int(rng.integers(0, 3)))
+        nodes = {g.vid[v]: v for v in range(g.num_vertices())}
+        edges = {}
+        for e in g.edges():
+            edges[(g.vid[g.esrc[e]], g.vid[g.etgt[e]])] = e  # (a repeated pair keeps its last edge, as a dict would)
+        # retire a few names from the map (their edges must vanish) and re-insert one (it moves to the end)
+        names = list(nodes)
+        for name in names[:: max(7, nv // 9)][:5]:
+            nodes.pop(name)
+        if len(names) > 3 and names[1] in nodes:
+            v = nodes.pop(names[1])
+            nodes[names[1]] = v
+        a = stage_graph_from_state(g, nodes, edges, gfa_path=str(tmp_path / "a.gfa"))
+        try:
+            scan_a = backend.graph_ops.refresh(a[0])
+            err_a = None
+        except FloatingPointError as e:
+            err_a = str(e)
+        try:
+            b = backend.graph_ops.reinit(g, nodes, edges, str(tmp_path / "b.gfa"))
+            err_b = None
+        except FloatingPointError as e:
+            err_b = str(e)
+        assert (tmp_path / "a.gfa").read_bytes() == (tmp_path / "b.gfa").read_bytes()
+        assert err_a == err_b
+        if err_a is not None:
+            continue
+        ga, gb = a[0], b[0]
+        assert list(a[1].items()) == list(b[1].items()) and list(a[2].items()) == list(b[2].items())
+        assert ga.adj == gb.adj and ga.nout == gb.nout and ga.esrc == gb.esrc and ga.etgt == gb.etgt and ga.eovl == gb.eovl
+        assert ga.vid == gb.vid and ga.vdp == gb.vdp and ga.vseq == gb.vseq and ga.eflow == gb.eflow
+        sb = b[4]
+        assert (scan_a.nontrivial, scan_a.fork_kind, scan_a.chain_next, scan_a.chain_top, scan_a.chain_rank) == \
+               (sb.nontrivial, sb.fork_kind, sb.chain_next, sb.chain_top, sb.chain_rank)

@@ -26,16 +26,37 @@ from .formats import (ContigDict, path_length, path_sequence, read_stage_gfa, st
 from .ops import GraphOps, GraphScan, LiveLinks, nontrivial_ids
 
 
+class _Snapshot:
+    """What a freshly re-initialised stage looked like (and the bytes of its GFA file).  If the next
+    re-initialisation finds the very same state -- a pass that split, forked or contracted nothing:
+    about a third of the re-initialisations of a run -- the file it would write holds the same bytes
+    and the graph it would read back is this graph: vertices already in map order, edges numbered
+    in map order, no freed index, flows as recomputed.  Comparing a handful of lists is all it takes."""
+
+    __slots__ = ("key", "text")
+
+    def __init__(self, g: AsmGraph, nodes: NodeMap, edges: EdgeMap, text: str):
+        self.key = self.state(g, nodes, edges)
+        self.text = text
+
+    @staticmethod
+    def state(g: AsmGraph, nodes: NodeMap, edges: EdgeMap):
+        return (id(g), list(nodes.values()), list(edges.values()), list(g.vdp), list(g.vblack), list(g.eblack), list(g.eflow),
+                list(g.eovl), len(g._free), g._n_edges, len(g.vid))
+
+
 class Stage:
     """One re-initialised graph: container, the two ordered maps, and its device scan."""
 
-    __slots__ = ("g", "nodes", "edges", "scan")
+    __slots__ = ("g", "nodes", "edges", "scan", "snap")
 
-    def __init__(self, g: AsmGraph, nodes: NodeMap, edges: EdgeMap, scan: Optional[GraphScan] = None):
+    def __init__(self, g: AsmGraph, nodes: NodeMap, edges: EdgeMap, scan: Optional[GraphScan] = None,
+                 snap: Optional[_Snapshot] = None):
         self.g = g
         self.nodes = nodes
         self.edges = edges
         self.scan = scan
+        self.snap = snap
 
     def triple(self):
         return self.g, self.nodes, self.edges
@@ -44,11 +65,24 @@ class Stage:
 def reinit(stage: Stage, ops: GraphOps, logger, filename: str) -> Stage:
     """``store_reinit_graph`` (IO.py:630-642): write the stage GFA, rebuild the graph from that
     file (drops gray objects, resets vertex order to map order), recompute every edge flow."""
+    snap = stage.snap
+    if snap is not None and snap.key == _Snapshot.state(stage.g, stage.nodes, stage.edges):
+        # nothing changed since this stage was made (node / edge ids never change in place; vertex and
+        # edge sets, colours, depths, flows and overlaps are compared above)
+        with open(filename, "w") as fh:
+            fh.write(snap.text)
+        logger.info(filename + " is stored..")
+        return Stage(stage.g, stage.nodes, stage.edges, stage.scan, snap)
     # one pass: the file write_stage_gfa would write, and the graph read_stage_gfa(filename) would
     # give back (float(repr(dp)) == dp), without the parse
-    g, nodes, edges = stage_graph_from_state(stage.g, stage.nodes, stage.edges, gfa_path=filename)
-    logger.info(filename + " is stored..")
-    return Stage(g, nodes, edges, ops.refresh(g))
+    if hasattr(ops, "reinit"):  # the device backend does rebuild + flows + scan in one library call
+        g, nodes, edges, text, scan = ops.reinit(stage.g, stage.nodes, stage.edges, filename)
+        logger.info(filename + " is stored..")
+    else:
+        g, nodes, edges, text = stage_graph_from_state(stage.g, stage.nodes, stage.edges, gfa_path=filename, want_text=True)
+        logger.info(filename + " is stored..")
+        scan = ops.refresh(g)
+    return Stage(g, nodes, edges, scan, _Snapshot(g, nodes, edges, text))
 
 
 def load_stage(filename: str, ops: GraphOps, with_flow: bool) -> Stage:

@@ -61,8 +61,8 @@ def read_stage_gfa(filename: str) -> Tuple[AsmGraph, NodeMap, EdgeMap]:
     return g, nodes, edges
 
 
-def stage_graph_from_state(g: AsmGraph, nodes: NodeMap, edges: EdgeMap,
-                           gfa_path: Optional[str] = None) -> Tuple[AsmGraph, NodeMap, EdgeMap]:
+def stage_graph_from_state(g: AsmGraph, nodes: NodeMap, edges: EdgeMap, gfa_path: Optional[str] = None,
+                           want_text: bool = False):
     """The graph ``read_stage_gfa(write_stage_gfa(...))`` would give, without the file: same
     filtering and order; ``float(repr(x)) == x`` so dp survives exactly.  This runs once per
     re-initialisation (~100 times per run), so the rows are built in place instead of through
@@ -117,9 +117,13 @@ def stage_graph_from_state(g: AsmGraph, nodes: NodeMap, edges: EdgeMap,
     ng.eflow = [0.0] * ne_count
     ng.eblack = [BLACK] * ne_count
     ng._n_edges = ne_count
+    text = None
     if chunks is not None:
+        text = "".join(chunks)
         with open(gfa_path, "w") as fh:
-            fh.write("".join(chunks))
+            fh.write(text)
+    if want_text:
+        return ng, nn, ne, text
     return ng, nn, ne
 
 

@@ -68,6 +68,78 @@ class HipGraphOps(GraphOps):
         return GraphScan(nt[:nv].astype(bool).tolist(), fk[:nv].tolist(), nxt[:nv].tolist(), top[:nv].tolist(),
                          rank[:nv].tolist())
 
+    def reinit(self, g: AsmGraph, nodes, edges, gfa_path: str):
+        """``formats.stage_graph_from_state`` + ``refresh`` with the per-edge work in the library
+        (``vs_stage_rebuild``): this side filters the surviving vertices and edges (map order, by
+        name, as the reference's ``graph_to_gfa`` does, IO.py:345-369), writes the stage GFA, and
+        gets back the adjacency in the container's order together with the flows and the scan.
+        -> (graph, node map, edge map, GFA text, scan)"""
+        from .asm_graph import BLACK
+
+        vblack, vid, vdp, vseq = g.vblack, g.vid, g.vdp, g.vseq
+        keep = [v for v in nodes.values() if vblack[v]]
+        n_vid = [vid[v] for v in keep]
+        n_vdp = [vdp[v] for v in keep]
+        n_vseq = [vseq[v] for v in keep]
+        nv = len(keep)
+        nn = dict(zip(n_vid, range(nv)))
+        chunks = ["S\t%s\t%s\tDP:f:%r\n" % t for t in zip(n_vid, n_vseq, n_vdp)]
+        eblack, eovl_src = g.eblack, g.eovl
+        get = nn.get
+        src: List[int] = []
+        tgt: List[int] = []
+        ovl: List[int] = []
+        kept_keys = []
+        for key, e in edges.items():
+            s_ = get(key[0])
+            t_ = get(key[1])
+            if s_ is None or t_ is None or not eblack[e]:
+                continue
+            src.append(s_)
+            tgt.append(t_)
+            ovl.append(eovl_src[e])
+            kept_keys.append(key)
+        n_e = len(src)
+        chunks.extend(["L\t%s\t+\t%s\t+\t%dM\n" % (k[0], k[1], o) for k, o in zip(kept_keys, ovl)])
+        text = "".join(chunks)
+        with open(gfa_path, "w") as fh:
+            fh.write(text)
+        a_src = np.asarray(src, dtype=np.uint32)
+        a_tgt = np.asarray(tgt, dtype=np.uint32)
+        a_dp = np.asarray(n_vdp, dtype=np.float64)
+        row_ptr = np.zeros(nv + 1, dtype=np.uint64)
+        n_out = np.zeros(max(nv, 1), dtype=np.uint32)
+        nbr = np.zeros(max(2 * n_e, 1), dtype=np.uint32)
+        eidx = np.zeros(max(2 * n_e, 1), dtype=np.uint32)
+        flow = np.zeros(max(n_e, 1), dtype=np.float64)
+        nt = np.zeros(max(nv, 1), dtype=np.uint8)
+        fk = np.zeros(max(nv, 1), dtype=np.uint8)
+        nxt = np.full(max(nv, 1), -1, dtype=np.int32)
+        top = np.zeros(max(nv, 1), dtype=np.int32)
+        rank = np.zeros(max(nv, 1), dtype=np.int32)
+        bad = C.c_uint32(0xFFFFFFFF)
+        nat.check(self.ctx._h, nat.lib().vs_stage_rebuild(
+            self.ctx._h, nv, n_e, _ptr(a_src), _ptr(a_tgt), _ptr(a_dp), row_ptr.ctypes.data, n_out.ctypes.data,
+            nbr.ctypes.data, eidx.ctypes.data, flow.ctypes.data, nt.ctypes.data, fk.ctypes.data, nxt.ctypes.data,
+            top.ctypes.data, rank.ctypes.data, C.byref(bad)))
+        self.calls += 1
+        ng = AsmGraph()
+        ng.vid, ng.vdp, ng.vseq = n_vid, n_vdp, n_vseq
+        ng.vblack = [BLACK] * nv
+        pairs = list(zip(nbr[: 2 * n_e].tolist(), eidx[: 2 * n_e].tolist()))
+        ptr = row_ptr.tolist()
+        ng.adj = [pairs[a:b] for a, b in zip(ptr[:-1], ptr[1:])]
+        ng.nout = n_out[:nv].tolist()
+        ng.esrc, ng.etgt, ng.eovl = src, tgt, ovl
+        ng.eflow = flow[:n_e].tolist()
+        ng.eblack = [BLACK] * n_e
+        ng._n_edges = n_e
+        if bad.value != 0xFFFFFFFF:
+            raise FloatingPointError("divide by zero encountered in edge flow of edge %s -> %s"
+                                     % (n_vid[src[bad.value]], n_vid[tgt[bad.value]]))
+        ne = dict(zip(kept_keys, range(n_e)))
+        return ng, nn, ne, text, self._as_scan(ng, nt, fk, nxt, top, rank)
+
     def edge_flows(self, g: AsmGraph) -> None:
         flow, _, _, _, _, _, bad = self._refresh(g)
         self._apply_flows(g, flow, bad)
