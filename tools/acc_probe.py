@@ -49,7 +49,15 @@ def main():
     same_l = (L[1:] == L[:-1]).all(axis=1)
     same_r = (Rr[1:] == Rr[:-1]).all(axis=1)
     print("end repeats the previous pair's list: left %.3f right %.3f both %.3f" % (same_l.mean(), same_r.mean(), (same_l & same_r).mean()))
-    # run lengths of equal left lists
+    # distinct end lists of the whole block (a global table of lists would turn short_mat into one weighted
+    # expansion per distinct list)
+    allv = np.ascontiguousarray(lists).view([("", lists.dtype)] * lists.shape[1]).ravel()
+    uniq, cnt = np.unique(allv, return_counts=True)
+    un = np.array([int((np.frombuffer(u.tobytes(), dtype=np.uint32) != 0xFFFFFFFF).sum()) for u in uniq[:: max(1, len(uniq) // 20000)]])
+    print("ends %d, distinct lists %d (%.4f); mean length of a distinct list %.2f -> ~%.3g weighted short_mat increments instead of %.3g" % (
+        n, len(uniq), len(uniq) / n, un.mean(), len(uniq) * (un * (un + 1) / 2).mean(), float((counts.astype(np.int64) * (counts + 1) // 2).sum())))
+    top = np.sort(cnt)[::-1]
+    print("most frequent lists hold %s ends; lists seen once: %d" % (top[:5].tolist(), int((cnt == 1).sum())))
     print("increments per pair %.1f (node_mat %.1f, short_mat %.1f)" % (inc.mean(), (nl * nr).mean(), (inc - nl * nr).mean()))
 
 

@@ -825,7 +825,8 @@ k_pe_tiles(PeParams P) {
 #define ACC_BITS 14
 #endif
 #define ACC_SLOTS (1u << ACC_BITS)
-#define ACC_LDS_BYTES ((2u * ACC_SLOTS + (ACC_TPB / 64) * 66u + (LC + 1u) + (LC + 1u) * 40u + 4u) * 4u)
+#define ACC_DEDUP_SLOTS (2u * ACC_TPB)  // one slot per read end of a round: at most a fifth of them get claimed
+#define ACC_LDS_BYTES ((2u * ACC_SLOTS + (ACC_TPB / 64) * 66u + (LC + 1u) + (LC + 1u) * 40u + 4u + 2u * ACC_DEDUP_SLOTS) * 4u)
 // Work units: a list row is cut into runs of at most ACC_RUN partners, one lane per run, so that
 // every lane of a wavefront has about the same (small, fully unrolled) amount of work:
 //   node_mat : left node a against right positions [4c, 4c+4)           -> nl * ceil(nr/4) runs
@@ -858,7 +859,7 @@ template <> struct AccTable<unsigned long long> {
 // Slow side of vs_cell_add: the slot is empty or holds another cell.  Kept out of line so that
 // the common case (the cell is already in the table) stays a short straight-line sequence.
 template <typename KT>
-__device__ __noinline__ bool vs_cell_claim(KT *s_key, uint32_t *s_cnt, uint32_t *s_used, KT key, uint32_t at) {
+__device__ __noinline__ bool vs_cell_claim(KT *s_key, uint32_t *s_cnt, uint32_t *s_used, KT key, uint32_t at, uint32_t wgt) {
     for (uint32_t pr = 0; pr < 8u; pr++) {
         KT kx = s_key[at];
         if (kx == AccTable<KT>::EMPTY) {
@@ -866,7 +867,7 @@ __device__ __noinline__ bool vs_cell_claim(KT *s_key, uint32_t *s_cnt, uint32_t 
             if (kx == AccTable<KT>::EMPTY) { atomicAdd(s_used, 1u); kx = key; }
         }
         if (kx == key) {
-            atomicAdd(&s_cnt[at], 1u);
+            atomicAdd(&s_cnt[at], wgt);
             return true;
         }
         at = (at + 1u) & ((1u << AccTable<KT>::BITS) - 1u);
@@ -877,28 +878,28 @@ __device__ __noinline__ bool vs_cell_claim(KT *s_key, uint32_t *s_cnt, uint32_t 
 template <typename KT>
 __device__ __forceinline__ void vs_cell_add(KT *s_key, uint32_t *s_cnt, uint32_t &s_used, uint32_t &s_lost, bool use_table,
                                             uint32_t mat, uint32_t x, uint32_t yv, uint32_t N,
-                                            uint32_t *node_mat, uint32_t *short_mat) {
+                                            uint32_t *node_mat, uint32_t *short_mat, uint32_t wgt) {
     const uint32_t cx = (mat && yv < x) ? yv : x, cy = (mat && yv < x) ? x : yv;
     bool done = false;
     if (use_table) {
         const KT key = AccTable<KT>::key(mat, cx, cy, N);
         const uint32_t at = AccTable<KT>::slot(key);
         if (s_key[at] == key) {
-            atomicAdd(&s_cnt[at], 1u);
+            atomicAdd(&s_cnt[at], wgt);
             done = true;
         } else {
-            done = vs_cell_claim<KT>(s_key, s_cnt, &s_used, key, at);
+            done = vs_cell_claim<KT>(s_key, s_cnt, &s_used, key, at, wgt);
             if (!done) atomicAdd(&s_lost, 1u);
         }
     }
-    if (!done) atomicAdd((mat ? short_mat : node_mat) + (uint64_t)cx * N + cy, 1u);
+    if (!done) atomicAdd((mat ? short_mat : node_mat) + (uint64_t)cx * N + cy, wgt);
 }
 
 template <typename KT>
 __global__ void __launch_bounds__(ACC_TPB)
 k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_slots_pairs,
                 uint32_t pairs_per_wg, uint32_t N, uint32_t use_table, uint32_t fill_limit,
-                uint32_t *__restrict__ node_mat, uint32_t *__restrict__ short_mat, uint32_t *__restrict__ queue) {
+                uint32_t *__restrict__ node_mat, uint32_t *__restrict__ short_mat, uint32_t *__restrict__ queue, uint32_t merge) {
     constexpr uint32_t SLOTS = 1u << AccTable<KT>::BITS;
     KT *s_key = (KT *)vs_lds;                      // [SLOTS] keys: ACC_SLOTS words either way
     uint32_t *s_cnt = vs_lds + ACC_SLOTS;          // [SLOTS]
@@ -907,6 +908,14 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
     uint32_t *s_ua = s_g + (LC + 1u);                                     // [LC + 1][ACC_GMAX]: run -> position a
     uint32_t &s_used = s_ua[(LC + 1u) * ACC_GMAX];
     uint32_t &s_lost = s_ua[(LC + 1u) * ACC_GMAX + 1u];
+    // Equal end lists of a round (1024 locus-ordered pairs: four of five ends repeat the list of another
+    // end) are merged: the first end that brings a list owns it, the others only add to its multiplicity,
+    // and the owner's short_mat cells (PE_Inference.py:174-184: one increment per end holding both nodes)
+    // are incremented once, by that multiplicity.  s_down[slot] = tag << 11 | owner end, s_dmul[slot] =
+    // how many further ends hold the same list.  The tag is an order-independent fingerprint (the lists
+    // arrive in no particular order); a tag match is confirmed node by node against the owner's row.
+    uint32_t *s_down = s_ua + (LC + 1u) * ACC_GMAX + 4u;  // [ACC_DEDUP_SLOTS]
+    uint32_t *s_dmul = s_down + ACC_DEDUP_SLOTS;          // [ACC_DEDUP_SLOTS]
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     for (uint32_t i = tid; i < SLOTS; i += ACC_TPB) { s_key[i] = AccTable<KT>::EMPTY; s_cnt[i] = 0; }
     if (tid <= LC) {
@@ -943,7 +952,79 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
             const uint2 c = *(const uint2 *)(wcounts + 2u * lane);
             nl = c.x; nr = c.y;
         }
-        const uint32_t u = nl * ((nr + ACC_RUN - 1u) / ACC_RUN) + s_g[nl] + s_g[nr];
+        // multiplicity of this pair's two lists: 0 = merged into another end's list (no short_mat work
+        // of its own), m >= 1 = this end expands its list m-fold
+        uint32_t ml = nl ? 1u : 0u, mr = nr ? 1u : 0u;
+        if (merge) {
+            for (uint32_t i = tid; i < ACC_DEDUP_SLOTS; i += ACC_TPB) { s_down[i] = 0xFFFFFFFFu; s_dmul[i] = 0u; }
+            __syncthreads();
+            uint32_t slot_of[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
+            for (uint32_t side = 0; side < 2u; side++) {
+                const uint32_t n = side ? nr : nl;
+                if (n == 0u) continue;
+                const uint32_t me = 2u * (wv * 64u + lane) + side;  // end index within the round
+                const uint32_t *row = wlists + (2u * lane + side) * LC;
+                uint32_t mine[LC];
+                {
+                    const VsQuad a = *(const VsQuad *)row, b = n > 4u ? *(const VsQuad *)(row + 4) : VsQuad{0, 0, 0, 0};
+                    const VsQuad c = n > 8u ? *(const VsQuad *)(row + 8) : VsQuad{0, 0, 0, 0}, d = n > 12u ? *(const VsQuad *)(row + 12) : VsQuad{0, 0, 0, 0};
+                    const uint32_t v[LC] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+                    for (uint32_t i = 0; i < LC; i++) mine[i] = i < n ? v[i] : 0xFFFFFFFFu;
+                }
+                uint32_t fp = n * 0x9E3779B1u;
+#pragma unroll
+                for (uint32_t i = 0; i < LC; i++)
+                    if (i < n) {
+                        uint32_t h = mine[i] * 0x85EBCA6Bu;
+                        h ^= h >> 15;
+                        fp += h * 0xC2B2AE35u;  // (a sum: the order of the nodes does not matter)
+                    }
+                // tag: 17 bits of the fingerprint and the list length (the owner's length comes with the table
+                // word: no load for it); all ones with owner 2047 would read as an empty slot -- n - 1 <= 15
+                // only together with tag bits all ones, so clear one
+                uint32_t tag = (((fp ^ (fp >> 13)) & 0x1FFFFu) << 4) | (n - 1u);
+                if (tag == 0x1FFFFFu) tag ^= 0x10u;
+                uint32_t at = (fp * 0x9E3779B1u) >> (32u - 11u);  // ACC_DEDUP_SLOTS = 2048
+                for (uint32_t pr = 0; pr < 6u; pr++) {
+                    uint32_t w0 = s_down[at];
+                    if (w0 == 0xFFFFFFFFu) {
+                        w0 = atomicCAS(&s_down[at], 0xFFFFFFFFu, (tag << 11) | me);
+                        if (w0 == 0xFFFFFFFFu) { slot_of[side] = at; break; }  // this end owns the list
+                    }
+                    if ((w0 >> 11) == tag) {
+                        // same fingerprint and length: the same set of nodes?  (the owner's row is input data,
+                        // nobody writes it; its quads are fetched together)
+                        const uint32_t oe = w0 & 0x7FFu;
+                        const uint32_t *orow = lists + (2u * base + oe) * (uint64_t)LC;
+                        const VsQuad o0 = *(const VsQuad *)orow, o1 = n > 4u ? *(const VsQuad *)(orow + 4) : VsQuad{0, 0, 0, 0};
+                        const VsQuad o2 = n > 8u ? *(const VsQuad *)(orow + 8) : VsQuad{0, 0, 0, 0}, o3 = n > 12u ? *(const VsQuad *)(orow + 12) : VsQuad{0, 0, 0, 0};
+                        const uint32_t ov[LC] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w, o2.x, o2.y, o2.z, o2.w, o3.x, o3.y, o3.z, o3.w};
+                        bool same = true;
+#pragma unroll
+                        for (uint32_t k2 = 0; k2 < LC; k2++) {
+                            bool found = false;
+#pragma unroll
+                            for (uint32_t i = 0; i < LC; i++) found |= mine[i] == ov[k2];
+                            same &= found || k2 >= n;
+                        }
+                        if (same) {  // merged: the owner expands for this end too
+                            atomicAdd(&s_dmul[at], 1u);
+                            if (side) mr = 0u; else ml = 0u;
+                            break;
+                        }
+                    }
+                    at = (at + 1u) & (ACC_DEDUP_SLOTS - 1u);
+                }
+            }
+            __syncthreads();
+            if (slot_of[0] != 0xFFFFFFFFu) ml += s_dmul[slot_of[0]];
+            if (slot_of[1] != 0xFFFFFFFFu) mr += s_dmul[slot_of[1]];
+        }
+        // (list length, multiplicity) travel together through the cross-lane reads below
+        const uint32_t nlw = nl | (ml << 8), nrw = nr | (mr << 8);
+        const uint32_t u = nl * ((nr + ACC_RUN - 1u) / ACC_RUN) + (ml ? s_g[nl] : 0u) + (mr ? s_g[nr] : 0u);
         uint32_t incl = u;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -969,11 +1050,12 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
             while (s_pref[wv][a0 + 1u] <= t) a0++;
             uint32_t r = t - s_pref[wv][a0];
             // list lengths of pair a0: lane a0 holds them (cross-lane read, no memory round trip)
-            const uint32_t ql = __shfl(nl, (int)a0, 64), qr = __shfl(nr, (int)a0, 64);
+            const uint32_t qlw = __shfl(nlw, (int)a0, 64), qrw = __shfl(nrw, (int)a0, 64);
             if (t_raw >= U) break;
+            const uint32_t ql = qlw & 0xFFu, qr = qrw & 0xFFu;
             const uint32_t row = 2u * a0 * LC;
             const uint32_t cq = (qr + ACC_RUN - 1u) / ACC_RUN;
-            uint32_t x, mat, off, bi, be;
+            uint32_t x, mat, off, bi, be, wgt = 1u;
             if (r < ql * cq) {  // node_mat: left node a, right positions of run c
                 const uint32_t a = cq == 1u ? r : cq == 2u ? r >> 1 : cq == 4u ? r >> 2 : (r * 43691u) >> 17;
                 x = wlists[row + a]; mat = 0u; off = row + LC; bi = ACC_RUN * (r - a * cq); be = qr;
@@ -981,7 +1063,9 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
                 r -= ql * cq;
                 uint32_t n = ql;
                 off = row;
-                if (r >= s_g[ql]) { r -= s_g[ql]; n = qr; off = row + LC; }
+                wgt = qlw >> 8;
+                const uint32_t gl = wgt ? s_g[ql] : 0u;  // (a merged left list has no runs of its own)
+                if (r >= gl) { r -= gl; n = qr; off = row + LC; wgt = qrw >> 8; }
                 const uint32_t a = s_ua[n * ACC_GMAX + r];
                 const uint32_t crun = r - (s_g[n] - s_g[n - a]);  // runs of positions before a: g(n) - g(n-a)
                 x = wlists[off + a]; mat = 1u; bi = a + ACC_RUN * crun; be = n;
@@ -990,7 +1074,9 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
             // past `be` stays inside the lists buffer, which carries padding, and is ignored)
             const VsQuad yq = *(const VsQuad *)(wlists + off + bi);  // one 16-byte load
             const uint32_t y0 = yq.x, y1 = yq.y, y2 = yq.z, y3 = yq.w;
-            if (use_table) {
+            if (use_table == 2u) {
+                if ((y0 ^ y1 ^ y2 ^ y3 ^ x) == 0xDEADBEEFu) atomicAdd(&s_lost, 1u);  // (timing experiment: decode only)
+            } else if (use_table) {
                 // the four cells' slots are read together (independent LDS loads), then counted; a
                 // slot that does not hold the cell yet goes the slow way (claim / probe / global)
                 const uint32_t ys[4] = {y0, y1, y2, y3};
@@ -1010,27 +1096,31 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
                 for (uint32_t j = 0; j < 4u; j++) {
                     if (!live[j]) continue;
                     if (seen[j] == key[j]) {
-                        atomicAdd(&s_cnt[at[j]], 1u);
-                    } else if (!vs_cell_claim<KT>(s_key, s_cnt, &s_used, key[j], at[j])) {
+                        atomicAdd(&s_cnt[at[j]], wgt);
+                    } else if (!vs_cell_claim<KT>(s_key, s_cnt, &s_used, key[j], at[j], wgt)) {
                         atomicAdd(&s_lost, 1u);
-                        atomicAdd((mat ? short_mat : node_mat) + AccTable<KT>::cell_of(key[j], N), 1u);
+                        atomicAdd((mat ? short_mat : node_mat) + AccTable<KT>::cell_of(key[j], N), wgt);
                     }
                 }
             } else {
-                vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y0, N, node_mat, short_mat);  // bi < be always
-                if (bi + 1u < be) vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y1, N, node_mat, short_mat);
-                if (bi + 2u < be) vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y2, N, node_mat, short_mat);
-                if (bi + 3u < be) vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y3, N, node_mat, short_mat);
+                vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y0, N, node_mat, short_mat, wgt);  // bi < be always
+                if (bi + 1u < be) vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y1, N, node_mat, short_mat, wgt);
+                if (bi + 2u < be) vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y2, N, node_mat, short_mat, wgt);
+                if (bi + 3u < be) vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y3, N, node_mat, short_mat, wgt);
             }
         }
         __syncthreads();
         const bool spill = s_used > fill_limit || s_lost > 4096u;
         __syncthreads();
         if (spill) {
+            // (everything goes, also the cells of the locus still being worked on: keeping those across
+            // write-outs was measured -- 3.1 -> 3.9 ms -- the table is only fast while nearly empty, when a
+            // cell sits in the first slot its key hashes to)
             for (uint32_t i = tid; i < SLOTS; i += ACC_TPB) {
                 const KT key = s_key[i];
                 if (key != AccTable<KT>::EMPTY) {
-                    atomicAdd((AccTable<KT>::mat_of(key, N) ? short_mat : node_mat) + AccTable<KT>::cell_of(key, N), s_cnt[i]);
+                    if (use_table != 3u)  // (3: timing experiment without the write-outs)
+                        atomicAdd((AccTable<KT>::mat_of(key, N) ? short_mat : node_mat) + AccTable<KT>::cell_of(key, N), s_cnt[i]);
                     s_key[i] = AccTable<KT>::EMPTY;
                     s_cnt[i] = 0;
                 }
@@ -1541,18 +1631,24 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         uint32_t fill_limit = slots / 16u;
         if (const char *fv = getenv("VS_ACC_FILL")) fill_limit = (uint32_t)((uint64_t)slots * (uint32_t)atoi(fv) / 100u);
         const char *ev = getenv("VS_NO_AGG");
-        const uint32_t use_table = (ev && atoi(ev) != 0) ? 0u : 1u;
+        uint32_t use_table = (ev && atoi(ev) != 0) ? 0u : 1u;
+        if (const char *ab = getenv("VS_ACC_ABLATE")) use_table = (uint32_t)atoi(ab);  // 2: decode only, 3: no write-outs (timing only)
+        // VS_ACC_MERGE=1: equal end lists of a round are merged (one weighted short_mat expansion per distinct
+        // list).  Exact and tested, but off by default: it removes 47 % of the increments at configs[2] and
+        // the kernel takes the same 3.2 ms -- the cell table is not what the time goes into there -- while it
+        // costs 8-20 % on graphs with short lists (configs[1], [3]) and gains 10 % at configs[4].
+        const uint32_t merge = (getenv("VS_ACC_MERGE") && atoi(getenv("VS_ACC_MERGE")) != 0) ? 1u : 0u;
         VS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
         if (wide) {
             VS_HIP(ctx, hipFuncSetAttribute((const void *)k_pe_accumulate<unsigned long long>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES));
             hipLaunchKernelGGL(k_pe_accumulate<unsigned long long>, dim3(acc_grid), dim3(ACC_TPB), ACC_LDS_BYTES, st,
                                (const uint32_t *)ctx->d_lists, (const uint32_t *)ctx->d_list_counts, slots_pairs, per_wg,
-                               idx.n_nodes, use_table, fill_limit, d_node_mat, d_short_mat, acc_queue);
+                               idx.n_nodes, use_table, fill_limit, d_node_mat, d_short_mat, acc_queue, merge);
         } else {
             VS_HIP(ctx, hipFuncSetAttribute((const void *)k_pe_accumulate<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES));
             hipLaunchKernelGGL(k_pe_accumulate<uint32_t>, dim3(acc_grid), dim3(ACC_TPB), ACC_LDS_BYTES, st,
                                (const uint32_t *)ctx->d_lists, (const uint32_t *)ctx->d_list_counts, slots_pairs, per_wg,
-                               idx.n_nodes, use_table, fill_limit, d_node_mat, d_short_mat, acc_queue);
+                               idx.n_nodes, use_table, fill_limit, d_node_mat, d_short_mat, acc_queue, merge);
         }
     }
     VS_HIP(ctx, hipEventRecord(ctx->ev[1], st));
