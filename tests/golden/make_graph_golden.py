@@ -128,9 +128,28 @@ def sparse_info(text):
     return "%d\n%s\n" % (sum(1 for l in lines if l), "\n".join(keep))
 
 
+def info_log_lines(text, out_dir):
+    """vstrains.log -> the INFO lines the pipeline wrote between "pipeline started" and the closing
+    banner, without time stamps and with the output directory spelled OUT (the reference runs with
+    -d here, so its log also holds DEBUG lines: dropped; header and footer hold versions, dates and
+    the elapsed time: dropped)."""
+    import re
+
+    out = []
+    for line in text.split("\n"):
+        m = re.match(r"^\d{4}-\d\d-\d\d [\d:,]+ - (\w+) - (.*)$", line)
+        if m and m.group(1) == "INFO":
+            out.append(m.group(2).replace(os.path.abspath(out_dir), "OUT").replace(out_dir, "OUT"))
+    return "\n".join(out) + "\n"
+
+
 def collect(out_dir):
     """reference output tree -> {relative name: digest-form text}"""
     res = {}
+    log = os.path.join(out_dir, "vstrains.log")
+    if os.path.isfile(log):
+        with open(log) as fh:
+            res["vstrains.log.info"] = info_log_lines(fh.read(), out_dir)
     for sub in ("gfa", "tmp", "aln", ""):
         d = os.path.join(out_dir, sub) if sub else out_dir
         for name in sorted(os.listdir(d)):

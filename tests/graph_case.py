@@ -85,12 +85,31 @@ def quiet_logger(name="vstrains-test"):
     return lg
 
 
+def file_logger(out_dir, name="vstrains-test-file"):
+    """Logger that writes OUT/vstrains.log the way the reference's CLI does while its pipeline runs
+    (vstrains:245-247: "%(asctime)s - %(levelname)s - %(message)s", DEBUG level as under -d), so that
+    the INFO lines can be compared with the reference's (make_graph_golden.info_log_lines)."""
+    lg = logging.getLogger(name)
+    for h in list(lg.handlers):
+        lg.removeHandler(h)
+        h.close()
+    fh = logging.FileHandler(os.path.join(out_dir, "vstrains.log"), mode="w")
+    fh.setLevel(logging.DEBUG)
+    fh.setFormatter(logging.Formatter("%(asctime)s - %(levelname)s - %(message)s"))
+    lg.addHandler(fh)
+    lg.setLevel(logging.DEBUG)
+    lg.propagate = False
+    return lg
+
+
 def compare(case, out_dir, skip=()):
     got = gold.collect(out_dir)
     problems = []
     for rel in case.meta["files"]:
         if rel in skip:
             continue
+        if rel == "vstrains.log.info" and rel not in got:
+            continue  # (this run kept no log file: nothing to compare the reference's INFO lines with)
         if rel not in got:
             problems.append("missing " + rel)
         elif got[rel] != case.expected[rel]:

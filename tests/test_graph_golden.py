@@ -5,7 +5,7 @@ import os
 
 import pytest
 
-from graph_case import Case, case_names, compare, quiet_logger
+from graph_case import Case, case_names, compare, file_logger, quiet_logger
 from oracle import graph_ops as chk
 from oracle import pe_oracle
 from vstrains_amd.graph import pipeline
@@ -39,13 +39,17 @@ def test_pipeline_matches_reference_outputs(name, literal, tmp_path):
     case = Case(name)
     inp = case.inputs(str(tmp_path))
     out = str(tmp_path / "out")
+    args = case.args(inp, out)
+    logger = file_logger(out)  # OUT/vstrains.log: its INFO lines are compared with the reference's too
     if case.meta["returncode"] != 0:
         # the reference exits non-zero (its PE subprocess raises KeyError); so must this build, after
         # writing the same files up to that point
         with pytest.raises(KeyError):
-            pipeline.run(case.args(inp, out), quiet_logger(), CheckerBackend(case, literal))
+            pipeline.run(args, logger, CheckerBackend(case, literal))
     else:
-        pipeline.run(case.args(inp, out), quiet_logger(), CheckerBackend(case, literal))
+        pipeline.run(args, logger, CheckerBackend(case, literal))
+    for h in list(logger.handlers):
+        h.flush()
     # files the reference itself does not produce deterministically (they change with
     # PYTHONHASHSEED, see case.json) are compared too, but only the deterministic ones are binding
     problems, _ = compare(case, out)

@@ -26,6 +26,8 @@ class HipGraphOps(GraphOps):
     def __init__(self, ctx):
         self.ctx = ctx
         self.calls = 0
+        self._seg_lines: Dict[str, tuple] = {}   # id -> (depth, "S ..." line)
+        self._link_lines: Dict[tuple, tuple] = {}  # (id, id) -> (overlap, "L ..." line)
 
     def _refresh(self, g: AsmGraph):
         nv = g.num_vertices()
@@ -83,7 +85,17 @@ class HipGraphOps(GraphOps):
         n_vseq = [vseq[v] for v in keep]
         nv = len(keep)
         nn = dict(zip(n_vid, range(nv)))
-        chunks = ["S\t%s\t%s\tDP:f:%r\n" % t for t in zip(n_vid, n_vseq, n_vdp)]
+        # GFA lines: most vertices and edges of a stage were there, unchanged, in the stage before --
+        # their lines are kept (a segment line by id, checked against depth and sequence object)
+        sl = self._seg_lines
+        chunks = []
+        add = chunks.append
+        for t in zip(n_vid, n_vseq, n_vdp):
+            hit = sl.get(t[0])
+            if hit is None or hit[0] != t[2] or hit[2] is not t[1]:  # (same depth, the very same sequence object)
+                hit = (t[2], "S\t%s\t%s\tDP:f:%r\n" % t, t[1])
+                sl[t[0]] = hit
+            add(hit[1])
         eblack, eovl_src = g.eblack, g.eovl
         get = nn.get
         src: List[int] = []
@@ -100,7 +112,17 @@ class HipGraphOps(GraphOps):
             ovl.append(eovl_src[e])
             kept_keys.append(key)
         n_e = len(src)
-        chunks.extend(["L\t%s\t+\t%s\t+\t%dM\n" % (k[0], k[1], o) for k, o in zip(kept_keys, ovl)])
+        ll = self._link_lines
+        for k, o in zip(kept_keys, ovl):
+            hit = ll.get(k)
+            if hit is None or hit[0] != o:
+                hit = (o, "L\t%s\t+\t%s\t+\t%dM\n" % (k[0], k[1], o))
+                ll[k] = hit
+            add(hit[1])
+        if len(sl) > 8 * nv + 4096:  # (ids of retired nodes pile up over a run: start over now and then)
+            sl.clear()
+        if len(ll) > 8 * n_e + 4096:
+            ll.clear()
         text = "".join(chunks)
         with open(gfa_path, "w") as fh:
             fh.write(text)
