@@ -124,8 +124,15 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # (VS_DIST_BACKEND=gloo VS_DIST_DEVICE=0: all ranks on one GPU, sums through gloo -- a functional run of
+        # the multi-rank step on a one-GPU box, tests only; its numbers mean nothing)
+        backend = os.environ.get("VS_DIST_BACKEND", "nccl")
+        local_rank = int(os.environ.get("VS_DIST_DEVICE", str(local_rank)))
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)

@@ -494,3 +494,58 @@ def test_fastq_block_refuses_non_ascii_sequence_bytes_and_takes_dirty_reads(host
     ref = pe_oracle_c.Oracle(g.seqs, 21).count_pairs(f, r)
     assert np.array_equal(node_mat, ref[0]) and np.array_equal(short_mat, ref[1])
     assert stats == tuple(int(x) for x in ref[2])
+
+
+def test_sharded_drop_in_two_ranks_on_one_gpu(tmp_path):
+    """The PE drop-in under torchrun with two ranks: each rank counts its contiguous block of the
+    pairs with the real kernels, the counters are summed, rank 0 alone touches the output
+    directory and writes the files -- byte-identical to the reference's.  One GPU here, so both
+    ranks use device 0 and the sum goes through gloo (RCCL needs a device per rank; the RCCL call
+    itself is exercised by the one-rank tests and by bench.py --gpus N)."""
+    import socket
+
+    name, d, meta = [c for c in pe_cases() if c[0] == "errors_k21"][0]
+    out = tmp_path / "aln"
+    out.mkdir()
+    (out / "stale_file").write_text("x")  # rank 0 wipes the directory (PE_Inference.py:93-96); nobody else may
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, VS_DIST_BACKEND="gloo", VS_DIST_DEVICE="0")
+    proc = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), "-m", "vstrains_amd.pe_inference", "-g", os.path.join(d, "graph.gfa"), "-o", str(out),
+         "-f", os.path.join(d, "fwd.fq"), "-r", os.path.join(d, "rve.fq"), "-k", str(meta["k"])],
+        cwd=ROOT, capture_output=True, text=True, env=env, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    assert _read(out / "pe_info") == _read(os.path.join(d, "pe_info"))
+    assert _read(out / "st_info") == _read(os.path.join(d, "st_info"))
+    assert sorted(os.listdir(out)) == ["pe_info", "st_info"]
+    assert proc.stdout.count("result stored in:") == 1  # rank 0 only
+
+
+def test_bench_step_with_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's multi-rank step (two counter buffers, the all-reduce of step i waited for when its
+    buffer comes up again, max over ranks, one JSON line from rank 0) with two ranks sharing the
+    one GPU and gloo as the collective: the line must account for both ranks' pairs.  (A functional
+    run; the rate of two processes sharing a GPU says nothing.)"""
+    import json
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, VS_DIST_BACKEND="gloo", VS_DIST_DEVICE="0")
+    proc = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), "bench.py", "--gpus", "2", "--config", "1", "--pairs", "200000", "--steps", "3", "--warmup", "1",
+         "--cpu-seconds", "0", "--no-extract"],
+        cwd=ROOT, capture_output=True, text=True, env=env, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    line = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
+    assert abs(out["value"] - 2 * 200000 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    st = out["pe_stats"]
+    assert st["n_reads"] + st["short_reads"] + st["used_reads"] == 2 * 200000  # both ranks' pairs, summed

@@ -119,9 +119,16 @@ def main(argv=None):
         import torch.distributed as dist
 
         local = int(os.environ.get("LOCAL_RANK", "0"))
+        # (VS_DIST_BACKEND=gloo VS_DIST_DEVICE=0: several ranks on ONE GPU, counters summed through gloo --
+        # how the sharded drop-in is exercised end to end on a one-GPU box; RCCL wants one device per rank)
+        backend = os.environ.get("VS_DIST_BACKEND", "nccl")
+        local = int(os.environ.get("VS_DIST_DEVICE", str(local)))
         torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
         args.device = local
         # every rank indexes both FASTQ files on the host: share the cores between the local ranks
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
