@@ -58,6 +58,11 @@ const Rccl &rccl() {
     return r;
 }
 
+int rccl_missing(vs_ctx *ctx) {
+    const char *why = dlerror();
+    return vs_fail(ctx, VS_E_HIP, "RCCL (librccl.so.1) cannot be loaded: %s", why ? why : "entry points not found");
+}
+
 int rccl_fail(vs_ctx *ctx, const char *what, int code) {
     const Rccl &r = rccl();
     return vs_fail(ctx, VS_E_HIP, "%s failed: %s (rccl code %d)", what, r.error_string ? r.error_string(code) : "?", code);
@@ -90,7 +95,7 @@ int vs_counts_fold(vs_ctx *ctx, uint32_t *d_counts, int64_t *d_wide, uint64_t n)
 int vs_comm_unique_id(vs_ctx *ctx, uint8_t id[128]) {
     if (!id) return vs_fail(ctx, VS_E_ARG, "vs_comm_unique_id: id is NULL");
     const Rccl &r = rccl();
-    if (!r.ok()) return vs_fail(ctx, VS_E_HIP, "RCCL (librccl.so.1) cannot be loaded: %s", dlerror());
+    if (!r.ok()) return rccl_missing(ctx);
     RcclUniqueId u;
     int rc = r.get_unique_id(&u);
     if (rc) return rccl_fail(ctx, "ncclGetUniqueId", rc);
@@ -102,7 +107,7 @@ int vs_comm_init_rank(vs_ctx *ctx, int n_ranks, const uint8_t id[128], int rank,
     if (!ctx || !id || !comm || n_ranks < 1 || rank < 0 || rank >= n_ranks) return vs_fail(ctx, VS_E_ARG, "vs_comm_init_rank: bad argument");
     *comm = nullptr;
     const Rccl &r = rccl();
-    if (!r.ok()) return vs_fail(ctx, VS_E_HIP, "RCCL (librccl.so.1) cannot be loaded: %s", dlerror());
+    if (!r.ok()) return rccl_missing(ctx);
     VS_HIP(ctx, hipSetDevice(ctx->device));
     RcclUniqueId u;
     memcpy(u.internal, id, 128);
@@ -114,7 +119,7 @@ int vs_comm_init_rank(vs_ctx *ctx, int n_ranks, const uint8_t id[128], int rank,
 int vs_comm_destroy(vs_ctx *ctx, void *comm) {
     if (!comm) return VS_OK;
     const Rccl &r = rccl();
-    if (!r.ok()) return vs_fail(ctx, VS_E_HIP, "RCCL (librccl.so.1) cannot be loaded");
+    if (!r.ok()) return rccl_missing(ctx);
     if (ctx) {
         VS_HIP(ctx, hipSetDevice(ctx->device));
         VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -127,7 +132,7 @@ int vs_comm_destroy(vs_ctx *ctx, void *comm) {
 int vs_pe_allreduce(vs_ctx *ctx, void *comm, void *d_node_mat, void *d_short_mat, uint64_t *d_stats, uint32_t n, int wide) {
     if (!ctx || !comm || !d_node_mat || !d_short_mat) return vs_fail(ctx, VS_E_ARG, "vs_pe_allreduce: bad argument");
     const Rccl &r = rccl();
-    if (!r.ok()) return vs_fail(ctx, VS_E_HIP, "RCCL (librccl.so.1) cannot be loaded: %s", dlerror());
+    if (!r.ok()) return rccl_missing(ctx);
     VS_HIP(ctx, hipSetDevice(ctx->device));
     const size_t cells = (size_t)n * n;
     const int dt = wide ? RCCL_INT64 : RCCL_UINT32;
