@@ -859,7 +859,7 @@ template <> struct AccTable<unsigned long long> {
 // Slow side of vs_cell_add: the slot is empty or holds another cell.  Kept out of line so that
 // the common case (the cell is already in the table) stays a short straight-line sequence.
 template <typename KT>
-__device__ __noinline__ bool vs_cell_claim(KT *s_key, uint32_t *s_cnt, uint32_t *s_used, KT key, uint32_t at, uint32_t wgt) {
+__device__ __forceinline__ bool vs_cell_claim(KT *s_key, uint32_t *s_cnt, uint32_t *s_used, KT key, uint32_t at, uint32_t wgt) {
     for (uint32_t pr = 0; pr < 8u; pr++) {
         KT kx = s_key[at];
         if (kx == AccTable<KT>::EMPTY) {
@@ -1039,10 +1039,19 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         uint32_t cur = 0;  // wave-uniform: first pair whose runs reach into the current window
-        for (uint32_t t0 = 0; t0 < U; t0 += 64u) {
+        // One window of 64 runs: which pair and which of its runs a lane takes, the run's first node and
+        // its (up to) four partners.  The two list loads of window i+1 are issued before window i is
+        // counted, so their round trip (L2) is covered by the cell-table work instead of preceding it.
+        struct Run {
+            uint32_t x, mat, bi, be, wgt;
+            VsQuad yq;
+            bool ok;
+        };
+        auto fetch = [&](uint32_t t0) {
+            Run R;
             while (s_pref[wv][cur + 1u] <= t0) cur++;
             const uint32_t t_raw = t0 + lane;
-            const uint32_t t = t_raw < U ? t_raw : U - 1u;  // (lanes past the end ride along until the cross-lane read)
+            const uint32_t t = t_raw < U ? t_raw : U - 1u;  // (lanes past the end ride along, their result is dropped)
             uint32_t a0 = cur;  // last pair of this wavefront with pref <= t
             a0 += s_pref[wv][a0 + 1u] <= t ? 1u : 0u;
             a0 += s_pref[wv][a0 + 1u] <= t ? 1u : 0u;
@@ -1051,28 +1060,40 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
             uint32_t r = t - s_pref[wv][a0];
             // list lengths of pair a0: lane a0 holds them (cross-lane read, no memory round trip)
             const uint32_t qlw = __shfl(nlw, (int)a0, 64), qrw = __shfl(nrw, (int)a0, 64);
-            if (t_raw >= U) break;
+            R.ok = t_raw < U;
             const uint32_t ql = qlw & 0xFFu, qr = qrw & 0xFFu;
             const uint32_t row = 2u * a0 * LC;
             const uint32_t cq = (qr + ACC_RUN - 1u) / ACC_RUN;
-            uint32_t x, mat, off, bi, be, wgt = 1u;
+            uint32_t off;
+            R.wgt = 1u;
             if (r < ql * cq) {  // node_mat: left node a, right positions of run c
                 const uint32_t a = cq == 1u ? r : cq == 2u ? r >> 1 : cq == 4u ? r >> 2 : (r * 43691u) >> 17;
-                x = wlists[row + a]; mat = 0u; off = row + LC; bi = ACC_RUN * (r - a * cq); be = qr;
+                R.x = wlists[row + a]; R.mat = 0u; off = row + LC; R.bi = ACC_RUN * (r - a * cq); R.be = qr;
             } else {
                 r -= ql * cq;
                 uint32_t n = ql;
                 off = row;
-                wgt = qlw >> 8;
-                const uint32_t gl = wgt ? s_g[ql] : 0u;  // (a merged left list has no runs of its own)
-                if (r >= gl) { r -= gl; n = qr; off = row + LC; wgt = qrw >> 8; }
+                R.wgt = qlw >> 8;
+                const uint32_t gl = R.wgt ? s_g[ql] : 0u;  // (a merged left list has no runs of its own)
+                if (r >= gl) { r -= gl; n = qr; off = row + LC; R.wgt = qrw >> 8; }
                 const uint32_t a = s_ua[n * ACC_GMAX + r];
                 const uint32_t crun = r - (s_g[n] - s_g[n - a]);  // runs of positions before a: g(n) - g(n-a)
-                x = wlists[off + a]; mat = 1u; bi = a + ACC_RUN * crun; be = n;
+                R.x = wlists[off + a]; R.mat = 1u; R.bi = a + ACC_RUN * crun; R.be = n;
             }
             // up to ACC_RUN partners, loaded together (the row holds LC entries; reading a few words
             // past `be` stays inside the lists buffer, which carries padding, and is ignored)
-            const VsQuad yq = *(const VsQuad *)(wlists + off + bi);  // one 16-byte load
+            R.yq = *(const VsQuad *)(wlists + off + R.bi);  // one 16-byte load
+            return R;
+        };
+        Run nxt;
+        nxt.ok = false;
+        if (U) nxt = fetch(0u);
+        for (uint32_t t0 = 0; t0 < U; t0 += 64u) {
+            const Run c = nxt;
+            if (t0 + 64u < U) nxt = fetch(t0 + 64u);
+            if (!c.ok) continue;
+            const uint32_t x = c.x, mat = c.mat, bi = c.bi, be = c.be, wgt = c.wgt;
+            const VsQuad yq = c.yq;
             const uint32_t y0 = yq.x, y1 = yq.y, y2 = yq.z, y3 = yq.w;
             if (use_table == 2u) {
                 if ((y0 ^ y1 ^ y2 ^ y3 ^ x) == 0xDEADBEEFu) atomicAdd(&s_lost, 1u);  // (timing experiment: decode only)
