@@ -44,7 +44,10 @@
 #ifndef TILES_WAVES
 #define TILES_WAVES 5        // k_pe_tiles is compiled for 5 waves per SIMD (<= 96 VGPRs); its LDS tile fits 5 times too
 #endif
-#define CHUNK (TPB * PPT)
+#ifndef TTPB
+#define TTPB 256             // threads per k_pe_tiles workgroup (a tile holds TTPB / 4 read ends)
+#endif
+#define CHUNK (TTPB * PPT)
 
 struct PeParams {
     VsIndexDev idx;
@@ -391,15 +394,17 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
 // (7, 3) = 2 x 97..112.  Every LDS array then sits at a constant offset (folded into the LDS
 // instructions) instead of costing a scalar register and an add, the divisions by pmax / wpe and
 // k+1 / seed length / stride become constants.  The host picks one when the block has that shape.
-#define STD_EPT 64u
-#define STD_POOL_BITS 10u
+#ifndef STD_EPT
+#define STD_EPT (TTPB / 4u)
+#endif
+#define STD_POOL_BITS (STD_EPT > 32u ? 10u : STD_EPT > 16u ? 9u : 8u)  // pool_for(STD_EPT)
 #define STD_K 56u   // k + 1
 #define STD_W 31u   // seed length and probe stride that follow from it (seed_geometry)
 #define STD_S 26u
 // MODE 0: generic loops (masked reads through the validity mask, any stride / read length);
 //      1: straight-line comparison, stride <= 32, reads <= w + 160; 2: the same for stride <= 128, reads <= w + 256.
 template <int MODE, uint32_t SW, uint32_t SP>
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(TTPB)
 __attribute__((amdgpu_waves_per_eu(MODE == 2 ? TILES_WAVES - 1 : TILES_WAVES, MODE == 2 ? TILES_WAVES - 1 : TILES_WAVES)))
 k_pe_tiles(PeParams P) {
     constexpr bool FAST = MODE != 0;
@@ -453,7 +458,7 @@ k_pe_tiles(PeParams P) {
     const uint64_t tile_hi = tile_lo + P.tiles_per_wg < P.n_tiles ? tile_lo + P.tiles_per_wg : P.n_tiles;
     // The headers of a tile (pair order -> end index -> word offset, length) are two dependent
     // global loads; they run ahead in registers, one link per tile (pair order two tiles ahead, word
-    // offset and length one tile ahead; one end per thread, ept <= TPB), so that neither waits for
+    // offset and length one tile ahead; one end per thread, ept <= TTPB), so that neither waits for
     // the other and both are covered by the previous tiles' work.
     uint32_t pf_gend = 0, pf_gwoff = 0, pf_meta = 0, pf_inv = 0xFFFFFFFFu, pf_pair = 0xFFFFFFFFu;
     uint32_t cur_inv = 0xFFFFFFFFu;  // this thread's end of the CURRENT tile (goes to LDS at the top of the tile)
@@ -510,7 +515,7 @@ k_pe_tiles(PeParams P) {
         cur_inv = pf_inv;
         if (tid < 8u) { s_words[words_cap + tid] = 0u; s_words[wcap + words_cap + tid] = 0u; }  // pads of both copies
         __syncthreads();
-        for (uint32_t i = tid; i < ne0 * wpe; i += TPB) {
+        for (uint32_t i = tid; i < ne0 * wpe; i += TTPB) {
             const uint32_t e = STD ? i / STD_WPE : vs_fastdiv(i, P.magic_wpe), k = i - e * wpe;
             const uint32_t nw = ((s_meta[e] & VS_LEN_MASK) + 15u) >> 4;
             s_words[i] = k < nw ? P.rd.words[s_gwoff[e] + k] : 0u;
@@ -546,7 +551,7 @@ k_pe_tiles(PeParams P) {
             s_inv[tid] = cur_inv;
             cur_inv = pf_inv;
         }
-        for (uint32_t i = tid; i < pool; i += TPB) {
+        for (uint32_t i = tid; i < pool; i += TTPB) {
             s_hkey[i] = EMPTY_NODE;
             s_hcnt[i] = 0;
             s_hminp[i] = 0xFFFFFFFFu;
@@ -557,7 +562,7 @@ k_pe_tiles(PeParams P) {
         prefetch_pair(tile + 3u);
         // packed reads of the next tile: one end per wpe-word slot; a wavefront's load instruction
         // fills 64 consecutive LDS words, every lane from its own global address
-        for (uint32_t b64 = wv0 * 64u; b64 < ne1 * wpe; b64 += TPB) {
+        for (uint32_t b64 = wv0 * 64u; b64 < ne1 * wpe; b64 += TTPB) {
             const uint32_t i = b64 + lane0;
             if (i < ne1 * wpe) {
                 const uint32_t e = STD ? i / STD_WPE : vs_fastdiv(i, P.magic_wpe), k = i - e * wpe;
@@ -583,7 +588,7 @@ k_pe_tiles(PeParams P) {
         __syncthreads();
         if (debug_stop == 1u) continue;
         // ---- P1: probes
-        for (uint32_t it = tid; it < NI; it += TPB) {
+        for (uint32_t it = tid; it < NI; it += TTPB) {
             uint32_t e = STD ? it / STD_PMAX : vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
             uint32_t cnt = 0, pa = 0, pb = 0;
             if (e < ne && (s_state[e] & 3u) == 1u) {
@@ -612,7 +617,7 @@ k_pe_tiles(PeParams P) {
         if (debug_stop == 2u) continue;
         // ---- P2: inclusive scan of the postings per probe, s_pcnt[0..NI)
         {
-            const uint32_t chunk = (NI + TPB - 1u) / TPB;
+            const uint32_t chunk = (NI + TTPB - 1u) / TTPB;
             const uint32_t b = tid * chunk;
             uint32_t local = 0;
             for (uint32_t i = 0; i < chunk; i++)
@@ -644,9 +649,9 @@ k_pe_tiles(PeParams P) {
         const uint32_t total = s_pcnt[NI - 1u];
         if (count_postings && tid == 0) atomicAdd((unsigned long long *)(P.slow_count + 2), (unsigned long long)total);
         for (uint32_t c0 = 0; c0 < total; c0 += CHUNK) {
-            for (uint32_t i = tid; i < CHUNK; i += TPB) s_owner[i] = 0;
+            for (uint32_t i = tid; i < CHUNK; i += TTPB) s_owner[i] = 0;
             __syncthreads();
-            for (uint32_t it = tid; it < NI; it += TPB) {
+            for (uint32_t it = tid; it < NI; it += TTPB) {
                 const uint32_t incl = s_pcnt[it], excl = s_pcnt[(int)it - 1];
                 if (incl > excl) {
                     const uint32_t lo = excl > c0 ? excl : c0;
@@ -674,7 +679,7 @@ k_pe_tiles(PeParams P) {
             uint32_t carry = __shfl_up(incl, 1, 64);
             if (lane == 0u) carry = 0;
             __syncthreads();
-            {   // the wavefronts before this one (TPB = 256: at most three)
+            {   // the wavefronts before this one (TTPB = 256: at most three)
                 const uint32_t m0 = s_misc[4], m1 = s_misc[5], m2 = s_misc[6], wv = tid >> 6;
                 if (wv > 0u) carry = m0 > carry ? m0 : carry;
                 if (wv > 1u) carry = m1 > carry ? m1 : carry;
@@ -761,7 +766,7 @@ k_pe_tiles(PeParams P) {
         __syncthreads();
         if (debug_stop == 4u) continue;
         // ---- P4: acceptance test per table slot; accepted nodes go to the end's list
-        for (uint32_t i = tid; i < pool; i += TPB) {
+        for (uint32_t i = tid; i < pool; i += TTPB) {
             uint32_t key = s_hkey[i];
             if (key != EMPTY_NODE) {
                 uint32_t e = key >> 25, node = key & 0x01FFFFFFu;
@@ -792,12 +797,12 @@ k_pe_tiles(PeParams P) {
         // length 0 for ends of dropped pairs and of pairs the slow path takes)
         if (accumulate) {
             uint32_t *ol = P.out_lists + tile * ept * LC;
-            for (uint32_t i = tid; i < ne * LC; i += TPB) ol[i] = s_list[i];
-            for (uint32_t i = tid; i < ne; i += TPB)
+            for (uint32_t i = tid; i < ne * LC; i += TTPB) ol[i] = s_list[i];
+            for (uint32_t i = tid; i < ne; i += TTPB)
                 P.out_counts[tile * ept + i] = (s_state[i] & 3u) == 1u ? s_ns[i] : 0u;
         }
         if (want_dbg) {
-            for (uint32_t i = tid; i < ne; i += TPB) {
+            for (uint32_t i = tid; i < ne; i += TTPB) {
                 if (s_state[i] & 2u) continue;  // the slow kernel reports these
                 uint32_t n = s_ns[i];
                 const uint64_t ge = s_gend[i];
@@ -1414,16 +1419,16 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     const uint32_t pmax = maxlen >= idx.w ? (maxlen - idx.w) / idx.s + 1u : 1u;
     const uint32_t wpe = maxlen ? (maxlen + 15u) / 16u : 1u;
     if (idx.n_nodes > 0x01FFFFFEu) return vs_fail(ctx, VS_E_RANGE, "more than 2^25-2 nodes");
-    uint32_t ept = 64;
+    uint32_t ept = STD_EPT;
     if (const char *ev = getenv("VS_EPT")) ept = (uint32_t)atoi(ev) & ~1u;
-    if (ept < 2 || ept > 128) ept = 64;
+    if (ept < 2 || ept > TTPB / 2u) ept = STD_EPT;
     while (ept > 2 && (ept * pmax > NI_CAP || lds_bytes(ept, pmax, ept * wpe) > LDS_BUDGET_BYTES)) ept -= 2;
     // (LDS is handed out in 1280-byte pieces: 32 000 B per workgroup lets five share a CU, 40 000 four.  A tile of
     // at least 32 ends that fits one of these is taken over a larger one that wastes the rest.)
     if (!getenv("VS_EPT")) {
-        for (size_t fit : {(size_t)32000, (size_t)40000}) {
+        for (size_t fit : {(size_t)(TTPB == 256 ? 32000 : TTPB == 128 ? 15360 : 7680), (size_t)(TTPB == 256 ? 40000 : TTPB == 128 ? 17920 : 8960)}) {
             uint32_t e2 = ept;
-            while (e2 > 32 && lds_bytes(e2, pmax, e2 * wpe) > fit) e2 -= 2;
+            while (e2 > STD_EPT / 2u && lds_bytes(e2, pmax, e2 * wpe) > fit) e2 -= 2;
             if (lds_bytes(e2, pmax, e2 * wpe) <= fit) { ept = e2; break; }
         }
     }
@@ -1558,7 +1563,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         VS_HIP(ctx, hipFuncSetAttribute(tiles_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (getenv("VS_DEBUG_OCC")) {
         int nb = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tiles_fn, TPB, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tiles_fn, TTPB, lds);
         fprintf(stderr, "[vs] k_pe_tiles: %zu B of LDS per workgroup, %d workgroups per CU\n", lds, nb);
     }
     uint64_t grid = P.n_tiles;
@@ -1610,17 +1615,17 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
                        : fast_long      ? "k_pe_tiles<2, 0u, 0u>"
                                         : "k_pe_tiles<0, 0u, 0u>";
     if (std_shape == 1)
-        hipLaunchKernelGGL((k_pe_tiles<1, 10u, 5u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
+        hipLaunchKernelGGL((k_pe_tiles<1, 10u, 5u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
     else if (std_shape == 2)
-        hipLaunchKernelGGL((k_pe_tiles<1, 8u, 4u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
+        hipLaunchKernelGGL((k_pe_tiles<1, 8u, 4u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
     else if (std_shape == 3)
-        hipLaunchKernelGGL((k_pe_tiles<1, 7u, 3u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
+        hipLaunchKernelGGL((k_pe_tiles<1, 7u, 3u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
     else if (fast)
-        hipLaunchKernelGGL((k_pe_tiles<1, 0u, 0u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
+        hipLaunchKernelGGL((k_pe_tiles<1, 0u, 0u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
     else if (fast_long)
-        hipLaunchKernelGGL((k_pe_tiles<2, 0u, 0u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
+        hipLaunchKernelGGL((k_pe_tiles<2, 0u, 0u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
     else
-        hipLaunchKernelGGL((k_pe_tiles<0, 0u, 0u>), dim3((unsigned)grid), dim3(TPB), lds, st, P);
+        hipLaunchKernelGGL((k_pe_tiles<0, 0u, 0u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
     if (d_node_mat) {
         // the last tile may be partly empty: its unused rows must read as length 0
         const uint64_t used_ends = 2ull * n_pairs;
