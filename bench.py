@@ -91,7 +91,10 @@ def strain_extract(ctx, counter, pre, names, logger, out_dir):
         prof.disable()
         pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(30)
     n_stage_graphs = len([f for f in os.listdir(os.path.join(out_dir, "gfa")) if f.endswith(".gfa")])
+    from vstrains_amd import graph as graph_pkg
+
     return {"seconds": secs, "strains": len(strains), "stage_graphs_written": n_stage_graphs,
+            "host_modules": graph_pkg.host_modules(),
             "graph_refresh_launches": backend.graph_ops.calls, "link_table_launches": table.calls,
             "longest_strain_bp": max([rec[1] for rec in strains.values()] or [0])}
 

@@ -32,6 +32,7 @@
 // second, fully general kernel (dense per-workgroup node state in HBM) works through.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "vs_internal.h"
 
@@ -839,73 +840,92 @@ k_pe_tiles(PeParams P) {
 //              g(n) = sum_{m=1..n} ceil(m/4)
 #define ACC_RUN 4u
 #define ACC_GMAX 40u  // g(16)
-// The cell table comes in two widths: 32-bit keys (mat * N*N + x * N + y; 16 k slots) while
-// 2*N*N fits 32 bits (N <= 46340), 64-bit keys (mat << 60 | x * N + y; 8 k slots) above that.
-template <typename KT> struct AccTable;
-template <> struct AccTable<uint32_t> {
+// The cell table comes in three shapes (16 k words of keys + 16 k words of counts either way):
+//   Acc32      one table of 16 k slots, 32-bit keys mat * N*N + x * N + y, while 2*N*N fits 32 bits (N <= 46340)
+//   Acc32Split one 8 k-slot table per matrix, 32-bit keys x * N + y, while N*N fits (N <= 65535): the matrix is
+//              the upper bit of the slot index, a probe sequence stays inside its half
+//   Acc64      8 k slots, 64-bit keys mat << 60 | x * N + y, above that
+struct Acc32 {
+    typedef uint32_t KT;
     static constexpr uint32_t BITS = ACC_BITS;
     static constexpr uint32_t EMPTY = 0xFFFFFFFFu;
     __device__ static uint32_t key(uint32_t mat, uint32_t x, uint32_t y, uint32_t N) { return (mat * N + x) * N + y; }
-    __device__ static uint32_t slot(uint32_t k) { return (k * 0x9E3779B1u) >> (32u - BITS); }
-    __device__ static uint32_t mat_of(uint32_t k, uint32_t N) { return k >= N * N ? 1u : 0u; }
+    __device__ static uint32_t slot(uint32_t, uint32_t k) { return (k * 0x9E3779B1u) >> (32u - BITS); }
+    __device__ static uint32_t next(uint32_t at) { return (at + 1u) & ((1u << BITS) - 1u); }
+    __device__ static uint32_t mat_of(uint32_t k, uint32_t N, uint32_t) { return k >= N * N ? 1u : 0u; }
     __device__ static uint64_t cell_of(uint32_t k, uint32_t N) { return k >= N * N ? (uint64_t)(k - N * N) : (uint64_t)k; }
 };
-template <> struct AccTable<unsigned long long> {
+struct Acc32Split {
+    typedef uint32_t KT;
+    static constexpr uint32_t BITS = ACC_BITS;
+    static constexpr uint32_t HALF = 1u << (ACC_BITS - 1u);
+    static constexpr uint32_t EMPTY = 0xFFFFFFFFu;  // (N <= 65535: the largest cell is N*N - 1 < 2^32 - 1)
+    __device__ static uint32_t key(uint32_t, uint32_t x, uint32_t y, uint32_t N) { return x * N + y; }
+    __device__ static uint32_t slot(uint32_t mat, uint32_t k) { return (mat ? HALF : 0u) | ((k * 0x9E3779B1u) >> (33u - BITS)); }
+    __device__ static uint32_t next(uint32_t at) { return (at & HALF) | ((at + 1u) & (HALF - 1u)); }
+    __device__ static uint32_t mat_of(uint32_t, uint32_t, uint32_t i) { return i >> (BITS - 1u); }
+    __device__ static uint64_t cell_of(uint32_t k, uint32_t) { return (uint64_t)k; }
+};
+struct Acc64 {
+    typedef unsigned long long KT;
     static constexpr uint32_t BITS = ACC_BITS - 1u;
     static constexpr unsigned long long EMPTY = ~0ull;
     __device__ static unsigned long long key(uint32_t mat, uint32_t x, uint32_t y, uint32_t N) {
         return ((unsigned long long)mat << 60) | ((unsigned long long)x * N + y);
     }
-    __device__ static uint32_t slot(unsigned long long k) { return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> (64u - BITS)); }
-    __device__ static uint32_t mat_of(unsigned long long k, uint32_t) { return (uint32_t)(k >> 60); }
+    __device__ static uint32_t slot(uint32_t, unsigned long long k) { return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> (64u - BITS)); }
+    __device__ static uint32_t next(uint32_t at) { return (at + 1u) & ((1u << BITS) - 1u); }
+    __device__ static uint32_t mat_of(unsigned long long k, uint32_t, uint32_t) { return (uint32_t)(k >> 60); }
     __device__ static uint64_t cell_of(unsigned long long k, uint32_t) { return k & ((1ull << 60) - 1ull); }
 };
 
 // Slow side of vs_cell_add: the slot is empty or holds another cell.  Kept out of line so that
 // the common case (the cell is already in the table) stays a short straight-line sequence.
-template <typename KT>
-__device__ __forceinline__ bool vs_cell_claim(KT *s_key, uint32_t *s_cnt, uint32_t *s_used, KT key, uint32_t at, uint32_t wgt) {
+template <typename TB>
+__device__ __forceinline__ bool vs_cell_claim(typename TB::KT *s_key, uint32_t *s_cnt, uint32_t *s_used, typename TB::KT key, uint32_t at, uint32_t wgt) {
     for (uint32_t pr = 0; pr < 8u; pr++) {
-        KT kx = s_key[at];
-        if (kx == AccTable<KT>::EMPTY) {
-            kx = atomicCAS(&s_key[at], AccTable<KT>::EMPTY, key);
-            if (kx == AccTable<KT>::EMPTY) { atomicAdd(s_used, 1u); kx = key; }
+        typename TB::KT kx = s_key[at];
+        if (kx == TB::EMPTY) {
+            kx = atomicCAS(&s_key[at], TB::EMPTY, key);
+            if (kx == TB::EMPTY) { atomicAdd(s_used, 1u); kx = key; }
         }
         if (kx == key) {
             atomicAdd(&s_cnt[at], wgt);
             return true;
         }
-        at = (at + 1u) & ((1u << AccTable<KT>::BITS) - 1u);
+        at = TB::next(at);
     }
     return false;
 }
 
-template <typename KT>
-__device__ __forceinline__ void vs_cell_add(KT *s_key, uint32_t *s_cnt, uint32_t &s_used, uint32_t &s_lost, bool use_table,
+template <typename TB>
+__device__ __forceinline__ void vs_cell_add(typename TB::KT *s_key, uint32_t *s_cnt, uint32_t &s_used, uint32_t &s_lost, bool use_table,
                                             uint32_t mat, uint32_t x, uint32_t yv, uint32_t N,
                                             uint32_t *node_mat, uint32_t *short_mat, uint32_t wgt) {
     const uint32_t cx = (mat && yv < x) ? yv : x, cy = (mat && yv < x) ? x : yv;
     bool done = false;
     if (use_table) {
-        const KT key = AccTable<KT>::key(mat, cx, cy, N);
-        const uint32_t at = AccTable<KT>::slot(key);
+        const typename TB::KT key = TB::key(mat, cx, cy, N);
+        const uint32_t at = TB::slot(mat, key);
         if (s_key[at] == key) {
             atomicAdd(&s_cnt[at], wgt);
             done = true;
         } else {
-            done = vs_cell_claim<KT>(s_key, s_cnt, &s_used, key, at, wgt);
+            done = vs_cell_claim<TB>(s_key, s_cnt, &s_used, key, at, wgt);
             if (!done) atomicAdd(&s_lost, 1u);
         }
     }
     if (!done) atomicAdd((mat ? short_mat : node_mat) + (uint64_t)cx * N + cy, wgt);
 }
 
-template <typename KT>
+template <typename TB>
 __global__ void __launch_bounds__(ACC_TPB)
 k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_slots_pairs,
                 uint32_t pairs_per_wg, uint32_t N, uint32_t use_table, uint32_t fill_limit,
-                uint32_t *__restrict__ node_mat, uint32_t *__restrict__ short_mat, uint32_t *__restrict__ queue, uint32_t merge) {
-    constexpr uint32_t SLOTS = 1u << AccTable<KT>::BITS;
+                uint32_t *__restrict__ node_mat, uint32_t *__restrict__ short_mat, uint32_t *__restrict__ queue, uint32_t merge,
+                uint32_t *__restrict__ dbg) {  // VS_DEBUG_ACC: [0] increments past the table, [1] write-outs, [2] cells written, [3] rounds
+    using KT = typename TB::KT;
+    constexpr uint32_t SLOTS = 1u << TB::BITS;
     KT *s_key = (KT *)vs_lds;                      // [SLOTS] keys: ACC_SLOTS words either way
     uint32_t *s_cnt = vs_lds + ACC_SLOTS;          // [SLOTS]
     uint32_t(*s_pref)[66] = (uint32_t(*)[66])(vs_lds + 2u * ACC_SLOTS);  // [ACC_TPB / 64][66]
@@ -922,7 +942,7 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
     uint32_t *s_down = s_ua + (LC + 1u) * ACC_GMAX + 4u;  // [ACC_DEDUP_SLOTS]
     uint32_t *s_dmul = s_down + ACC_DEDUP_SLOTS;          // [ACC_DEDUP_SLOTS]
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    for (uint32_t i = tid; i < SLOTS; i += ACC_TPB) { s_key[i] = AccTable<KT>::EMPTY; s_cnt[i] = 0; }
+    for (uint32_t i = tid; i < SLOTS; i += ACC_TPB) { s_key[i] = TB::EMPTY; s_cnt[i] = 0; }
     if (tid <= LC) {
         uint32_t gsum = 0;
         for (uint32_t m = 1; m <= tid; m++) gsum += (m + ACC_RUN - 1u) / ACC_RUN;
@@ -937,6 +957,20 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
     // chunks of pairs_per_wg pairs: chunk blockIdx.x, or (queue) whichever chunk is next when this
     // workgroup is free -- the table then lives across chunks and is written out on fill only
     uint32_t &s_chunk = s_ua[(LC + 1u) * ACC_GMAX + 2u];
+    // every cell of the table to its counter (one global atomic per cell), the table emptied
+    auto write_out = [&]() {
+        for (uint32_t i = tid; i < SLOTS; i += ACC_TPB) {
+            const KT key = s_key[i];
+            if (key != TB::EMPTY) {
+                if (use_table != 3u)  // (3: timing experiment without the write-outs)
+                    atomicAdd((TB::mat_of(key, N, i) ? short_mat : node_mat) + TB::cell_of(key, N), s_cnt[i]);
+                s_key[i] = TB::EMPTY;
+                s_cnt[i] = 0;
+            }
+        }
+        if (tid == 0) { s_used = 0; s_lost = 0; }
+        __syncthreads();
+    };
     for (;;) {
     uint64_t chunk = blockIdx.x;
     if (queue) {
@@ -1114,8 +1148,8 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
                     live[j] = bi + j < be;  // j = 0 always
                     const uint32_t yv = ys[j];
                     const uint32_t cx = (mat && yv < x) ? yv : x, cy = (mat && yv < x) ? x : yv;
-                    key[j] = AccTable<KT>::key(mat, cx, cy, N);
-                    at[j] = AccTable<KT>::slot(key[j]);
+                    key[j] = TB::key(mat, cx, cy, N);
+                    at[j] = TB::slot(mat, key[j]);
                     seen[j] = s_key[at[j]];
                 }
 #pragma unroll
@@ -1123,45 +1157,38 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
                     if (!live[j]) continue;
                     if (seen[j] == key[j]) {
                         atomicAdd(&s_cnt[at[j]], wgt);
-                    } else if (!vs_cell_claim<KT>(s_key, s_cnt, &s_used, key[j], at[j], wgt)) {
+                    } else if (!vs_cell_claim<TB>(s_key, s_cnt, &s_used, key[j], at[j], wgt)) {
                         atomicAdd(&s_lost, 1u);
-                        atomicAdd((mat ? short_mat : node_mat) + AccTable<KT>::cell_of(key[j], N), wgt);
+                        atomicAdd((mat ? short_mat : node_mat) + TB::cell_of(key[j], N), wgt);
                     }
                 }
             } else {
-                vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y0, N, node_mat, short_mat, wgt);  // bi < be always
-                if (bi + 1u < be) vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y1, N, node_mat, short_mat, wgt);
-                if (bi + 2u < be) vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y2, N, node_mat, short_mat, wgt);
-                if (bi + 3u < be) vs_cell_add<KT>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y3, N, node_mat, short_mat, wgt);
+                vs_cell_add<TB>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y0, N, node_mat, short_mat, wgt);  // bi < be always
+                if (bi + 1u < be) vs_cell_add<TB>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y1, N, node_mat, short_mat, wgt);
+                if (bi + 2u < be) vs_cell_add<TB>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y2, N, node_mat, short_mat, wgt);
+                if (bi + 3u < be) vs_cell_add<TB>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y3, N, node_mat, short_mat, wgt);
             }
         }
         __syncthreads();
         const bool spill = s_used > fill_limit || s_lost > 4096u;
-        __syncthreads();
-        if (spill) {
-            // (everything goes, also the cells of the locus still being worked on: keeping those across
-            // write-outs was measured -- 3.1 -> 3.9 ms -- the table is only fast while nearly empty, when a
-            // cell sits in the first slot its key hashes to)
-            for (uint32_t i = tid; i < SLOTS; i += ACC_TPB) {
-                const KT key = s_key[i];
-                if (key != AccTable<KT>::EMPTY) {
-                    if (use_table != 3u)  // (3: timing experiment without the write-outs)
-                        atomicAdd((AccTable<KT>::mat_of(key, N) ? short_mat : node_mat) + AccTable<KT>::cell_of(key, N), s_cnt[i]);
-                    s_key[i] = AccTable<KT>::EMPTY;
-                    s_cnt[i] = 0;
-                }
-            }
-            if (tid == 0) { s_used = 0; s_lost = 0; }
-            __syncthreads();
+        if (dbg && tid == 0) {
+            atomicAdd(dbg + 3, 1u);
+            if (spill) { atomicAdd(dbg + 0, s_lost); atomicAdd(dbg + 1, 1u); atomicAdd(dbg + 2, s_used); }
         }
+        __syncthreads();
+        // (everything goes, also the cells of the locus still being worked on: keeping those across
+        // write-outs was measured -- 3.1 -> 3.9 ms -- the table is only fast while nearly empty, when a
+        // cell sits in the first slot its key hashes to)
+        if (spill) write_out();
     }
     if (!queue) break;
     }
     __syncthreads();
+    if (dbg && tid == 0) atomicAdd(dbg + 0, s_lost);
     for (uint32_t i = tid; i < SLOTS; i += ACC_TPB) {
         const KT key = s_key[i];
-        if (key != AccTable<KT>::EMPTY)
-            atomicAdd((AccTable<KT>::mat_of(key, N) ? short_mat : node_mat) + AccTable<KT>::cell_of(key, N), s_cnt[i]);
+        if (key != TB::EMPTY)
+            atomicAdd((TB::mat_of(key, N, i) ? short_mat : node_mat) + TB::cell_of(key, N), s_cnt[i]);
     }
 }
 
@@ -1650,7 +1677,11 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         }
         // 32-bit cell keys while 2*N*N fits, 64-bit keys (half the slots) above; VS_ACC_WIDE=1 forces
         // the wide table, VS_NO_AGG=1 turns the table off (every increment a global atomic)
-        const bool wide = 2ull * idx.n_nodes * idx.n_nodes >= 0xFFFFFFFFull || (getenv("VS_ACC_WIDE") && atoi(getenv("VS_ACC_WIDE")) != 0);
+        // table shape (see Acc32 / Acc32Split / Acc64); VS_ACC_WIDE=1 forces the 64-bit keys, =2 the split tables
+        const int force_shape = getenv("VS_ACC_WIDE") ? atoi(getenv("VS_ACC_WIDE")) : 0;
+        const bool fits32 = 2ull * idx.n_nodes * idx.n_nodes < 0xFFFFFFFFull, fits_split = idx.n_nodes <= 65535u;
+        const int shape = force_shape == 1 ? 2 : (force_shape == 2 && fits_split) ? 1 : fits32 ? 0 : fits_split ? 1 : 2;
+        const bool wide = shape == 2;
         const uint32_t slots = wide ? ACC_SLOTS / 2u : ACC_SLOTS;
         // the table is written out once this many of its slots are taken: linear probing stays
         // short at a low fill, and cells of loci the run has left do not pile up (VS_ACC_FILL: percent)
@@ -1664,18 +1695,19 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         // the kernel takes the same 3.2 ms -- the cell table is not what the time goes into there -- while it
         // costs 8-20 % on graphs with short lists (configs[1], [3]) and gains 10 % at configs[4].
         const uint32_t merge = (getenv("VS_ACC_MERGE") && atoi(getenv("VS_ACC_MERGE")) != 0) ? 1u : 0u;
+        uint32_t *acc_dbg = getenv("VS_DEBUG_ACC") ? (uint32_t *)ctx->d_slow_count + 4 : nullptr;
         VS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
-        if (wide) {
-            VS_HIP(ctx, hipFuncSetAttribute((const void *)k_pe_accumulate<unsigned long long>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES));
-            hipLaunchKernelGGL(k_pe_accumulate<unsigned long long>, dim3(acc_grid), dim3(ACC_TPB), ACC_LDS_BYTES, st,
-                               (const uint32_t *)ctx->d_lists, (const uint32_t *)ctx->d_list_counts, slots_pairs, per_wg,
-                               idx.n_nodes, use_table, fill_limit, d_node_mat, d_short_mat, acc_queue, merge);
-        } else {
-            VS_HIP(ctx, hipFuncSetAttribute((const void *)k_pe_accumulate<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES));
-            hipLaunchKernelGGL(k_pe_accumulate<uint32_t>, dim3(acc_grid), dim3(ACC_TPB), ACC_LDS_BYTES, st,
-                               (const uint32_t *)ctx->d_lists, (const uint32_t *)ctx->d_list_counts, slots_pairs, per_wg,
-                               idx.n_nodes, use_table, fill_limit, d_node_mat, d_short_mat, acc_queue, merge);
-        }
+        const void *acc_fn = shape == 2 ? (const void *)k_pe_accumulate<Acc64> : shape == 1 ? (const void *)k_pe_accumulate<Acc32Split>
+                                                                                              : (const void *)k_pe_accumulate<Acc32>;
+        VS_HIP(ctx, hipFuncSetAttribute(acc_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES));
+#define VS_ACC_LAUNCH(TB)                                                                                                         \
+    hipLaunchKernelGGL(k_pe_accumulate<TB>, dim3(acc_grid), dim3(ACC_TPB), ACC_LDS_BYTES, st, (const uint32_t *)ctx->d_lists,     \
+                       (const uint32_t *)ctx->d_list_counts, slots_pairs, per_wg, idx.n_nodes, use_table, fill_limit, d_node_mat, \
+                       d_short_mat, acc_queue, merge, acc_dbg)
+        if (shape == 2) VS_ACC_LAUNCH(Acc64);
+        else if (shape == 1) VS_ACC_LAUNCH(Acc32Split);
+        else VS_ACC_LAUNCH(Acc32);
+#undef VS_ACC_LAUNCH
     }
     VS_HIP(ctx, hipEventRecord(ctx->ev[1], st));
     hipLaunchKernelGGL(k_pe_slow, dim3(SLOW_GRID), dim3(TPB), 0, st, P, (uint32_t *)ctx->d_dense, (uint32_t)n_pairs);
@@ -1710,6 +1742,11 @@ extern "C" int vs_pe_last_timing(vs_ctx *ctx, double ms[5]) {
         unsigned long long np = 0;
         VS_HIP(ctx, hipMemcpy(&np, (char *)ctx->d_slow_count + 8, sizeof np, hipMemcpyDeviceToHost));
         fprintf(stderr, "[vs] postings expanded by the last vs_pe_count: %llu\n", np);
+    }
+    if (getenv("VS_DEBUG_ACC")) {
+        uint32_t d4[4] = {0, 0, 0, 0};
+        VS_HIP(ctx, hipMemcpy(d4, (char *)ctx->d_slow_count + 16, sizeof d4, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[vs] k_pe_accumulate: %u increments went past the cell table, %u write-outs of %u cells, %u rounds\n", d4[0], d4[1], d4[2], d4[3]);
     }
     ctx->last_ms[0] = a; ctx->last_ms[1] = b; ctx->last_ms[2] = n_slow;
     return VS_OK;
