@@ -71,8 +71,26 @@ def drop_duplicate_contigs(contigs: ContigDict, logger) -> ContigDict:
     return contigs
 
 
+class _Closure(dict):
+    """id -> ordered set of the ids it ended up as, for the ids of the graph before the pass
+    (anything else is a KeyError, as with the plain dict); filled on first use."""
+
+    __slots__ = ("_leaves", "known")
+
+    def __init__(self, leaves, known):
+        super().__init__()
+        self._leaves = leaves
+        self.known = known
+
+    def __missing__(self, name):
+        if name not in self.known:
+            raise KeyError(name)
+        out = self[name] = self._leaves(name)
+        return out
+
+
 def remap_contigs(g: AsmGraph, nodes: NodeMap, edges: EdgeMap, contigs: ContigDict,
-                  id_mapping: Dict[str, Dict[str, None]], prev_ids: List[str], logger) -> Dict[str, Dict[str, None]]:
+                  id_mapping: Dict[str, Dict[str, None]], prev_ids: List[str], logger):
     """Follow ``id_mapping`` (id -> ids it was forked into) transitively, then re-thread every
     contig through the forked ids along existing edges.  Returns the transitive mapping as
     ordered sets (dict keys)."""
@@ -87,10 +105,11 @@ def remap_contigs(g: AsmGraph, nodes: NodeMap, edges: EdgeMap, contigs: ContigDi
         return out
 
     logger.info("contig resolution..")
-    closure: Dict[str, Dict[str, None]] = {}
     for name in prev_ids:
         id_mapping[name]  # the reference indexes it directly: unknown ids are an error
-        closure[name] = leaves(name)
+    # (the closure of an id is worked out when somebody asks for it: a pass forks a handful of the
+    # thousands of ids, and the callers index by id only)
+    closure = _Closure(leaves, set(prev_ids))
 
     def images(ids: List[str]) -> List[List[str]]:
         paths = [[s] for s in closure[ids[0]]]

@@ -33,16 +33,21 @@ class _Snapshot:
     and the graph it would read back is this graph: vertices already in map order, edges numbered
     in map order, no freed index, flows as recomputed.  Comparing a handful of lists is all it takes."""
 
-    __slots__ = ("key", "text")
+    __slots__ = ("sizes", "lists", "text")
 
     def __init__(self, g: AsmGraph, nodes: NodeMap, edges: EdgeMap, text: str):
-        self.key = self.state(g, nodes, edges)
+        self.sizes = (id(g), len(g._free), g._n_edges, len(g.vid), len(nodes), len(edges))
+        self.lists = (list(nodes.values()), list(edges.values()), list(g.vdp), list(g.vblack), list(g.eblack), list(g.eflow),
+                      list(g.eovl))
         self.text = text
 
-    @staticmethod
-    def state(g: AsmGraph, nodes: NodeMap, edges: EdgeMap):
-        return (id(g), list(nodes.values()), list(edges.values()), list(g.vdp), list(g.vblack), list(g.eblack), list(g.eflow),
-                list(g.eovl), len(g._free), g._n_edges, len(g.vid))
+    def matches(self, g: AsmGraph, nodes: NodeMap, edges: EdgeMap) -> bool:
+        """The live lists against the copies taken then (no new copies; the cheap counts first)."""
+        if self.sizes != (id(g), len(g._free), g._n_edges, len(g.vid), len(nodes), len(edges)):
+            return False
+        a, b, vdp, vblack, eblack, eflow, eovl = self.lists
+        return (g.vblack == vblack and g.eblack == eblack and g.vdp == vdp and g.eflow == eflow and g.eovl == eovl
+                and list(nodes.values()) == a and list(edges.values()) == b)
 
 
 class Stage:
@@ -66,7 +71,7 @@ def reinit(stage: Stage, ops: GraphOps, logger, filename: str) -> Stage:
     """``store_reinit_graph`` (IO.py:630-642): write the stage GFA, rebuild the graph from that
     file (drops gray objects, resets vertex order to map order), recompute every edge flow."""
     snap = stage.snap
-    if snap is not None and snap.key == _Snapshot.state(stage.g, stage.nodes, stage.edges):
+    if snap is not None and snap.matches(stage.g, stage.nodes, stage.edges):
         # nothing changed since this stage was made (node / edge ids never change in place; vertex and
         # edge sets, colours, depths, flows and overlaps are compared above)
         with open(filename, "w") as fh:
@@ -373,23 +378,38 @@ def trivial_split(stage: Stage, links: LiveLinks, logger):
     return forks, id_mapping
 
 
+_NO_KIDS: Dict[str, None] = {}  # never written to
+
+
 def global_trivial_split(stage: Stage, logger):
     """Fixpoint of single-sided forks over ALL vertices (Decomposition.py:691-819)."""
     logger.info("graph trivial split..")
     g, nodes, edges = stage.triple()
     bound = len(nodes) ** 2
     forks = 0
-    id_mapping: Dict[str, Dict[str, None]] = {name: {} for name in nodes.keys()}
+    # (one shared empty dict stands for "not forked" until a vertex really is: remap_contigs only reads)
+    id_mapping: Dict[str, Dict[str, None]] = dict.fromkeys(nodes.keys(), _NO_KIDS)
+    vblack, adj, nout = g.vblack, g.adj, g.nout
     progressed = True
     while progressed and forks < bound:
         progressed = False
         for name in list(nodes.keys()):
             v = nodes[name]
-            if not g.vblack[v]:
+            if not vblack[v]:
                 continue
-            id_mapping.setdefault(name, {})
+            if name not in id_mapping:
+                id_mapping[name] = _NO_KIDS
+            # a fork needs one black edge on one side and several on the other: the stored degrees
+            # (gray edges included) rule most vertices out before any list is built
+            n_o = nout[v]
+            n_i = len(adj[v]) - n_o
+            if n_o == 0 or n_i == 0 or n_o + n_i < 3:
+                continue
             ines = g.black_in_edges(v)
             outes = g.black_out_edges(v)
+            if (len(ines) == 1 and len(outes) > 1) or (len(ines) > 1 and len(outes) == 1):
+                if id_mapping[name] is _NO_KIDS:
+                    id_mapping[name] = {}
             if len(ines) == 1 and len(outes) > 1:
                 g.vblack[v] = GRAY
                 ine = ines[0]

@@ -230,7 +230,7 @@ def path_extension(stage: Stage, contigs: ContigDict, table: LinkTable, frozen: 
     rid = 1
     while len(contigs) > 0:
         prev_ids = list(stage.nodes.keys())
-        _, id_mapping = global_trivial_split(stage, logger)
+        n_forks, id_mapping = global_trivial_split(stage, logger)
         stage = reinit(stage, ops, logger, "{0}/gfa/graph_S{1}.gfa".format(temp_dir, rid))
         g, nodes, edges = stage.triple()
         closure = remap_contigs(g, nodes, edges, contigs, id_mapping, prev_ids, logger)
@@ -250,10 +250,16 @@ def path_extension(stage: Stage, contigs: ContigDict, table: LinkTable, frozen: 
                             if (uu, ww) not in kept and nodes[uu] in ins and nodes[ww] in outs:
                                 kept[(uu, ww)] = pe
             table[no] = kept
-        for no, used in list(usages.items()):
-            usages.pop(no)
-            for new_no in closure[no]:
-                usages[new_no] = used
+        if n_forks == 0:  # nothing forked: every id stands for itself, and popping and re-inserting
+            # every key in turn leaves the dict as it was
+            for no in usages:
+                if no not in closure.known:
+                    raise KeyError(no)
+        else:
+            for no, used in list(usages.items()):
+                usages.pop(no)
+                for new_no in closure[no]:
+                    usages[new_no] = used
 
         longest, (contig, clen, ccov) = max(contigs.items(), key=lambda kv: kv[1][1])
         contigs.pop(longest)
