@@ -64,7 +64,7 @@ def main():
                         si=si.astype(np.int32), sj=sj.astype(np.int32), sv=short_mat[si, sj].astype(np.int64))
     backend = HipBackend(ctx=ctx)
     times = []
-    for rep in range(3):
+    for rep in range(5):
         out_dir = os.path.join(work_dir, "out%d" % rep)
         os.makedirs(os.path.join(out_dir, "gfa"), exist_ok=True)
         os.makedirs(os.path.join(out_dir, "tmp"), exist_ok=True)
