@@ -90,6 +90,7 @@ def strain_extract(ctx, counter, pre, names, logger, out_dir):
 
         prof.disable()
         pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(30)
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(40)
     n_stage_graphs = len([f for f in os.listdir(os.path.join(out_dir, "gfa")) if f.endswith(".gfa")])
     from vstrains_amd import graph as graph_pkg
 

@@ -59,6 +59,28 @@ def main():
     top = np.sort(cnt)[::-1]
     print("most frequent lists hold %s ends; lists seen once: %d" % (top[:5].tolist(), int((cnt == 1).sum())))
     print("increments per pair %.1f (node_mat %.1f, short_mat %.1f)" % (inc.mean(), (nl * nr).mean(), (inc - nl * nr).mean()))
+    # distinct (left list, right list) combinations: one weighted node_mat expansion each
+    _, l_id = np.unique(np.ascontiguousarray(lists[0::2]).view([("", lists.dtype)] * cap).ravel(), return_inverse=True)
+    _, r_id = np.unique(np.ascontiguousarray(lists[1::2]).view([("", lists.dtype)] * cap).ravel(), return_inverse=True)
+    combo = l_id.astype(np.int64) * (int(r_id.max()) + 1) + r_id
+    ucombo, first = np.unique(combo, return_index=True)
+    cl = counts[0::2].astype(np.int64)[first]
+    cr = counts[1::2].astype(np.int64)[first]
+    print("pairs %d, distinct (left, right) combinations %d (%.4f) -> %.3g weighted node_mat increments instead of %.3g" % (
+        M, len(ucombo), len(ucombo) / M, float((cl * cr).sum()), float((counts[0::2].astype(np.int64) * counts[1::2]).sum())))
+    # the floor for global atomics: distinct node_mat cells of the block (from the distinct combinations)
+    if (cl * cr).sum() < 4e8:
+        Ls = lists[0::2][first]
+        Rs = lists[1::2][first]
+        N = len(seqs)
+        cells = []
+        for lo in range(0, len(first), 200000):
+            a = Ls[lo:lo + 200000].astype(np.int64)[:, :, None]
+            b = Rs[lo:lo + 200000].astype(np.int64)[:, None, :]
+            ok = (a != 0xFFFFFFFF) & (b != 0xFFFFFFFF)
+            cells.append(np.unique((a * N + b)[ok]))
+        cells = np.unique(np.concatenate(cells))
+        print("distinct node_mat cells touched by the block: %d" % len(cells))
 
 
 if __name__ == "__main__":

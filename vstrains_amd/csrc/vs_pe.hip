@@ -48,6 +48,9 @@
 #ifndef TTPB
 #define TTPB 256             // threads per k_pe_tiles workgroup (a tile holds TTPB / 4 read ends)
 #endif
+#ifndef TILES_WAVES_LONG
+#define TILES_WAVES_LONG 5   // the long-window instantiation (k = 127) too: 21.9 ms at configs[3] against 23.3 at 4 waves (118 VGPRs)
+#endif
 #define CHUNK (TTPB * PPT)
 
 struct PeParams {
@@ -406,7 +409,7 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
 //      1: straight-line comparison, stride <= 32, reads <= w + 160; 2: the same for stride <= 128, reads <= w + 256.
 template <int MODE, uint32_t SW, uint32_t SP>
 __global__ void __launch_bounds__(TTPB)
-__attribute__((amdgpu_waves_per_eu(MODE == 2 ? TILES_WAVES - 1 : TILES_WAVES, MODE == 2 ? TILES_WAVES - 1 : TILES_WAVES)))
+__attribute__((amdgpu_waves_per_eu(MODE == 2 ? TILES_WAVES_LONG : TILES_WAVES, MODE == 2 ? TILES_WAVES_LONG : TILES_WAVES)))
 k_pe_tiles(PeParams P) {
     constexpr bool FAST = MODE != 0;
     constexpr uint32_t AB = MODE == 2 ? 9u : 8u;  // bits of the read offset packed under the node length (credit / P4)
