@@ -82,7 +82,9 @@ int vs_reads_unpack(vs_ctx *ctx, const vs_reads *reads, uint8_t *out, uint32_t *
  * = lines 4r..4r+3, sequence = line 4r+1 minus its last character (the newline, or a real
  * character on a final line without one), n_pairs = min(lines_f // 4, lines_r // 4).
  * vs_fastq_open maps and indexes both files on the host cores (VS_HOST_THREADS overrides the
- * count); vs_fastq_block turns pairs [first, first+count) into a device read block. */
+ * count); a file that starts with the gzip magic is inflated into memory first (zlib; several
+ * members in a row are fine, a cut-off stream is VS_E_ARG).  vs_fastq_block turns pairs
+ * [first, first+count) into a device read block. */
 typedef struct vs_fastq vs_fastq;
 int vs_fastq_open(vs_ctx *ctx, const char *fwd_path, const char *rve_path, vs_fastq **out);
 void vs_fastq_close(vs_fastq *fq);

@@ -317,6 +317,32 @@ def test_native_fastq_ingest_odd_inputs(tmp_path):
         assert len(fq) == len(want), name
         assert [fq.sequence(0, i) for i in range(len(want))] == want, name
         fq.close()
+    # gzip input: one member, several members, CRLF inside, an empty member; a cut-off stream is refused
+    import gzip
+
+    raw = b"".join(b"@r%d\nACGT%s\n+\nIIII\n" % (i, b"ACGT" * (i % 7)) for i in range(3000)) + b"@x\r\nGGA\r\n+\r\nIII"
+    plain = tmp_path / "plain.fq"
+    plain.write_bytes(raw)
+    want = pe_oracle.fastq_sequences(str(plain))
+    members = {"one": [raw], "three": [raw[:1000], raw[1000:50000], raw[50000:]], "empty_first": [b"", raw]}
+    for name, parts in members.items():
+        gz = tmp_path / (name + ".fq.gz")
+        gz.write_bytes(b"".join(gzip.compress(x) for x in parts))
+        for threads in ("1", "5"):
+            os.environ["VS_HOST_THREADS"] = threads
+            try:
+                fq = host.FastqPair(str(gz), str(plain))
+            finally:
+                os.environ.pop("VS_HOST_THREADS")
+            assert len(fq) == len(want), name
+            assert [fq.sequence(0, i) for i in range(len(want))] == want, name
+            assert [fq.sequence(1, i) for i in range(len(want))] == want, name
+            fq.close()
+    cut = tmp_path / "cut.fq.gz"
+    cut.write_bytes(gzip.compress(raw)[:-30])
+    with pytest.raises(Exception) as ei:
+        host.FastqPair(str(cut), str(plain))
+    assert "gzip" in str(ei.value)
     # non-ASCII bytes: fine in header / quality lines (text mode decodes them, nothing uses them),
     # refused in a sequence line -- where the bytes are first read
     ok = tmp_path / "utf8_header.fq"

@@ -107,6 +107,27 @@ def test_cli_drop_in_writes_identical_files(tmp_path):
     assert lines[-1] == "result stored in:  %s/pe_info" % out
 
 
+def test_cli_drop_in_reads_gzip_fastq(tmp_path):
+    """gzip input (beyond the reference, which opens text only): the files a plain-text run writes."""
+    import gzip
+
+    name, d, meta = [c for c in pe_cases() if c[0] == "errors_k21"][0]
+    for which in ("fwd", "rve"):
+        with open(os.path.join(d, which + ".fq"), "rb") as fh:
+            raw = fh.read()
+        with open(tmp_path / (which + ".fq.gz"), "wb") as fh:  # (two members, as bgzip and `cat a.gz b.gz` make them)
+            fh.write(gzip.compress(raw[: len(raw) // 3]))
+            fh.write(gzip.compress(raw[len(raw) // 3:]))
+    out = tmp_path / "aln"
+    proc = subprocess.run(
+        [sys.executable, "-m", "vstrains_amd.pe_inference", "-g", os.path.join(d, "graph.gfa"), "-o", str(out) + "/",
+         "-f", str(tmp_path / "fwd.fq.gz"), "-r", str(tmp_path / "rve.fq.gz"), "-k", str(meta["k"])],
+        cwd=ROOT, capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stderr
+    assert _read(out / "pe_info") == _read(os.path.join(d, "pe_info"))
+    assert _read(out / "st_info") == _read(os.path.join(d, "st_info"))
+
+
 def test_cli_drop_in_fails_like_reference_on_bad_node(tmp_path):
     (case,) = [c for c in pe_cases(ok_only=False) if c[2]["returncode"] != 0]
     name, d, meta = case

@@ -13,12 +13,20 @@
 // No Python objects, no per-record allocation.
 #include <errno.h>
 #include <fcntl.h>
+#include <pthread.h>
+#include <stdio.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <memory>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -26,13 +34,26 @@
 
 namespace {
 
+// per-record arrays: allocated without a fill (every entry is written by the part of the index
+// pass that owns its line, which is also the thread that first touches the page)
+template <typename T>
+struct RawArray {
+    std::unique_ptr<T[]> p;
+    size_t n = 0;
+    void alloc(size_t k) { p.reset(k ? new T[k] : nullptr); n = k; }
+    size_t size() const { return n; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+};
+
 struct FqFile {
     const uint8_t *data = nullptr;
     size_t size = 0;
     int fd = -1;
+    std::vector<uint8_t> inflated;     // only for a gzip file: its text (data / size then describe this copy)
     std::vector<uint8_t> translated;   // only when the file holds '\r': universal-newline copy
-    std::vector<uint64_t> seq_start;   // per record: first byte of line 4r+1
-    std::vector<uint32_t> seq_len;     // ... its length after dropping the last character
+    RawArray<uint64_t> seq_start;      // per record: first byte of line 4r+1
+    RawArray<uint32_t> seq_len;        // ... its length after dropping the last character
     uint64_t n_lines = 0;
     const uint8_t *text() const { return translated.empty() ? data : translated.data(); }
     size_t text_size() const { return translated.empty() ? size : translated.size(); }
@@ -44,25 +65,146 @@ unsigned n_threads() {
     return std::max(1u, std::min(n, 64u));
 }
 
-template <typename F>
-void parallel_for(unsigned parts, F fn) {
-    std::vector<std::thread> th;
-    for (unsigned p = 1; p < parts; p++) th.emplace_back(fn, p);
-    fn(0u);
-    for (auto &t : th) t.join();
+// Worker threads that outlive a call: the ingest runs a dozen short parallel loops per block, and
+// starting 64 threads for each costs more than some of the loops.  Parts are claimed off a counter
+// by the workers and by the caller; one loop at a time (callers queue on `turn`).  The pool is a
+// leaked heap object with detached threads, replaced in a forked child (which has no workers).
+class Pool {
+  public:
+    void run(unsigned parts, const std::function<void(unsigned)> &fn) {
+        if (parts <= 1) {
+            if (parts) fn(0u);
+            return;
+        }
+        std::lock_guard<std::mutex> one_at_a_time(turn_);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            while (workers_ + 1u < parts) {
+                std::thread([this] { work(); }).detach();
+                workers_++;
+            }
+            fn_ = &fn;
+            parts_ = parts;
+            next_ = 0;
+            done_ = 0;
+            gen_++;
+        }
+        cv_job_.notify_all();
+        claim_and_run();
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [&] { return done_ == parts_; });
+        fn_ = nullptr;
+    }
+
+  private:
+    void claim_and_run() {
+        for (;;) {
+            const std::function<void(unsigned)> *fn;
+            unsigned i;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (!fn_ || next_ >= parts_) return;
+                i = next_++;
+                fn = fn_;
+            }
+            (*fn)(i);
+            std::lock_guard<std::mutex> lk(m_);
+            if (++done_ == parts_) cv_done_.notify_all();
+        }
+    }
+    void work() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_job_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+            }
+            claim_and_run();
+        }
+    }
+    std::mutex turn_, m_;
+    std::condition_variable cv_job_, cv_done_;
+    const std::function<void(unsigned)> *fn_ = nullptr;
+    unsigned parts_ = 0, next_ = 0, done_ = 0, workers_ = 0;
+    uint64_t gen_ = 0;
+};
+Pool *g_pool = nullptr;
+std::once_flag g_pool_once;
+
+Pool &pool() {
+    std::call_once(g_pool_once, [] {
+        g_pool = new Pool();
+        pthread_atfork(nullptr, nullptr, [] { g_pool = new Pool(); });  // (the child starts its own workers)
+    });
+    return *g_pool;
 }
 
-int map_file(vs_ctx *ctx, const char *path, FqFile &f) {
+template <typename F>
+void parallel_for(unsigned parts, F fn) {
+    const std::function<void(unsigned)> f = fn;
+    pool().run(parts, f);
+}
+
+// (errors go to `err`: the two files of a pair are mapped by two threads)
+int map_file(std::string &err, const char *path, FqFile &f) {
+    auto fail = [&](int code, const char *fmt, auto... args) {
+        char buf[512];
+        snprintf(buf, sizeof buf, fmt, args...);
+        err = buf;
+        return code;
+    };
     f.fd = open(path, O_RDONLY);
-    if (f.fd < 0) return vs_fail(ctx, VS_E_ARG, "cannot open %s: %s", path, strerror(errno));
+    if (f.fd < 0) return fail(VS_E_ARG, "cannot open %s: %s", path, strerror(errno));
     struct stat st;
-    if (fstat(f.fd, &st) != 0) return vs_fail(ctx, VS_E_ARG, "cannot stat %s: %s", path, strerror(errno));
+    if (fstat(f.fd, &st) != 0) return fail(VS_E_ARG, "cannot stat %s: %s", path, strerror(errno));
     f.size = (size_t)st.st_size;
     if (f.size) {
         void *p = mmap(nullptr, f.size, PROT_READ, MAP_PRIVATE, f.fd, 0);
-        if (p == MAP_FAILED) return vs_fail(ctx, VS_E_OOM, "cannot map %s: %s", path, strerror(errno));
+        if (p == MAP_FAILED) return fail(VS_E_OOM, "cannot map %s: %s", path, strerror(errno));
         f.data = (const uint8_t *)p;
         madvise(p, f.size, MADV_SEQUENTIAL);
+    }
+    // A gzip file (magic 1f 8b; several members in a row as bgzip writes them are fine) is inflated
+    // into memory once and then treated like the text it holds.  Beyond the reference, which opens
+    // plain text only (SURVEY 8f-2 "optional"); one stream inflates on one core, the two files of a
+    // pair side by side (vs_fastq_open).
+    if (f.size >= 2 && f.data[0] == 0x1f && f.data[1] == 0x8b) {
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, 15 + 16) != Z_OK) return fail(VS_E_OOM, "%s: zlib cannot start", path);
+        std::vector<uint8_t> &out = f.inflated;
+        out.resize(std::max<size_t>(f.size * 4, 1u << 16));
+        size_t have = 0, in_at = 0;
+        int rc = Z_OK;
+        for (;;) {
+            const size_t in_now = std::min<size_t>(f.size - in_at, 1u << 30);
+            zs.next_in = const_cast<Bytef *>(f.data + in_at);
+            zs.avail_in = (uInt)in_now;
+            if (out.size() - have < (1u << 16)) out.resize(out.size() + out.size() / 2);
+            const size_t out_now = std::min<size_t>(out.size() - have, 1u << 30);
+            zs.next_out = out.data() + have;
+            zs.avail_out = (uInt)out_now;
+            rc = inflate(&zs, Z_NO_FLUSH);
+            in_at += in_now - zs.avail_in;
+            have += out_now - zs.avail_out;
+            if (rc == Z_STREAM_END) {
+                if (in_at >= f.size) break;
+                if (inflateReset(&zs) != Z_OK) { rc = Z_DATA_ERROR; break; }  // next member
+                continue;
+            }
+            if (rc == Z_BUF_ERROR && zs.avail_out == 0) continue;  // (output full: grown at the top of the loop)
+            if (rc != Z_OK) break;
+            if (in_at >= f.size && zs.avail_out != 0) { rc = Z_DATA_ERROR; break; }  // truncated stream
+        }
+        inflateEnd(&zs);
+        if (rc != Z_STREAM_END) return fail(VS_E_ARG, "%s: not a complete gzip stream (zlib code %d)", path, rc);
+        out.resize(have);
+        munmap((void *)f.data, f.size);
+        close(f.fd);
+        f.fd = -1;
+        f.data = out.data();
+        f.size = have;
     }
     return VS_OK;
 }
@@ -123,8 +265,9 @@ int index_file(vs_ctx *ctx, const char *path, FqFile &f) {
     const bool open_tail = n > 0 && txt[n - 1] != '\n';
     f.n_lines = n_newlines + (open_tail ? 1 : 0);
     const uint64_t n_rec = f.n_lines / 4;
-    f.seq_start.assign(n_rec, 0);
-    f.seq_len.assign(n_rec, 0);
+    f.seq_start.alloc(n_rec);
+    f.seq_len.alloc(n_rec);
+    std::vector<uint64_t> too_long(T, UINT64_MAX);  // per part: first record whose sequence line does not fit
     // the newline that ends line L (0-based) is newline number L; a sequence line has L % 4 == 1; it
     // starts right after newline L-1 (possibly the last one of an earlier part)
     parallel_for(T, [&](unsigned p) {
@@ -141,6 +284,7 @@ int index_file(vs_ctx *ctx, const char *path, FqFile &f) {
             if ((line & 3u) == 1u && (line >> 2) < n_rec) {
                 f.seq_start[line >> 2] = start;
                 f.seq_len[line >> 2] = (uint32_t)(v[i] - start);  // the dropped char is the newline
+                if (v[i] - start > VS_LEN_MASK && too_long[p] == UINT64_MAX) too_long[p] = line >> 2;
             }
             start = v[i] + 1;
         }
@@ -155,13 +299,15 @@ int index_file(vs_ctx *ctx, const char *path, FqFile &f) {
             f.seq_len[line >> 2] = (uint32_t)(n - start - 1);
         }
     }
-    for (uint64_t r = 0; r < n_rec; r++)
-        if (f.seq_len[r] > VS_LEN_MASK) return vs_fail(ctx, VS_E_RANGE, "%s: record %llu has a %u-byte sequence line", path, (unsigned long long)r, f.seq_len[r]);
+    for (unsigned p = 0; p < T; p++)
+        if (too_long[p] != UINT64_MAX)
+            return vs_fail(ctx, VS_E_RANGE, "%s: record %llu has a %u-byte sequence line", path, (unsigned long long)too_long[p], f.seq_len[too_long[p]]);
     return VS_OK;
 }
 
 void close_file(FqFile &f) {
-    if (f.data) munmap((void *)f.data, f.size);
+    if (f.data && f.inflated.empty()) munmap((void *)f.data, f.size);
+    f.inflated = std::vector<uint8_t>();
     if (f.fd >= 0) close(f.fd);
     f.data = nullptr;
     f.fd = -1;
@@ -242,8 +388,17 @@ int vs_fastq_open(vs_ctx *ctx, const char *fwd_path, const char *rve_path, vs_fa
     *out = nullptr;
     vs_fastq *fq = new vs_fastq();
     const char *paths[2] = {fwd_path, rve_path};
+    // (mapping -- and, for gzip files, inflating -- the two files side by side; errors are reported in file order)
+    int map_rc[2] = {VS_OK, VS_OK};
+    std::string map_err[2];
+    {
+        std::thread second([&] { map_rc[1] = map_file(map_err[1], paths[1], fq->f[1]); });
+        map_rc[0] = map_file(map_err[0], paths[0], fq->f[0]);
+        second.join();
+    }
     for (int i = 0; i < 2; i++) {
-        int rc = map_file(ctx, paths[i], fq->f[i]);
+        int rc = map_rc[i];
+        if (rc != VS_OK) vs_fail(ctx, rc, "%s", map_err[i].c_str());
         if (rc == VS_OK) rc = index_file(ctx, paths[i], fq->f[i]);
         if (rc != VS_OK) {
             close_file(fq->f[0]);
