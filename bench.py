@@ -353,18 +353,24 @@ def fastq_ingest(ctx, host, st, cum, seed, L, k, sub_thresh, n_thresh, M, work_d
     warm = host.FastqPair(paths[0], paths[1], ctx)  # (first use: pinned staging and device buffers get allocated)
     pe_inference.count_fastq(ctx, warm, counter, 0, min(len(warm), 2 * pe_inference.BATCH_PAIRS))
     warm.close()
-    counter.reset()
-    t0 = time.perf_counter()
-    fq = host.FastqPair(paths[0], paths[1], ctx)
-    t1 = time.perf_counter()
-    pe_inference.count_fastq(ctx, fq, counter, 0, len(fq))
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    n = len(fq)
-    fq.close()
+    passes = []
+    for _ in range(3):  # (host threads under a cgroup quota: single passes scatter by 2x; the median is reported)
+        counter.reset()
+        t0 = time.perf_counter()
+        fq = host.FastqPair(paths[0], paths[1], ctx)
+        t1 = time.perf_counter()
+        pe_inference.count_fastq(ctx, fq, counter, 0, len(fq))
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        n = len(fq)
+        fq.close()
+        passes.append((t2 - t0, t1 - t0, t2 - t1))
+    passes.sort()
+    total_s, open_s, count_s = passes[1]
     return {"pairs": n, "fastq_bytes": size, "host_threads": os.cpu_count(),
-            "open_index_s": t1 - t0, "pack_upload_count_s": t2 - t1,
-            "pairs_per_s": n / (t2 - t0), "pairs_per_s_after_open": n / (t2 - t1),
+            "open_index_s": open_s, "pack_upload_count_s": count_s,
+            "pairs_per_s": n / total_s, "pairs_per_s_after_open": n / count_s,
+            "pairs_per_s_passes": [n / p[0] for p in passes],
             "note": "files in page cache; blocks of %d pairs, host packing of block i+1 overlapped with the device counting block i; "
                     "PCIe-inclusive; never reported as value" % pe_inference.BATCH_PAIRS}
 

@@ -85,6 +85,11 @@ int vs_reads_unpack(vs_ctx *ctx, const vs_reads *reads, uint8_t *out, uint32_t *
  * count); a file that starts with the gzip magic is inflated into memory first (zlib; several
  * members in a row are fine, a cut-off stream is VS_E_ARG).  vs_fastq_block turns pairs
  * [first, first+count) into a device read block. */
+/* The host packer the ingest uses on every sequence line: `len` bytes -> ceil(len/16) words, 16
+ * bases per word, LSB first, A C G T = 0 1 2 3, any other byte packs as 0; *flags: bit 0 an 'N',
+ * bit 1 another ASCII byte outside ACGT, bit 7 a byte >= 0x80.  plain != 0 takes the byte-by-byte
+ * body instead of the vector one (same result; tests compare the two). */
+int vs_pack_sequence(const uint8_t *seq, uint32_t len, uint32_t *words, uint32_t *flags, int plain);
 typedef struct vs_fastq vs_fastq;
 int vs_fastq_open(vs_ctx *ctx, const char *fwd_path, const char *rve_path, vs_fastq **out);
 void vs_fastq_close(vs_fastq *fq);

@@ -360,3 +360,53 @@ def test_native_fastq_ingest_odd_inputs(tmp_path):
     fq.close()
     with pytest.raises(FileNotFoundError):
         host.FastqPair(str(tmp_path / "nope.fq"), str(bad))
+
+
+def test_vector_host_packer_equals_the_byte_loop():
+    """vs_pack_sequence: the SSE2 / AVX2 body against the byte-by-byte one and against a Python
+    statement of the format (16 bases per word, LSB first, ACGT = 0123, other bytes 0 + flag)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from vstrains_amd import _native as nat
+
+    lib = nat.lib()
+    rng = np.random.default_rng(5)
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+
+    def want(seq):
+        words = [0] * ((len(seq) + 15) // 16)
+        flags = 0
+        for i, c in enumerate(seq):
+            if c in code:
+                words[i // 16] |= code[c] << (2 * (i % 16))
+            elif c == 78:
+                flags |= 1
+            elif c < 128:
+                flags |= 2
+            else:
+                flags |= 0x80
+        return words, flags
+
+    def run(seq, plain):
+        buf = np.frombuffer(bytes(seq) + b"\x00", dtype=np.uint8).copy()
+        out = np.full((len(seq) + 15) // 16 + 1, 0xDEADBEEF, dtype=np.uint32)
+        fl = C.c_uint32(0)
+        assert lib.vs_pack_sequence(buf.ctypes.data, len(seq), out.ctypes.data, C.byref(fl), plain) == 0
+        assert out[-1] == 0xDEADBEEF  # nothing written past the last word
+        return out[:-1].tolist(), fl.value
+
+    cases = [b"", b"A", b"ACGT" * 4, b"ACGT" * 8, b"T" * 33, b"ACGTN" * 13, b"acgt" * 9, b"ACGT" * 7 + b"\xc3\xa9"]
+    for n in list(range(0, 70)) + [149, 150, 151, 250, 1000, 1023]:
+        cases.append(bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n)))
+    for n in (15, 16, 17, 31, 32, 33, 47, 48, 64, 150):
+        for _ in range(20):
+            s = bytearray(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n))
+            for _ in range(int(rng.integers(1, 4))):
+                s[int(rng.integers(0, n))] = int(rng.choice(np.frombuffer(b"NnRY@\x7f\x80\xff", dtype=np.uint8)))
+            cases.append(bytes(s))
+    for seq in cases:
+        w = want(seq)
+        assert run(seq, 0) == w, seq
+        assert run(seq, 1) == w, seq

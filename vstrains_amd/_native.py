@@ -29,6 +29,7 @@ SYMBOLS = {
     "vs_reads_free": (None, [C.c_void_p, C.c_void_p]),
     "vs_reads_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "vs_reads_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vs_pack_sequence": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
     "vs_fastq_open": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]),
     "vs_fastq_close": (None, [C.c_void_p]),
     "vs_fastq_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),

@@ -111,6 +111,13 @@ void vs_ctx_destroy(vs_ctx *ctx) {
     for (void *q : ctx->scratch)
         if (q) (void)hipFree(q);
     for (auto &b : ctx->cache) (void)hipFree(b.p);
+    for (FqStage &st : ctx->fq_stage) {
+        if (st.in_flight && st.done) (void)hipEventSynchronize(st.done);
+        if (st.words) (void)hipHostFree(st.words);
+        if (st.woff) (void)hipHostFree(st.woff);
+        if (st.meta) (void)hipHostFree(st.meta);
+        if (st.done) (void)hipEventDestroy(st.done);
+    }
     for (int i = 0; i < 5; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     delete ctx;

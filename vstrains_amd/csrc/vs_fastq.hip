@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "vs_internal.h"
+#include "vs_pack_host.h"
 
 namespace {
 
@@ -315,31 +316,12 @@ void close_file(FqFile &f) {
 
 }  // namespace
 
-// pinned staging of one block in flight: packed words (+ pad), word offsets, lengths | flags
-struct FqStage {
-    uint32_t *words = nullptr, *woff = nullptr, *meta = nullptr;
-    size_t words_cap = 0, ends_cap = 0;
-    hipEvent_t done = nullptr;  // the uploads out of this set have finished
-    bool in_flight = false;
-};
-
 struct vs_fastq {
     FqFile f[2];
     uint64_t n_pairs = 0;
-    FqStage stage[2];  // alternate: the cores fill one while the other is still being uploaded
-    unsigned next_stage = 0;
 };
 
 namespace {
-// 2-bit code of a sequence byte: 0..3 = ACGT, 4 = 'N', 5 = any other byte
-struct CodeLut {
-    uint8_t v[256];
-    CodeLut() {
-        for (int i = 0; i < 256; i++) v[i] = i < 128 ? 5 : 8;  // (8: non-ASCII, refused)
-        v['A'] = 0; v['C'] = 1; v['G'] = 2; v['T'] = 3; v['N'] = 4;
-    }
-};
-const CodeLut g_code;
 // Python's text mode decodes the file; header and quality lines may hold any valid UTF-8, but a
 // byte >= 0x80 inside a sequence line would count as a character of its own there, which packing by
 // bytes cannot mirror: such a file is refused where its sequence bytes are first read.
@@ -350,38 +332,18 @@ inline bool has_high_bit(const uint8_t *q, uint32_t len) {
     return (acc & 0x80u) != 0;
 }
 
-// pack one sequence; returns the flags (VS_FLAG_N / VS_FLAG_INVALID)
-inline uint32_t pack_sequence(const uint8_t *q, uint32_t len, uint32_t *out) {
-    uint32_t flags = 0;
-    const uint32_t nw = (len + 15u) >> 4;
-    for (uint32_t wi = 0; wi < nw; wi++) {
-        const uint32_t b0 = wi * 16u, m = len - b0 < 16u ? len - b0 : 16u;
-        uint32_t v = 0, odd = 0;
-        for (uint32_t i = 0; i < m; i++) {
-            const uint32_t c = g_code.v[q[b0 + i]];
-            v |= (c & 3u) << (2u * i);
-            odd |= c;
-        }
-        out[wi] = v;
-        if (odd > 3u) {  // rare: look again for which kind
-            for (uint32_t i = 0; i < m; i++) {
-                const uint32_t c = g_code.v[q[b0 + i]];
-                if (c == 4u) flags |= VS_FLAG_N; else if (c == 5u) flags |= VS_FLAG_INVALID; else if (c == 8u) flags |= 0x80u;
-            }
-            // (the code of such a byte is whatever its low bits say: masked out / never matched)
-            uint32_t v2 = 0;
-            for (uint32_t i = 0; i < m; i++) {
-                const uint32_t c = g_code.v[q[b0 + i]];
-                v2 |= (c > 3u ? 0u : c) << (2u * i);
-            }
-            out[wi] = v2;
-        }
-    }
-    return flags;
-}
+// pack one sequence; returns the flags (VS_FLAG_N / VS_FLAG_INVALID, 0x80 for non-ASCII bytes): vs_pack_host.cpp
+static_assert(VS_PACK_FLAG_N == VS_FLAG_N && VS_PACK_FLAG_INVALID == VS_FLAG_INVALID, "flag values");
+inline uint32_t pack_sequence(const uint8_t *q, uint32_t len, uint32_t *out) { return vs_pack_sequence_host(q, len, out); }
 }  // namespace
 
 extern "C" {
+
+int vs_pack_sequence(const uint8_t *seq, uint32_t len, uint32_t *words, uint32_t *flags, int plain) {
+    if ((!seq && len) || !words || !flags) return VS_E_ARG;
+    *flags = plain ? vs_pack_sequence_host_plain(seq, len, words) : vs_pack_sequence_host(seq, len, words);
+    return VS_OK;
+}
 
 int vs_fastq_open(vs_ctx *ctx, const char *fwd_path, const char *rve_path, vs_fastq **out) {
     if (!fwd_path || !rve_path || !out) return vs_fail(ctx, VS_E_ARG, "vs_fastq_open: bad argument");
@@ -414,13 +376,6 @@ int vs_fastq_open(vs_ctx *ctx, const char *fwd_path, const char *rve_path, vs_fa
 
 void vs_fastq_close(vs_fastq *fq) {
     if (!fq) return;
-    for (FqStage &st : fq->stage) {
-        if (st.in_flight && st.done) (void)hipEventSynchronize(st.done);
-        if (st.words) (void)hipHostFree(st.words);
-        if (st.woff) (void)hipHostFree(st.woff);
-        if (st.meta) (void)hipHostFree(st.meta);
-        if (st.done) (void)hipEventDestroy(st.done);
-    }
     close_file(fq->f[0]);
     close_file(fq->f[1]);
     delete fq;
@@ -484,8 +439,10 @@ int vs_fastq_block(vs_ctx *ctx, vs_fastq *fq, uint64_t first, uint64_t count, vs
     const uint64_t n_ends = 2 * count;
     if (n_ends > 0xFFFFFFF0ull) return vs_fail(ctx, VS_E_RANGE, "vs_fastq_block: split the input into blocks of < 2^31 pairs");
     VS_HIP(ctx, hipSetDevice(ctx->device));
-    FqStage &st = fq->stage[fq->next_stage];
-    fq->next_stage ^= 1u;
+    // (the two pinned staging sets belong to the context: pinning 100 MB costs as much as packing it,
+    // and a process opens one FASTQ pair after another -- shards, retries -- on the same context)
+    FqStage &st = ctx->fq_stage[ctx->fq_next];
+    ctx->fq_next ^= 1u;
     if (!st.done) VS_HIP(ctx, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
     if (st.in_flight) {  // the block that used this set two calls ago
         VS_HIP(ctx, hipEventSynchronize(st.done));

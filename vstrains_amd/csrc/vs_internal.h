@@ -88,10 +88,21 @@ struct VsReadsDev {
 #define VS_LEN_MASK 0x00FFFFFFu
 
 // ---- host-side objects -----------------------------------------------------------------------
+// pinned staging of one FASTQ block in flight (vs_fastq_block): packed words (+ pad), word offsets,
+// lengths | flags; two sets alternate, the cores fill one while the other is still being uploaded
+struct FqStage {
+    uint32_t *words = nullptr, *woff = nullptr, *meta = nullptr;
+    size_t words_cap = 0, ends_cap = 0;
+    hipEvent_t done = nullptr;  // the uploads out of this set have finished
+    bool in_flight = false;
+};
+
 struct vs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
+    FqStage fq_stage[2];
+    unsigned fq_next = 0;
     bool has_index = false;
     VsIndexDev idx{};
     // owned device allocations of the index
