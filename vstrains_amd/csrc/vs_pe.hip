@@ -450,7 +450,7 @@ k_pe_tiles(PeParams P) {
     const uint32_t ppt = ept / 2u;
     const bool has_inv = FAST && P.rd.inv4 != nullptr;  // (the generic kernel reads the mask instead)
 
-    if (tid < 3) s_misc[8 + tid] = 0;  // workgroup-local stats
+    if (tid < 3) s_misc[12 + tid] = 0;  // workgroup-local stats
     if (tid == 3) vs_lds[T.pcnt] = 0;
     // a workgroup takes a contiguous run of the locus-sorted tiles (node text stays in L1/L2)
     // Workgroups go to the 8 XCDs round-robin (blockIdx % 8).  The runs are handed out so that XCD x
@@ -582,7 +582,7 @@ k_pe_tiles(PeParams P) {
             if (((mf | mr) >> 24) & VS_FLAG_N) cls = 0;
             else if ((mf & VS_LEN_MASK) < K || (mr & VS_LEN_MASK) < K) cls = 1;
             else cls = 2;
-            atomicAdd(&s_misc[8 + cls], 1u);
+            atomicAdd(&s_misc[12 + cls], 1u);
             uint32_t st = (cls == 2) ? 1u : 0u;
             // (an end with more bytes outside ACGT than vs_seed_limits can hold: the pair takes the overflow path)
             if (FAST && st && (((mf | mr) >> 24) & VS_FLAG_MANY)) st = 3u;
@@ -684,10 +684,12 @@ k_pe_tiles(PeParams P) {
             if (lane == 0u) carry = 0;
             __syncthreads();
             {   // the wavefronts before this one (TTPB = 256: at most three)
-                const uint32_t m0 = s_misc[4], m1 = s_misc[5], m2 = s_misc[6], wv = tid >> 6;
-                if (wv > 0u) carry = m0 > carry ? m0 : carry;
-                if (wv > 1u) carry = m1 > carry ? m1 : carry;
-                if (wv > 2u) carry = m2 > carry ? m2 : carry;
+                const uint32_t wv = tid >> 6;
+#pragma unroll
+                for (uint32_t pw = 0; pw + 1u < TTPB / 64u; pw++) {
+                    const uint32_t mw = s_misc[4u + pw];
+                    if (wv > pw) carry = mw > carry ? mw : carry;
+                }
             }
             // The thread's PPT postings go through stages with every stage done for all of them before
             // the next one starts: A) which posting (LDS) and its record (one global load for
@@ -816,7 +818,7 @@ k_pe_tiles(PeParams P) {
         }
     }
     __syncthreads();
-    if (tid < 3 && P.stats && s_misc[8 + tid]) atomicAdd(&P.stats[tid], (unsigned long long)s_misc[8 + tid]);
+    if (tid < 3 && P.stats && s_misc[12 + tid]) atomicAdd(&P.stats[tid], (unsigned long long)s_misc[12 + tid]);
 }
 
 // ---- K4: counters ------------------------------------------------------------------------------------
@@ -1456,7 +1458,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     // (LDS is handed out in 1280-byte pieces: 32 000 B per workgroup lets five share a CU, 40 000 four.  A tile of
     // at least 32 ends that fits one of these is taken over a larger one that wastes the rest.)
     if (!getenv("VS_EPT")) {
-        for (size_t fit : {(size_t)(TTPB == 256 ? 32000 : TTPB == 128 ? 15360 : 7680), (size_t)(TTPB == 256 ? 40000 : TTPB == 128 ? 17920 : 8960)}) {
+        for (size_t fit : {(size_t)(TTPB >= 256 ? 32000 : TTPB == 128 ? 15360 : 7680), (size_t)(TTPB >= 256 ? 40000 : TTPB == 128 ? 17920 : 8960)}) {
             uint32_t e2 = ept;
             while (e2 > STD_EPT / 2u && lds_bytes(e2, pmax, e2 * wpe) > fit) e2 -= 2;
             if (lds_bytes(e2, pmax, e2 * wpe) <= fit) { ept = e2; break; }
