@@ -393,3 +393,42 @@ def test_native_reinit_equals_the_python_rebuild(backend, tmp_path):
         sb = b[4]
         assert (scan_a.nontrivial, scan_a.fork_kind, scan_a.chain_next, scan_a.chain_top, scan_a.chain_rank) == \
                (sb.nontrivial, sb.fork_kind, sb.chain_next, sb.chain_top, sb.chain_rank)
+
+
+@pytest.mark.parametrize("config", [1, 2])
+def test_extraction_on_the_device_equals_the_checker_at_bench_size(backend, config, tmp_path):
+    """The strain-extract leg of bench configs[1] / configs[2] (853 / 5 039 nodes, the reference cannot run
+    the latter): every file the device run writes -- 116 stage GFAs at configs[2], contig files,
+    strain.paths, strain.fasta -- against the same host logic over the numpy checker (Python rebuild
+    instead of vs_stage_rebuild, numpy flows / scans, link sums off the host copy of the counters)."""
+    import copy
+    import hashlib
+
+    import profile_extract_cpu as pec  # tests/profile_extract_cpu.py: checker backend + digests
+    from vstrains_amd import pe as host
+    from vstrains_amd.graph import pipeline
+    from vstrains_amd.graph.hip_ops import HipPeLinks
+    from vstrains_amd.workloads import CONFIGS, workload_for
+
+    cfg = CONFIGS[config]
+    st, pre, names, seqs, cum, logger, _ = workload_for(config, str(tmp_path / "work"))
+    ctx = backend.ctx
+    ctx.build_index(seqs, cfg["k"])
+    reads = ctx.synth_pairs(st.genomes, cum, 20250000 + config, 0, 1_000_000, cfg["read_len"], int(0.005 * 2 ** 32), int(0.001 * 2 ** 32))
+    counter = host.PeCounter(ctx)
+    counter.add(reads)
+    node_mat, short_mat, _ = counter.result()
+    outs = []
+    for which in ("device", "checker"):
+        out = str(tmp_path / which)
+        for sub in ("gfa", "tmp"):
+            os.makedirs(os.path.join(out, sub), exist_ok=True)
+        if which == "device":
+            strains = pipeline.extract_strains(copy.deepcopy(pre), HipPeLinks.from_counter(ctx, counter, names), backend, logger, out)
+        else:
+            strains = pipeline.extract_strains(copy.deepcopy(pre), pec.NumpyPeLinks(names, node_mat, short_mat), pec.Backend(), logger, out)
+        outs.append((pec.digests(out), len(strains)))
+    (dev, n_dev), (ref, n_ref) = outs
+    assert n_dev == n_ref and n_dev > 0
+    assert sorted(dev) == sorted(ref) and len(dev) > 40
+    assert [f for f in dev if dev[f] != ref[f]] == []
