@@ -112,26 +112,33 @@ __device__ __forceinline__ void vs_agree_fast(const uint32_t *rw, uint32_t rbase
     // the read's side of the same five windows: eleven consecutive LDS words, one shift
     const uint32_t rr = rbase + rj, rsh = (rr & 15u) * 2u;
     const uint32_t *rp = rw + (rr >> 4);
-    const uint32_t r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4], r5 = rp[5], r6 = rp[6], r7 = rp[7],
-                   r8 = rp[8], r9 = W4 ? 0u : rp[9], r10 = W4 ? 0u : rp[10];
+    const uint32_t r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4];
     auto rw64 = [&](uint32_t w0, uint32_t w1, uint32_t w2) {
         return (uint64_t)__builtin_amdgcn_alignbit(w1, w0, rsh) | ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, rsh) << 32);
     };
     const uint64_t xl = (vs_win(rw, rbase + j - n0) ^ vs_win(tw, tl - n0)) & vs_lowmask(2u * n0);
     const uint64_t x0 = rw64(r0, r1, r2) ^ tw64(q0.x, q0.y, q0.z);
     const uint64_t x1 = rw64(r2, r3, r4) ^ tw64(q0.z, q0.w, q1.x);
-    const uint64_t x2 = rw64(r4, r5, r6) ^ tw64(q1.x, q1.y, q1.z);
-    const uint64_t x3 = rw64(r6, r7, r8) ^ tw64(q1.z, q1.w, q2.x);
-    const uint64_t x4 = W4 ? 0ull : rw64(r8, r9, r10) ^ tw64(q2.x, q2.y, q2.z);
     *left_out = xl ? n0 - 1u - (uint32_t)((63 - __clzll((long long)xl)) >> 1) : n0;
+    // Windows 2..4 only where the match can reach them: on a graph of nodes hardly longer than k+1 most
+    // wavefronts have no such posting and skip the block (a branch on "any lane", not on data of one lane).
+    uint32_t far = 160u;  // (nothing differs within reach: clipped by rem below)
+    if (rem > 64u) {
+        const uint32_t r5 = rp[5], r6 = rp[6], r7 = rp[7], r8 = rp[8], r9 = W4 ? 0u : rp[9], r10 = W4 ? 0u : rp[10];
+        const uint64_t x2 = rw64(r4, r5, r6) ^ tw64(q1.x, q1.y, q1.z);
+        const uint64_t x3 = rw64(r6, r7, r8) ^ tw64(q1.z, q1.w, q2.x);
+        const uint64_t x4 = W4 ? 0ull : rw64(r8, r9, r10) ^ tw64(q2.x, q2.y, q2.z);
+        uint64_t xs = x4;  // (W4: zero -- no difference found inside 128 bases means ext = 160, clipped by rem <= 128)
+        uint32_t xb = 128u;
+        if (x3) { xs = x3; xb = 96u; }
+        if (x2) { xs = x2; xb = 64u; }
+        if (xs) far = xb + ((uint32_t)(__ffsll((long long)xs) - 1) >> 1);
+    }
     // first window that differs (selects), then one find-first-set
-    uint64_t xs = x4;  // (W4: zero -- no difference found inside 128 bases means ext = 160, clipped by rem <= 128)
-    uint32_t xb = 128u;
-    if (x3) { xs = x3; xb = 96u; }
-    if (x2) { xs = x2; xb = 64u; }
-    if (x1) { xs = x1; xb = 32u; }
-    if (x0) { xs = x0; xb = 0u; }
-    const uint32_t ext = xs ? xb + ((uint32_t)(__ffsll((long long)xs) - 1) >> 1) : 160u;
+    uint64_t xn = x1;
+    uint32_t xb = 32u;
+    if (x0) { xn = x0; xb = 0u; }
+    const uint32_t ext = xn ? xb + ((uint32_t)(__ffsll((long long)xn) - 1) >> 1) : far;
     *ext_out = ext < rem ? ext : rem;
 }
 
