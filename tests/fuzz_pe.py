@@ -4,7 +4,7 @@ boundaries where vs_pe_count switches kernels (seed geometry, straight-line vs l
 comparison, compile-time tile shapes, dirty-byte lists vs mask, list overflow), counts on the device and
 compares node_mat / short_mat / stats with the C oracle.  Prints the parameters of every failing draw.
 
-    python tools/fuzz_pe.py [seconds=300] [seed=1]
+    python tests/fuzz_pe.py [seconds=300] [seed=1]        (test infrastructure: the oracle is the checker)
 """
 import os
 import sys

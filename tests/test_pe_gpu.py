@@ -575,13 +575,13 @@ def test_bench_step_with_two_ranks_on_one_gpu(tmp_path):
 
 @pytest.mark.parametrize("mode", ["boundaries", "tile_shapes"])
 def test_randomized_campaign_short(mode):
-    """tools/fuzz_pe.py for ten seconds per mode: random graph / read shapes around the points where
+    """tests/fuzz_pe.py for ten seconds per mode: random graph / read shapes around the points where
     vs_pe_count switches kernels, every draw against the C oracle (the full campaigns of the round:
     4 510 draws, no mismatch -- DESIGN.md 8)."""
     env = dict(os.environ)
     if mode == "tile_shapes":
         env["FUZZ_STD"] = "1"
-    proc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_pe.py"), "10", "7"], cwd=ROOT, env=env,
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_pe.py"), "10", "7"], cwd=ROOT, env=env,
                           capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
     assert "mismatches 0" in proc.stdout and "draws 0," not in proc.stdout, proc.stdout[-500:]

@@ -14,8 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
-from oracle import pe_oracle_c  # noqa: E402  (only its read generator, to write the input files)
-from vstrains_amd import cli, synth  # noqa: E402
+from vstrains_amd import cli, pe as host, synth  # noqa: E402
 
 
 def main():
@@ -37,12 +36,19 @@ def main():
     for tag in ("f", "r"):
         paths[tag] = os.path.join(tmp, "reads_%s.fq" % tag)
     CH = 500_000
+    ctx = host.Context(0)  # the device generator writes the reads (vs_synth_pairs + vs_reads_unpack), as in bench.py
     with open(paths["f"], "wb") as ff, open(paths["r"], "wb") as fr:
         for first in range(0, M, CH):
             n = min(CH, M - first)
-            fw, rv = pe_oracle_c.synth_pairs(st.genomes, cum, 20250001, first, n, L, int(0.005 * 2 ** 32), int(0.001 * 2 ** 32))
+            block = ctx.synth_pairs(st.genomes, cum, 20250001, first, n, L, int(0.005 * 2 ** 32), int(0.001 * 2 ** 32))
+            text, lens, flags = block.unpack()
+            block.free()
+            text = text.reshape(n, 2, L).copy()
+            text[(flags.reshape(n, 2) & 1).astype(bool), 0] = ord("N")
+            fw, rv = text[:, 0], text[:, 1]
             ff.write(b"".join(b"@f%d\n%s\n+\n%s\n" % (first + i, fw[i].tobytes(), qual) for i in range(n)))
             fr.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (first + i, rv[i].tobytes(), qual) for i in range(n)))
+    del ctx
     prep_s = time.time() - t0
     out = os.path.join(tmp, "out")
     t1 = time.time()
