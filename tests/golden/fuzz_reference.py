@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Build container only: randomized campaign of the whole pipeline against the REAL reference CLI.
+
+Every draw is a seeded synthetic case in the parameter ranges of the committed fixtures
+(make_graph_golden.CASES).  The reference (``/root/reference/vstrains`` behind
+``tests/golden/gt_standin``, exactly as make_graph_golden.py runs it: both in-edge-order models,
+hash seeds 0-3) writes its outputs into a scratch golden directory; this build's pipeline then runs
+on the same inputs with the checker backend (as tests/test_graph_golden.py does) and every file
+that the reference itself produces deterministically must be identical -- stage GFAs, contig
+files, pe_info / st_info, strain.paths, strain.fasta, the INFO log lines.  Nothing is committed
+from here except the tally.
+
+    python tests/golden/fuzz_reference.py [draws=40] [seed=1] [workers=4]
+"""
+import json
+import multiprocessing as mp
+import os
+import shutil
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TESTS = os.path.dirname(HERE)
+ROOT = os.path.dirname(TESTS)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, TESTS)
+sys.path.insert(0, HERE)
+
+
+def one(job):
+    idx, kwargs, extra, scratch = job
+    import contextlib
+    import io
+
+    import numpy as np  # noqa: F401
+
+    import graph_case
+    import make_graph_golden as gold
+    from test_graph_golden import CheckerBackend
+    from vstrains_amd.graph import pipeline
+
+    name = "fuzz_%04d" % idx
+    gold.OUT = scratch
+    graph_case.GOLDEN = scratch
+    gold.CASES[name] = (kwargs, extra)
+    with contextlib.redirect_stdout(io.StringIO()) as line:
+        try:
+            gold.emit(name)
+        except Exception as err:  # (a draw the generator cannot make)
+            return dict(idx=idx, status="generator", detail=repr(err))
+    case = graph_case.Case(name)
+    res = dict(idx=idx, kwargs=kwargs, extra=extra, rc=case.meta["returncode"], files=len(case.meta["files"]),
+               inedge_invariant=case.meta["inedge_invariant"], hashseed_invariant=case.meta["hashseed_invariant"],
+               ops=case.meta.get("operations_in_reference_log"))
+    with tempfile.TemporaryDirectory() as tmp:
+        inp = case.inputs(tmp)
+        out = os.path.join(tmp, "out")
+        args = case.args(inp, out)
+        logger = graph_case.file_logger(out, "fuzz-%d" % idx)
+        err = None
+        try:
+            pipeline.run(args, logger, CheckerBackend(case, False))
+        except BaseException as e:  # noqa: B036 (KeyError / SystemExit where the reference exits non-zero too)
+            err = "%s: %s" % (type(e).__name__, e)
+        for h in list(logger.handlers):
+            h.flush()
+        problems, _ = graph_case.compare(case, out)
+        binding = [p for p in problems if p.split(" ", 1)[1] not in case.meta["differs_under_other_hashseeds"]]
+    if (err is None) != (case.meta["returncode"] == 0):
+        binding.append("exit: ours %r, reference rc %d" % (err, case.meta["returncode"]))
+    res["status"] = "ok" if not binding else "MISMATCH"
+    res["binding_problems"] = binding
+    res["non_binding"] = len(problems) - len([p for p in binding if not p.startswith("exit")])
+    shutil.rmtree(os.path.join(scratch, name), ignore_errors=True)
+    return res
+
+
+def main():
+    import numpy as np
+
+    draws = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    workers = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    scratch = tempfile.mkdtemp(prefix="vstrains_fuzz_ref_")
+    jobs = []
+    for i in range(draws):
+        k = int(rng.choice([21, 21, 31, 55]))
+        L = int(rng.choice([100, 120, 150])) if k < 55 else 150
+        kwargs = dict(n_strains=int(rng.integers(2, 7)), genome_len=int(rng.integers(1400, 4500)) if k < 55 else int(rng.integers(3000, 6500)),
+                      snp_rate=float(rng.choice([0.004, 0.008, 0.01, 0.012, 0.015, 0.02])), k=k,
+                      n_pairs=int(rng.integers(1500, 9000)), read_len=L, seed=int(rng.integers(1000, 10 ** 6)),
+                      abundance_ratio=float(rng.choice([0.45, 0.55, 0.6, 0.7, 0.8, 0.95])))
+        if rng.random() < 0.5:
+            kwargs["scramble"] = True
+        if rng.random() < 0.2:
+            kwargs["error_strain_depth"] = float(rng.choice([3.0, 6.0]))
+        if rng.random() < 0.15:
+            kwargs["repeat_len"] = int(rng.choice([80, 120]))
+        if rng.random() < 0.15:
+            kwargs["circular"] = True
+        if rng.random() < 0.2:
+            kwargs["sub_rate"] = float(rng.choice([0.002, 0.004]))
+        if rng.random() < 0.1:
+            kwargs["gapped_contigs"] = int(rng.integers(1, 5))
+        if rng.random() < 0.1:
+            kwargs["depth_tags"] = "kc"
+        extra = []
+        if rng.random() < 0.15:
+            extra = ["-mc", str(int(rng.choice([10, 20, 60, 150])))]
+        elif rng.random() < 0.1:
+            extra = ["-ml", "100"]
+        jobs.append((i, kwargs, extra, scratch))
+    tally = {"ok": 0, "MISMATCH": 0, "generator": 0}
+    stats = dict(rc_nonzero=0, inedge_invariant=0, hashseed_invariant=0, files=0, with_link_split=0, with_cov_match=0, with_trivial=0)
+    with mp.get_context("spawn").Pool(workers) as pool:
+        for res in pool.imap_unordered(one, jobs):
+            tally[res["status"]] += 1
+            if res["status"] == "MISMATCH":
+                print("MISMATCH", json.dumps(res), flush=True)
+            if res["status"] != "generator":
+                stats["rc_nonzero"] += int(res["rc"] != 0)
+                stats["inedge_invariant"] += int(res["inedge_invariant"])
+                stats["hashseed_invariant"] += int(res["hashseed_invariant"])
+                stats["files"] += res["files"]
+                ops = res.get("ops") or {}
+                stats["with_link_split"] += int(ops.get("link_split", 0) > 0)
+                stats["with_cov_match"] += int(ops.get("coverage_match", 0) > 0)
+                stats["with_trivial"] += int(ops.get("trivial_split", 0) > 0)
+            print("draw %d: %s" % (res["idx"], res["status"]), flush=True)
+    shutil.rmtree(scratch, ignore_errors=True)
+    print("draws %d: %s; %s" % (draws, tally, stats))
+    return 1 if tally["MISMATCH"] else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
