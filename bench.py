@@ -279,6 +279,7 @@ def main():
         }
         out["config"]["input_gfa_nodes"] = n_input_nodes
         out["roofline"].update(pmc_traffic(args.config, R, kernel_name) if not args.dirty else {"traffic": None})
+        out["roofline"].update(stream_copy(dev, achieved))
         want_extract = (cfg["extract"] or args.extract) and not args.no_extract
         try:
             if not want_extract:
@@ -299,6 +300,26 @@ def main():
 
         dist.barrier()
         dist.destroy_process_group()
+
+
+def stream_copy(dev, achieved_gbs):
+    """what a plain device-to-device copy reaches on this box (1 GiB read + 1 GiB written per
+    pass, HIP events on torch's stream), next to the nominal HBM peak the fraction is quoted against."""
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.int32, device=dev).fill_(1)
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    gbs = reps * 2.0 * 4.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del a, b
+    return {"measured_stream_copy_GBs": gbs, "frac_of_measured_stream_copy": achieved_gbs / gbs}
 
 
 def dirty_block(ctx, reads, frac, seed):

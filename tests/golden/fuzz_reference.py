@@ -66,9 +66,27 @@ def one(job):
             h.flush()
         problems, _ = graph_case.compare(case, out)
         binding = [p for p in problems if p.split(" ", 1)[1] not in case.meta["differs_under_other_hashseeds"]]
+        # the reference iterates sets of contig names: four hash seeds can agree by chance.  A file that
+        # differs is tried against the reference under further seeds before it counts as a mismatch.
+        differing = [p.split(" ", 1)[1] for p in binding if p.startswith("differs ")]
+        if differing:
+            ours = gold.collect(out)
+            pc = graph_case.synth.make_pipeline_case(**kwargs)
+            full = dict(inp)
+            for key, text in (("fwd", graph_case.synth.fastq_text(pc.fwd, "f")), ("rve", graph_case.synth.fastq_text(pc.rve, "r"))):
+                full[key] = os.path.join(tmp, key + "_full.fq")
+                with open(full[key], "w") as fh:
+                    fh.write(text)
+            for hs in range(4, 16):
+                _, files_hs, _ = gold.run_reference(full, extra, "rotate", hs)
+                differing = [f for f in differing if files_hs.get(f) != ours.get(f)]
+                if not differing:
+                    res["matches_reference_under_hashseed"] = hs
+                    break
+            binding = [p for p in binding if not p.startswith("differs ") or p.split(" ", 1)[1] in differing]
     if (err is None) != (case.meta["returncode"] == 0):
         binding.append("exit: ours %r, reference rc %d" % (err, case.meta["returncode"]))
-    res["status"] = "ok" if not binding else "MISMATCH"
+    res["status"] = "MISMATCH" if binding else "ok_other_hashseed" if "matches_reference_under_hashseed" in res else "ok"
     res["binding_problems"] = binding
     res["non_binding"] = len(problems) - len([p for p in binding if not p.startswith("exit")])
     shutil.rmtree(os.path.join(scratch, name), ignore_errors=True)
@@ -110,7 +128,7 @@ def main():
         elif rng.random() < 0.1:
             extra = ["-ml", "100"]
         jobs.append((i, kwargs, extra, scratch))
-    tally = {"ok": 0, "MISMATCH": 0, "generator": 0}
+    tally = {"ok": 0, "ok_other_hashseed": 0, "MISMATCH": 0, "generator": 0}
     stats = dict(rc_nonzero=0, inedge_invariant=0, hashseed_invariant=0, files=0, with_link_split=0, with_cov_match=0, with_trivial=0)
     with mp.get_context("spawn").Pool(workers) as pool:
         for res in pool.imap_unordered(one, jobs):
