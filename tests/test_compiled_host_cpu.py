@@ -51,3 +51,52 @@ def test_a_compiled_module_is_dropped_when_its_source_changed(tmp_path):
     finally:
         with open(_compile.STAMP, "w") as fh:
             fh.write(saved)
+
+
+def test_typed_front_half_of_reinit_equals_the_python_rebuild(tmp_path):
+    """_stage_fast.prepare (typed Cython, no .py twin) against formats.stage_graph_from_state on random
+    stages: gray vertices and edges, names dropped from the map, a re-inserted name, duplicate edge keys,
+    odd depths (ints, 1e-300, 1e22, -0.0): same kept ids / depths / sequences, same maps, same edge arrays,
+    the same GFA bytes."""
+    import random
+
+    import numpy as np
+
+    from vstrains_amd.graph import fast_module
+    from vstrains_amd.graph.asm_graph import AsmGraph
+    from vstrains_amd.graph.formats import stage_graph_from_state
+
+    fast = fast_module("_stage_fast")
+    if fast is None:
+        pytest.skip("_stage_fast is not built")
+    rng = random.Random(9)
+    cache = {}
+    for trial in range(40):
+        nv, ne = rng.randint(0, 120), rng.randint(0, 300)
+        g = AsmGraph()
+        for v in range(nv):
+            dp = rng.choice([rng.random() * 1000, float(rng.randint(0, 50)), 1e-300, 1e22, -0.0, 123456789.123456789, rng.randint(1, 9)])
+            g.add_vertex("n%d%s" % (v, rng.choice(["", "*A", "&x", "*0*B"])), dp, "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 90))),
+                         rng.random() > 0.15)
+        for _ in range(ne if nv else 0):
+            g.add_edge(rng.randrange(nv), rng.randrange(nv), rng.choice([21, 31, 55, 0, 127]), 0.0, rng.random() > 0.15)
+        nodes = {g.vid[v]: v for v in range(nv)}
+        edges = {(g.vid[g.esrc[e]], g.vid[g.etgt[e]]): e for e in g.edges()}
+        names = list(nodes)
+        for name in names[::7][:4]:
+            nodes.pop(name)
+        if len(names) > 3 and names[1] in nodes:
+            nodes[names[1]] = nodes.pop(names[1])
+        ref_g, ref_nn, ref_ne, ref_text = stage_graph_from_state(g, nodes, edges, gfa_path=str(tmp_path / "a.gfa"), want_text=True)
+        n_vid, n_vdp, n_vseq, nn, kept_keys, src, tgt, ovl, a_src, a_tgt, a_dp, text = fast.prepare(
+            g.vblack, g.vid, g.vdp, g.vseq, g.eblack, g.eovl, nodes, edges, cache)
+        assert text == ref_text.encode()
+        assert (n_vid, n_vdp, n_vseq) == (ref_g.vid, ref_g.vdp, ref_g.vseq)
+        assert list(nn.items()) == list(ref_nn.items())
+        assert dict(zip(kept_keys, range(len(src)))) == ref_ne and list(dict(zip(kept_keys, range(len(src))))) == list(ref_ne)
+        assert (src, tgt, ovl) == (ref_g.esrc, ref_g.etgt, ref_g.eovl)
+        assert a_src.tolist() == src and a_tgt.tolist() == tgt and a_dp.tolist() == [float(x) for x in n_vdp]
+        assert a_src.dtype == np.uint32 and a_dp.dtype == np.float64
+    # ids that are not str take the Python path: a TypeError, nothing else
+    with pytest.raises(TypeError):
+        fast.prepare([True], [5], [1.0], ["ACGT"], [], [], {5: 0}, {}, cache)

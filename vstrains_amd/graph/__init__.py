@@ -39,6 +39,19 @@ def _route_imports():
 COMPILED = _route_imports()  # {module: runs as a compiled extension module}
 
 
+def fast_module(name: str):
+    """A module of `_compile.NATIVE_ONLY` (typed Cython, no .py twin), or None when it is not built from
+    the present source or VS_GRAPH_INTERPRETED is set -- the caller then runs its Python statement."""
+    if os.environ.get("VS_GRAPH_INTERPRETED", "") not in ("", "0") or not _compile.current().get(name):
+        return None
+    import importlib
+
+    try:
+        return importlib.import_module(__name__ + "." + name)
+    except ImportError:
+        return None
+
+
 def host_modules() -> str:
     """'compiled' / 'interpreted' / 'mixed' -- reported by bench.py next to strain_extract_s."""
     vals = set(COMPILED.values())

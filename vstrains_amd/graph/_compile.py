@@ -18,12 +18,19 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 MODULES = ["asm_graph", "contigs", "disentangle", "extend", "formats", "hip_ops", "ops"]
+# hand-typed Cython without an interpreted twin: imported only when built from the present source
+# (`vstrains_amd.graph.fast_module`); its callers carry the Python statement of the same thing
+NATIVE_ONLY = ["_stage_fast"]
 STAMP = os.path.join(HERE, "compiled.json")
 BUILD_DIR = os.path.join(HERE, "_cbuild")
 
 
+def source_path(module: str) -> str:
+    return os.path.join(HERE, module + (".pyx" if module in NATIVE_ONLY else ".py"))
+
+
 def source_digest(module: str) -> str:
-    with open(os.path.join(HERE, module + ".py"), "rb") as fh:
+    with open(source_path(module), "rb") as fh:
         return hashlib.sha256(fh.read()).hexdigest()
 
 
@@ -48,12 +55,12 @@ def read_stamp() -> dict:
 def current() -> dict:
     """{module: True when a compiled module built from exactly the present source is in place}."""
     stamp = read_stamp()
-    return {m: compiled_path(m) is not None and stamp.get(m) == source_digest(m) for m in MODULES}
+    return {m: compiled_path(m) is not None and stamp.get(m) == source_digest(m) for m in MODULES + NATIVE_ONLY}
 
 
 def build(force: bool = False, quiet: bool = True) -> None:
     state = current()
-    todo = [m for m in MODULES if force or not state[m]]
+    todo = [m for m in MODULES + NATIVE_ONLY if force or not state[m]]
     if not todo:
         return
     from Cython.Build import cythonize
@@ -64,7 +71,7 @@ def build(force: bool = False, quiet: bool = True) -> None:
     cwd = os.getcwd()
     os.chdir(root)  # (module paths below are relative to the repository root)
     try:
-        exts = [Extension("vstrains_amd.graph.%s" % m, [os.path.join("vstrains_amd", "graph", m + ".py")],
+        exts = [Extension("vstrains_amd.graph.%s" % m, [os.path.relpath(source_path(m), root)],
                           extra_compile_args=["-O2", "-g0"]) for m in todo]
         exts = cythonize(exts, language_level=3, build_dir=BUILD_DIR, quiet=quiet,
                          compiler_directives={"binding": True, "boundscheck": True, "wraparound": True})

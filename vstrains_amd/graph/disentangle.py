@@ -74,7 +74,7 @@ def reinit(stage: Stage, ops: GraphOps, logger, filename: str) -> Stage:
     if snap is not None and snap.matches(stage.g, stage.nodes, stage.edges):
         # nothing changed since this stage was made (node / edge ids never change in place; vertex and
         # edge sets, colours, depths, flows and overlaps are compared above)
-        with open(filename, "w") as fh:
+        with open(filename, "wb" if isinstance(snap.text, bytes) else "w") as fh:
             fh.write(snap.text)
         logger.info(filename + " is stored..")
         return Stage(stage.g, stage.nodes, stage.edges, stage.scan, snap)

@@ -28,6 +28,10 @@ class HipGraphOps(GraphOps):
         self.calls = 0
         self._seg_lines: Dict[str, tuple] = {}   # id -> (depth, "S ..." line)
         self._link_lines: Dict[tuple, tuple] = {}  # (id, id) -> (overlap, "L ..." line)
+        from . import fast_module
+
+        self._fast = fast_module("_stage_fast")   # typed Cython front half of reinit, or None
+        self._dp_repr: Dict[float, bytes] = {}     # depth -> repr(depth) as it goes into a segment line
 
     def _refresh(self, g: AsmGraph):
         nv = g.num_vertices()
@@ -78,6 +82,20 @@ class HipGraphOps(GraphOps):
         -> (graph, node map, edge map, GFA text, scan)"""
         from .asm_graph import BLACK
 
+        fast = self._fast
+        if fast is not None:
+            try:
+                (n_vid, n_vdp, n_vseq, nn, kept_keys, src, tgt, ovl, a_src, a_tgt, a_dp, text) = fast.prepare(
+                    g.vblack, g.vid, g.vdp, g.vseq, g.eblack, g.eovl, nodes, edges, self._dp_repr)
+            except TypeError:  # (ids that are not str, overlaps that are not int: the Python statement handles them)
+                fast = None
+        if fast is not None:
+            if len(self._dp_repr) > 1 << 20:
+                self._dp_repr.clear()
+            nv, n_e = len(n_vid), len(src)
+            with open(gfa_path, "wb") as fh:
+                fh.write(text)
+            return self._rebuild(n_vid, n_vdp, n_vseq, nn, kept_keys, src, tgt, ovl, a_src, a_tgt, a_dp, text)
         vblack, vid, vdp, vseq = g.vblack, g.vid, g.vdp, g.vseq
         keep = [v for v in nodes.values() if vblack[v]]
         n_vid = [vid[v] for v in keep]
@@ -129,6 +147,14 @@ class HipGraphOps(GraphOps):
         a_src = np.asarray(src, dtype=np.uint32)
         a_tgt = np.asarray(tgt, dtype=np.uint32)
         a_dp = np.asarray(n_vdp, dtype=np.float64)
+        return self._rebuild(n_vid, n_vdp, n_vseq, nn, kept_keys, src, tgt, ovl, a_src, a_tgt, a_dp, text)
+
+    def _rebuild(self, n_vid, n_vdp, n_vseq, nn, kept_keys, src, tgt, ovl, a_src, a_tgt, a_dp, text):
+        """Back half of ``reinit``: adjacency, flows and scan of the filtered stage (``vs_stage_rebuild``),
+        unpacked into a fresh ``AsmGraph``."""
+        from .asm_graph import BLACK
+
+        nv, n_e = len(n_vid), len(src)
         row_ptr = np.zeros(nv + 1, dtype=np.uint64)
         n_out = np.zeros(max(nv, 1), dtype=np.uint32)
         nbr = np.zeros(max(2 * n_e, 1), dtype=np.uint32)
