@@ -35,7 +35,7 @@ class _Snapshot:
 
     __slots__ = ("sizes", "lists", "text")
 
-    def __init__(self, g: AsmGraph, nodes: NodeMap, edges: EdgeMap, text: str):
+    def __init__(self, g: AsmGraph, nodes: NodeMap, edges: EdgeMap, text):  # (str, or bytes from the typed front half)
         self.sizes = (id(g), len(g._free), g._n_edges, len(g.vid), len(nodes), len(edges))
         self.lists = (list(nodes.values()), list(edges.values()), list(g.vdp), list(g.vblack), list(g.eblack), list(g.eflow),
                       list(g.eovl))
