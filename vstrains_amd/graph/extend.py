@@ -234,22 +234,43 @@ def path_extension(stage: Stage, contigs: ContigDict, table: LinkTable, frozen: 
         stage = reinit(stage, ops, logger, "{0}/gfa/graph_S{1}.gfa".format(temp_dir, rid))
         g, nodes, edges = stage.triple()
         closure = remap_contigs(g, nodes, edges, contigs, id_mapping, prev_ids, logger)
-        for no in list(table.keys()):
-            if no not in nodes:
-                table.pop(no)
-                continue
-            kept = table.pop(no)
-            v = nodes[no]
-            ins = g.in_neighbors(v)
-            outs = g.out_neighbors(v)
-            for (u, w), pe in list(kept.items()):
-                kept.pop((u, w))
-                if len(closure[u]) == 1 or len(closure[w]) == 1:
-                    for uu in closure[u]:
-                        for ww in closure[w]:
-                            if (uu, ww) not in kept and nodes[uu] in ins and nodes[ww] in outs:
-                                kept[(uu, ww)] = pe
-            table[no] = kept
+        if n_forks == 0:
+            # Nothing forked: every id stands for itself and the graph is the one the pass started from, so the
+            # rewrite below only drops what no longer is a link between an in- and an out-neighbour; popping
+            # and re-inserting every key in turn leaves the survivors in their order -- done in place, and
+            # without building the closure of every id the table mentions.  (A link to an id that is no
+            # node raises KeyError here as there.)
+            for no in list(table.keys()):
+                if no not in nodes:
+                    table.pop(no)
+                    continue
+                kept = table[no]
+                if len(kept) == 0:
+                    continue
+                v = nodes[no]
+                ins = g.in_neighbors(v)
+                outs = g.out_neighbors(v)
+                for link in list(kept.keys()):
+                    a, b = nodes[link[0]], nodes[link[1]]  # (both looked up, as the closure of both is there)
+                    if not (a in ins and b in outs):
+                        del kept[link]
+        else:
+            for no in list(table.keys()):
+                if no not in nodes:
+                    table.pop(no)
+                    continue
+                kept = table.pop(no)
+                v = nodes[no]
+                ins = g.in_neighbors(v)
+                outs = g.out_neighbors(v)
+                for (u, w), pe in list(kept.items()):
+                    kept.pop((u, w))
+                    if len(closure[u]) == 1 or len(closure[w]) == 1:
+                        for uu in closure[u]:
+                            for ww in closure[w]:
+                                if (uu, ww) not in kept and nodes[uu] in ins and nodes[ww] in outs:
+                                    kept[(uu, ww)] = pe
+                table[no] = kept
         if n_forks == 0:  # nothing forked: every id stands for itself, and popping and re-inserting
             # every key in turn leaves the dict as it was
             for no in usages:
