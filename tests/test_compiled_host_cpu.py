@@ -87,9 +87,20 @@ def test_typed_front_half_of_reinit_equals_the_python_rebuild(tmp_path):
             nodes.pop(name)
         if len(names) > 3 and names[1] in nodes:
             nodes[names[1]] = nodes.pop(names[1])
+        # what the by-index shortcut must not get wrong: an edge filed under names that are not those of
+        # its own ends, key strings that are equal to the ids without being the same objects, a vertex
+        # that sits in the map under another name, two kept vertices with one id
+        if trial % 4 == 1 and nv > 6 and edges:
+            (ka, kb), e0 = next(iter(edges.items()))
+            edges[(g.vid[nv - 1], g.vid[nv - 2])] = e0
+        if trial % 4 == 2 and edges:
+            edges = {("".join(list(a)), "".join(list(b))): e for (a, b), e in edges.items()}
+        if trial % 4 == 3 and nv > 6:
+            nodes["alias"] = nodes.pop(g.vid[nv - 1], nv - 1)
+            g.vid[nv - 3] = g.vid[nv - 4]
         ref_g, ref_nn, ref_ne, ref_text = stage_graph_from_state(g, nodes, edges, gfa_path=str(tmp_path / "a.gfa"), want_text=True)
         n_vid, n_vdp, n_vseq, nn, kept_keys, src, tgt, ovl, a_src, a_tgt, a_dp, text = fast.prepare(
-            g.vblack, g.vid, g.vdp, g.vseq, g.eblack, g.eovl, nodes, edges, cache)
+            g.vblack, g.vid, g.vdp, g.vseq, g.eblack, g.eovl, g.esrc, g.etgt, nodes, edges, cache)
         assert text == ref_text.encode()
         assert (n_vid, n_vdp, n_vseq) == (ref_g.vid, ref_g.vdp, ref_g.vseq)
         assert list(nn.items()) == list(ref_nn.items())
@@ -99,4 +110,4 @@ def test_typed_front_half_of_reinit_equals_the_python_rebuild(tmp_path):
         assert a_src.dtype == np.uint32 and a_dp.dtype == np.float64
     # ids that are not str take the Python path: a TypeError, nothing else
     with pytest.raises(TypeError):
-        fast.prepare([True], [5], [1.0], ["ACGT"], [], [], {5: 0}, {}, cache)
+        fast.prepare([True], [5], [1.0], ["ACGT"], [], [], [], [], {5: 0}, {}, cache)

@@ -33,7 +33,8 @@ cdef struct Piece:
     Py_ssize_t n
 
 
-def prepare(list vblack, list vid, list vdp, list vseq, list eblack, list eovl, dict nodes, dict edges, dict dp_repr):
+def prepare(list vblack, list vid, list vdp, list vseq, list eblack, list eovl, list esrc, list etgt, dict nodes, dict edges,
+            dict dp_repr):
     """-> (n_vid, n_vdp, n_vseq, nn, kept_keys, src, tgt, ovl, a_src, a_tgt, a_dp, text)"""
     cdef Py_ssize_t pos = 0, v, e, i, nv = 0, n_e = 0, ln, total = 0
     cdef PyObject *k
@@ -58,9 +59,18 @@ def prepare(list vblack, list vid, list vdp, list vseq, list eblack, list eovl, 
     cdef char numbuf[32]
     cdef char *out
     cdef int nd
-    if seg == NULL or lnk == NULL or ovl_c == NULL:
-        free(seg); free(lnk); free(ovl_c)
+    # An edge's ends are looked up by NAME (the reference goes through the GFA text).  With tens of
+    # thousands of nodes those two dict lookups per edge are cache misses and most of the pass, so the
+    # common case goes by index: the edge's source vertex carries the very string the key holds, that
+    # vertex was kept, and no two kept vertices share an id -- then nn[name] is that vertex's new index.
+    cdef Py_ssize_t n_old = PyList_GET_SIZE(vid), sv, tv, si, ti
+    cdef int *new_of_old = <int *>malloc(sizeof(int) * (n_old + 1))
+    cdef bint by_index
+    if seg == NULL or lnk == NULL or ovl_c == NULL or new_of_old == NULL:
+        free(seg); free(lnk); free(ovl_c); free(new_of_old)
         raise MemoryError()
+    for i in range(n_old):
+        new_of_old[i] = -1
     try:
         # ---- vertices: map order, black ones
         while PyDict_Next(nodes, &pos, &k, &val):
@@ -77,6 +87,7 @@ def prepare(list vblack, list vid, list vdp, list vseq, list eblack, list eovl, 
             n_vseq.append(seq)
             dpv[nv] = dp
             PyDict_SetItem(nn, name, nv)
+            new_of_old[v] = <int>nv
             if dpv[nv] == 0.0:   # 0.0 and -0.0 are one dict key and two reprs: not through the cache
                 rep = repr(dp).encode()
                 alive.append(rep)
@@ -96,27 +107,41 @@ def prepare(list vblack, list vid, list vdp, list vseq, list eblack, list eovl, 
             total += 2 + seg[3 * nv].n + 1 + seg[3 * nv + 1].n + 6 + seg[3 * nv + 2].n + 1
             nv += 1
         # ---- edges: map order, both ends among the kept names, black
+        by_index = len(nn) == nv   # (no id twice among the kept vertices)
         pos = 0
         while PyDict_Next(edges, &pos, &k, &val):
             key = <object>k
-            a = <object>PyTuple_GET_ITEM(key, 0)
-            b = <object>PyTuple_GET_ITEM(key, 1)
-            hs = PyDict_GetItem(nn, a)
-            if hs == NULL:
-                continue
-            ht = PyDict_GetItem(nn, b)
-            if ht == NULL:
-                continue
             e = PyLong_AsSsize_t(<object>val)
             if not PyObject_IsTrue(<object>PyList_GET_ITEM(eblack, e)):
                 continue
+            a = <object>PyTuple_GET_ITEM(key, 0)
+            b = <object>PyTuple_GET_ITEM(key, 1)
+            si = -1
+            ti = -1
+            if by_index:
+                sv = PyLong_AsSsize_t(<object>PyList_GET_ITEM(esrc, e))
+                tv = PyLong_AsSsize_t(<object>PyList_GET_ITEM(etgt, e))
+                if 0 <= sv < n_old and PyList_GET_ITEM(vid, sv) == PyTuple_GET_ITEM(key, 0):
+                    si = new_of_old[sv]
+                if 0 <= tv < n_old and PyList_GET_ITEM(vid, tv) == PyTuple_GET_ITEM(key, 1):
+                    ti = new_of_old[tv]
+            if si < 0:
+                hs = PyDict_GetItem(nn, a)
+                if hs == NULL:
+                    continue
+                si = PyLong_AsSsize_t(<object>hs)
+            if ti < 0:
+                ht = PyDict_GetItem(nn, b)
+                if ht == NULL:
+                    continue
+                ti = PyLong_AsSsize_t(<object>ht)
             o = <object>PyList_GET_ITEM(eovl, e)
-            src.append(<object>hs)
-            tgt.append(<object>ht)
+            src.append(si)
+            tgt.append(ti)
             ovl.append(o)
             kept_keys.append(key)
-            srcv[n_e] = <unsigned int>PyLong_AsSsize_t(<object>hs)
-            tgtv[n_e] = <unsigned int>PyLong_AsSsize_t(<object>ht)
+            srcv[n_e] = <unsigned int>si
+            tgtv[n_e] = <unsigned int>ti
             ovl_c[n_e] = PyLong_AsLong(o)
             if type(a) is not str or type(b) is not str:
                 raise TypeError("edge key holds a non-string id")
@@ -152,4 +177,5 @@ def prepare(list vblack, list vid, list vdp, list vseq, list eblack, list eovl, 
         free(seg)
         free(lnk)
         free(ovl_c)
+        free(new_of_old)
     return n_vid, n_vdp, n_vseq, nn, kept_keys, src, tgt, ovl, a_src[:n_e], a_tgt[:n_e], a_dp[:nv], text

@@ -86,7 +86,7 @@ class HipGraphOps(GraphOps):
         if fast is not None:
             try:
                 (n_vid, n_vdp, n_vseq, nn, kept_keys, src, tgt, ovl, a_src, a_tgt, a_dp, text) = fast.prepare(
-                    g.vblack, g.vid, g.vdp, g.vseq, g.eblack, g.eovl, nodes, edges, self._dp_repr)
+                    g.vblack, g.vid, g.vdp, g.vseq, g.eblack, g.eovl, g.esrc, g.etgt, nodes, edges, self._dp_repr)
             except TypeError:  # (ids that are not str, overlaps that are not int: the Python statement handles them)
                 fast = None
         if fast is not None:
