@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# (the 'untouched' hints of the graph stages are verified against the snapshot in every test run)
+os.environ.setdefault("VS_CHECK_UNTOUCHED", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -10,6 +10,8 @@ two runs write must be identical.  Test infrastructure (uses the oracle).
 """
 import copy
 import os
+
+os.environ.setdefault("VS_CHECK_UNTOUCHED", "1")  # (hints of the graph stages verified)
 import shutil
 import sys
 import tempfile

@@ -15,6 +15,8 @@ from here except the tally.
 import json
 import multiprocessing as mp
 import os
+
+os.environ.setdefault("VS_CHECK_UNTOUCHED", "1")  # (hints of the graph stages verified)
 import shutil
 import sys
 import tempfile

@@ -11,6 +11,8 @@ import copy
 import hashlib
 import json
 import os
+
+os.environ.setdefault("VS_CHECK_UNTOUCHED", "1")  # (hints of the graph stages verified)
 import sys
 import tempfile
 import time

@@ -231,7 +231,9 @@ def path_extension(stage: Stage, contigs: ContigDict, table: LinkTable, frozen: 
     while len(contigs) > 0:
         prev_ids = list(stage.nodes.keys())
         n_forks, id_mapping = global_trivial_split(stage, logger)
-        stage = reinit(stage, ops, logger, "{0}/gfa/graph_S{1}.gfa".format(temp_dir, rid))
+        # (from the second path on, nothing lies between the re-initialisation that closed the previous
+        # round and this one except the trivial split: no fork, no change)
+        stage = reinit(stage, ops, logger, "{0}/gfa/graph_S{1}.gfa".format(temp_dir, rid), untouched=(n_forks == 0 and rid > 1))
         g, nodes, edges = stage.triple()
         closure = remap_contigs(g, nodes, edges, contigs, id_mapping, prev_ids, logger)
         if n_forks == 0:
