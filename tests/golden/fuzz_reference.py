@@ -29,6 +29,9 @@ sys.path.insert(0, TESTS)
 sys.path.insert(0, HERE)
 
 
+REFERENCE_LIMIT_S = 900
+
+
 def one(job):
     idx, kwargs, extra, scratch = job
     import contextlib
@@ -45,9 +48,20 @@ def one(job):
     gold.OUT = scratch
     graph_case.GOLDEN = scratch
     gold.CASES[name] = (kwargs, extra)
+    import subprocess
+
+    plain_run = subprocess.run
+
+    def run_with_limit(*a, **kw):  # (the reference's trivial-split fixpoint runs up to N^2 rounds on some circular graphs)
+        kw.setdefault("timeout", REFERENCE_LIMIT_S)
+        return plain_run(*a, **kw)
+
+    gold.subprocess.run = run_with_limit
     with contextlib.redirect_stdout(io.StringIO()) as line:
         try:
             gold.emit(name)
+        except subprocess.TimeoutExpired:
+            return dict(idx=idx, status="reference_timeout", kwargs=kwargs)
         except Exception as err:  # (a draw the generator cannot make)
             return dict(idx=idx, status="generator", detail=repr(err))
     case = graph_case.Case(name)
@@ -68,10 +82,11 @@ def one(job):
             h.flush()
         problems, _ = graph_case.compare(case, out)
         binding = [p for p in problems if p.split(" ", 1)[1] not in case.meta["differs_under_other_hashseeds"]]
-        # the reference iterates sets of contig names: four hash seeds can agree by chance.  A file that
-        # differs is tried against the reference under further seeds before it counts as a mismatch.
-        differing = [p.split(" ", 1)[1] for p in binding if p.startswith("differs ")]
-        if differing:
+        # The reference iterates sets of contig names: its outputs -- down to how many paths it extracts, hence
+        # which files exist -- depend on PYTHONHASHSEED, and four seeds can agree by chance.  Before anything
+        # counts as a mismatch the reference is run under further seeds: a seed under which EVERY file it
+        # writes equals this build's settles it.
+        if binding:
             ours = gold.collect(out)
             pc = graph_case.synth.make_pipeline_case(**kwargs)
             full = dict(inp)
@@ -79,13 +94,12 @@ def one(job):
                 full[key] = os.path.join(tmp, key + "_full.fq")
                 with open(full[key], "w") as fh:
                     fh.write(text)
-            for hs in range(4, 16):
+            for hs in range(1, 16):
                 _, files_hs, _ = gold.run_reference(full, extra, "rotate", hs)
-                differing = [f for f in differing if files_hs.get(f) != ours.get(f)]
-                if not differing:
+                if all(ours.get(f) == files_hs[f] for f in files_hs) and set(ours) <= set(files_hs) | {"vstrains.log.info"}:
                     res["matches_reference_under_hashseed"] = hs
+                    binding = []
                     break
-            binding = [p for p in binding if not p.startswith("differs ") or p.split(" ", 1)[1] in differing]
     if (err is None) != (case.meta["returncode"] == 0):
         binding.append("exit: ours %r, reference rc %d" % (err, case.meta["returncode"]))
     res["status"] = "MISMATCH" if binding else "ok_other_hashseed" if "matches_reference_under_hashseed" in res else "ok"
@@ -130,14 +144,14 @@ def main():
         elif rng.random() < 0.1:
             extra = ["-ml", "100"]
         jobs.append((i, kwargs, extra, scratch))
-    tally = {"ok": 0, "ok_other_hashseed": 0, "MISMATCH": 0, "generator": 0}
+    tally = {"ok": 0, "ok_other_hashseed": 0, "MISMATCH": 0, "generator": 0, "reference_timeout": 0}
     stats = dict(rc_nonzero=0, inedge_invariant=0, hashseed_invariant=0, files=0, with_link_split=0, with_cov_match=0, with_trivial=0)
     with mp.get_context("spawn").Pool(workers) as pool:
         for res in pool.imap_unordered(one, jobs):
             tally[res["status"]] += 1
             if res["status"] == "MISMATCH":
                 print("MISMATCH", json.dumps(res), flush=True)
-            if res["status"] != "generator":
+            if res["status"] not in ("generator", "reference_timeout"):
                 stats["rc_nonzero"] += int(res["rc"] != 0)
                 stats["inedge_invariant"] += int(res["inedge_invariant"])
                 stats["hashseed_invariant"] += int(res["hashseed_invariant"])
