@@ -410,3 +410,41 @@ def test_vector_host_packer_equals_the_byte_loop():
         w = want(seq)
         assert run(seq, 0) == w, seq
         assert run(seq, 1) == w, seq
+
+
+def _child_reads_fastq(path, q):
+    from vstrains_amd import pe as host
+
+    fq = host.FastqPair(path, path)
+    q.put([fq.sequence(0, i) for i in range(len(fq))])
+    fq.close()
+
+
+def test_fastq_ingest_after_fork(tmp_path):
+    """The ingest keeps worker threads across calls; a forked child has none of them and must start
+    its own instead of waiting for the parent's (pthread_atfork in csrc/vs_fastq.hip)."""
+    import multiprocessing as mp
+
+    from vstrains_amd import pe as host
+
+    raw = b"".join(b"@r%d\nACGT%s\n+\nIIII\n" % (i, b"GATTACA" * (i % 5)) for i in range(4000))
+    path = tmp_path / "a.fq"
+    path.write_bytes(raw)
+    want = pe_oracle.fastq_sequences(str(path))
+    os.environ["VS_HOST_THREADS"] = "6"
+    try:
+        fq = host.FastqPair(str(path), str(path))  # (the pool exists from here on)
+        assert [fq.sequence(0, i) for i in range(len(fq))] == want
+        ctx = mp.get_context("fork")
+        q = ctx.Queue()
+        p = ctx.Process(target=_child_reads_fastq, args=(str(path), q))
+        p.start()
+        got = q.get(timeout=120)
+        p.join(timeout=60)
+        assert p.exitcode == 0 and got == want
+        fq2 = host.FastqPair(str(path), str(path))  # (and the parent's pool still works)
+        assert [fq2.sequence(1, i) for i in range(len(fq2))] == want
+        fq.close()
+        fq2.close()
+    finally:
+        os.environ.pop("VS_HOST_THREADS")
