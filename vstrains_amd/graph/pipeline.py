@@ -136,6 +136,19 @@ def _extract_strains(pre: Prepared, table, backend, logger, out: str):
 
 
 def run(args, logger, backend=None):
+    """``VStrains_SPAdes.run``: preparation, PE inference, strain extraction.  (The cycle collector is
+    paused for the whole command, see ``extract_strains``: the preparation builds the same kind of
+    cycle-free containers.)"""
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        return _run(args, logger, backend)
+    finally:
+        if was_enabled:
+            gc.enable()
+
+
+def _run(args, logger, backend=None):
     if backend is None:
         from .hip_ops import HipBackend
 
