@@ -50,6 +50,19 @@ def test_matrix_writer_matches_reference_format(tmp_path):
     p = tmp_path / "pe_info"
     host.write_matrix_text(str(p), ids, mat)
     assert open(p).read() == pe_oracle.matrix_text(ids, mat)
+    # the writer works in blocks of whole rows (256 MB; a 50 k-node matrix is 36 GB of text): the same bytes
+    # whatever the block size, also when one row is larger than a block
+    rng = np.random.default_rng(3)
+    ids = ["n%d%s" % (i, "*A" * (i % 3)) for i in range(57)]
+    mat = rng.integers(0, 10 ** 9, size=(57, 57)).astype(np.int64) * (rng.random((57, 57)) < 0.3)
+    want = pe_oracle.matrix_text(ids, mat)
+    for block in ("1", "100", "2000", "100000"):
+        os.environ["VS_TEXT_BLOCK"] = block
+        try:
+            host.write_matrix_text(str(p), ids, mat)
+        finally:
+            os.environ.pop("VS_TEXT_BLOCK")
+        assert open(p).read() == want, block
 
 
 def _rank_main(rank, world, port, case_dir, k, q):

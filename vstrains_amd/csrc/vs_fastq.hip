@@ -586,43 +586,61 @@ extern "C" int vs_write_matrix_text(vs_ctx *ctx, const char *path, const uint8_t
         }
     });
     for (uint32_t i = 0; i < n; i++) row_off[i + 1] += row_off[i];
-    const uint64_t total = row_off[n];
-    char *buf = (char *)malloc(total ? total : 1);
-    if (!buf) return vs_fail(ctx, VS_E_OOM, "vs_write_matrix_text: %llu bytes", (unsigned long long)total);
-    parallel_for(T, [&](unsigned p) {
-        uint32_t lo = (uint32_t)((uint64_t)n * p / T), hi = (uint32_t)((uint64_t)n * (p + 1) / T);
-        for (uint32_t i = lo; i < hi; i++) {
-            char *q = buf + row_off[i];
-            const uint8_t *idi = ids + id_off[i];
-            const uint64_t li = id_off[i + 1] - id_off[i];
-            const int64_t *row = mat + (uint64_t)i * n;
-            for (uint32_t j = 0; j < n; j++) {
-                memcpy(q, idi, li); q += li;
-                *q++ = ':';
-                const uint64_t lj = id_off[j + 1] - id_off[j];
-                memcpy(q, ids + id_off[j], lj); q += lj;
-                *q++ = ':';
-                q = put_dec(q, (uint64_t)row[j]);
-                *q++ = '\n';
-            }
-        }
-    });
+    // The text of a 50 k-node graph is 36 GB per file: rows are formatted and written in blocks of at most
+    // ~256 MB (whole rows; one row alone may be larger), the buffer reused.
+    uint64_t BLOCK = 256ull << 20;
+    if (const char *ev = getenv("VS_TEXT_BLOCK")) BLOCK = std::max<uint64_t>(1u, (uint64_t)atoll(ev));  // (tests: many small blocks)
+    uint64_t cap = 0;
+    for (uint32_t i0 = 0; i0 < n;) {
+        uint32_t i1 = i0 + 1u;
+        while (i1 < n && row_off[i1 + 1] - row_off[i0] <= BLOCK) i1++;
+        cap = std::max(cap, row_off[i1] - row_off[i0]);
+        i0 = i1;
+    }
+    char *buf = (char *)malloc(cap ? cap : 1);
+    if (!buf) return vs_fail(ctx, VS_E_OOM, "vs_write_matrix_text: %llu bytes", (unsigned long long)cap);
     int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (fd < 0) {
         free(buf);
         return vs_fail(ctx, VS_E_ARG, "cannot open %s for writing: %s", path, strerror(errno));
     }
-    uint64_t done = 0;
-    while (done < total) {
-        ssize_t w = write(fd, buf + done, (size_t)std::min<uint64_t>(total - done, 1u << 30));
-        if (w < 0 && errno == EINTR) continue;
-        if (w < 0) {
-            int e = errno;
-            close(fd);
-            free(buf);
-            return vs_fail(ctx, VS_E_ARG, "write to %s failed: %s", path, strerror(e));
+    for (uint32_t i0 = 0; i0 < n;) {
+        uint32_t i1 = i0 + 1u;
+        while (i1 < n && row_off[i1 + 1] - row_off[i0] <= BLOCK) i1++;
+        const uint64_t base = row_off[i0], bytes = row_off[i1] - base;
+        const uint32_t rows = i1 - i0;
+        parallel_for(std::min<unsigned>(T, rows), [&](unsigned p) {
+            const unsigned parts = std::min<unsigned>(T, rows);
+            uint32_t lo = i0 + (uint32_t)((uint64_t)rows * p / parts), hi = i0 + (uint32_t)((uint64_t)rows * (p + 1) / parts);
+            for (uint32_t i = lo; i < hi; i++) {
+                char *q = buf + (row_off[i] - base);
+                const uint8_t *idi = ids + id_off[i];
+                const uint64_t li = id_off[i + 1] - id_off[i];
+                const int64_t *row = mat + (uint64_t)i * n;
+                for (uint32_t j = 0; j < n; j++) {
+                    memcpy(q, idi, li); q += li;
+                    *q++ = ':';
+                    const uint64_t lj = id_off[j + 1] - id_off[j];
+                    memcpy(q, ids + id_off[j], lj); q += lj;
+                    *q++ = ':';
+                    q = put_dec(q, (uint64_t)row[j]);
+                    *q++ = '\n';
+                }
+            }
+        });
+        uint64_t done = 0;
+        while (done < bytes) {
+            ssize_t w = write(fd, buf + done, (size_t)std::min<uint64_t>(bytes - done, 1u << 30));
+            if (w < 0 && errno == EINTR) continue;
+            if (w < 0) {
+                int e = errno;
+                close(fd);
+                free(buf);
+                return vs_fail(ctx, VS_E_ARG, "write to %s failed: %s", path, strerror(e));
+            }
+            done += (uint64_t)w;
         }
-        done += (uint64_t)w;
+        i0 = i1;
     }
     close(fd);
     free(buf);
