@@ -218,12 +218,14 @@ def _rank_range(rank, world, port, q):
     _set_cell(a, 0, 0, 3, 7 + rank)
     a.all_reduce()
     out.append(("u32", a.wide is None, a.pairs_in_buffer, a.result()))
+    how = [getattr(a, "last_all_reduce", None)]
     # (b) they cannot: every rank folds, the int64 totals are summed
     b = _cpu_counter(4, 2 ** 31 - 1)
     _set_cell(b, 1, 2, 2, 2 ** 32 - 1)
     _set_cell(b, 0, 0, 3, 2 ** 31 + rank)
     b.all_reduce()
     out.append(("wide", b.wide is not None, b.pairs_in_buffer, b.result()))
+    how.append(getattr(b, "last_all_reduce", None))
     # (c) one rank already holds int64 totals: all of them switch
     c = _cpu_counter(4, 10)
     _set_cell(c, 0, 1, 1, 5)
@@ -239,22 +241,42 @@ def _rank_range(rank, world, port, q):
         out.append(("async", False, 0, None))
     except OverflowError:
         out.append(("async", True, 0, None))
+    # the two exchanges on random mostly-zero counters, cell for cell (values beyond 2^31 included)
+    import torch
+
+    from vstrains_amd import dist as vdist
+
+    gen = torch.Generator().manual_seed(100 + rank)
+    for dtype, top in ((torch.int32, 2 ** 31 - 1), (torch.int64, 2 ** 40)):
+        m = torch.randint(0, top, (2, 60, 60), generator=gen, dtype=torch.int64)
+        m = (m * (torch.rand((2, 60, 60), generator=gen) < 0.05)).to(dtype)
+        if dtype == torch.int32:
+            m[0, 3, 4] = -7  # (uint32 2^32 - 7 in int32 storage)
+        dense, sparse = m.clone(), m.clone()
+        dist.all_reduce(dense, op=dist.ReduceOp.SUM)
+        vdist.sum_counts_sparse(sparse)
+        assert torch.equal(dense, sparse)
+        assert vdist.count_nonzero_cells(m) == int((m != 0).sum())
     if rank == 0:
-        q.put(out)
+        q.put((out, how))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_counter_range_across_two_ranks_gloo():
+@pytest.mark.parametrize("exchange", ["dense", "sparse"])
+def test_counter_range_across_two_ranks_gloo(exchange, monkeypatch):
+    """... and the same sums when the ranks exchange their non-zero cells instead of the dense buffers
+    (what PeCounter.all_reduce does for counters of several GB that are mostly zero; forced here)."""
     import torch.multiprocessing as mp
 
+    monkeypatch.setenv("VS_SPARSE_ALLREDUCE_BYTES", "1" if exchange == "sparse" else "0")
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
-    port = 29500 + ((os.getpid() + 41) % 500)
+    port = 29500 + ((os.getpid() + (41 if exchange == "dense" else 97)) % 500)
     procs = [ctxm.Process(target=_rank_range, args=(rk, 2, port, q)) for rk in range(2)]
     for p in procs:
         p.start()
-    out = q.get(timeout=120)
+    out, how = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -263,6 +285,7 @@ def test_counter_range_across_two_ranks_gloo():
     assert fb and pb == 0 and rb[1][2, 2] == 2 * (2 ** 32 - 1) and rb[0][0, 3] == 2 ** 32 + 1
     assert fc and rc[0][1, 1] == 5 + 5 + 3
     assert fd
+    assert how == [exchange, exchange]
 
 
 def test_async_allreduce_without_process_group_is_a_no_op():

@@ -518,7 +518,8 @@ def test_fastq_block_refuses_non_ascii_sequence_bytes_and_takes_dirty_reads(host
     assert stats == tuple(int(x) for x in ref[2])
 
 
-def test_sharded_drop_in_two_ranks_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("exchange", ["dense", "sparse"])
+def test_sharded_drop_in_two_ranks_on_one_gpu(tmp_path, exchange):
     """The PE drop-in under torchrun with two ranks: each rank counts its contiguous block of the
     pairs with the real kernels, the counters are summed, rank 0 alone touches the output
     directory and writes the files -- byte-identical to the reference's.  One GPU here, so both
@@ -533,7 +534,9 @@ def test_sharded_drop_in_two_ranks_on_one_gpu(tmp_path):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, VS_DIST_BACKEND="gloo", VS_DIST_DEVICE="0")
+    # ("sparse": the ranks exchange their non-zero cells instead of the dense counters, as they would for a
+    # 50 k-node graph -- forced here by a one-byte threshold)
+    env = dict(os.environ, VS_DIST_BACKEND="gloo", VS_DIST_DEVICE="0", VS_SPARSE_ALLREDUCE_BYTES="1" if exchange == "sparse" else "0")
     proc = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
          "--master-port", str(port), "-m", "vstrains_amd.pe_inference", "-g", os.path.join(d, "graph.gfa"), "-o", str(out),

@@ -4,6 +4,7 @@ HIP library.  Torch is used for device buffers, the stream and torch.distributed
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -329,16 +330,31 @@ class PeCounter:
 
         if group_size() <= 1:
             return
+        from . import dist as vdist
+
         torch = self.torch
-        flags = torch.tensor([self.pairs_in_buffer, 1 if self.wide is not None else 0], dtype=torch.int64, device=self.device)
+        # (large and mostly zero -- the counters of a 50 k-node graph: the ranks also agree on exchanging the
+        # non-zero cells instead of the dense buffer when everybody's cells together are less data than one buffer)
+        min_bytes = int(os.environ.get("VS_SPARSE_ALLREDUCE_BYTES", vdist.SPARSE_MIN_BYTES))
+        dense_bytes = self.mats.numel() * self.mats.element_size()
+        may_sparse = min_bytes > 0 and dense_bytes >= min_bytes
+        nnz = (vdist.count_nonzero_cells(self.mats) + (vdist.count_nonzero_cells(self.wide) if self.wide is not None else 0)) if may_sparse else 0
+        flags = torch.tensor([self.pairs_in_buffer, 1 if self.wide is not None else 0, nnz], dtype=torch.int64, device=self.device)
         all_reduce_counts(None, flags)
-        total_in_buffers, any_wide = int(flags[0].item()), int(flags[1].item())
-        if any_wide or 2 * total_in_buffers >= U32_LIMIT:
+        total_in_buffers, any_wide, total_nnz = int(flags[0].item()), int(flags[1].item()), int(flags[2].item())
+        fold = bool(any_wide or 2 * total_in_buffers >= U32_LIMIT)
+        if fold:
             self.fold()
-            all_reduce_counts(self.wide, self.stats)
+        target = self.wide if fold else self.mats
+        sparse = may_sparse and total_nnz * (8 + target.element_size()) < target.numel() * target.element_size()
+        if sparse:
+            vdist.sum_counts_sparse(target)
+            all_reduce_counts(None, self.stats)
         else:
-            all_reduce_counts(self.mats, self.stats)
+            all_reduce_counts(target, self.stats)
+        if not fold:
             self.pairs_in_buffer = total_in_buffers
+        self.last_all_reduce = "sparse" if sparse else "dense"
 
     def all_reduce_async(self):
         """Overlapped form for fixed-size steps (bench.py): the caller keeps counting into a second
