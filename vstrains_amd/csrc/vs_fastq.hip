@@ -628,18 +628,24 @@ extern "C" int vs_write_matrix_text(vs_ctx *ctx, const char *path, const uint8_t
                 }
             }
         });
-        uint64_t done = 0;
-        while (done < bytes) {
-            ssize_t w = write(fd, buf + done, (size_t)std::min<uint64_t>(bytes - done, 1u << 30));
-            if (w < 0 && errno == EINTR) continue;
-            if (w < 0) {
-                int e = errno;
+        // the block goes out as parallel pwrite()s of slices (the copy into the page cache is the slow part)
+        const unsigned wparts = (unsigned)std::min<uint64_t>(T, std::max<uint64_t>(1u, bytes >> 22));
+        std::vector<int> werr(wparts, 0);
+        parallel_for(wparts, [&](unsigned p) {
+            uint64_t lo = bytes * p / wparts, hi = bytes * (p + 1) / wparts;
+            while (lo < hi) {
+                ssize_t w = pwrite(fd, buf + lo, (size_t)std::min<uint64_t>(hi - lo, 1u << 30), (off_t)(base + lo));
+                if (w < 0 && errno == EINTR) continue;
+                if (w < 0) { werr[p] = errno; return; }
+                lo += (uint64_t)w;
+            }
+        });
+        for (unsigned p = 0; p < wparts; p++)
+            if (werr[p]) {
                 close(fd);
                 free(buf);
-                return vs_fail(ctx, VS_E_ARG, "write to %s failed: %s", path, strerror(e));
+                return vs_fail(ctx, VS_E_ARG, "write to %s failed: %s", path, strerror(werr[p]));
             }
-            done += (uint64_t)w;
-        }
         i0 = i1;
     }
     close(fd);
