@@ -838,7 +838,9 @@ k_pe_tiles(PeParams P) {
 // first sums increments per cell in a 16k-slot LDS table and issues ONE global atomic per cell when
 // the table is written out.  One wavefront expands 64 pairs at a time, one lane per run of at
 // most four increments.
+#ifndef ACC_TPB
 #define ACC_TPB 1024
+#endif
 #ifndef ACC_BITS
 #define ACC_BITS 14
 #endif
