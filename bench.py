@@ -117,6 +117,14 @@ def main():
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver calls it: nothing has touched the GPU yet, so the N
+        # ranks are started as a CHILD torchrun (never exec'd over this process) and rank 0's JSON line
+        # and the return code are relayed.
+        sys.exit(launch_ranks(args.gpus))
+    if args.gpus != int(os.environ.get("WORLD_SIZE", "1")) and os.environ.get("VS_BENCH_FORCE_DIST") != "1":
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ.get("WORLD_SIZE", "1")))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,7 +183,16 @@ def main():
     # more than one rank there are two counter buffers: the all-reduce of step i (RCCL's own stream)
     # runs while step i+1 counts into the other buffer; a buffer is reused only after its
     # all-reduce has been waited for, and everything outstanding is drained inside the timed region.
-    counters = [host.PeCounter(ctx) for _ in range(2 if use_dist else 1)]
+    # A graph whose dense [2,N,N] buffer is above the sparse-exchange threshold (configs[4]: 23.7 GB, ~0.7 s per
+    # dense ring all-reduce against 0.1 s of counting) sums its counters by exchanging the non-zero cells
+    # (PeCounter.all_reduce -> dist.sum_counts_sparse), blocking, one buffer; config.parallelism says which.
+    from vstrains_amd import dist as vdist
+
+    n_nodes = len(g.seqs)
+    dense_bytes = 2 * n_nodes * n_nodes * 4
+    sparse_min = int(os.environ.get("VS_SPARSE_ALLREDUCE_BYTES", vdist.SPARSE_MIN_BYTES))
+    blocking_exchange = use_dist and sparse_min > 0 and dense_bytes >= sparse_min
+    counters = [host.PeCounter(ctx) for _ in range(2 if (use_dist and not blocking_exchange) else 1)]
     pending = [[] for _ in counters]
     step_no = [0]
 
@@ -187,7 +204,10 @@ def main():
             wk.wait()
         c.reset()
         c.add(reads)
-        pending[b] = c.all_reduce_async() if use_dist else []
+        if blocking_exchange:
+            c.all_reduce()
+        else:
+            pending[b] = c.all_reduce_async() if use_dist else []
 
     def drain():
         for b in range(len(counters)):
@@ -235,6 +255,13 @@ def main():
     node_sum = int(counter.mats[0].sum(dtype=torch.int64).item())
     short_sum = int(counter.mats[1].sum(dtype=torch.int64).item())
 
+    rccl_ranks, coll_backend = 0, None
+    if use_dist:
+        import torch.distributed as dist
+
+        coll_backend = dist.get_backend()
+        rccl_ranks = dist.get_world_size() if coll_backend == "nccl" else 0
+    extract_failed = False
     if rank == 0:
         b_alg = 2 * ((L + 3) // 4) + 2 * (L - k) * 8 + 16
         ms_step = elapsed / args.steps * 1e3
@@ -262,12 +289,18 @@ def main():
                 "baseline_config": args.config,
                 "pairs_per_gpu": R, "read_len": L, "k": k, "nodes": len(g.seqs),
                 "node_bases": int(sum(len(s) for s in g.seqs)),
-                "parallelism": "read-block sharding x%d + all-reduce of [2,N,N] counters (RCCL, overlapped with the next block)" % world,
+                "parallelism": ("read-block sharding x%d + per-step exchange of the non-zero counter cells (%s; dense [2,N,N] = %.1f GB)"
+                                % (world, getattr(counter, "last_all_reduce", "n/a"), dense_bytes / 1e9)) if blocking_exchange else
+                               "read-block sharding x%d + all-reduce of [2,N,N] counters (RCCL, overlapped with the next block)" % world,
+                "rccl_ranks": rccl_ranks, "collective_backend": coll_backend,
                 "index": ctx.index_info, "index_build_s": index_s, "workload_build_s": workload_s,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS,
+                # the whole step (sort + mapping + counters + overflow [+ exchange]) against the same roof
+                "frac_step": R * b_alg / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": None,
                 "kernel": kernel_name, "kernel_ms_avg": avg_kernel_ms, "slow_kernel_ms_avg": float(np.mean(slow_ms)),
                 "locus_sort_ms_avg": float(np.mean(sort_ms)),
                 "accumulate_ms_avg": float(np.mean(acc_ms)),
@@ -281,15 +314,21 @@ def main():
         out["roofline"].update(pmc_traffic(args.config, R, kernel_name) if not args.dirty else {"traffic": None})
         out["roofline"].update(stream_copy(dev, achieved))
         want_extract = (cfg["extract"] or args.extract) and not args.no_extract
-        try:
-            if not want_extract:
-                raise RuntimeError("skipped (%s)" % ("--no-extract" if args.no_extract else "configs 3/4 run it with --extract"))
-            ex = strain_extract(ctx, counter, pre, names, logger, work_dir)
-            out["strain_extract_s"] = ex.pop("seconds")
-            out["strain_extract"] = ex
-        except Exception as err:  # the PE line must still be reported
+        if not want_extract:
             out["strain_extract_s"] = None
-            out["strain_extract"] = {"error": repr(err)}
+            out["strain_extract"] = {"skipped": "--no-extract" if args.no_extract else "configs 3/4 run it with --extract"}
+        else:
+            try:
+                ex = strain_extract(ctx, counter, pre, names, logger, work_dir)
+                out["strain_extract_s"] = ex.pop("seconds")
+                out["strain_extract"] = ex
+            except Exception as err:  # the PE line is still printed, but the run FAILS (exit status 1)
+                import traceback
+
+                traceback.print_exc()
+                out["strain_extract_s"] = None
+                out["strain_extract"] = {"error": repr(err)}
+                extract_failed = True
         if world == 1 and args.ingest_pairs > 0 and not args.no_extract:
             out["fastq_ingest"] = fastq_ingest(ctx, host, st, cum, seed, L, k, sub_thresh, n_thresh, min(args.ingest_pairs, R), work_dir)
         if world == 1 and args.cpu_seconds > 0:
@@ -300,6 +339,46 @@ def main():
 
         dist.barrier()
         dist.destroy_process_group()
+    if extract_failed:
+        sys.exit(1)
+
+
+def launch_ranks(n):
+    """One process per GPU through torch.distributed.run, as a child of this (GPU-free) process."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    for l in proc.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    if proc.returncode == 0 and not lines:
+        return 1
+    return proc.returncode
+
+
+def host_thread_budget():
+    """Host threads this process may really use: the affinity mask cut by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as qf:
+            a, b = qf.read().split()
+            quota = None if a == "max" else float(a) / float(b)
+    except Exception:
+        pass
+    budget = n if quota is None else max(1, min(n, int(quota + 0.5)))
+    return budget, n, quota
 
 
 def stream_copy(dev, achieved_gbs):
@@ -388,7 +467,9 @@ def fastq_ingest(ctx, host, st, cum, seed, L, k, sub_thresh, n_thresh, M, work_d
         passes.append((t2 - t0, t1 - t0, t2 - t1))
     passes.sort()
     total_s, open_s, count_s = passes[1]
-    return {"pairs": n, "fastq_bytes": size, "host_threads": os.cpu_count(),
+    budget, visible, quota = host_thread_budget()
+    return {"pairs": n, "fastq_bytes": size, "host_threads": min(budget, 64) if not os.environ.get("VS_HOST_THREADS") else int(os.environ["VS_HOST_THREADS"]),
+            "host_cpus_in_affinity_mask": visible, "cgroup_cpu_quota_cores": quota,
             "open_index_s": open_s, "pack_upload_count_s": count_s,
             "pairs_per_s": n / total_s, "pairs_per_s_after_open": n / count_s,
             "pairs_per_s_passes": [n / p[0] for p in passes],

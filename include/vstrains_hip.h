@@ -30,7 +30,9 @@ enum {
     VS_E_NODE_BASE = -4, /* a node of length >= k+1 holds a byte outside ACGT: the reference
                             dies with KeyError in reverse_seq (PE_Inference.py:12-13,122) */
     VS_E_STATE = -5,     /* call order (e.g. counting before an index exists) */
-    VS_E_RANGE = -6      /* a size exceeds what this build supports */
+    VS_E_RANGE = -6,     /* a size exceeds what this build supports */
+    VS_E_UTF8 = -7       /* a FASTQ sequence line holds bytes that are not valid UTF-8: the reference's
+                            text-mode readlines() raises UnicodeDecodeError (PE_Inference.py:147-152) */
 };
 
 typedef struct vs_ctx vs_ctx;     /* one per device */
@@ -80,7 +82,10 @@ int vs_reads_unpack(vs_ctx *ctx, const vs_reads *reads, uint8_t *out, uint32_t *
 /* ---- FASTQ ingest (host, multi-threaded) -----------------------------------------------------
  * Replaces PE_Inference.py:146-159: both files read in text mode (universal newlines), record r
  * = lines 4r..4r+3, sequence = line 4r+1 minus its last character (the newline, or a real
- * character on a final line without one), n_pairs = min(lines_f // 4, lines_r // 4).
+ * character on a final line without one), n_pairs = min(lines_f // 4, lines_r // 4).  Text mode means
+ * the reference sees CHARACTERS: a valid UTF-8 multi-byte sequence inside a sequence line is one character
+ * (counted once, every window over it misses); vs_fastq_sequence / _gather / _block deliver one byte per
+ * character ('?' for a multi-byte one); invalid UTF-8 there is VS_E_UTF8.
  * vs_fastq_open maps and indexes both files on the host cores (VS_HOST_THREADS overrides the
  * count); a file that starts with the gzip magic is inflated into memory first (zlib; several
  * members in a row are fine, a cut-off stream is VS_E_ARG).  vs_fastq_block turns pairs

@@ -48,7 +48,9 @@ def concat(seqs: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
     off = np.zeros(len(seqs) + 1, dtype=np.uint64)
     if len(seqs):
         off[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
-    data = np.frombuffer("".join(seqs).encode("latin-1"), dtype=np.uint8).copy()
+    # one byte per CHARACTER (the reference works on decoded text, PE_Inference.py:147-152): a character outside
+    # ASCII becomes '?', which like any byte outside ACGT makes the windows over it miss
+    data = np.frombuffer("".join(seqs).encode("ascii", "replace"), dtype=np.uint8).copy()
     if data.size == 0:
         data = np.zeros(1, dtype=np.uint8)
     return data, off
@@ -81,7 +83,7 @@ class Oracle:
         return int(lib().peo_table_entries(self._h))
 
     def map_end(self, read: str) -> List[int]:
-        buf = np.frombuffer(read.encode("latin-1"), dtype=np.uint8)
+        buf = np.frombuffer(read.encode("ascii", "replace"), dtype=np.uint8)
         out = np.zeros(max(self.n, 1), dtype=np.uint32)
         k = lib().peo_map_end(self._h, buf.ctypes.data if buf.size else None, buf.size,
                               out.ctypes.data, out.size)

@@ -5,6 +5,9 @@ import pytest
 
 # (the 'untouched' hints of the graph stages are verified against the snapshot in every test run)
 os.environ.setdefault("VS_CHECK_UNTOUCHED", "1")
+# the parity-safe tuning switches of vs_pe_count (VS_NO_SORT, VS_EPT, ...) exist only in a process started with
+# VS_EXPERIMENT=1; the variant tests flip them on a live context
+os.environ.setdefault("VS_EXPERIMENT", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -7,6 +7,8 @@ compares node_mat / short_mat / stats with the C oracle.  Prints the parameters 
     python tests/fuzz_pe.py [seconds=300] [seed=1]        (test infrastructure: the oracle is the checker)
 """
 import os
+
+os.environ.setdefault("VS_EXPERIMENT", "1")  # the draws flip tuning switches on a live context
 import sys
 import time
 

@@ -33,7 +33,7 @@ def emit(case, gfa_text, fwd_text, rve_text, k, note):
         shutil.rmtree(d)
     os.makedirs(d)
     for name, text in (("graph.gfa", gfa_text), ("fwd.fq", fwd_text), ("rve.fq", rve_text)):
-        with open(os.path.join(d, name), "w", newline="") as fh:
+        with open(os.path.join(d, name), "w", newline="", encoding="utf-8") as fh:
             fh.write(text)
     with tempfile.TemporaryDirectory() as tmp:
         aln = os.path.join(tmp, "aln")
@@ -222,6 +222,21 @@ def main():
     reads_r = [rand_seq(rng, int(rng.integers(2, 10))) for _ in range(40)]
     emit("tiny_k1", simple_graph(seqs, 1), synth.fastq_text(reads_f, "f"), synth.fastq_text(reads_r, "r"), 1, "split_len=2")
     emit("tiny_k2", simple_graph(seqs, 2), synth.fastq_text(reads_f, "f"), synth.fastq_text(reads_r, "r"), 2, "split_len=3")
+
+    # 14. bytes >= 0x80 in sequence lines: the reference reads the files in text mode (PE_Inference.py:147-152), so a
+    # valid UTF-8 sequence is ONE character of the read (counts once toward its length, every window over it misses,
+    # the pair stays in use); an upper-case N next to it still drops the pair
+    f, r = synth.sample_pairs(st, 40, 80, seed=141)
+    f[0] = f[0][:30] + "\u00e9" + f[0][31:]                 # two bytes, one character, read length unchanged
+    r[1] = "\u20ac" + r[1][1:]                              # three bytes at the start
+    f[2] = f[2][:40] + "\U0001F9EC" + f[2][41:]             # four bytes
+    r[3] = r[3][:25] + "\u00e9\u00e9" + r[3][27:]          # two characters in a row
+    f[4] = f[4][:10] + "\u00e9" + f[4][11:50] + "N" + f[4][51:]   # with an N: pair dropped
+    r[5] = r[5][:22] + "\u00df"                             # 23 characters: one window, missed
+    # (a sequence line is never the last line of a file it is taken from: records are whole groups of four lines)
+    ftxt = synth.fastq_text(f, "f").replace("@f_7\n", "@f_7 \u00e9tiquette\n")   # headers may hold anything that decodes
+    rtxt = synth.fastq_text(r, "r")
+    emit("utf8_reads_k21", g.gfa_text(), ftxt, rtxt, 21, "valid UTF-8 multi-byte characters inside sequence lines")
 
 
 if __name__ == "__main__":

@@ -313,8 +313,9 @@ def test_native_fastq_ingest_matches_reference_semantics(name, d, meta):
     readlines() + line[:-1] (PE_Inference.py:146-159): CRLF, missing final newline, unequal files."""
     from vstrains_amd import pe as host
 
-    wf = pe_oracle.fastq_sequences(os.path.join(d, "fwd.fq"))
-    wr = pe_oracle.fastq_sequences(os.path.join(d, "rve.fq"))
+    # (the ingest delivers one byte per CHARACTER; a character outside ASCII -- case utf8_reads_k21 -- arrives as '?')
+    wf = [s.encode("ascii", "replace").decode() for s in pe_oracle.fastq_sequences(os.path.join(d, "fwd.fq"))]
+    wr = [s.encode("ascii", "replace").decode() for s in pe_oracle.fastq_sequences(os.path.join(d, "rve.fq"))]
     for threads in ("1", "3", "8"):
         os.environ["VS_HOST_THREADS"] = threads
         try:
@@ -379,21 +380,33 @@ def test_native_fastq_ingest_odd_inputs(tmp_path):
     with pytest.raises(Exception) as ei:
         host.FastqPair(str(cut), str(plain))
     assert "gzip" in str(ei.value)
-    # non-ASCII bytes: fine in header / quality lines (text mode decodes them, nothing uses them),
-    # refused in a sequence line -- where the bytes are first read
+    # bytes >= 0x80: the reference reads in text mode, so valid UTF-8 is fine anywhere -- in a sequence line a
+    # multi-byte character is ONE character of the read (delivered as '?'); invalid UTF-8 in a sequence line is
+    # ValueError (the reference's readlines() raises UnicodeDecodeError, a ValueError)
     ok = tmp_path / "utf8_header.fq"
     ok.write_bytes("@r\u00e9ad 1\nACGT\n+\nII\u00e9I\n".encode("utf-8"))
     fq = host.FastqPair(str(ok), str(ok))
     assert len(fq) == 1 and fq.sequence(0, 0) == "ACGT"
     fq.close()
-    bad = tmp_path / "bad.fq"
-    bad.write_bytes(b"@a\nAC\xc3\xa9T\n+\nIIII\n")
-    fq = host.FastqPair(str(bad), str(bad))
-    with pytest.raises(ValueError):
-        fq.sequence(0, 0)
-    with pytest.raises(ValueError):
-        fq.gather(0, 1)
+    seq = tmp_path / "utf8_seq.fq"
+    seq.write_bytes("@a\nAC\u00e9T\n+\nIIII\n@b\n\u20acACG\U0001F9ECT\n+\nIIIIII\n@c\nACGT\u00e9\n+\nII\u00e9".encode("utf-8"))
+    fq = host.FastqPair(str(seq), str(seq))
+    assert [fq.sequence(0, i) for i in range(3)] == ["AC?T", "?ACG?T", "ACGT?"]
+    data, off = fq.gather(0, 3)
+    assert bytes(data[: int(off[-1])]) == b"AC?TAC?T?ACG?T?ACG?TACGT?ACGT?" and [int(x) for x in off] == [0, 4, 8, 14, 20, 25, 30]
     fq.close()
+    for raw in (b"@a\nAC\xc3T\n+\nIIII\n", b"@a\nAC\xa9T\n+\nIIII\n", b"@a\nAC\xed\xa0\x80T\n+\nI\n", b"@a\nAC\xc0\xafT\n+\nI\n",
+                b"@a\nAC\xf4\x90\x80\x80T\n+\nI\n"):  # cut short, stray continuation, surrogate, overlong, > U+10FFFF
+        bad = tmp_path / "bad.fq"
+        bad.write_bytes(raw)
+        with pytest.raises(UnicodeDecodeError):
+            raw.decode("utf-8")
+        fq = host.FastqPair(str(bad), str(bad))
+        with pytest.raises(ValueError):
+            fq.sequence(0, 0)
+        with pytest.raises(ValueError):
+            fq.gather(0, 1)
+        fq.close()
     with pytest.raises(FileNotFoundError):
         host.FastqPair(str(tmp_path / "nope.fq"), str(bad))
 

@@ -345,6 +345,41 @@ def test_every_kernel_variant_gives_the_same_counters(host, ctx, env, monkeypatc
     assert stats == tuple(int(x) for x in want[2])
 
 
+def test_switches_do_not_exist_outside_experiment_mode(tmp_path):
+    """A production process (no VS_EXPERIMENT) never reads the tuning environment: with the timing-only
+    switches set -- VS_DEBUG_STOP stops k_pe_tiles after its first phase, VS_ACC_ABLATE=2 skips the counting,
+    both give WRONG counters in experiment mode -- the counters still equal the oracle's and the default
+    kernel runs.  With VS_EXPERIMENT=1 they stay unreachable too (that needs VS_EXPERIMENT=timing)."""
+    script = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from oracle import pe_oracle_c
+from vstrains_amd import pe as host, synth
+st = synth.make_strains(5, 4000, 0.04, seed=31)
+g = synth.compact_dbg(st, 55)
+fwd, rve = synth.sample_pairs(st, 12000, 150, seed=32, sub_rate=0.01, n_rate=0.01)
+want = pe_oracle_c.Oracle(g.seqs, 55).count_pairs(fwd, rve)
+ctx = host.Context(0)
+ctx.build_index(g.seqs, 55)
+c = host.PeCounter(ctx)
+c.add(ctx.pack_pairs(fwd, rve))
+node_mat, short_mat, stats = c.result()
+assert np.array_equal(node_mat, want[0]) and np.array_equal(short_mat, want[1]), "counters differ"
+print("KERNEL", ctx.last_kernel)
+""" % ROOT
+    kernels = []
+    for mode in (None, "1"):
+        env = dict(os.environ, VS_DEBUG_STOP="1", VS_ACC_ABLATE="2", VS_NO_STD="1")
+        env.pop("VS_EXPERIMENT", None)
+        if mode:
+            env["VS_EXPERIMENT"] = mode
+        proc = subprocess.run([sys.executable, "-c", script], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+        kernels.append([l.split(" ", 1)[1] for l in proc.stdout.splitlines() if l.startswith("KERNEL")][0])
+    # production ignores VS_NO_STD as well; experiment mode honours it (a parity-safe switch)
+    assert kernels[0] != kernels[1], kernels
+
+
 def test_full_size_block_properties(host, ctx):
     """BASELINE configs[2] size (10 M pairs of 2x150 bp, ~4.5 k nodes) through size-independent
     properties: the counters of one 10 M block equal the sum over two 5 M halves and over four
@@ -484,12 +519,13 @@ def test_rccl_allreduce_through_the_c_abi_one_rank(host, ctx):
     nat.check(ctx._h, L.vs_comm_destroy(ctx._h, comm))
 
 
-def test_fastq_block_refuses_non_ascii_sequence_bytes_and_takes_dirty_reads(host, ctx, tmp_path):
-    """vs_fastq_block packs on the host cores: a byte >= 0x80 in a sequence line is refused there
-    (ValueError; a header may hold UTF-8), a block with lower-case / IUPAC bytes falls back to the
-    device packer (mask + position lists) and counts like the oracle."""
+def test_fastq_block_refuses_invalid_utf8_and_takes_dirty_reads(host, ctx, tmp_path):
+    """vs_fastq_block packs on the host cores: sequence bytes that are not valid UTF-8 are refused there
+    (ValueError, as the reference's text-mode read raises UnicodeDecodeError; VALID multi-byte characters are
+    read as the reference reads them -- golden case utf8_reads_k21), a block with lower-case / IUPAC bytes
+    falls back to the device packer (mask + position lists) and counts like the oracle."""
     bad = tmp_path / "bad.fq"
-    bad.write_bytes("@r\u00e9ad\nACGTACGTAC\n+\nIIIIIIIIII\n@b\nAC\u00e9TACGTAC\n+\nIIIIIIIIII\n".encode("utf-8"))
+    bad.write_bytes("@r\u00e9ad\nACGTACGTAC\n+\nIIIIIIIIII\n@b\nAC".encode("utf-8") + b"\xc3TACGTAC\n+\nIIIIIIIIII\n")
     fq = host.FastqPair(str(bad), str(bad), ctx)
     with pytest.raises(ValueError):
         fq.block(0, len(fq))
@@ -550,20 +586,18 @@ def test_sharded_drop_in_two_ranks_on_one_gpu(tmp_path, exchange):
 
 
 def test_bench_step_with_two_ranks_on_one_gpu(tmp_path):
-    """bench.py's multi-rank step (two counter buffers, the all-reduce of step i waited for when its
+    """`bench.py --gpus 2` launches its own ranks.  bench.py's multi-rank step (two counter buffers, the all-reduce of step i waited for when its
     buffer comes up again, max over ranks, one JSON line from rank 0) with two ranks sharing the
     one GPU and gloo as the collective: the line must account for both ranks' pairs.  (A functional
     run; the rate of two processes sharing a GPU says nothing.)"""
     import json
-    import socket
 
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    # `python bench.py --gpus 2` exactly as the driver calls it: bench.py itself starts the two ranks
+    # (a child torchrun, before anything touches the GPU) and relays rank 0's line and the exit status
     env = dict(os.environ, VS_DIST_BACKEND="gloo", VS_DIST_DEVICE="0")
+    env.pop("WORLD_SIZE", None)
     proc = subprocess.run(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-         "--master-port", str(port), "bench.py", "--gpus", "2", "--config", "1", "--pairs", "200000", "--steps", "3", "--warmup", "1",
+        [sys.executable, "bench.py", "--gpus", "2", "--config", "1", "--pairs", "200000", "--steps", "3", "--warmup", "1",
          "--cpu-seconds", "0", "--no-extract"],
         cwd=ROOT, capture_output=True, text=True, env=env, timeout=900)
     assert proc.returncode == 0, proc.stderr[-3000:]
@@ -571,6 +605,8 @@ def test_bench_step_with_two_ranks_on_one_gpu(tmp_path):
     assert len(line) == 1
     out = json.loads(line[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
+    assert out["config"]["collective_backend"] == "gloo" and out["config"]["rccl_ranks"] == 0  # (nccl -> rccl_ranks = 2)
+    assert 0 < out["roofline"]["frac_step"] <= out["roofline"]["frac"]
     assert abs(out["value"] - 2 * 200000 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
     st = out["pe_stats"]
     assert st["n_reads"] + st["short_reads"] + st["used_reads"] == 2 * 200000  # both ranks' pairs, summed

@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU-side: parity tests for the PE kernels, then timing lines (map ms, accumulate ms, sort ms, slow ms, step ms)
 # QUICK_ENVS="A=1 B=2": one extra timing line per listed setting
+export VS_EXPERIMENT=timing  # the switches below exist only in experiment mode (VsTuning)
 cd "$GRAFT_REPO_ROOT"
 python -m pytest tests/test_pe_gpu.py -x -q 2>&1 | tail -3
 P='import sys,json; d=json.loads(sys.stdin.read()); r=d["roofline"]; print(r["kernel_ms_avg"], r["accumulate_ms_avg"], r["locus_sort_ms_avg"], r["slow_kernel_ms_avg"], d["ms_per_step"])'

@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU-side iteration: PE parity tests, then timing lines per config (map ms, accumulate ms, sort ms, slow ms, step ms)
 #   ITER_TESTS="tests/test_pe_gpu.py tests/test_configs_gpu.py"  ITER_CONFIGS="2 1 4 3"  QUICK_ENVS="A=1 B=2"
+export VS_EXPERIMENT=timing  # the switches below exist only in experiment mode (VsTuning)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
 T="${ITER_TESTS:-tests/test_pe_gpu.py}"
 timeout 1500 python -m pytest $T -x -q 2>&1 | tail -${ITER_TAIL:-12}

@@ -1,5 +1,6 @@
 #!/bin/bash
 # GPU-side experiment: phase ablation of k_pe_tiles and the locus-sort / LDS-aggregation switches
+export VS_EXPERIMENT=timing  # the switches below exist only in experiment mode (VsTuning)
 cd "$GRAFT_REPO_ROOT"
 P='import sys,json; d=json.loads(sys.stdin.read()); r=d["roofline"]; print(r["kernel_ms_avg"], r["locus_sort_ms_avg"], r["slow_kernel_ms_avg"], d["pe_stats"]["slow_pairs_per_step"], d["ms_per_step"])'
 run() { timeout 300 python bench.py --pairs ${PAIRS:-10000000} --steps 3 --warmup 1 --cpu-seconds 0 --no-extract 2>/dev/null | python -c "$P"; }

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvstrains_hip.so")
 
 VS_OK = 0
-VS_E_ARG, VS_E_HIP, VS_E_OOM, VS_E_NODE_BASE, VS_E_STATE, VS_E_RANGE = -1, -2, -3, -4, -5, -6
+VS_E_ARG, VS_E_HIP, VS_E_OOM, VS_E_NODE_BASE, VS_E_STATE, VS_E_RANGE, VS_E_UTF8 = -1, -2, -3, -4, -5, -6, -7
 
 # name -> (restype, argtypes); every symbol include/vstrains_hip.h declares
 SYMBOLS = {

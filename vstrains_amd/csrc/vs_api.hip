@@ -1,6 +1,8 @@
 // Context, errors, device-memory helpers and the generic exclusive scan.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "vs_internal.h"
 
@@ -14,6 +16,36 @@ int vs_fail(vs_ctx *ctx, int code, const char *fmt, ...) {
     va_end(ap);
     if (ctx) ctx->err = buf; else g_create_err = buf;
     return code;
+}
+
+static bool env_on(const char *name) {
+    const char *v = getenv(name);
+    return v && atoi(v) != 0;
+}
+
+void vs_tuning_load(VsTuning &t, int level) {
+    t = VsTuning();
+    if (level < 1) return;
+    if (const char *v = getenv("VS_EPT")) t.ept = (uint32_t)atoi(v) & ~1u;
+    if (const char *v = getenv("VS_GRID_PER_CU")) t.grid_per_cu = atoi(v) > 0 ? (uint32_t)atoi(v) : 128u;
+    if (const char *v = getenv("VS_ACC_GRID_PER_CU")) t.acc_grid_per_cu = atoi(v) > 0 ? (uint32_t)atoi(v) : 32u;
+    if (const char *v = getenv("VS_ACC_FILL")) t.acc_fill_pct = atoi(v);
+    if (const char *v = getenv("VS_ACC_WIDE")) t.acc_wide = atoi(v);
+    if (const char *v = getenv("VS_SHORTCUT")) t.shortcut = atoi(v) != 0 ? 1 : 0;
+    t.no_sort = env_on("VS_NO_SORT");
+    t.locus_global = env_on("VS_LOCUS_GLOBAL");
+    t.no_xcd_map = env_on("VS_NO_XCD_MAP");
+    t.no_fast = env_on("VS_NO_FAST");
+    t.no_std = env_on("VS_NO_STD");
+    t.no_agg = env_on("VS_NO_AGG");
+    if (const char *v = getenv("VS_ACC_QUEUE")) t.acc_queue = atoi(v) != 0;
+    t.acc_merge = env_on("VS_ACC_MERGE");
+    t.debug_postings = getenv("VS_DEBUG_POSTINGS") != nullptr;
+    t.debug_occ = getenv("VS_DEBUG_OCC") != nullptr;
+    t.debug_acc = getenv("VS_DEBUG_ACC") != nullptr;
+    if (level < 2) return;
+    if (const char *v = getenv("VS_DEBUG_STOP")) t.debug_stop = (uint32_t)atoi(v);
+    if (const char *v = getenv("VS_ACC_ABLATE")) t.acc_ablate = atoi(v);
 }
 
 void *vs_cache_alloc(vs_ctx *ctx, size_t bytes) {
@@ -72,6 +104,8 @@ int vs_ctx_create(int device, vs_ctx **out) {
     if (e != hipSuccess) return vs_fail(nullptr, VS_E_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
     vs_ctx *ctx = new vs_ctx();
     ctx->device = device;
+    if (const char *ev = getenv("VS_EXPERIMENT")) ctx->experiment_level = strcmp(ev, "timing") == 0 ? 2 : strcmp(ev, "1") == 0 ? 1 : 0;
+    vs_tuning_load(ctx->tune, ctx->experiment_level);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
     for (int i = 0; i < 5; i++) {

@@ -14,6 +14,8 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <pthread.h>
+#include <sched.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 #include <sys/mman.h>
@@ -60,8 +62,27 @@ struct FqFile {
     size_t text_size() const { return translated.empty() ? size : translated.size(); }
 };
 
+// Host threads of the ingest: what this process may really run on -- the affinity mask cut by the
+// cgroup CPU quota (a box that shows 256 CPUs under a 16-core quota throttles 64 busy threads at the
+// next period boundary) -- unless VS_HOST_THREADS says otherwise.
 unsigned n_threads() {
-    unsigned n = std::thread::hardware_concurrency();
+    static const unsigned machine = [] {
+        unsigned n = std::thread::hardware_concurrency();
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) n = (unsigned)CPU_COUNT(&set);
+        if (FILE *fh = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char a[32] = {0};
+            double period = 0.0;
+            if (fscanf(fh, "%31s %lf", a, &period) == 2 && strcmp(a, "max") != 0 && period > 0.0) {
+                const double cores = atof(a) / period;
+                if (cores >= 1.0 && cores < (double)n) n = (unsigned)(cores + 0.5);
+            }
+            fclose(fh);
+        }
+        return n;
+    }();
+    unsigned n = machine;
     if (const char *ev = getenv("VS_HOST_THREADS")) n = (unsigned)atoi(ev);
     return std::max(1u, std::min(n, 64u));
 }
@@ -322,14 +343,61 @@ struct vs_fastq {
 };
 
 namespace {
-// Python's text mode decodes the file; header and quality lines may hold any valid UTF-8, but a
-// byte >= 0x80 inside a sequence line would count as a character of its own there, which packing by
-// bytes cannot mirror: such a file is refused where its sequence bytes are first read.
-const char *const NON_ASCII_MSG = "a sequence line holds non-ASCII bytes; the reference's text-mode decoding is not reproduced";
+// Python's text mode decodes the file (UTF-8), so the reference works on CHARACTERS: a valid multi-byte
+// sequence inside a sequence line is ONE character of the read -- it counts once toward the read length and,
+// being no key of the table, makes every window over it miss (PE_Inference.py:147-152, :25-26) -- and the
+// "last character" a line loses (:158-159) is a whole character.  Sequences that hold a byte >= 0x80 (rare)
+// are therefore turned into one byte per character before they are packed: ASCII bytes as they are, every
+// multi-byte character as '?' (any byte outside ACGTN would do).  Bytes that are not valid UTF-8 make the
+// reference's readlines() raise UnicodeDecodeError; here that is VS_E_UTF8.
+const char *const BAD_UTF8_MSG = "a sequence line holds non-ASCII bytes that are not valid UTF-8 (the reference's text-mode read raises UnicodeDecodeError)";
 inline bool has_high_bit(const uint8_t *q, uint32_t len) {
     uint8_t acc = 0;
     for (uint32_t i = 0; i < len; i++) acc |= q[i];
     return (acc & 0x80u) != 0;
+}
+// length in bytes of the UTF-8 character that starts at q[0] (n bytes available), 0 if invalid (Python's strict
+// decoder: no overlong forms, no surrogates, nothing above U+10FFFF)
+inline uint32_t utf8_char_len(const uint8_t *q, size_t n) {
+    const uint8_t c = q[0];
+    if (c < 0x80u) return 1u;
+    auto cont = [&](size_t i) { return i < n && (q[i] & 0xC0u) == 0x80u; };
+    if (c >= 0xC2u && c <= 0xDFu) return cont(1) ? 2u : 0u;
+    if (c >= 0xE0u && c <= 0xEFu) {
+        if (!cont(1) || !cont(2)) return 0u;
+        if (c == 0xE0u && q[1] < 0xA0u) return 0u;   // overlong
+        if (c == 0xEDu && q[1] >= 0xA0u) return 0u;  // surrogates
+        return 3u;
+    }
+    if (c >= 0xF0u && c <= 0xF4u) {
+        if (!cont(1) || !cont(2) || !cont(3)) return 0u;
+        if (c == 0xF0u && q[1] < 0x90u) return 0u;   // overlong
+        if (c == 0xF4u && q[1] >= 0x90u) return 0u;  // > U+10FFFF
+        return 4u;
+    }
+    return 0u;
+}
+// The characters of record `rec`'s sequence (one byte each) into dst (may be NULL: count only).  Returns
+// false on invalid UTF-8.  (The character a sequence line loses is always its newline: a record is four whole
+// lines, so a sequence line never ends the file.)
+inline bool seq_chars(const FqFile &f, uint64_t rec, uint8_t *dst, uint32_t *n_chars) {
+    const uint8_t *q = f.text() + f.seq_start[rec];
+    const uint32_t l = f.seq_len[rec];
+    if (!has_high_bit(q, l)) {
+        if (dst && l) memcpy(dst, q, l);
+        *n_chars = l;
+        return true;
+    }
+    uint32_t n = 0;
+    for (size_t i = 0; i < l;) {
+        const uint32_t cl = utf8_char_len(q + i, l - i);
+        if (!cl) return false;
+        if (dst) dst[n] = cl == 1u ? q[i] : (uint8_t)'?';
+        n++;
+        i += cl;
+    }
+    *n_chars = n;
+    return true;
 }
 
 // pack one sequence; returns the flags (VS_FLAG_N / VS_FLAG_INVALID, 0x80 for non-ASCII bytes): vs_pack_host.cpp
@@ -395,9 +463,11 @@ int vs_fastq_sequence(const vs_fastq *fq, int which, uint64_t record, uint8_t *b
     if (!fq || which < 0 || which > 1 || !len) return VS_E_ARG;
     const FqFile &f = fq->f[which];
     if (record >= f.seq_start.size()) return VS_E_RANGE;
-    *len = f.seq_len[record];
-    if (has_high_bit(f.text() + f.seq_start[record], *len)) return vs_fail(nullptr, VS_E_ARG, "%s", NON_ASCII_MSG);
-    if (buf && cap >= *len && *len) memcpy(buf, f.text() + f.seq_start[record], *len);
+    if (!seq_chars(f, record, nullptr, len)) return vs_fail(nullptr, VS_E_UTF8, "%s", BAD_UTF8_MSG);
+    if (buf && cap >= *len && *len) {
+        uint32_t n = 0;
+        seq_chars(f, record, buf, &n);
+    }
     return VS_OK;
 }
 
@@ -405,27 +475,31 @@ int vs_fastq_sequence(const vs_fastq *fq, int which, uint64_t record, uint8_t *b
 // that want the bytes).  ascii must hold off[2*count] bytes; call with ascii == NULL to size it.
 int vs_fastq_gather(const vs_fastq *fq, uint64_t first, uint64_t count, uint64_t *off, uint8_t *ascii) {
     if (!fq || !off || first + count > fq->n_pairs) return VS_E_ARG;
-    off[0] = 0;
-    for (uint64_t r = 0; r < count; r++) {
-        off[2 * r + 1] = off[2 * r] + fq->f[0].seq_len[first + r];
-        off[2 * r + 2] = off[2 * r + 1] + fq->f[1].seq_len[first + r];
-    }
-    if (!ascii) return VS_OK;
+    // lengths in CHARACTERS (= bytes unless a sequence holds multi-byte UTF-8, see seq_chars)
     const unsigned T = n_threads();
     std::vector<int> bad(T, 0);
     parallel_for(T, [&](unsigned p) {
         uint64_t lo = count * p / T, hi = count * (p + 1) / T;
-        for (uint64_t r = lo; r < hi; r++) {
+        for (uint64_t r = lo; r < hi; r++)
             for (int w = 0; w < 2; w++) {
-                const FqFile &f = fq->f[w];
-                const uint32_t l = f.seq_len[first + r];
-                if (l) memcpy(ascii + off[2 * r + w], f.text() + f.seq_start[first + r], l);
-                if (has_high_bit(f.text() + f.seq_start[first + r], l)) bad[p] = 1;
+                uint32_t n = 0;
+                if (!seq_chars(fq->f[w], first + r, nullptr, &n)) bad[p] = 1;
+                off[2 * r + w + 1] = n;
             }
-        }
     });
     for (unsigned p = 0; p < T; p++)
-        if (bad[p]) return vs_fail(nullptr, VS_E_ARG, "%s", NON_ASCII_MSG);
+        if (bad[p]) return vs_fail(nullptr, VS_E_UTF8, "%s", BAD_UTF8_MSG);
+    off[0] = 0;
+    for (uint64_t e = 0; e < 2 * count; e++) off[e + 1] += off[e];
+    if (!ascii) return VS_OK;
+    parallel_for(T, [&](unsigned p) {
+        uint64_t lo = count * p / T, hi = count * (p + 1) / T;
+        for (uint64_t r = lo; r < hi; r++)
+            for (int w = 0; w < 2; w++) {
+                uint32_t n = 0;
+                seq_chars(fq->f[w], first + r, ascii + off[2 * r + w], &n);
+            }
+    });
     return VS_OK;
 }
 
@@ -506,13 +580,13 @@ int vs_fastq_block(vs_ctx *ctx, vs_fastq *fq, uint64_t first, uint64_t count, vs
     for (uint32_t i = 0; i < VS_PAD_WORDS; i++) st.words[words + i] = 0u;
     uint32_t any = 0, maxlen = 0;
     for (unsigned p = 0; p < T; p++) { any |= part_flags[p]; maxlen = part_max[p] > maxlen ? part_max[p] : maxlen; }
-    if (any & 0x80u) return vs_fail(ctx, VS_E_ARG, "%s", NON_ASCII_MSG);
-    if (any & VS_FLAG_INVALID) {
+    if (any & (VS_FLAG_INVALID | 0x80u)) {
         // some read holds a byte outside ACGTN (rare): the device packer also builds the validity
-        // mask and the position lists -- take that path with the plain bytes of this block
+        // mask and the position lists -- take that path with the plain bytes of this block (one byte
+        // per CHARACTER: a multi-byte UTF-8 character arrives as one '?', see seq_chars)
         std::vector<uint64_t> off(n_ends + 1);
         int rc = vs_fastq_gather(fq, first, count, off.data(), nullptr);
-        if (rc) return vs_fail(ctx, rc, "vs_fastq_block: gather failed");
+        if (rc) return vs_fail(ctx, rc, "%s", rc == VS_E_UTF8 ? BAD_UTF8_MSG : "vs_fastq_block: gather failed");
         std::vector<uint8_t> bytes(off[n_ends] ? off[n_ends] : 1);
         rc = vs_fastq_gather(fq, first, count, off.data(), bytes.data());
         if (rc) return vs_fail(ctx, rc, "vs_fastq_block: gather failed");

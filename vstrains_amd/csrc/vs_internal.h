@@ -97,8 +97,31 @@ struct FqStage {
     bool in_flight = false;
 };
 
+// Experiment switches of vs_pe_count (tuning sweeps, parity-test variants, timing ablations).  A production
+// context never reads the environment per call: the switches exist only when the process was started with
+// VS_EXPERIMENT=1 (parity-safe ones: every one of them is a test variant) or VS_EXPERIMENT=timing (also the
+// ones that stop kernels early / skip work and therefore produce WRONG counters); they are then re-read on
+// every call so that a test can flip them on a live context.  Defaults = the measured best.
+struct VsTuning {
+    uint32_t ept = 0;               // VS_EPT (0 = automatic)
+    uint32_t grid_per_cu = 128;     // VS_GRID_PER_CU
+    uint32_t acc_grid_per_cu = 32;  // VS_ACC_GRID_PER_CU
+    int acc_fill_pct = -1;          // VS_ACC_FILL (-1 = 1/16 of the slots)
+    int acc_wide = 0;               // VS_ACC_WIDE (1: 64-bit keys, 2: split tables)
+    int shortcut = -1;              // VS_SHORTCUT (-1 = by index statistics)
+    bool no_sort = false, locus_global = false, no_xcd_map = false, no_fast = false, no_std = false, no_agg = false;
+    bool acc_queue = true, acc_merge = false;
+    bool debug_postings = false, debug_occ = false, debug_acc = false;
+    // timing only (VS_EXPERIMENT=timing): wrong counters by design
+    uint32_t debug_stop = 0;        // VS_DEBUG_STOP=1..5
+    int acc_ablate = -1;            // VS_ACC_ABLATE=2|3
+};
+void vs_tuning_load(VsTuning &t, int level);  // level 0: defaults, 1: parity-safe switches, 2: + timing-only ones
+
 struct vs_ctx {
     int device = 0;
+    int experiment_level = 0;  // VS_EXPERIMENT at vs_ctx_create: 0 none, 1 "1", 2 "timing"
+    VsTuning tune;
     hipStream_t stream = nullptr;
     std::string err;
     FqStage fq_stage[2];

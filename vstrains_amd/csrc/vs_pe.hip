@@ -1460,13 +1460,15 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     const uint32_t pmax = maxlen >= idx.w ? (maxlen - idx.w) / idx.s + 1u : 1u;
     const uint32_t wpe = maxlen ? (maxlen + 15u) / 16u : 1u;
     if (idx.n_nodes > 0x01FFFFFEu) return vs_fail(ctx, VS_E_RANGE, "more than 2^25-2 nodes");
-    uint32_t ept = STD_EPT;
-    if (const char *ev = getenv("VS_EPT")) ept = (uint32_t)atoi(ev) & ~1u;
+    // experiment switches: fixed defaults unless the process runs with VS_EXPERIMENT (see VsTuning)
+    if (ctx->experiment_level) vs_tuning_load(ctx->tune, ctx->experiment_level);
+    const VsTuning &tn = ctx->tune;
+    uint32_t ept = tn.ept ? tn.ept : STD_EPT;
     if (ept < 2 || ept > TTPB / 2u) ept = STD_EPT;
     while (ept > 2 && (ept * pmax > NI_CAP || lds_bytes(ept, pmax, ept * wpe) > LDS_BUDGET_BYTES)) ept -= 2;
     // (LDS is handed out in 1280-byte pieces: 32 000 B per workgroup lets five share a CU, 40 000 four.  A tile of
     // at least 32 ends that fits one of these is taken over a larger one that wastes the rest.)
-    if (!getenv("VS_EPT")) {
+    if (!tn.ept) {
         for (size_t fit : {(size_t)(TTPB >= 256 ? 32000 : TTPB == 128 ? 15360 : 7680), (size_t)(TTPB >= 256 ? 40000 : TTPB == 128 ? 17920 : 8960)}) {
             uint32_t e2 = ept;
             while (e2 > STD_EPT / 2u && lds_bytes(e2, pmax, e2 * wpe) > fit) e2 -= 2;
@@ -1503,7 +1505,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     VS_HIP(ctx, hipMemsetAsync(ctx->d_slow_count, 0, 32, st));
 
     // locus order of the pairs (see k_pe_locus); VS_NO_SORT=1 keeps the input order
-    const bool use_sort = !(getenv("VS_NO_SORT") && atoi(getenv("VS_NO_SORT")) != 0) && n_pairs >= 4096 && n_pairs < 0xFFFFFFF0ull;
+    const bool use_sort = !tn.no_sort && n_pairs >= 4096 && n_pairs < 0xFFFFFFF0ull;
     if (use_sort) {
         const uint64_t nk = (uint64_t)idx.n_nodes + 2u;
         if (ctx->locus_cap < n_pairs) {
@@ -1552,14 +1554,11 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     P.pmax = pmax;
     P.words_cap = ept * wpe;
     P.pool = pool_for(ept, &P.pool_bits);
-    {
-        const char *dbg = getenv("VS_DEBUG_STOP");
-        P.debug_stop = dbg ? (uint32_t)atoi(dbg) : 0u;
-    }
+    P.debug_stop = tn.debug_stop;  // (VS_EXPERIMENT=timing only)
     P.n_pairs = n_pairs;
     P.n_tiles = (n_pairs + ept / 2 - 1) / (ept / 2);
     P.wpe = wpe;
-    P.count_postings = getenv("VS_DEBUG_POSTINGS") ? 1u : 0u;
+    P.count_postings = tn.debug_postings ? 1u : 0u;
     P.magic_pmax = pmax > 1u ? (uint32_t)(0x100000000ull / pmax) + 1u : 0u;
     P.magic_wpe = wpe > 1u ? (uint32_t)(0x100000000ull / wpe) + 1u : 0u;
     P.perm = use_sort ? (const uint32_t *)ctx->d_perm : nullptr;
@@ -1569,31 +1568,31 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     P.dbg_counts = d_dbg_counts;
     P.dbg_cap = dbg_cap;
     P.accumulate = d_node_mat ? 1u : 0u;
-    P.no_xcd_map = (getenv("VS_NO_XCD_MAP") && atoi(getenv("VS_NO_XCD_MAP")) != 0) ? 1u : 0u;
+    P.no_xcd_map = tn.no_xcd_map ? 1u : 0u;
     // The shortcut spares a single posting its extension when the previous probe already owns the
     // match; it pays on graphs whose seeds are mostly unique.  Where seeds repeat (a compacted de
     // Bruijn graph of many strains: 3.5 postings per distinct seed at configs[2]) nearly every
     // wavefront holds some single posting and all 64 lanes walk through the test for it: 6.0 ms with,
     // 5.8 ms without.  VS_SHORTCUT=0/1 overrides.
     P.shortcut = ctx->n_distinct && ctx->n_seed_pos < 2 * ctx->n_distinct ? 1u : 0u;
-    if (const char *sv = getenv("VS_SHORTCUT")) P.shortcut = atoi(sv) != 0 ? 1u : 0u;
+    if (tn.shortcut >= 0) P.shortcut = (uint32_t)tn.shortcut;
 
     // straight-line extension when the whole block qualifies (see vs_extend_fast)
     // (reads with bytes outside ACGT qualify through their position lists, see k_inv4 / vs_seed_limits)
     const bool fast = (!reads->d_mask || reads->d_inv4) && idx.s <= 32u && maxlen <= 128u + idx.w + 32u &&
-                      !(getenv("VS_NO_FAST") && atoi(getenv("VS_NO_FAST")) != 0);
+                      !tn.no_fast;
     // compile-time-shape instantiations (see k_pe_tiles): 1 = (10, 5), 2 = (8, 4), 3 = (7, 3)
     int std_shape = 0;
     if (fast && ept == STD_EPT && P.pool_bits == STD_POOL_BITS && maxlen <= 159u && idx.K == STD_K && idx.w == STD_W &&
         idx.s == STD_S && P.accumulate && !P.debug_stop && !P.count_postings && !P.dbg_counts &&
-        !(getenv("VS_NO_STD") && atoi(getenv("VS_NO_STD")) != 0)) {
+        !tn.no_std) {
         if (wpe == 10u && pmax == 5u) std_shape = 1;
         else if (wpe == 8u && pmax == 4u) std_shape = 2;
         else if (wpe == 7u && pmax == 3u) std_shape = 3;
     }
     // longer strides and reads (k = 127 with 2 x 250 bases): the straight-line kernel with more windows
     const bool fast_long = !fast && (!reads->d_mask || reads->d_inv4) && idx.s <= 128u && maxlen <= idx.w + 256u &&
-                           ctx->max_node_len < (1u << 23) && !(getenv("VS_NO_FAST") && atoi(getenv("VS_NO_FAST")) != 0);
+                           ctx->max_node_len < (1u << 23) && !tn.no_fast;
     const void *tiles_fn = std_shape == 1   ? (const void *)k_pe_tiles<1, 10u, 5u>
                            : std_shape == 2 ? (const void *)k_pe_tiles<1, 8u, 4u>
                            : std_shape == 3 ? (const void *)k_pe_tiles<1, 7u, 3u>
@@ -1602,7 +1601,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
                                             : (const void *)k_pe_tiles<0, 0u, 0u>;
     if (lds > 64u * 1024u)
         VS_HIP(ctx, hipFuncSetAttribute(tiles_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (getenv("VS_DEBUG_OCC")) {
+    if (tn.debug_occ) {
         int nb = 0;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tiles_fn, TTPB, lds);
         fprintf(stderr, "[vs] k_pe_tiles: %zu B of LDS per workgroup, %d workgroups per CU\n", lds, nb);
@@ -1611,15 +1610,14 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     // Many more workgroups than fit at once (4 per CU): loci differ a lot in postings per read, and
     // short runs let the dispatcher even that out (runs of ~10 tiles at configs[2]: 8.4 ms, against
     // 10.0 ms with 8 workgroups per CU and 9.0 ms with one tile per workgroup)
-    uint64_t max_grid = (uint64_t)ctx->n_cu * 128u;
-    if (const char *ev = getenv("VS_GRID_PER_CU")) max_grid = (uint64_t)ctx->n_cu * (uint64_t)(atoi(ev) > 0 ? atoi(ev) : 128);
+    const uint64_t max_grid = (uint64_t)ctx->n_cu * tn.grid_per_cu;
     if (grid > max_grid) grid = max_grid;
     P.tiles_per_wg = (uint32_t)((P.n_tiles + grid - 1) / grid);
     grid = (P.n_tiles + P.tiles_per_wg - 1) / P.tiles_per_wg;
     VS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
     if (use_sort) {
         const uint64_t nk = (uint64_t)idx.n_nodes + 2u;
-        const bool lds_sort = nk <= LOCUS_LDS_KEYS && !(getenv("VS_LOCUS_GLOBAL") && atoi(getenv("VS_LOCUS_GLOBAL")) != 0);
+        const bool lds_sort = nk <= LOCUS_LDS_KEYS && !tn.locus_global;
         if (lds_sort) {
             const uint32_t n_wg = LOCUS_WGS;
             const uint32_t chunk = (uint32_t)((n_pairs + n_wg - 1) / n_wg);
@@ -1675,8 +1673,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         const uint64_t slots_pairs = list_ends / 2;
         // one workgroup fits per CU (the cell table); 32 per CU queued, for the same reason as above
         // (4.9 -> 3.9 ms), each at least one round of ACC_TPB pairs
-        uint32_t acc_grid = (uint32_t)ctx->n_cu * 32u;
-        if (const char *gv = getenv("VS_ACC_GRID_PER_CU")) acc_grid = (uint32_t)ctx->n_cu * (uint32_t)(atoi(gv) > 0 ? atoi(gv) : 32);
+        uint32_t acc_grid = (uint32_t)ctx->n_cu * tn.acc_grid_per_cu;
         uint32_t per_wg = (uint32_t)((slots_pairs + acc_grid - 1) / acc_grid);
         per_wg = (per_wg + ACC_TPB - 1) / ACC_TPB * ACC_TPB;
         acc_grid = (uint32_t)((slots_pairs + per_wg - 1) / per_wg);
@@ -1684,7 +1681,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         // counter whenever they are free, so a cell table lives across chunks and is written out on
         // fill only (3.85 -> 3.6 ms against one workgroup per chunk; VS_ACC_QUEUE=0 for that)
         uint32_t *acc_queue = nullptr;
-        if (!(getenv("VS_ACC_QUEUE") && atoi(getenv("VS_ACC_QUEUE")) == 0)) {
+        if (tn.acc_queue) {
             acc_queue = (uint32_t *)ctx->d_slow_count + 1;
             const uint32_t wgs = (uint32_t)ctx->n_cu * 2u;
             if (acc_grid > wgs) acc_grid = wgs;
@@ -1692,7 +1689,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         // 32-bit cell keys while 2*N*N fits, 64-bit keys (half the slots) above; VS_ACC_WIDE=1 forces
         // the wide table, VS_NO_AGG=1 turns the table off (every increment a global atomic)
         // table shape (see Acc32 / Acc32Split / Acc64); VS_ACC_WIDE=1 forces the 64-bit keys, =2 the split tables
-        const int force_shape = getenv("VS_ACC_WIDE") ? atoi(getenv("VS_ACC_WIDE")) : 0;
+        const int force_shape = tn.acc_wide;
         const bool fits32 = 2ull * idx.n_nodes * idx.n_nodes < 0xFFFFFFFFull, fits_split = idx.n_nodes <= 65535u;
         const int shape = force_shape == 1 ? 2 : (force_shape == 2 && fits_split) ? 1 : fits32 ? 0 : fits_split ? 1 : 2;
         const bool wide = shape == 2;
@@ -1700,16 +1697,15 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         // the table is written out once this many of its slots are taken: linear probing stays
         // short at a low fill, and cells of loci the run has left do not pile up (VS_ACC_FILL: percent)
         uint32_t fill_limit = slots / 16u;
-        if (const char *fv = getenv("VS_ACC_FILL")) fill_limit = (uint32_t)((uint64_t)slots * (uint32_t)atoi(fv) / 100u);
-        const char *ev = getenv("VS_NO_AGG");
-        uint32_t use_table = (ev && atoi(ev) != 0) ? 0u : 1u;
-        if (const char *ab = getenv("VS_ACC_ABLATE")) use_table = (uint32_t)atoi(ab);  // 2: decode only, 3: no write-outs (timing only)
+        if (tn.acc_fill_pct >= 0) fill_limit = (uint32_t)((uint64_t)slots * (uint32_t)tn.acc_fill_pct / 100u);
+        uint32_t use_table = tn.no_agg ? 0u : 1u;
+        if (tn.acc_ablate >= 0) use_table = (uint32_t)tn.acc_ablate;  // 2: decode only, 3: no write-outs (VS_EXPERIMENT=timing only)
         // VS_ACC_MERGE=1: equal end lists of a round are merged (one weighted short_mat expansion per distinct
         // list).  Exact and tested, but off by default: it removes 47 % of the increments at configs[2] and
         // the kernel takes the same 3.2 ms -- the cell table is not what the time goes into there -- while it
         // costs 8-20 % on graphs with short lists (configs[1], [3]) and gains 10 % at configs[4].
-        const uint32_t merge = (getenv("VS_ACC_MERGE") && atoi(getenv("VS_ACC_MERGE")) != 0) ? 1u : 0u;
-        uint32_t *acc_dbg = getenv("VS_DEBUG_ACC") ? (uint32_t *)ctx->d_slow_count + 4 : nullptr;
+        const uint32_t merge = tn.acc_merge ? 1u : 0u;
+        uint32_t *acc_dbg = tn.debug_acc ? (uint32_t *)ctx->d_slow_count + 4 : nullptr;
         VS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
         const void *acc_fn = shape == 2 ? (const void *)k_pe_accumulate<Acc64> : shape == 1 ? (const void *)k_pe_accumulate<Acc32Split>
                                                                                               : (const void *)k_pe_accumulate<Acc32>;
@@ -1752,12 +1748,12 @@ extern "C" int vs_pe_last_timing(vs_ctx *ctx, double ms[5]) {
     uint32_t n_slow = 0;
     VS_HIP(ctx, hipMemcpy(&n_slow, ctx->d_slow_count, sizeof n_slow, hipMemcpyDeviceToHost));
     ms[0] = a; ms[1] = b; ms[2] = (double)n_slow; ms[3] = c; ms[4] = d;
-    if (getenv("VS_DEBUG_POSTINGS")) {
+    if (ctx->tune.debug_postings) {
         unsigned long long np = 0;
         VS_HIP(ctx, hipMemcpy(&np, (char *)ctx->d_slow_count + 8, sizeof np, hipMemcpyDeviceToHost));
         fprintf(stderr, "[vs] postings expanded by the last vs_pe_count: %llu\n", np);
     }
-    if (getenv("VS_DEBUG_ACC")) {
+    if (ctx->tune.debug_acc) {
         uint32_t d4[4] = {0, 0, 0, 0};
         VS_HIP(ctx, hipMemcpy(d4, (char *)ctx->d_slow_count + 16, sizeof d4, hipMemcpyDeviceToHost));
         fprintf(stderr, "[vs] k_pe_accumulate: %u increments went past the cell table, %u write-outs of %u cells, %u rounds\n", d4[0], d4[1], d4[2], d4[3]);

@@ -35,6 +35,14 @@ def all_reduce_counts(mats, stats):
             dist.all_reduce(stats, op=dist.ReduceOp.SUM)
 
 
+def all_reduce_max(t):
+    """In-place maximum over the ranks of a small tensor."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+
+
 def all_reduce_counts_async(mats, stats):
     """Same sums, enqueued behind the work already on the current stream and NOT waited for: returns
     the work handles (``w.wait()`` makes the then-current stream wait), or [] when there is no process

@@ -51,8 +51,6 @@ class FastqPair:
         rc = nat.lib().vs_fastq_open(ctx._h if ctx is not None else None, fwd.encode(), rve.encode(), C.byref(h))
         if rc != nat.VS_OK:
             msg = nat.lib().vs_last_error(ctx._h if ctx is not None else None).decode("utf-8", "replace")
-            if "non-ASCII" in msg:
-                raise ValueError(msg)
             if "cannot open" in msg:
                 raise FileNotFoundError(msg)
             raise nat.NativeError(rc, msg)
@@ -79,14 +77,15 @@ class FastqPair:
     @staticmethod
     def _raise(ctx_h, rc):
         msg = nat.lib().vs_last_error(ctx_h).decode("utf-8", "replace")
-        if "non-ASCII" in msg:
+        if rc == nat.VS_E_UTF8:  # the reference's readlines() raises UnicodeDecodeError, a ValueError (PE_Inference.py:147-152)
             raise ValueError(msg)
         raise nat.NativeError(rc, msg)
 
     def sequence(self, which: int, record: int) -> str:
+        """The CHARACTERS of a sequence line, one byte each ('?' stands for a multi-byte UTF-8 character)."""
         n = C.c_uint32(0)
         rc = nat.lib().vs_fastq_sequence(self._h, which, record, None, 0, C.byref(n))
-        if rc == nat.VS_E_ARG and "non-ASCII" in nat.lib().vs_last_error(None).decode("utf-8", "replace"):
+        if rc == nat.VS_E_UTF8:
             self._raise(None, rc)
         if rc != nat.VS_OK:
             raise IndexError(record)
@@ -96,7 +95,9 @@ class FastqPair:
 
     def gather(self, first: int, count: int) -> Tuple[np.ndarray, np.ndarray]:
         off = np.zeros(2 * count + 1, dtype=np.uint64)
-        assert nat.lib().vs_fastq_gather(self._h, first, count, off.ctypes.data, None) == nat.VS_OK
+        rc = nat.lib().vs_fastq_gather(self._h, first, count, off.ctypes.data, None)
+        if rc != nat.VS_OK:
+            self._raise(None, rc)
         data = np.zeros(max(int(off[-1]), 1), dtype=np.uint8)
         rc = nat.lib().vs_fastq_gather(self._h, first, count, off.ctypes.data, data.ctypes.data)
         if rc != nat.VS_OK:
@@ -107,7 +108,7 @@ class FastqPair:
         h = C.c_void_p()
         rc = nat.lib().vs_fastq_block(self._ctx._h, self._h, first, count, C.byref(h))
         if rc != nat.VS_OK:
-            self._raise(self._ctx._h, rc)  # ValueError for non-ASCII sequence bytes (a text-mode open would decode them)
+            self._raise(self._ctx._h, rc)  # ValueError for sequence bytes that are not valid UTF-8
         return ReadBlock(self._ctx, h)
 
 
@@ -289,6 +290,7 @@ class PeCounter:
         self.wide = None          # int64 totals, allocated by the first fold
         self.pairs_in_buffer = 0  # pairs counted into ``mats`` since it was last empty (all ranks, after a sum)
         self.pairs_seen = 0
+        self.last_all_reduce = None  # "dense" / "sparse" after all_reduce()
 
     def reset(self):
         self.mats.zero_()
@@ -339,14 +341,20 @@ class PeCounter:
         dense_bytes = self.mats.numel() * self.mats.element_size()
         may_sparse = min_bytes > 0 and dense_bytes >= min_bytes
         nnz = (vdist.count_nonzero_cells(self.mats) + (vdist.count_nonzero_cells(self.wide) if self.wide is not None else 0)) if may_sparse else 0
-        flags = torch.tensor([self.pairs_in_buffer, 1 if self.wide is not None else 0, nnz], dtype=torch.int64, device=self.device)
+        # one agreement round: sums of (pairs in the buffers, "holds int64 totals", "would exchange sparsely") and the
+        # LARGEST non-zero count -- sum_counts_sparse gathers lists padded to the longest rank, so world * longest is
+        # what moves; a rank whose environment disables the sparse path vetoes it for everybody (no mismatched collectives)
+        flags = torch.tensor([self.pairs_in_buffer, 1 if self.wide is not None else 0, 1 if may_sparse else 0], dtype=torch.int64, device=self.device)
         all_reduce_counts(None, flags)
-        total_in_buffers, any_wide, total_nnz = int(flags[0].item()), int(flags[1].item()), int(flags[2].item())
+        longest = torch.tensor([nnz], dtype=torch.int64, device=self.device)
+        vdist.all_reduce_max(longest)
+        total_in_buffers, any_wide, sparse_votes, max_nnz = int(flags[0].item()), int(flags[1].item()), int(flags[2].item()), int(longest.item())
+        world = group_size()
         fold = bool(any_wide or 2 * total_in_buffers >= U32_LIMIT)
         if fold:
             self.fold()
         target = self.wide if fold else self.mats
-        sparse = may_sparse and total_nnz * (8 + target.element_size()) < target.numel() * target.element_size()
+        sparse = sparse_votes == world and world * max_nnz * (8 + target.element_size()) < target.numel() * target.element_size()
         if sparse:
             vdist.sum_counts_sparse(target)
             all_reduce_counts(None, self.stats)

@@ -53,6 +53,12 @@ def count_fastq(ctx, fq, counter, first: int, last: int, batch: int = BATCH_PAIR
     pairs at a time.  The host cores pack block i+1 (``vs_fastq_block``: 2 bits per base into
     pinned staging, upload enqueued) while the device still counts block i."""
     spans = [(lo, min(last, lo + batch)) for lo in range(first, last, batch)]
+    # the uploads of a block are enqueued on the context's stream: make that the stream the counting runs on
+    # BEFORE the first block is made (PeCounter.add sets the same stream again for every block)
+    import torch
+
+    with torch.cuda.device(counter.device):
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     nxt = fq.block(spans[0][0], spans[0][1] - spans[0][0]) if spans else None
     for i, (lo, hi) in enumerate(spans):
         if progress:
