@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VS_ABI_VERSION 3
+#define VS_ABI_VERSION 4
 
 enum {
     VS_OK = 0,
@@ -60,6 +60,25 @@ int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint64_t *node_
 /* Index facts for reporting: info[0]=seed length w, [1]=probe stride s, [2]=seed positions
  * indexed, [3]=hash slots, [4]=distinct seeds, [5]=bytes of device memory held by the index. */
 int vs_index_info(const vs_ctx *ctx, uint64_t info[6]);
+
+/* Walk index (built by vs_index_build next to the seed index): node sets that certify as proper overlap graphs of
+ * (k+1)-mers -- every (k+1)-mer of PE_Inference.py:116-135's table has ONE entry, nodes continue into each other only
+ * at their ends (compacted de Bruijn graphs) -- are mapped by following the read through the graph instead of
+ * probing seeds (csrc/vs_walk.h states the conditions).  info[0] = 1 if certified, [1] = (k+1)-mers entered (both
+ * strands), [2] = presence mers, [3] = successor links, [4] / [5] = slots of the two tables, [6] = device bytes,
+ * [7] = presence-mer length; why (may be NULL) receives the reason a node set was not certified. */
+int vs_walk_info(const vs_ctx *ctx, uint64_t info[8], char *why, size_t why_cap);
+/* The same certification on the host alone (no device, no context): what vs_index_build would decide. */
+int vs_walk_certify_host(const uint8_t *node_ascii, const uint64_t *node_off, uint32_t n_nodes, uint32_t ksize,
+                         uint64_t info[8], char *why, size_t why_cap);
+
+/* Host twin of the graph-following kernel's per-end work (tests, no device): the read ends are mapped by the very
+ * function k_pe_walk runs per lane.  lists[n_ends * cap], counts[n_ends]: accepted node indices per end (the result of
+ * single_end_read_mapping, PE_Inference.py:16-48, in no particular order); counts[e] = 0xFFFFFFFF where the kernel would
+ * send the pair to the overflow kernel.  Returns 0; 1 when the node set does not certify (nothing mapped). */
+int vs_walk_map_ends_host(const uint8_t *node_ascii, const uint64_t *node_off, uint32_t n_nodes, uint32_t ksize,
+                          const uint8_t *read_ascii, const uint64_t *read_off, uint64_t n_ends, uint32_t cap,
+                          uint32_t *lists, uint32_t *counts);
 
 /* ---- read blocks ----------------------------------------------------------------------------
  * Replaces the FASTQ record slicing of PE_Inference.py:146-159 from the point where the two

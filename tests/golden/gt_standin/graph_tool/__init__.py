@@ -15,14 +15,18 @@ per vertex, out-edges in ``[0, n_out)``, in-edges behind them):
 * ``copy()``: vertices first, then edges re-added in ``edges()`` order with fresh indices.
 * ``hash(Vertex) == index``; ``hash(Edge) == edge index``.
 
-``INEDGE_ROTATION = False`` switches to plain insertion order for in-edges; the fixture maker
-runs every case under both settings and records whether the outputs agree (SURVEY.md 8c:
-"parity unpinned at the graph-tool boundary").
+``GT_STANDIN_INEDGE=plain`` switches to plain insertion order for in-edges, ``=plain_outrev`` additionally
+reverses the out-entries; the fixture maker runs every case under all three settings and records which
+outputs agree ("parity unpinned at the graph-tool boundary").
 """
 import os
 from collections import deque
 
-INEDGE_ROTATION = os.environ.get("GT_STANDIN_INEDGE", "rotate") != "plain"
+MODEL = os.environ.get("GT_STANDIN_INEDGE", "rotate")
+INEDGE_ROTATION = MODEL == "rotate"
+# third model (fixtures are kept "fully invariant" only if they also survive this one): in-entries in plain
+# insertion order AND out-entries in REVERSE insertion order
+OUT_REVERSED = MODEL == "plain_outrev"
 
 
 class _PropMap:
@@ -225,7 +229,9 @@ class Graph:
             self._next_eidx += 1
         ses = self._adj[s]
         pos = self._nout[s]
-        if pos < len(ses):
+        if OUT_REVERSED:
+            ses.insert(0, (t, idx))
+        elif pos < len(ses):
             if INEDGE_ROTATION:
                 ses.append(ses[pos])
                 ses[pos] = (t, idx)

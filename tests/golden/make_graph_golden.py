@@ -215,6 +215,7 @@ def emit(case):
             if log_to:
                 shutil.copy(own_log, log_to)
         rc2, files2, _ = run_reference(inp, extra, "plain", 0)
+        rc4, files4, _ = run_reference(inp, extra, "plain_outrev", 0)
         seed_variant = set()
         for hs in (1, 2, 3):
             rc3, files3, _ = run_reference(inp, extra, "rotate", hs)
@@ -225,6 +226,9 @@ def emit(case):
                       "rve": md5(rve_text)},
         "inedge_invariant": bool(rc == rc2 and files == files2),
         "differs_under_plain_inedge_order": sorted(k for k in files if files2.get(k) != files[k]),
+        # third adjacency model (in-entries plain AND out-entries reversed)
+        "differs_under_reversed_out_order": sorted(k for k in files if files4.get(k) != files[k]),
+        "adjacency_invariant": bool(rc == rc2 == rc4 and files == files2 == files4),
         "files": sorted(files),
         "hashseed": 0,
         "hashseed_invariant": not seed_variant,
@@ -253,14 +257,23 @@ def search_invariant(n_seeds):
     whose debug log shows the operations the model could influence (branch split, coverage
     matching, trivial split).  Prints entries for INVARIANT_CASES."""
     templates = [
-        ("inv3_k21", dict(n_strains=3, genome_len=2600, snp_rate=0.009, k=21, n_pairs=5000, read_len=100, abundance_ratio=0.55)),
-        ("inv4_k21", dict(n_strains=4, genome_len=3000, snp_rate=0.01, k=21, n_pairs=7000, read_len=100, abundance_ratio=0.6)),
-        ("inv4_k31", dict(n_strains=4, genome_len=3600, snp_rate=0.012, k=31, n_pairs=8000, read_len=120, abundance_ratio=0.65)),
-        ("inv5_k21", dict(n_strains=5, genome_len=3200, snp_rate=0.012, k=21, n_pairs=9000, read_len=100, abundance_ratio=0.7)),
+        ("inv3_k21", dict(n_strains=3, genome_len=2600, snp_rate=0.009, k=21, n_pairs=5000, read_len=100, abundance_ratio=0.55), []),
+        ("inv4_k21", dict(n_strains=4, genome_len=3000, snp_rate=0.01, k=21, n_pairs=7000, read_len=100, abundance_ratio=0.6), []),
+        ("inv4_k31", dict(n_strains=4, genome_len=3600, snp_rate=0.012, k=31, n_pairs=8000, read_len=120, abundance_ratio=0.65), []),
+        ("inv5_k21", dict(n_strains=5, genome_len=3200, snp_rate=0.012, k=21, n_pairs=9000, read_len=100, abundance_ratio=0.7), []),
+        ("inv4_k55", dict(n_strains=4, genome_len=5000, snp_rate=0.012, k=55, n_pairs=9000, read_len=150, abundance_ratio=0.65), []),
+        ("inv3_k55", dict(n_strains=3, genome_len=4500, snp_rate=0.01, k=55, n_pairs=7000, read_len=150, abundance_ratio=0.55), []),
+        ("inv4_k21_mc", dict(n_strains=4, genome_len=3000, snp_rate=0.01, k=21, n_pairs=7000, read_len=100, abundance_ratio=0.6), ["-mc", "15"]),
+        ("inv5_k31_mc", dict(n_strains=5, genome_len=3600, snp_rate=0.012, k=31, n_pairs=9000, read_len=120, abundance_ratio=0.7), ["-mc", "12"]),
+        ("inv4_k21_scr", dict(n_strains=4, genome_len=3000, snp_rate=0.01, k=21, n_pairs=7000, read_len=100, abundance_ratio=0.6, scramble=True), []),
     ]
+    only = os.environ.get("VS_SEARCH_TEMPLATES")
+    if only:
+        templates = [t for t in templates if t[0] in only.split(",")]
+    first = int(os.environ.get("VS_SEARCH_FIRST_SEED", "200"))
     found = 0
-    for seed in range(200, 200 + n_seeds):
-        for tname, base in templates:
+    for seed in range(first, first + n_seeds):
+        for tname, base, extra in templates:
             kwargs = dict(base, seed=seed)
             pc = synth.make_pipeline_case(**kwargs)
             with tempfile.TemporaryDirectory() as tmp:
@@ -271,18 +284,21 @@ def search_invariant(n_seeds):
                     with open(inp[key], "w") as fh:
                         fh.write(text)
                 log = os.path.join(tmp, "run.log")
-                rc, files, _ = run_reference(inp, [], "rotate", 0, log)
+                rc, files, _ = run_reference(inp, extra, "rotate", 0, log)
                 if rc != 0 or not os.path.exists(log):
                     continue
                 text = open(log).read()
                 ops = {k: (sum(text.count(x) for x in v) if isinstance(v, tuple) else text.count(v)) for k, v in PHRASES.items()}
                 if not all(ops.values()):
                     continue
-                rc2, files2, _ = run_reference(inp, [], "plain", 0)
+                rc2, files2, _ = run_reference(inp, extra, "plain", 0)
                 if rc2 != 0 or files2 != files:
                     continue
+                rc4, files4, _ = run_reference(inp, extra, "plain_outrev", 0)
+                if rc4 != 0 or files4 != files:
+                    continue
             found += 1
-            print('    "%s_s%d": (%r, []),  # %s, %d strains out' % (tname, seed, kwargs, ops, files.get("strain.paths", "").count("NODE_")),
+            print('    "%s_s%d": (%r, %r),  # %s, %d strains out' % (tname, seed, kwargs, extra, ops, files.get("strain.paths", "").count("NODE_")),
                   flush=True)
     print("found", found)
 

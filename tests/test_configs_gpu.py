@@ -1,4 +1,7 @@
-"""BASELINE.json configs[3] and configs[4] at their real graph sizes (the generators bench.py
+"""Every BASELINE.json config on the device.  configs[0] / configs[1]: ALL pairs of the config (100 k / 1 M) against
+the C oracle; configs[0..2]: the HIP path against digests of the pe_info / st_info files the REAL reference script
+wrote for the bench stream (tests/golden/reference_digests.json, made by tools/time_reference.py);
+configs[3] and configs[4] at their real graph sizes (the generators bench.py
 --config uses): the code paths only these sizes take -- 64-bit cell keys in the counter kernel and
 the global-atomic locus sort above 46 k / 36 k nodes, 2 x 10 GB counters, the generic-loop mapping
 kernel for k = 127 / 2 x 250 -- against the C oracle on a prefix of the read stream, plus the
@@ -115,3 +118,66 @@ def test_config3_10k_nodes_k127_reads_of_250(host, ctx, tmp_path):
     prefix = _count(host, ctx, st, cum, seed, L, [(0, M)], sub, nth)
     orc = pe_oracle_c.Oracle(seqs, cfg["k"])
     _assert_equals_oracle(prefix, orc, st, cum, seed, L, M, sub, nth)
+
+
+@pytest.mark.parametrize("config", [0, 1])
+def test_config_all_pairs_equal_the_oracle(host, ctx, tmp_path, config):
+    """configs[0] (6-strain HIV-like, ~200 nodes, 100 k pairs) and configs[1] (5-strain HCV-like, ~1 k nodes, 1 M
+    pairs): EVERY pair of the config's bench stream counted on the device, every cell compared with the C
+    oracle's (the port does 2e5 pairs/s: seconds), plus the partition property."""
+    import torch
+
+    from vstrains_amd.workloads import CONFIGS, workload_for
+
+    cfg = CONFIGS[config]
+    st, pre, names, seqs, cum, logger, n_in = workload_for(config, str(tmp_path))
+    assert (150 <= len(seqs) <= 300) if config == 0 else (800 <= len(seqs) <= 1200), len(seqs)
+    ctx.build_index(seqs, cfg["k"])
+    L, seed, R = cfg["read_len"], 20250000 + config, cfg["total_pairs"]
+    sub, nth = int(0.005 * 2 ** 32), int(0.001 * 2 ** 32)
+    whole = _count(host, ctx, st, cum, seed, L, [(0, R)], sub, nth)
+    parts = _count(host, ctx, st, cum, seed, L, [(0, R // 3), (R // 3, 1), (R // 3 + 1, R - R // 3 - 1)], sub, nth)
+    assert torch.equal(whole.mats, parts.mats) and torch.equal(whole.stats, parts.stats)
+    orc = pe_oracle_c.Oracle(seqs, cfg["k"])
+    _assert_equals_oracle(whole, orc, st, cum, seed, L, R, sub, nth)
+
+
+@pytest.mark.parametrize("config", [0, 1, 2])
+def test_hip_path_reproduces_the_files_of_the_real_reference_script(host, ctx, tmp_path, config):
+    """The expected value here did not come out of the port: tools/time_reference.py ran the REAL
+    utils/VStrains_PE_Inference.py (its text dump is PE_Inference.py:190-207) in the build container on the bench
+    stream of configs[0] (all 100 k pairs) and on the 200 k-pair prefixes of configs[1] / configs[2], and committed
+    the SHA-256 of its pe_info / st_info (and of the s_graph_L1.gfa it read).  Here the same pairs are regenerated
+    with vs_synth_pairs, counted by the HIP path, written with vs_write_matrix_text, and hashed."""
+    import hashlib
+    import json
+    import os
+
+    from conftest import GOLDEN
+    from vstrains_amd.workloads import CONFIGS, workload_for
+
+    with open(os.path.join(GOLDEN, "reference_digests.json")) as fh:
+        want = json.load(fh)["configs[%d]" % config]
+    cfg = CONFIGS[config]
+    st, pre, names, seqs, cum, logger, n_in = workload_for(config, str(tmp_path))
+
+    def sha(path):
+        h = hashlib.sha256()
+        with open(path, "rb") as fh:
+            for chunk in iter(lambda: fh.read(1 << 24), b""):
+                h.update(chunk)
+        return h.hexdigest()
+
+    assert len(seqs) == want["nodes"] and cfg["k"] == want["k"] and cfg["read_len"] == want["read_len"]
+    assert sha(os.path.join(str(tmp_path), "gfa", "s_graph_L1.gfa")) == want["s_graph_L1_gfa_sha256"]  # the same graph, byte for byte
+    ids, gseqs = host.read_gfa_segments(os.path.join(str(tmp_path), "gfa", "s_graph_L1.gfa"))
+    assert gseqs == list(seqs)
+    ctx.build_index(gseqs, cfg["k"])
+    counter = _count(host, ctx, st, cum, want["stream_seed"], cfg["read_len"], [(0, want["pairs"])], want["sub_thresh"], want["n_thresh"])
+    node_mat, short_mat, stats = counter.result()
+    assert sum(stats) == want["pairs"]
+    for name, mat in (("pe_info", node_mat), ("st_info", short_mat)):
+        path = os.path.join(str(tmp_path), name)
+        host.write_matrix_text(path, ids, mat)
+        assert os.path.getsize(path) == want[name + "_bytes"]
+        assert sha(path) == want[name + "_sha256"], name

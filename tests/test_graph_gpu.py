@@ -401,9 +401,9 @@ def test_native_reinit_equals_the_python_rebuild(backend, tmp_path, front_half, 
                (sb.nontrivial, sb.fork_kind, sb.chain_next, sb.chain_top, sb.chain_rank)
 
 
-@pytest.mark.parametrize("config", [1, 2])
+@pytest.mark.parametrize("config", [0, 1, 2])
 def test_extraction_on_the_device_equals_the_checker_at_bench_size(backend, config, tmp_path):
-    """The strain-extract leg of bench configs[1] / configs[2] (853 / 5 039 nodes, the reference cannot run
+    """The strain-extract leg of bench configs[0] / configs[1] / configs[2] (216 / 853 / 5 039 nodes, the reference cannot run
     the latter): every file the device run writes -- 116 stage GFAs at configs[2], contig files,
     strain.paths, strain.fasta -- against the same host logic over the numpy checker (Python rebuild
     instead of vs_stage_rebuild, numpy flows / scans, link sums off the host copy of the counters)."""
@@ -420,7 +420,7 @@ def test_extraction_on_the_device_equals_the_checker_at_bench_size(backend, conf
     st, pre, names, seqs, cum, logger, _ = workload_for(config, str(tmp_path / "work"))
     ctx = backend.ctx
     ctx.build_index(seqs, cfg["k"])
-    reads = ctx.synth_pairs(st.genomes, cum, 20250000 + config, 0, 1_000_000, cfg["read_len"], int(0.005 * 2 ** 32), int(0.001 * 2 ** 32))
+    reads = ctx.synth_pairs(st.genomes, cum, 20250000 + config, 0, min(1_000_000, cfg["total_pairs"]), cfg["read_len"], int(0.005 * 2 ** 32), int(0.001 * 2 ** 32))
     counter = host.PeCounter(ctx)
     counter.add(reads)
     node_mat, short_mat, _ = counter.result()
@@ -452,3 +452,6 @@ def test_randomized_extraction_campaign_short():
                           capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
     assert "mismatches 0" in proc.stdout and "draws 0," not in proc.stdout, proc.stdout[-500:]
+    import warnings
+
+    warnings.warn(UserWarning("fuzz_graph: %s" % [l for l in proc.stdout.splitlines() if l.startswith("draws ")][-1]))

@@ -21,7 +21,7 @@ def test_library_exports_every_symbol_of_the_header():
     assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
     for name in declared:
         assert hasattr(L, name)
-    assert L.vs_abi_version() == 3
+    assert L.vs_abi_version() == 4
 
 
 def test_no_device_means_loud_failure_not_fallback():

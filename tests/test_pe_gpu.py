@@ -380,21 +380,25 @@ print("KERNEL", ctx.last_kernel)
     assert kernels[0] != kernels[1], kernels
 
 
-def test_full_size_block_properties(host, ctx):
-    """BASELINE configs[2] size (10 M pairs of 2x150 bp, ~4.5 k nodes) through size-independent
-    properties: the counters of one 10 M block equal the sum over two 5 M halves and over four
-    unequal pieces (any partition gives the same integer sums -- what read-block sharding relies on),
-    the three pair classes add up to 10 M, short_mat is upper triangular with a positive diagonal
-    wherever a row has any count, and a 200 k-pair prefix equals the CPU oracle bit for bit."""
-    from vstrains_amd import synth
+def test_full_size_block_properties(host, ctx, tmp_path):
+    """BASELINE configs[2] itself -- `workload_for(2)`: the 5 039-node s_graph_L1 and the 10 M pairs of 2x150 bp of
+    bench.py's default run (same stream seed) -- through size-independent properties: the counters of one 10 M
+    block equal the sum over two 5 M halves and over four unequal pieces (any partition gives the same integer
+    sums -- what read-block sharding relies on), the three pair classes add up to 10 M, short_mat is upper
+    triangular with a positive diagonal wherever a row has any count, and a 200 k-pair prefix equals the CPU
+    oracle bit for bit."""
+    from vstrains_amd.workloads import CONFIGS, workload_for
 
-    st = synth.make_strains(15, 10800, 0.09, seed=1003)
-    g = synth.compact_dbg(st, 55)
-    ab = np.array(st.abundance)
-    cum = np.minimum(np.floor(np.cumsum(ab) / ab.sum() * 2 ** 32), 2 ** 32 - 1).astype(np.uint32)
-    cum[-1] = 0xFFFFFFFF
-    sub, nth, seed, L, R = int(0.005 * 2 ** 32), int(0.001 * 2 ** 32), 77, 150, 10_000_000
-    ctx.build_index(g.seqs, 55)
+    cfg = CONFIGS[2]
+    st, pre, names, seqs, cum, logger, _ = workload_for(2, str(tmp_path))
+    assert len(seqs) >= 5000, len(seqs)
+
+    class g:  # (the node set PE inference runs on)
+        pass
+
+    g.seqs = list(seqs)
+    sub, nth, seed, L, R = int(0.005 * 2 ** 32), int(0.001 * 2 ** 32), 20250000 + 2, cfg["read_len"], cfg["total_pairs"]
+    ctx.build_index(g.seqs, cfg["k"])
 
     def count(pieces):
         counter = host.PeCounter(ctx)
@@ -624,3 +628,7 @@ def test_randomized_campaign_short(mode):
                           capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
     assert "mismatches 0" in proc.stdout and "draws 0," not in proc.stdout, proc.stdout[-500:]
+    # the number of draws this run really covered goes into the pytest summary (warnings section of the log)
+    import warnings
+
+    warnings.warn(UserWarning("fuzz_pe %s: %s" % (mode, [l for l in proc.stdout.splitlines() if l.startswith("draws ")][-1])))

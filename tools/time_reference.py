@@ -4,7 +4,12 @@ the C restatement on the same inputs on the same box, so that the two boxes can 
 (SURVEY.md 8d "CPU baseline").  Measurement tooling like bench.py's cpu_baseline leg: it may call
 oracle/; nothing of the product imports it.
 
-    python tools/time_reference.py [--configs 0,1,2] [--prefix 200000] [--out profiles/r2/cpu_reference.json]
+    python tools/time_reference.py [--configs 0,1,2] [--prefix 200000] [--out profiles/r3/cpu_reference.json]
+                                   [--digests tests/golden/reference_digests.json]
+
+Also writes the SHA-256 of the pe_info / st_info files the REAL script produced (and of the s_graph_L1.gfa it
+read) as a small fixture: a `-m gpu` test regenerates the same pairs on the device, counts them with the HIP
+path, formats the text with vs_write_matrix_text and must arrive at the same digests.
 
 Per config: the bench workload of that BASELINE.json config (vstrains_amd.workloads) is written as
 s_graph_L1.gfa + two FASTQ files (reads from the CPU twin of the device generator, so they are the
@@ -45,8 +50,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="0,1,2")
     ap.add_argument("--prefix", type=int, default=200_000, help="pairs given to the reference for configs > 0")
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r2", "cpu_reference.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r3", "cpu_reference.json"))
+    ap.add_argument("--digests", default=os.path.join(ROOT, "tests", "golden", "reference_digests.json"))
     args = ap.parse_args()
+    import hashlib
+
+    def sha256_file(path):
+        h = hashlib.sha256()
+        with open(path, "rb") as fh:
+            for chunk in iter(lambda: fh.read(1 << 24), b""):
+                h.update(chunk)
+        return h.hexdigest()
+
+    digests = {}
     from oracle import pe_oracle, pe_oracle_c
     from vstrains_amd.workloads import CONFIGS, workload_for
 
@@ -73,6 +89,14 @@ def main():
         wall = time.perf_counter() - t0
         assert proc.returncode == 0, proc.stderr[-2000:]
         glob_s = [float(l.split()[-1]) for l in proc.stdout.splitlines() if l.startswith("Global time elapsed")][0]
+        digests["configs[%d]" % ci] = {
+            "workload": cfg["tag"], "nodes": len(seqs), "pairs": int(n_pairs), "read_len": L, "k": k, "stream_seed": seed,
+            "sub_thresh": int(0.005 * 2 ** 32), "n_thresh": int(0.001 * 2 ** 32),
+            "s_graph_L1_gfa_sha256": sha256_file(gfa),
+            "pe_info_sha256": sha256_file(os.path.join(out_dir, "pe_info")), "st_info_sha256": sha256_file(os.path.join(out_dir, "st_info")),
+            "pe_info_bytes": os.path.getsize(os.path.join(out_dir, "pe_info")), "st_info_bytes": os.path.getsize(os.path.join(out_dir, "st_info")),
+            "produced_by": "utils/VStrains_PE_Inference.py (the real reference script, PE_Inference.py:190-207) run by tools/time_reference.py "
+                           "in the build container on the first `pairs` pairs of the bench stream of this config"}
         # its table build: time an empty-reads run of the same script on the same graph
         empty = os.path.join(work, "empty.fq")
         open(empty, "w").close()
@@ -122,6 +146,16 @@ def main():
     with open(args.out, "w") as fh:
         json.dump(result, fh, indent=1, sort_keys=True)
     print("written", args.out)
+    if digests:
+        old = {}
+        if os.path.exists(args.digests):
+            with open(args.digests) as fh:
+                old = json.load(fh)
+        old.update(digests)
+        with open(args.digests, "w") as fh:
+            json.dump(old, fh, indent=1, sort_keys=True)
+            fh.write("\n")
+        print("written", args.digests)
 
 
 if __name__ == "__main__":

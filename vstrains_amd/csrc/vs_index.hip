@@ -260,6 +260,16 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
         ctx->n_slots = n_slots;
         ctx->n_distinct = h_flags[1];
         ctx->has_index = true;
+        // walk index (vs_walk.h): certified on the host, tables uploaded; a node set that fails keeps the seed kernels
+        {
+            VsWalkHost wh;
+            vs_walk_build_host(node_ascii, node_off, n_nodes, K, woff.data(), d.rc_delta, wh);
+            ctx->walk_why = wh.why;
+            if (wh.certified) {
+                rc = vs_walk_upload(ctx, wh);
+                if (rc) goto done;
+            }
+        }
     }
 done:
     (void)hipStreamSynchronize(st);
@@ -282,5 +292,61 @@ extern "C" int vs_index_info(const vs_ctx *ctx, uint64_t info[6]) {
     info[3] = ctx->n_slots;
     info[4] = ctx->n_distinct;
     info[5] = ctx->index_bytes;
+    return VS_OK;
+}
+
+// ---- walk index: device copies -----------------------------------------------------------------------------------
+int vs_walk_upload(vs_ctx *ctx, const VsWalkHost &h) {
+    const size_t b_rec = sizeof(VsWalkRec) * h.rec.size(), b_k = sizeof(VsKSlot) * h.ktab.size(), b_p = sizeof(uint64_t) * h.pset.size();
+    VS_HIP(ctx, hipMalloc(&ctx->d_wrec, b_rec ? b_rec : 16));
+    VS_HIP(ctx, hipMalloc(&ctx->d_wktab, b_k ? b_k : 16));
+    VS_HIP(ctx, hipMalloc(&ctx->d_wpset, b_p ? b_p : 16));
+    VS_HIP(ctx, hipMemcpyAsync(ctx->d_wrec, h.rec.data(), b_rec, hipMemcpyHostToDevice, ctx->stream));
+    VS_HIP(ctx, hipMemcpyAsync(ctx->d_wktab, h.ktab.data(), b_k, hipMemcpyHostToDevice, ctx->stream));
+    VS_HIP(ctx, hipMemcpyAsync(ctx->d_wpset, h.pset.data(), b_p, hipMemcpyHostToDevice, ctx->stream));
+    VS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (the host vectors go away with the caller)
+    ctx->walk.rec = (const VsWalkRec *)ctx->d_wrec;
+    ctx->walk.ktab = (const VsKSlot *)ctx->d_wktab;
+    ctx->walk.pset = (const uint64_t *)ctx->d_wpset;
+    ctx->walk.k_bits = h.k_bits;
+    ctx->walk.p_bits = h.p_bits;
+    ctx->walk.wp = h.wp;
+    ctx->walk.nw = h.nw;
+    ctx->walk_info[0] = h.n_kmers; ctx->walk_info[1] = h.n_pmers; ctx->walk_info[2] = h.n_succ;
+    ctx->walk_info[3] = h.ktab.size(); ctx->walk_info[4] = h.pset.size(); ctx->walk_info[5] = b_rec + b_k + b_p;
+    ctx->index_bytes += b_rec + b_k + b_p;
+    ctx->walk_ok = true;
+    return VS_OK;
+}
+
+extern "C" int vs_walk_info(const vs_ctx *ctx, uint64_t info[8], char *why, size_t why_cap) {
+    if (!ctx || !info) return VS_E_ARG;
+    if (!ctx->has_index) return VS_E_STATE;
+    info[0] = ctx->walk_ok ? 1u : 0u;
+    for (int i = 0; i < 6; i++) info[1 + i] = ctx->walk_ok ? ctx->walk_info[i] : 0u;
+    info[7] = ctx->walk_ok ? ctx->walk.wp : 0u;
+    if (why && why_cap) snprintf(why, why_cap, "%s", ctx->walk_why.c_str());
+    return VS_OK;
+}
+
+// Host only (no device, no context): would this node set be certified?  The same code vs_index_build runs.
+extern "C" int vs_walk_certify_host(const uint8_t *node_ascii, const uint64_t *node_off, uint32_t n_nodes, uint32_t ksize,
+                                    uint64_t info[8], char *why, size_t why_cap) {
+    if (!node_off || !info || (!node_ascii && n_nodes && node_off[n_nodes]) || ksize < 1) return VS_E_ARG;
+    std::vector<uint32_t> woff(n_nodes + 1);
+    uint64_t words = 0;
+    for (uint32_t i = 0; i < n_nodes; i++) {
+        woff[i] = (uint32_t)words;
+        words += (node_off[i + 1] - node_off[i] + 15) / 16;
+        if (words > 0x0FFFFFF0ull) return VS_E_RANGE;
+    }
+    woff[n_nodes] = (uint32_t)words;
+    VsWalkHost wh;
+    vs_walk_build_host(node_ascii, node_off, n_nodes, ksize + 1, woff.data(), (uint32_t)(words + VS_PAD_WORDS), wh);
+    info[0] = wh.certified ? 1u : 0u;
+    info[1] = wh.n_kmers; info[2] = wh.n_pmers; info[3] = wh.n_succ; info[4] = wh.ktab.size(); info[5] = wh.pset.size();
+    info[6] = sizeof(VsWalkRec) * wh.rec.size() + sizeof(VsKSlot) * wh.ktab.size() + sizeof(uint64_t) * wh.pset.size();
+    info[7] = wh.wp;
+    if (why && why_cap) snprintf(why, why_cap, "%s", wh.why.c_str());
     return VS_OK;
 }

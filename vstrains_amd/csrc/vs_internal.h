@@ -8,6 +8,8 @@
 #include <vector>
 
 #include "../../include/vstrains_hip.h"
+#define VS_WALK_HOST_DECL
+#include "vs_walk.h"
 
 #define VS_WAVE 64
 #define VS_PAD_WORDS 16  // zero words behind every packed text buffer (window reads may overshoot)
@@ -111,6 +113,7 @@ struct VsTuning {
     int shortcut = -1;              // VS_SHORTCUT (-1 = by index statistics)
     bool no_sort = false, locus_global = false, no_xcd_map = false, no_fast = false, no_std = false, no_agg = false;
     bool acc_queue = true, acc_merge = false;
+    bool no_walk = false;           // VS_NO_WALK: certified graphs through the seed kernels too
     bool debug_postings = false, debug_occ = false, debug_acc = false;
     // timing only (VS_EXPERIMENT=timing): wrong counters by design
     uint32_t debug_stop = 0;        // VS_DEBUG_STOP=1..5
@@ -132,6 +135,12 @@ struct vs_ctx {
     void *d_meta = nullptr, *d_fwd = nullptr, *d_rc = nullptr, *d_table = nullptr, *d_post = nullptr;
     uint64_t n_seed_pos = 0, n_slots = 0, n_distinct = 0, index_bytes = 0;
     uint32_t max_node_len = 0;
+    // walk index (vs_walk.h): present when the node set passed the certification
+    bool walk_ok = false;
+    std::string walk_why;          // why not
+    VsWalkDev walk{};
+    void *d_wrec = nullptr, *d_wktab = nullptr, *d_wpset = nullptr;
+    uint64_t walk_info[6] = {0, 0, 0, 0, 0, 0};  // (k+1)-mers, presence mers, successor links, table slots, set slots, device bytes
     // scratch for vs_pe_count
     void *d_slow_list = nullptr;   // pair indices sent to the slow path
     uint64_t slow_cap = 0;
@@ -174,6 +183,24 @@ struct vs_reads {
         return r;
     }
 };
+
+// launch parameters of k_pe_walk (vs_walk.hip): the certified-graph mapping kernel
+struct VsWalkParams {
+    VsIndexDev idx;
+    VsWalkDev wk;
+    VsReadsDev rd;
+    const uint32_t *perm;  // pair order of the tiles (locus-sorted) or NULL = input order
+    uint64_t n_pairs, n_tiles;
+    uint32_t wpe, tiles_per_wg, magic_ws, no_xcd_map, accumulate, dbg_cap;
+    uint32_t *out_lists, *out_counts;
+    unsigned long long *stats;
+    uint32_t *slow_list, *slow_count, *dbg_lists, *dbg_counts;
+};
+#define VS_WALK_EPT 256u  // read ends per tile of k_pe_walk (= its workgroup size)
+size_t vs_walk_lds_bytes(uint32_t wpe);
+int vs_walk_launch(vs_ctx *ctx, const VsWalkParams &P, uint32_t grid, hipStream_t st);
+const char *vs_walk_kernel_name(uint32_t nw);
+int vs_walk_upload(vs_ctx *ctx, const VsWalkHost &h);  // host tables -> device (vs_index.hip)
 
 int vs_fail(vs_ctx *ctx, int code, const char *fmt, ...);
 // grow-only cache of device buffers (see vs_ctx::cache); NULL on allocation failure

@@ -1463,6 +1463,10 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     // experiment switches: fixed defaults unless the process runs with VS_EXPERIMENT (see VsTuning)
     if (ctx->experiment_level) vs_tuning_load(ctx->tune, ctx->experiment_level);
     const VsTuning &tn = ctx->tune;
+    // Certified graphs (vs_walk.h) are mapped by following the read through the graph (k_pe_walk); everything else, and
+    // blocks whose dirty reads come with a validity mask only, by the seed kernels below.
+    const bool use_walk = ctx->walk_ok && !tn.no_walk && (!reads->d_mask || reads->d_inv4) && !tn.debug_stop && !tn.debug_postings &&
+                          vs_walk_lds_bytes(wpe) <= 64u * 1024u && maxlen < (1u << 20);
     uint32_t ept = tn.ept ? tn.ept : STD_EPT;
     if (ept < 2 || ept > TTPB / 2u) ept = STD_EPT;
     while (ept > 2 && (ept * pmax > NI_CAP || lds_bytes(ept, pmax, ept * wpe) > LDS_BUDGET_BYTES)) ept -= 2;
@@ -1476,8 +1480,9 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         }
     }
     size_t lds = lds_bytes(ept, pmax, ept * wpe);
-    if (lds > 160u * 1024u)
+    if (!use_walk && lds > 160u * 1024u)
         return vs_fail(ctx, VS_E_RANGE, "reads of %u bases with k+1=%u need %zu B of LDS per pair (limit 160 KiB)", maxlen, idx.K, lds);
+    if (use_walk) ept = VS_WALK_EPT;  // (tile size of k_pe_walk: the list rows below are laid out for it)
 
     // scratch: slow list (one slot per pair), counter, dense state
     if (ctx->slow_cap < n_pairs) {
@@ -1599,7 +1604,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
                            : fast           ? (const void *)k_pe_tiles<1, 0u, 0u>
                            : fast_long      ? (const void *)k_pe_tiles<2, 0u, 0u>
                                             : (const void *)k_pe_tiles<0, 0u, 0u>;
-    if (lds > 64u * 1024u)
+    if (!use_walk && lds > 64u * 1024u)
         VS_HIP(ctx, hipFuncSetAttribute(tiles_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (tn.debug_occ) {
         int nb = 0;
@@ -1647,6 +1652,36 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     }
     VS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     if (!d_node_mat) VS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
+    if (use_walk) {
+        VsWalkParams W;
+        W.idx = idx;
+        W.wk = ctx->walk;
+        W.rd = reads->dev();
+        W.perm = P.perm;
+        W.n_pairs = n_pairs;
+        W.n_tiles = P.n_tiles;
+        W.wpe = wpe;
+        const uint32_t ws = wpe | 1u;
+        W.magic_ws = ws > 1u ? (uint32_t)(0x100000000ull / ws) + 1u : 0u;
+        W.no_xcd_map = P.no_xcd_map;
+        W.accumulate = P.accumulate;
+        W.dbg_cap = dbg_cap;
+        W.out_lists = P.out_lists;
+        W.out_counts = P.out_counts;
+        W.stats = P.stats;
+        W.slow_list = P.slow_list;
+        W.slow_count = P.slow_count;
+        W.dbg_lists = d_dbg_lists;
+        W.dbg_counts = d_dbg_counts;
+        uint64_t wgrid = W.n_tiles;
+        const uint64_t wmax = (uint64_t)ctx->n_cu * (tn.grid_per_cu < 32u ? tn.grid_per_cu : 32u);
+        if (wgrid > wmax) wgrid = wmax;
+        W.tiles_per_wg = (uint32_t)((W.n_tiles + wgrid - 1) / wgrid);
+        wgrid = (W.n_tiles + W.tiles_per_wg - 1) / W.tiles_per_wg;
+        ctx->last_kernel = vs_walk_kernel_name(ctx->walk.nw);
+        int wrc = vs_walk_launch(ctx, W, (uint32_t)wgrid, st);
+        if (wrc) return wrc;
+    } else {
     ctx->last_kernel = std_shape == 1   ? "k_pe_tiles<1, 10u, 5u>"
                        : std_shape == 2 ? "k_pe_tiles<1, 8u, 4u>"
                        : std_shape == 3 ? "k_pe_tiles<1, 7u, 3u>"
@@ -1665,6 +1700,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         hipLaunchKernelGGL((k_pe_tiles<2, 0u, 0u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
     else
         hipLaunchKernelGGL((k_pe_tiles<0, 0u, 0u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
+    }
     if (d_node_mat) {
         // the last tile may be partly empty: its unused rows must read as length 0
         const uint64_t used_ends = 2ull * n_pairs;
