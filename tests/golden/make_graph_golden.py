@@ -215,7 +215,8 @@ def emit(case):
             if log_to:
                 shutil.copy(own_log, log_to)
         rc2, files2, _ = run_reference(inp, extra, "plain", 0)
-        rc4, files4, _ = run_reference(inp, extra, "plain_outrev", 0)
+        rc4, files4, _ = run_reference(inp, extra, "inrev", 0)
+        rc5, files5, _ = run_reference(inp, extra, "plain_outrev", 0)
         seed_variant = set()
         for hs in (1, 2, 3):
             rc3, files3, _ = run_reference(inp, extra, "rotate", hs)
@@ -226,9 +227,11 @@ def emit(case):
                       "rve": md5(rve_text)},
         "inedge_invariant": bool(rc == rc2 and files == files2),
         "differs_under_plain_inedge_order": sorted(k for k in files if files2.get(k) != files[k]),
-        # third adjacency model (in-entries plain AND out-entries reversed)
-        "differs_under_reversed_out_order": sorted(k for k in files if files4.get(k) != files[k]),
+        # third adjacency model (in-entries in reverse insertion order); "adjacency_invariant" = the same under all three
+        "differs_under_reversed_inedge_order": sorted(k for k in files if files4.get(k) != files[k]),
         "adjacency_invariant": bool(rc == rc2 == rc4 and files == files2 == files4),
+        # reported only: out-entries reversed (changes which way the orientation walk of gfa_to_graph goes)
+        "differs_under_reversed_out_order": sorted(k for k in files if files5.get(k) != files[k]),
         "files": sorted(files),
         "hashseed": 0,
         "hashseed_invariant": not seed_variant,
@@ -294,7 +297,7 @@ def search_invariant(n_seeds):
                 rc2, files2, _ = run_reference(inp, extra, "plain", 0)
                 if rc2 != 0 or files2 != files:
                     continue
-                rc4, files4, _ = run_reference(inp, extra, "plain_outrev", 0)
+                rc4, files4, _ = run_reference(inp, extra, "inrev", 0)
                 if rc4 != 0 or files4 != files:
                     continue
             found += 1

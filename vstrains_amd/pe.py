@@ -116,7 +116,9 @@ def encode_seqs(seqs: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
     off = np.zeros(len(seqs) + 1, dtype=np.uint64)
     if len(seqs):
         off[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
-    data = np.frombuffer("".join(seqs).encode("latin-1"), dtype=np.uint8)
+    # one byte per CHARACTER (the reference works on decoded text): a character beyond latin-1 becomes '?', which like
+    # any byte outside ACGT makes the windows over it miss
+    data = np.frombuffer("".join(seqs).encode("latin-1", "replace"), dtype=np.uint8)
     if data.size == 0:
         data = np.zeros(1, dtype=np.uint8)
     return np.ascontiguousarray(data), off
