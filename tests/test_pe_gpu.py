@@ -42,8 +42,13 @@ def _gpu_matrices(host, ctx, seqs, fwd, rve, k):
     return res, block
 
 
+@pytest.mark.parametrize("mapper", ["seeds", "walk"])
 @pytest.mark.parametrize("name,d,meta", pe_cases(), ids=[c[0] for c in pe_cases()])
-def test_golden_files_bit_exact(host, ctx, name, d, meta):
+def test_golden_files_bit_exact(host, ctx, name, d, meta, mapper, monkeypatch):
+    """mapper "walk": VS_WALK=1 -- node sets that certify (csrc/vs_walk.h) go through k_pe_walk, the others (repeats,
+    palindromes) through the seed kernels either way."""
+    if mapper == "walk":
+        monkeypatch.setenv("VS_WALK", "1")
     ids, seqs = host.read_gfa_segments(os.path.join(d, "graph.gfa"))
     fq = host.FastqPair(os.path.join(d, "fwd.fq"), os.path.join(d, "rve.fq"), ctx)  # native ingest
     ctx.build_index(seqs, meta["k"])
@@ -56,10 +61,17 @@ def test_golden_files_bit_exact(host, ctx, name, d, meta):
     f = pe_oracle.fastq_sequences(os.path.join(d, "fwd.fq"))
     r = pe_oracle.fastq_sequences(os.path.join(d, "rve.fq"))
     assert stats == pe_oracle.pe_matrices(seqs, f, r, meta["k"])[2]
+    if mapper == "walk" and len(f) and len(r):
+        certified = name not in ("palindrome_k5", "odd_split_k6", "repeats_k9", "tiny_k1", "tiny_k2")
+        assert ctx.walk_info["certified"] == certified, ctx.walk_info
+        assert ctx.last_kernel.startswith("k_pe_walk" if certified else "k_pe_tiles"), ctx.last_kernel
 
 
+@pytest.mark.parametrize("mapper", ["seeds", "walk"])
 @pytest.mark.parametrize("name,d,meta", pe_cases(), ids=[c[0] for c in pe_cases()])
-def test_per_end_lists_match_oracle(host, ctx, name, d, meta):
+def test_per_end_lists_match_oracle(host, ctx, name, d, meta, mapper, monkeypatch):
+    if mapper == "walk":
+        monkeypatch.setenv("VS_WALK", "1")
     K = meta["k"] + 1
     ids, seqs = host.read_gfa_segments(os.path.join(d, "graph.gfa"))
     f = pe_oracle.fastq_sequences(os.path.join(d, "fwd.fq"))
@@ -323,6 +335,7 @@ def test_device_read_generator_equals_cpu_twin(host, ctx):
     {"VS_ACC_QUEUE": "0"}, {"VS_ACC_GRID_PER_CU": "1", "VS_ACC_QUEUE": "0"}, {"VS_NO_XCD_MAP": "1"}, {"VS_GRID_PER_CU": "8"}, {"VS_NO_STD": "1"}, {"VS_SHORTCUT": "1"}, {"VS_SHORTCUT": "0"},
     {"VS_ACC_MERGE": "1"}, {"VS_ACC_MERGE": "1", "VS_NO_AGG": "1"}, {"VS_ACC_MERGE": "1", "VS_ACC_WIDE": "1", "VS_ACC_FILL": "1"},
     {"VS_ACC_WIDE": "2"}, {"VS_ACC_WIDE": "2", "VS_ACC_FILL": "1"}, {"VS_ACC_WIDE": "2", "VS_ACC_FILL": "100", "VS_ACC_MERGE": "1"},
+    {"VS_WALK": "1"}, {"VS_WALK": "1", "VS_NO_SORT": "1"}, {"VS_WALK": "1", "VS_NO_XCD_MAP": "1", "VS_GRID_PER_CU": "1"}, {"VS_WALK": "1", "VS_ACC_WIDE": "2"},
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_every_kernel_variant_gives_the_same_counters(host, ctx, env, monkeypatch):
     """The tuning switches select other code paths (input order instead of locus order, global
@@ -343,6 +356,7 @@ def test_every_kernel_variant_gives_the_same_counters(host, ctx, env, monkeypatc
     assert np.array_equal(node_mat, want[0])
     assert np.array_equal(short_mat, want[1])
     assert stats == tuple(int(x) for x in want[2])
+    assert ctx.last_kernel.startswith("k_pe_walk") == ("VS_WALK" in env), ctx.last_kernel
 
 
 def test_switches_do_not_exist_outside_experiment_mode(tmp_path):
@@ -616,7 +630,7 @@ def test_bench_step_with_two_ranks_on_one_gpu(tmp_path):
     assert st["n_reads"] + st["short_reads"] + st["used_reads"] == 2 * 200000  # both ranks' pairs, summed
 
 
-@pytest.mark.parametrize("mode", ["boundaries", "tile_shapes"])
+@pytest.mark.parametrize("mode", ["boundaries", "tile_shapes", "walk"])
 def test_randomized_campaign_short(mode):
     """tests/fuzz_pe.py for ten seconds per mode: random graph / read shapes around the points where
     vs_pe_count switches kernels, every draw against the C oracle (the full campaigns of the round:
@@ -624,6 +638,8 @@ def test_randomized_campaign_short(mode):
     env = dict(os.environ)
     if mode == "tile_shapes":
         env["FUZZ_STD"] = "1"
+    if mode == "walk":
+        env["FUZZ_WALK"] = "1"  # every draw with VS_WALK=1: k_pe_walk wherever the node set certifies
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_pe.py"), "10", "7"], cwd=ROOT, env=env,
                           capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]

@@ -38,7 +38,7 @@ void vs_tuning_load(VsTuning &t, int level) {
     t.no_fast = env_on("VS_NO_FAST");
     t.no_std = env_on("VS_NO_STD");
     t.no_agg = env_on("VS_NO_AGG");
-    t.no_walk = env_on("VS_NO_WALK");
+    t.walk = env_on("VS_WALK");
     if (const char *v = getenv("VS_ACC_QUEUE")) t.acc_queue = atoi(v) != 0;
     t.acc_merge = env_on("VS_ACC_MERGE");
     t.debug_postings = getenv("VS_DEBUG_POSTINGS") != nullptr;

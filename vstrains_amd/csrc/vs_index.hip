@@ -261,7 +261,8 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
         ctx->n_distinct = h_flags[1];
         ctx->has_index = true;
         // walk index (vs_walk.h): certified on the host, tables uploaded; a node set that fails keeps the seed kernels
-        {
+        if (ctx->experiment_level) vs_tuning_load(ctx->tune, ctx->experiment_level);
+        if (ctx->tune.walk) {  // (VS_WALK=1: the certification and the tables cost 0.1 s at 5 k nodes, only paid when asked for)
             VsWalkHost wh;
             vs_walk_build_host(node_ascii, node_off, n_nodes, K, woff.data(), d.rc_delta, wh);
             ctx->walk_why = wh.why;

@@ -113,7 +113,8 @@ struct VsTuning {
     int shortcut = -1;              // VS_SHORTCUT (-1 = by index statistics)
     bool no_sort = false, locus_global = false, no_xcd_map = false, no_fast = false, no_std = false, no_agg = false;
     bool acc_queue = true, acc_merge = false;
-    bool no_walk = false;           // VS_NO_WALK: certified graphs through the seed kernels too
+    bool walk = false;              // VS_WALK=1: certified graphs (vs_walk.h) through k_pe_walk instead of the seed kernels --
+                                    // exact and tested, but slower on every bench config, hence not the default
     bool debug_postings = false, debug_occ = false, debug_acc = false;
     // timing only (VS_EXPERIMENT=timing): wrong counters by design
     uint32_t debug_stop = 0;        // VS_DEBUG_STOP=1..5

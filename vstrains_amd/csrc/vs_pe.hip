@@ -1463,9 +1463,9 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     // experiment switches: fixed defaults unless the process runs with VS_EXPERIMENT (see VsTuning)
     if (ctx->experiment_level) vs_tuning_load(ctx->tune, ctx->experiment_level);
     const VsTuning &tn = ctx->tune;
-    // Certified graphs (vs_walk.h) are mapped by following the read through the graph (k_pe_walk); everything else, and
-    // blocks whose dirty reads come with a validity mask only, by the seed kernels below.
-    const bool use_walk = ctx->walk_ok && !tn.no_walk && (!reads->d_mask || reads->d_inv4) && !tn.debug_stop && !tn.debug_postings &&
+    // VS_WALK=1 (experiment mode): certified graphs (vs_walk.h) are mapped by following the read through the graph
+    // (k_pe_walk) -- exact, but 13.7 ms against the seed kernel's 5.7 ms at configs[2]: not the default.
+    const bool use_walk = ctx->walk_ok && tn.walk && (!reads->d_mask || reads->d_inv4) && !tn.debug_stop && !tn.debug_postings &&
                           vs_walk_lds_bytes(wpe) <= 64u * 1024u && maxlen < (1u << 20);
     uint32_t ept = tn.ept ? tn.ept : STD_EPT;
     if (ept < 2 || ept > TTPB / 2u) ept = STD_EPT;

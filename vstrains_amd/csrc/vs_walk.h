@@ -76,11 +76,7 @@ VS_HD uint32_t vs_walk_wp(uint32_t K) {
 }
 
 
-// ---- the walk of one read end, as steps (shared by k_pe_walk and by the host twin the CPU tests run) -------------------
-// An end is always in one of three classes: L (window j needs a lookup), W (window j sits at (ns, q): follow the node) or
-// P (a presence probe decides how far to skip).  The host twin takes the steps of one end one after the other; the
-// kernel keeps the ends of a tile in LDS queues per class and gives every lane one step of SOME end per pass, so that
-// lanes stay busy while the ends of a tile differ in how far they are (wavefront ballot + prefix sum compaction).
+// ---- the walk of one read end (shared by k_pe_walk and by the host twin the CPU tests run) ------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
 VS_HD uint64_t vsw_win(const uint32_t *w, uint32_t base) {  // 32 bases from base offset `base`: two funnel shifts
     const uint32_t i = base >> 4, sh = (base & 15u) * 2u;
@@ -131,36 +127,6 @@ VS_HD uint32_t vsw_next_inv(uint32_t inv4, uint32_t from, uint32_t rlen) {
     return best;
 }
 
-enum { VSW_DONE = 0, VSW_L = 1, VSW_W = 2, VSW_P = 3 };
-// probe modes of class P: the two flanks of a broken run's base p, or the skip search behind a missed lookup
-enum { VSW_P_FLANKS = 0, VSW_P_SKIP = 1 };
-
-struct VsWalkEnd {
-    uint32_t j;                 // next unresolved window (L, P), or the window that sits at (ns, q) (W)
-    uint32_t lo, hi;            // the clean stretch [lo, hi) of the read that j lies in
-    uint32_t ns, q;             // W: node strand and position of window j
-    uint32_t cur_node, cur_v, cur_coord, cur_kidx, cur_nlen;  // the visit being merged (cur_node = ~0: none)
-    uint32_t nt;                // nodes written to the row so far (may pass the row's capacity: overflow)
-    uint32_t pm;                // P: mode | d << 4 (skip search) or mode | p << 4 (flanks)
-    uint32_t over;              // the end needs the general path
-};
-
-VS_HD void vsw_end_init(VsWalkEnd &e, uint32_t rlen, uint32_t inv4, bool dirty) {
-    e.j = 0u; e.lo = 0u; e.hi = dirty ? vsw_next_inv(inv4, 0u, rlen) : rlen;
-    e.ns = 0u; e.q = 0u;
-    e.cur_node = 0xFFFFFFFFu; e.cur_v = e.cur_coord = e.cur_kidx = e.cur_nlen = 0u;
-    e.nt = 0u; e.pm = 0u; e.over = 0u;
-}
-// the node of the current visit differs from the one held (or the end is finished): settle the one held
-VS_HD void vsw_flush(VsWalkEnd &e, uint32_t *row, uint32_t cap, uint32_t rlen, uint32_t K) {
-    if (e.cur_node == 0xFFFFFFFFu) return;
-    for (uint32_t i = 0; i < e.nt && i < cap; i++)
-        if ((row[i] & 0x7FFFFFFFu) == e.cur_node) e.over = 1u;  // met before, not just now: general path
-    const uint32_t acc = vsw_accept(e.cur_v, e.cur_coord, e.cur_kidx, e.cur_nlen, rlen, K) ? 0x80000000u : 0u;
-    if (e.nt < cap) row[e.nt] = e.cur_node | acc; else e.over = 1u;
-    e.nt++;
-    e.cur_node = 0xFFFFFFFFu;
-}
 // is the wp-mer at read offset x absent from every node?
 VS_HD bool vsw_absent(const VsWalkDev &wk, const uint32_t *rw, uint32_t rbase, uint32_t x) {
     const uint64_t f = vsw_win(rw, rbase + x) & vsw_lowmask(2u * wk.wp);
@@ -175,152 +141,136 @@ VS_HD bool vsw_absent(const VsWalkDev &wk, const uint32_t *rw, uint32_t rbase, u
         s = (s + 1u) & pmask;
     }
 }
-// Class L, also the start of every end.  Moves to the next clean stretch when this one holds no window any more; one exact
-// lookup of window j: hit -> W at (ns, q), miss -> P (skip search).  Returns the next class.
-template <uint32_t NW>
-VS_HD uint32_t vsw_step_lookup(const VsWalkDev &wk, const uint32_t *text, uint32_t K, const uint32_t *rw, uint32_t rbase, uint32_t rlen,
-                               uint32_t inv4, VsWalkEnd &e) {
-    if (e.over) return VSW_DONE;
-    while (e.j + K > e.hi) {  // no window left in this clean stretch
-        if (e.hi >= rlen) return VSW_DONE;
-        e.lo = e.hi + 1u;
-        e.hi = vsw_next_inv(inv4, e.lo, rlen);
-        e.j = e.lo;
-    }
-    uint64_t wv[NW];
-    uint64_t h = vs_kmer_hash_init(K);
-    for (uint32_t i = 0; i < NW; i++) {
-        wv[i] = vsw_win(rw, rbase + e.j + 32u * i);
-        if (i == NW - 1u) wv[i] &= vsw_lowmask(2u * K - 64u * (NW - 1u));
-        h = vs_kmer_hash_step(h, wv[i]);
-    }
-    h = vs_kmer_hash_done(h);
-    const uint32_t tag = (uint32_t)(h >> 32), kmask = (1u << wk.k_bits) - 1u;
-    uint32_t s = (uint32_t)h & kmask;
-    for (;;) {
-        const VsKSlot sl = wk.ktab[s];
-        if (sl.ns == VS_WALK_EMPTY) break;
-        if (sl.tag == tag) {
-            const uint32_t tb = sl.woff * 16u + sl.pos;
-            bool same = true;
-            for (uint32_t i = 0; i < NW; i++) {
-                uint64_t tw = vsw_win(text, tb + 32u * i);
-                if (i == NW - 1u) tw &= vsw_lowmask(2u * K - 64u * (NW - 1u));
-                same = same && tw == wv[i];
-            }
-            if (same) {
-                e.ns = sl.ns;
-                e.q = sl.pos;
-                return VSW_W;
-            }
-        }
-        s = (s + 1u) & kmask;
-    }
-    e.pm = VSW_P_SKIP | ((K - wk.wp) << 4);  // window j coincides with nothing: how far can the scan skip?
-    return VSW_P;
-}
-// Class W: window j sits at (ns, q).  Compares up to 32 further bases of the read with the node, credits the windows that
-// coincide to the visit, and says where the end goes next: on in this node or into the successor the next base selects (W),
-// run broken at base p = j + K (P: flanks), stretch used up (L: next stretch, or done).
-VS_HD uint32_t vsw_step_walk(const VsWalkDev &wk, const uint32_t *text, uint32_t K, const uint32_t *rw, uint32_t rbase, uint32_t rlen,
-                             VsWalkEnd &e, uint32_t *row, uint32_t cap) {
-    const VsWalkRec r = wk.rec[e.ns];
-    const uint32_t nlen = r.len, u = e.j, qu = e.q;
-    const uint32_t in_node = nlen - K - e.q, in_read = e.hi - K - e.j;
-    uint32_t m = in_node < in_read ? in_node : in_read;  // windows that may follow here
-    const bool more = m > 32u;                           // (a long node: the rest in the next step)
-    if (more) m = 32u;
-    uint32_t adv = m;
-    if (m) {
-        const uint64_t tw = e.q == 0u ? ((uint64_t)r.tail_lo | ((uint64_t)r.tail_hi << 32)) : vsw_win(text, r.woff * 16u + e.q + K);
-        const uint64_t x = (tw ^ vsw_win(rw, rbase + e.j + K)) & vsw_lowmask(2u * m);
-        if (x) adv = vsw_first_diff(x);
-    }
-    const bool broke = adv < m;
-    e.j += adv;
-    e.q += adv;
-    {   // windows u .. j sit in this node
-        const uint32_t node = e.ns >> 1, add = e.j - u + 1u;
-        const uint32_t coord = (e.ns & 1u) ? nlen - K - e.q : qu;
-        if (node == e.cur_node) {
-            // (a step that continues a visit counts its first window with the previous step: see `more` below)
-            e.cur_v += add;
-            e.cur_coord = coord < e.cur_coord ? coord : e.cur_coord;
-        } else {
-            vsw_flush(e, row, cap, rlen, K);
-            e.cur_node = node; e.cur_v = add; e.cur_coord = coord; e.cur_kidx = u; e.cur_nlen = nlen;
-        }
-    }
-    if (e.over) return VSW_DONE;
-    if (!broke && more) {  // the same node goes on: window j is counted, the next step starts at j + 1
-        // next step re-counts nothing: it starts from window j (already credited), so take its own first window off
-        e.cur_v -= 1u;
-        return VSW_W;
-    }
-    uint32_t nxt = 0u;
-    if (!broke && e.j + K < e.hi) {  // the strand ends here and the read goes on: its next base picks the successor
-        const uint32_t pb = rbase + e.j + K;
-        const uint32_t b = (rw[pb >> 4] >> (2u * (pb & 15u))) & 3u;
-        nxt = b == 0u ? r.succ[0] : b == 1u ? r.succ[1] : b == 2u ? r.succ[2] : r.succ[3];
-    }
-    if (nxt) {
-        e.ns = nxt - 1u;
-        e.q = 0u;
-        e.j++;
-        return VSW_W;
-    }
-    if (broke || e.j + K < e.hi) {
-        // the run breaks at read base p = j + K: window j + 1 coincides with nothing (certified); whether any window over
-        // p can coincide is what the flank probes decide
-        e.pm = VSW_P_FLANKS | ((e.j + K) << 4);
-        return VSW_P;
-    }
-    e.j++;  // the stretch is used up (j + K == hi): the lookup step moves on to the next stretch or ends
-    return VSW_L;
-}
-// Class P: presence probes.  Flanks: every window over the broken run's base p holds the wp-mer that ends at p or the one
-// that starts at p; if neither occurs in a node, none of them coincides and the scan resumes at p + 1, else at the window
-// after the one the certification rules out.  Skip search (window j missed): every window that holds the wp-mer at x lies
-// in [x - (K - wp), x]; with x = j + d absent, all of [j, j + d] are empty.
-VS_HD uint32_t vsw_step_probe(const VsWalkDev &wk, uint32_t K, const uint32_t *rw, uint32_t rbase, VsWalkEnd &e) {
-    const uint32_t wp = wk.wp;
-    if ((e.pm & 15u) == VSW_P_FLANKS) {
-        const uint32_t p = e.pm >> 4;  // = j + K
-        const bool l_out = p + 1u < e.lo + wp, r_out = p + wp > e.hi;  // (a flank that leaves the stretch holds no window)
-        const bool none = (l_out || vsw_absent(wk, rw, rbase, p + 1u - wp)) && (r_out || vsw_absent(wk, rw, rbase, p));
-        e.j = none ? p + 1u : e.j + 2u;
-        return VSW_L;
-    }
-    const uint32_t d = e.pm >> 4;
-    if (vsw_absent(wk, rw, rbase, e.j + d)) {
-        e.j += d + 1u;
-        return VSW_L;
-    }
-    if (d == 0u) {
-        e.j += 1u;
-        return VSW_L;
-    }
-    e.pm = VSW_P_SKIP | ((d >> 1) << 4);
-    return VSW_P;
-}
 
-// One read end from start to finish (the host twin; the kernel schedules the same steps per class): row[cap] receives
-// node | accepted << 31 for every node the end touches; returns how many it touched, *over_out says whether the end needs
-// the general path (a node met again later, more than cap nodes).
+// One read end: rw = packed read words (the read starts at base offset rbase; words behind it are readable), rlen its
+// length, inv4 / dirty its bytes outside ACGT.  row[cap] receives node | accepted << 31 for every visit the end pays to a
+// node (a node met twice in a row -- an error inside it -- is one visit); returns the number of visits (more than cap:
+// overflow).  *over_out: the end needs the general path (a node visited again later: its counts would have to be merged).
+// Structure: rounds of { one exact lookup, a tight loop that follows the run node by node, the probes that decide where
+// the scan resumes }; all lanes of a wavefront go through the rounds together, so the loop that runs most often is the
+// shortest one.
 template <uint32_t NW>
 VS_HD uint32_t vs_walk_end(const VsWalkDev &wk, const uint32_t *text, uint32_t K, const uint32_t *rw, uint32_t rbase, uint32_t rlen,
                            uint32_t inv4, bool dirty, uint32_t *row, uint32_t cap, bool *over_out) {
-    VsWalkEnd e;
-    vsw_end_init(e, rlen, inv4, dirty);
-    uint32_t cls = VSW_L;
-    while (cls != VSW_DONE) {
-        if (cls == VSW_L) cls = vsw_step_lookup<NW>(wk, text, K, rw, rbase, rlen, inv4, e);
-        else if (cls == VSW_W) cls = vsw_step_walk(wk, text, K, rw, rbase, rlen, e, row, cap);
-        else cls = vsw_step_probe(wk, K, rw, rbase, e);
+    const uint32_t wp = wk.wp, kmask = (1u << wk.k_bits) - 1u;
+    uint32_t lo = 0u, hi = dirty ? vsw_next_inv(inv4, 0u, rlen) : rlen;
+    uint32_t j = 0u, nt = 0u;
+    uint32_t cur_node = 0xFFFFFFFFu, cur_v = 0u, cur_coord = 0u, cur_kidx = 0u, cur_nlen = 0u;
+    // the node of the current visit differs from the one held (or the end is finished): settle the one held
+    auto flush = [&]() {
+        if (cur_node == 0xFFFFFFFFu) return;
+        const uint32_t acc = vsw_accept(cur_v, cur_coord, cur_kidx, cur_nlen, rlen, K) ? 0x80000000u : 0u;
+        if (nt < cap) row[nt] = cur_node | acc;
+        nt++;
+    };
+    for (;;) {
+        if (j + K > hi) {  // no window left in this clean stretch
+            if (hi >= rlen) break;
+            lo = hi + 1u;
+            hi = vsw_next_inv(inv4, lo, rlen);
+            j = lo;
+            continue;
+        }
+        // ---- one exact lookup: where does window j sit?
+        uint32_t ns = 0xFFFFFFFFu, q = 0u;
+        {
+            uint64_t wv[NW];
+            uint64_t h = vs_kmer_hash_init(K);
+            for (uint32_t i = 0; i < NW; i++) {
+                wv[i] = vsw_win(rw, rbase + j + 32u * i);
+                if (i == NW - 1u) wv[i] &= vsw_lowmask(2u * K - 64u * (NW - 1u));
+                h = vs_kmer_hash_step(h, wv[i]);
+            }
+            h = vs_kmer_hash_done(h);
+            const uint32_t tag = (uint32_t)(h >> 32);
+            uint32_t s = (uint32_t)h & kmask;
+            for (;;) {
+                const VsKSlot sl = wk.ktab[s];
+                if (sl.ns == VS_WALK_EMPTY) break;
+                if (sl.tag == tag) {
+                    const uint32_t tb = sl.woff * 16u + sl.pos;
+                    bool same = true;
+                    for (uint32_t i = 0; i < NW; i++) {
+                        uint64_t tw = vsw_win(text, tb + 32u * i);
+                        if (i == NW - 1u) tw &= vsw_lowmask(2u * K - 64u * (NW - 1u));
+                        same = same && tw == wv[i];
+                    }
+                    if (same) { ns = sl.ns; q = sl.pos; break; }
+                }
+                s = (s + 1u) & kmask;
+            }
+        }
+        if (ns == 0xFFFFFFFFu) {
+            // window j coincides with nothing.  Skip as far as an absent wp-mer proves: every window that holds the
+            // wp-mer at x lies in [x - (K - wp), x], so with x = j + d all of [j, j + d] are empty.
+            uint32_t nj = j + 1u;
+            for (uint32_t d = K - wp;; d >>= 1) {
+                if (vsw_absent(wk, rw, rbase, j + d)) { nj = j + d + 1u; break; }
+                if (d == 0u) break;
+            }
+            j = nj;
+            continue;
+        }
+        // ---- follow the run: one turn per node (per 32 bases of a long one)
+        uint32_t p;  // read base at which the run breaks, or ~0 when the stretch is used up
+        for (;;) {
+            const VsWalkRec r = wk.rec[ns];
+            const uint32_t nlen = r.len;
+            const uint32_t in_node = nlen - K - q, in_read = hi - K - j;
+            const uint32_t m = in_node < in_read ? in_node : in_read;  // windows that may follow here
+            uint32_t adv = 0u;
+            if (m) {
+                uint64_t tw = q == 0u ? ((uint64_t)r.tail_lo | ((uint64_t)r.tail_hi << 32)) : vsw_win(text, r.woff * 16u + q + K);
+                for (;;) {
+                    const uint32_t n = m - adv < 32u ? m - adv : 32u;
+                    const uint64_t x = (tw ^ vsw_win(rw, rbase + j + K + adv)) & (~0ull >> (64u - 2u * n));
+                    if (x) { adv += vsw_first_diff(x); break; }
+                    adv += n;
+                    if (adv >= m) break;
+                    tw = vsw_win(text, r.woff * 16u + q + K + adv);
+                }
+            }
+            {   // windows j .. j + adv sit in this node
+                const uint32_t node = ns >> 1;
+                const uint32_t coord = (ns & 1u) ? nlen - K - q - adv : q;
+                if (node == cur_node) {
+                    cur_v += adv + 1u;
+                    cur_coord = coord < cur_coord ? coord : cur_coord;
+                } else {
+                    flush();
+                    cur_node = node; cur_v = adv + 1u; cur_coord = coord; cur_kidx = j; cur_nlen = nlen;
+                }
+            }
+            j += adv;
+            if (adv < m) { p = j + K; break; }            // mismatch inside the node
+            if (j + K >= hi) { p = 0xFFFFFFFFu; break; }   // the stretch is used up
+            // the strand ends here and the read goes on: its next base picks the successor
+            const uint32_t pb = rbase + j + K;
+            const uint32_t b = (rw[pb >> 4] >> (2u * (pb & 15u))) & 3u;
+            const uint32_t nxt = b == 0u ? r.succ[0] : b == 1u ? r.succ[1] : b == 2u ? r.succ[2] : r.succ[3];
+            if (!nxt) { p = j + K; break; }
+            ns = nxt - 1u;
+            q = 0u;
+            j++;
+        }
+        if (p == 0xFFFFFFFFu) {
+            j++;  // (j + K == hi: the loop head moves on to the next stretch or ends)
+            continue;
+        }
+        // ---- the run broke at read base p: window j + 1 coincides with nothing (certified), and if neither wp-mer that
+        // touches p occurs in a node, no window over p does
+        const bool l_out = p + 1u < lo + wp, r_out = p + wp > hi;  // (a flank that leaves the stretch holds no window)
+        const bool none = (l_out || vsw_absent(wk, rw, rbase, p + 1u - wp)) && (r_out || vsw_absent(wk, rw, rbase, p));
+        j = none ? p + 1u : j + 2u;
     }
-    vsw_flush(e, row, cap, rlen, K);
-    *over_out = e.over != 0u;
-    return e.nt;
+    flush();
+    // a node visited twice (not in a row): its two counts belong together -- the general path does that
+    bool over = nt > cap;
+    for (uint32_t a = 1; a < nt && a < cap; a++)
+        for (uint32_t b = 0; b < a; b++)
+            if (((row[a] ^ row[b]) & 0x7FFFFFFFu) == 0u) over = true;
+    *over_out = over;
+    return nt;
 }
 
 #if !defined(__HIPCC__) || defined(VS_WALK_HOST_DECL)
