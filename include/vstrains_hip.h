@@ -117,6 +117,20 @@ int vs_pack_sequence(const uint8_t *seq, uint32_t len, uint32_t *words, uint32_t
 typedef struct vs_fastq vs_fastq;
 int vs_fastq_open(vs_ctx *ctx, const char *fwd_path, const char *rve_path, vs_fastq **out);
 void vs_fastq_close(vs_fastq *fq);
+/* Cooperative open for one process per GPU, so that no rank reads a whole file (PE_Inference.py:146-154 reads both
+ * files completely; its total = min(lines_f // 4, lines_r // 4) follows from the ranks' counts):
+ *   1. every rank r calls vs_fastq_count_part(path, r, world, out) for both files: out[0] = newlines in its byte
+ *      range, out[1] = file size, out[2] = flags (bit 0: the range holds '\r', bit 1: gzip file, bit 2: the file does
+ *      not end in a newline); the ranks exchange these (an all-gather of three integers per file);
+ *   2. from the totals every rank derives its record range and calls vs_fastq_open_records with everybody's counts:
+ *      only the bytes of records [first, last) are indexed; the handle numbers them from 0.
+ * Files with '\r' or gzip files are opened whole (vs_fastq_open) by every rank instead. */
+int vs_fastq_count_part(const char *path, uint32_t part, uint32_t n_parts, uint64_t out[3]);
+int vs_fastq_open_records(vs_ctx *ctx, const char *fwd_path, const char *rve_path, uint32_t n_parts,
+                          const uint64_t *counts_f, const uint64_t *counts_r, uint64_t first, uint64_t last,
+                          vs_fastq **out);
+/* text bytes the handle went through when it was opened (both files) */
+uint64_t vs_fastq_bytes_indexed(const vs_fastq *fq);
 /* info[0] = pairs, [1] = lines of the forward file, [2] = lines of the reverse file */
 int vs_fastq_info(const vs_fastq *fq, uint64_t info[3]);
 int vs_fastq_sequence(const vs_fastq *fq, int which, uint64_t record, uint8_t *buf, uint32_t cap,

@@ -15,21 +15,27 @@ per vertex, out-edges in ``[0, n_out)``, in-edges behind them):
 * ``copy()``: vertices first, then edges re-added in ``edges()`` order with fresh indices.
 * ``hash(Vertex) == index``; ``hash(Edge) == edge index``.
 
-``GT_STANDIN_INEDGE=plain`` switches to plain insertion order for in-edges, ``=inrev`` to reverse insertion
-order, ``=plain_outrev`` reverses the out-entries instead; the fixture maker runs every case under all of them and
-records which outputs agree ("parity unpinned at the graph-tool boundary").
+``GT_STANDIN_INEDGE=plain`` switches to plain insertion order for in-edges, ``=lifo`` / ``=swappop`` vary the
+free-list and the remove_edge rule (below), ``=inrev`` / ``=plain_outrev`` reverse the in- or the out-entries; the
+fixture maker runs every case under all of them and records which outputs agree ("parity unpinned at the graph-tool boundary").
 """
 import os
 from collections import deque
 
 MODEL = os.environ.get("GT_STANDIN_INEDGE", "rotate")
 INEDGE_ROTATION = MODEL == "rotate"
-# third model (fixtures count as "adjacency invariant" only if they also survive this one): in-entries in REVERSE
-# insertion order (the newest in-edge first), out-entries in insertion order
+# Two further models vary the OTHER recalled rules (fixtures count as "adjacency invariant" only if they survive all of
+# rotate / plain / lifo / swappop): "lifo" reuses the index of the edge removed LAST (the free list as a stack instead of
+# a queue: changes hash(Edge), hence the order of the sets of edges the reference builds, IO.py:207, and which stale
+# property value a new edge meets); "swappop" lets remove_edge move the last entry of the segment into the hole instead
+# of closing it (order not kept).
+LIFO_REUSE = MODEL == "lifo"
+SWAP_POP = MODEL == "swappop"
+# Reported only (case.json lists what changes, nothing is required to survive them): in-entries in REVERSE insertion
+# order, and out-entries in reverse insertion order.  Either changes already which way gfa_to_graph's orientation walk
+# goes (IO.py:137-229 iterates all_edges()), so hardly any file stays the same: these are not small doubts about a rule
+# but different containers.
 IN_REVERSED = MODEL == "inrev"
-# fourth model, reported only: in-entries plain AND out-entries in REVERSE insertion order.  Out-edge order decides
-# already which way gfa_to_graph's orientation walk goes (IO.py:137-229), so hardly any file survives it; that
-# out-edges keep their insertion order is the one thing every adjacency-list container agrees on.
 OUT_REVERSED = MODEL == "plain_outrev"
 
 
@@ -227,7 +233,7 @@ class Graph:
     def add_edge(self, source, target):
         s, t = int(source), int(target)
         if self._free:
-            idx = self._free.popleft()
+            idx = self._free.pop() if LIFO_REUSE else self._free.popleft()
         else:
             idx = self._next_eidx
             self._next_eidx += 1
@@ -256,7 +262,13 @@ class Graph:
         ses = self._adj[s]
         for i in range(self._nout[s]):
             if ses[i] == (t, idx):
-                del ses[i]
+                if SWAP_POP:  # the last out-entry fills the hole, then the last in-entry fills ITS place
+                    last_out = self._nout[s] - 1
+                    ses[i] = ses[last_out]
+                    ses[last_out] = ses[-1]
+                    ses.pop()
+                else:
+                    del ses[i]
                 break
         else:
             raise ValueError("edge not found")
@@ -264,7 +276,11 @@ class Graph:
         tes = self._adj[t]
         for i in range(self._nout[t], len(tes)):
             if tes[i] == (s, idx):
-                del tes[i]
+                if SWAP_POP:
+                    tes[i] = tes[-1]
+                    tes.pop()
+                else:
+                    del tes[i]
                 break
         else:
             raise ValueError("edge not found")

@@ -497,3 +497,114 @@ def test_fastq_ingest_after_fork(tmp_path):
         fq2.close()
     finally:
         os.environ.pop("VS_HOST_THREADS")
+
+
+# ---- cooperative FASTQ open: one rank per GPU, nobody reads a whole file -------------------------------------------------
+def _open_all_shards(host, fwd, rve, world):
+    """Every rank's FastqPair.open_shard in one process: the exchange of the counts is a lookup in what all ranks counted."""
+    import ctypes as C
+
+    from vstrains_amd import _native as nat
+
+    per_rank = []
+    for rk in range(world):
+        vals = []
+        for path in (fwd, rve):
+            out = (C.c_uint64 * 3)()
+            assert nat.lib().vs_fastq_count_part(path.encode(), rk, world, out) == 0
+            vals += [int(out[0]), int(out[1]), int(out[2])]
+        per_rank.append(vals)
+    return [host.FastqPair.open_shard(fwd, rve, None, rk, world, all_gather=lambda mine: per_rank) for rk in range(world)]
+
+
+def test_cooperative_fastq_open_gives_every_rank_its_block_and_only_its_bytes(tmp_path):
+    """``FastqPair.open_shard``: the ranks' blocks, one after the other, are the records the whole-file open gives
+    (PE_Inference.py:146-159 incl. total = min(lines // 4)), and a rank goes through about 1 / world of the text."""
+    from vstrains_amd import pe as host
+    from vstrains_amd import synth
+
+    rng = np.random.default_rng(12)
+    st = synth.make_strains(3, 3000, 0.01, seed=5)
+    f, r = synth.sample_pairs(st, 2000, 90, seed=6)
+    f = [s[: int(rng.integers(1, 91))] for s in f]   # ragged: byte ranges do not line up with records
+    r = [s[: int(rng.integers(0, 91))] for s in r]
+    texts = {
+        "plain": (synth.fastq_text(f, "f"), synth.fastq_text(r, "r")),
+        "unequal": (synth.fastq_text(f, "f"), synth.fastq_text(r[:1500], "r") + "@partial\nACGT\n"),
+        "open_tail": (synth.fastq_text(f, "f")[:-1], synth.fastq_text(r, "r")[:-1]),
+        "tiny": (synth.fastq_text(f[:3], "f"), synth.fastq_text(r[:3], "r")),
+        "empty": ("", ""),
+    }
+    for name, (ft, rt) in texts.items():
+        fp, rp = str(tmp_path / (name + "_f.fq")), str(tmp_path / (name + "_r.fq"))
+        open(fp, "w").write(ft)
+        open(rp, "w").write(rt)
+        whole = host.FastqPair(fp, rp)
+        want = [(whole.sequence(0, i), whole.sequence(1, i)) for i in range(len(whole))]
+        whole_bytes = whole.bytes_indexed
+        whole.close()
+        for world in (1, 2, 3, 7):
+            shards = _open_all_shards(host, fp, rp, world)
+            got = []
+            for rk, fq in enumerate(shards):
+                assert fq.total_pairs == len(want) and not fq.whole, (name, world)
+                assert fq.first == len(got)
+                got += [(fq.sequence(0, i), fq.sequence(1, i)) for i in range(len(fq))]
+                if name == "plain" and world > 1:
+                    assert fq.bytes_indexed <= whole_bytes / world * 1.15 + 1000, (world, rk, fq.bytes_indexed, whole_bytes)
+                fq.close()
+            assert got == want, (name, world)
+    # carriage returns / gzip: every rank opens the files whole and takes its block
+    import gzip
+
+    fp, rp = str(tmp_path / "crlf_f.fq"), str(tmp_path / "gz_r.fq.gz")
+    open(fp, "w", newline="").write(synth.fastq_text(f[:200], "f", "\r\n"))
+    open(rp, "wb").write(gzip.compress(synth.fastq_text(r[:200], "r").encode()))
+    whole = host.FastqPair(fp, rp)
+    want = [(whole.sequence(0, i), whole.sequence(1, i)) for i in range(len(whole))]
+    whole.close()
+    got = []
+    for fq in _open_all_shards(host, fp, rp, 3):
+        assert fq.whole and fq.total_pairs == 200
+        got += [(fq.sequence(0, fq.block_offset + i), fq.sequence(1, fq.block_offset + i)) for i in range(len(fq))]
+        fq.close()
+    assert got == want
+
+
+def _rank_open_shard(rank, world, port, fwd, rve, q):
+    import torch.distributed as dist
+
+    from vstrains_amd import pe as host
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    fq = host.FastqPair.open_shard(fwd, rve, None, rank, world)  # (counts exchanged through torch.distributed.all_gather)
+    q.put((rank, fq.first, fq.total_pairs, fq.bytes_indexed, [fq.sequence(0, i) + "|" + fq.sequence(1, i) for i in range(len(fq))]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cooperative_fastq_open_two_ranks_gloo(tmp_path):
+    import torch.multiprocessing as mp
+
+    from vstrains_amd import pe as host
+    from vstrains_amd import synth
+
+    st = synth.make_strains(3, 3000, 0.01, seed=15)
+    f, r = synth.sample_pairs(st, 3001, 100, seed=16)
+    fp, rp = str(tmp_path / "f.fq"), str(tmp_path / "r.fq")
+    open(fp, "w").write(synth.fastq_text(f, "f"))
+    open(rp, "w").write(synth.fastq_text(r, "r"))
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29600 + (os.getpid() % 300)
+    procs = [ctxm.Process(target=_rank_open_shard, args=(rk, 2, port, fp, rp, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    total_bytes = os.path.getsize(fp) + os.path.getsize(rp)
+    assert [x[1] for x in res] == [0, 1500] and all(x[2] == 3001 for x in res)
+    assert all(x[3] <= total_bytes * 0.51 for x in res), [x[3] for x in res]  # each rank went through about half the text
+    assert res[0][4] + res[1][4] == [a + "|" + b for a, b in zip(f, r)]

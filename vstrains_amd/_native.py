@@ -36,6 +36,10 @@ SYMBOLS = {
     "vs_pack_sequence": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
     "vs_fastq_open": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]),
     "vs_fastq_close": (None, [C.c_void_p]),
+    "vs_fastq_count_part": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
+    "vs_fastq_open_records": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                        C.POINTER(C.c_void_p)]),
+    "vs_fastq_bytes_indexed": (C.c_uint64, [C.c_void_p]),
     "vs_fastq_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "vs_fastq_sequence": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "vs_fastq_gather": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),

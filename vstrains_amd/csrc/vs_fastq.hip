@@ -53,6 +53,8 @@ struct FqFile {
     const uint8_t *data = nullptr;
     size_t size = 0;
     int fd = -1;
+    const uint8_t *map_base = nullptr;  // what munmap gets back (data / size may describe a byte range of the mapping)
+    size_t map_size = 0;
     std::vector<uint8_t> inflated;     // only for a gzip file: its text (data / size then describe this copy)
     std::vector<uint8_t> translated;   // only when the file holds '\r': universal-newline copy
     RawArray<uint64_t> seq_start;      // per record: first byte of line 4r+1
@@ -185,6 +187,8 @@ int map_file(std::string &err, const char *path, FqFile &f) {
         void *p = mmap(nullptr, f.size, PROT_READ, MAP_PRIVATE, f.fd, 0);
         if (p == MAP_FAILED) return fail(VS_E_OOM, "cannot map %s: %s", path, strerror(errno));
         f.data = (const uint8_t *)p;
+        f.map_base = f.data;
+        f.map_size = f.size;
         madvise(p, f.size, MADV_SEQUENTIAL);
     }
     // A gzip file (magic 1f 8b; several members in a row as bgzip writes them are fine) is inflated
@@ -223,6 +227,8 @@ int map_file(std::string &err, const char *path, FqFile &f) {
         if (rc != Z_STREAM_END) return fail(VS_E_ARG, "%s: not a complete gzip stream (zlib code %d)", path, rc);
         out.resize(have);
         munmap((void *)f.data, f.size);
+        f.map_base = nullptr;
+        f.map_size = 0;
         close(f.fd);
         f.fd = -1;
         f.data = out.data();
@@ -328,7 +334,8 @@ int index_file(vs_ctx *ctx, const char *path, FqFile &f) {
 }
 
 void close_file(FqFile &f) {
-    if (f.data && f.inflated.empty()) munmap((void *)f.data, f.size);
+    if (f.map_base) munmap((void *)f.map_base, f.map_size);
+    f.map_base = nullptr;
     f.inflated = std::vector<uint8_t>();
     if (f.fd >= 0) close(f.fd);
     f.data = nullptr;
@@ -340,6 +347,7 @@ void close_file(FqFile &f) {
 struct vs_fastq {
     FqFile f[2];
     uint64_t n_pairs = 0;
+    uint64_t bytes_indexed = 0;  // text bytes this handle went through (both files)
 };
 
 namespace {
@@ -438,6 +446,122 @@ int vs_fastq_open(vs_ctx *ctx, const char *fwd_path, const char *rve_path, vs_fa
         }
     }
     fq->n_pairs = std::min(fq->f[0].seq_start.size(), fq->f[1].seq_start.size());  // PE_Inference.py:154
+    fq->bytes_indexed = fq->f[0].text_size() + fq->f[1].text_size();
+    *out = fq;
+    return VS_OK;
+}
+
+// ---- cooperative open (one process per GPU): nobody reads a whole file -------------------------------------------------
+// Step 1, every rank for its byte range `part` of `n_parts`: newlines in the range.  out[0] = newlines, out[1] = file
+// size, out[2] = flags: bit 0 the range holds a '\r' (universal-newline translation needed), bit 1 gzip file (cannot be
+// cut), bit 2 the file does not end in a newline (set by the part that holds the end).  Host only.
+int vs_fastq_count_part(const char *path, uint32_t part, uint32_t n_parts, uint64_t out[3]) {
+    if (!path || !out || !n_parts || part >= n_parts) return VS_E_ARG;
+    out[0] = out[1] = out[2] = 0;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return vs_fail(nullptr, VS_E_ARG, "cannot open %s: %s", path, strerror(errno));
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return vs_fail(nullptr, VS_E_ARG, "cannot stat %s: %s", path, strerror(errno)); }
+    const size_t size = (size_t)st.st_size;
+    out[1] = size;
+    if (!size) { close(fd); return VS_OK; }
+    void *p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (p == MAP_FAILED) { close(fd); return vs_fail(nullptr, VS_E_OOM, "cannot map %s: %s", path, strerror(errno)); }
+    const uint8_t *txt = (const uint8_t *)p;
+    if (size >= 2 && txt[0] == 0x1f && txt[1] == 0x8b) {
+        out[2] |= 2u;
+    } else {
+        const size_t lo = size / n_parts * part + std::min<size_t>(part, size % n_parts);
+        const size_t hi = size / n_parts * (part + 1u) + std::min<size_t>(part + 1u, size % n_parts);
+        const unsigned T = n_threads();
+        std::vector<uint64_t> cnt(T, 0);
+        std::vector<int> cr(T, 0);
+        parallel_for(T, [&](unsigned t) {
+            const size_t a = lo + (hi - lo) * t / T, b = lo + (hi - lo) * (t + 1) / T;
+            uint64_t n = 0;
+            const uint8_t *q = txt + a, *end = txt + b;
+            if (a < b && memchr(q, '\r', b - a)) cr[t] = 1;
+            while (q < end) {
+                const uint8_t *r = (const uint8_t *)memchr(q, '\n', (size_t)(end - q));
+                if (!r) break;
+                n++;
+                q = r + 1;
+            }
+            cnt[t] = n;
+        });
+        for (unsigned t = 0; t < T; t++) { out[0] += cnt[t]; if (cr[t]) out[2] |= 1u; }
+        if (hi == size && txt[size - 1] != '\n') out[2] |= 4u;
+    }
+    munmap(p, size);
+    close(fd);
+    return VS_OK;
+}
+
+namespace {
+// byte offset at which line `line` (0-based) starts, from the newline counts of the n_parts byte ranges of the file
+size_t line_start(const FqFile &f, uint64_t line, const uint64_t *counts, uint32_t n_parts) {
+    if (line == 0) return 0;
+    uint64_t before = 0;
+    for (uint32_t part = 0; part < n_parts; part++) {
+        if (before + counts[part] >= line) {  // the line-th newline lies in this range
+            const size_t lo = f.size / n_parts * part + std::min<size_t>(part, f.size % n_parts);
+            const size_t hi = f.size / n_parts * (part + 1u) + std::min<size_t>(part + 1u, f.size % n_parts);
+            uint64_t need = line - before;
+            const uint8_t *q = f.data + lo, *end = f.data + hi;
+            while (q < end) {
+                const uint8_t *r = (const uint8_t *)memchr(q, '\n', (size_t)(end - q));
+                if (!r) break;
+                if (--need == 0) return (size_t)(r - f.data) + 1u;
+                q = r + 1;
+            }
+            return f.size;  // (counts that do not describe this file)
+        }
+        before += counts[part];
+    }
+    return f.size;  // fewer lines than asked for: the range is empty
+}
+}  // namespace
+
+// Step 2, after the ranks have exchanged their counts (counts_f / counts_r: newlines of the n_parts byte ranges of the
+// two files): records [first, last) of the pair -- only their bytes are indexed.  Plain text files without '\r' (the
+// caller falls back to vs_fastq_open otherwise).  The handle numbers its records from 0; info[0] = last - first.
+int vs_fastq_open_records(vs_ctx *ctx, const char *fwd_path, const char *rve_path, uint32_t n_parts, const uint64_t *counts_f,
+                          const uint64_t *counts_r, uint64_t first, uint64_t last, vs_fastq **out) {
+    if (!fwd_path || !rve_path || !out || !counts_f || !counts_r || !n_parts || last < first) return vs_fail(ctx, VS_E_ARG, "vs_fastq_open_records: bad argument");
+    *out = nullptr;
+    vs_fastq *fq = new vs_fastq();
+    const char *paths[2] = {fwd_path, rve_path};
+    const uint64_t *counts[2] = {counts_f, counts_r};
+    for (int i = 0; i < 2; i++) {
+        std::string err;
+        int rc = map_file(err, paths[i], fq->f[i]);
+        if (rc != VS_OK) vs_fail(ctx, rc, "%s", err.c_str());
+        if (rc == VS_OK && !fq->f[i].inflated.empty()) rc = vs_fail(ctx, VS_E_ARG, "%s: a gzip file cannot be opened by record range", paths[i]);
+        if (rc == VS_OK) {
+            FqFile &f = fq->f[i];
+            const size_t b0 = line_start(f, 4u * first, counts[i], n_parts), b1 = line_start(f, 4u * last, counts[i], n_parts);
+            f.data += b0;
+            f.size = b1 > b0 ? b1 - b0 : 0;
+            fq->bytes_indexed += f.size;
+            rc = index_file(ctx, paths[i], f);
+            if (rc == VS_OK && !f.translated.empty()) rc = vs_fail(ctx, VS_E_ARG, "%s: holds '\\r'; open the whole file instead", paths[i]);
+        }
+        if (rc != VS_OK) {
+            close_file(fq->f[0]);
+            close_file(fq->f[1]);
+            delete fq;
+            return rc;
+        }
+    }
+    fq->n_pairs = std::min(fq->f[0].seq_start.size(), fq->f[1].seq_start.size());
+    if (fq->n_pairs != last - first) {
+        const uint64_t got = fq->n_pairs;
+        close_file(fq->f[0]);
+        close_file(fq->f[1]);
+        delete fq;
+        return vs_fail(ctx, VS_E_STATE, "vs_fastq_open_records: %llu records in the byte ranges, %llu expected (stale counts?)",
+                       (unsigned long long)got, (unsigned long long)(last - first));
+    }
     *out = fq;
     return VS_OK;
 }
@@ -455,6 +579,9 @@ int vs_fastq_info(const vs_fastq *fq, uint64_t info[3]) {
     info[1] = fq->f[0].n_lines;
     info[2] = fq->f[1].n_lines;
     return VS_OK;
+}
+
+uint64_t vs_fastq_bytes_indexed(const vs_fastq *fq) { return fq ? fq->bytes_indexed : 0;
 }
 
 // Sequence of record `record` of file `which` (0 forward, 1 reverse) into buf (cap bytes); *len

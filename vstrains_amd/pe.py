@@ -60,6 +60,70 @@ class FastqPair:
         self.n_pairs = int(info[0])
         self.lines = (int(info[1]), int(info[2]))
 
+    @classmethod
+    def open_shard(cls, fwd: str, rve: str, ctx: "Context", rank: int, world: int, all_gather=None) -> "FastqPair":
+        """This rank's contiguous block of the pairs without any rank reading a whole file: rank r counts the newlines
+        of byte range r of both files (``vs_fastq_count_part``), the counts are exchanged (``all_gather``: a callable
+        that takes this rank's list of integers and returns every rank's, default ``torch.distributed``), the total
+        ``min(lines_f // 4, lines_r // 4)`` (PE_Inference.py:154) and this rank's record range follow, and only the
+        bytes of those records are indexed (``vs_fastq_open_records``).  ``first`` / ``total_pairs`` say where the block
+        lies.  gzip files and files with carriage returns are opened whole by every rank (``whole = True``)."""
+        from .dist import shard_range
+
+        L = nat.lib()
+        mine = []
+        for path in (fwd, rve):
+            out = (C.c_uint64 * 3)()
+            rc = L.vs_fastq_count_part(path.encode(), rank, world, out)
+            if rc != nat.VS_OK:
+                msg = L.vs_last_error(None).decode("utf-8", "replace")
+                raise FileNotFoundError(msg) if "cannot open" in msg else nat.NativeError(rc, msg)
+            mine += [int(out[0]), int(out[1]), int(out[2])]
+        if all_gather is None:
+            import torch
+            import torch.distributed as dist
+
+            def all_gather(vals):
+                t = torch.tensor(vals, dtype=torch.int64)
+                if dist.get_backend() == "nccl":
+                    t = t.cuda()
+                got = [torch.zeros_like(t) for _ in range(world)]
+                dist.all_gather(got, t)
+                return [[int(x) for x in g.cpu().tolist()] for g in got]
+
+        everyone = all_gather(mine)
+        flags = 0
+        for vals in everyone:
+            flags |= vals[2] | vals[5]
+        if flags & 3:  # carriage returns or gzip somewhere: every rank opens the files whole and takes its block of them
+            fq = cls(fwd, rve, ctx)
+            fq.total_pairs = fq.n_pairs
+            fq.first, last = shard_range(fq.n_pairs, rank, world)
+            fq.block_offset = fq.first
+            fq.n_pairs = last - fq.first
+            fq.whole = True
+            return fq
+        counts = [np.asarray([vals[3 * i] for vals in everyone], dtype=np.uint64) for i in range(2)]
+        lines = [int(counts[i].sum()) + (1 if any(vals[3 * i + 2] & 4 for vals in everyone) else 0) for i in range(2)]
+        total = min(lines[0] // 4, lines[1] // 4)
+        first, last = shard_range(total, rank, world)
+        self = cls.__new__(cls)
+        self._ctx = ctx
+        h = C.c_void_p()
+        rc = L.vs_fastq_open_records(ctx._h if ctx is not None else None, fwd.encode(), rve.encode(), world, counts[0].ctypes.data,
+                                     counts[1].ctypes.data, first, last, C.byref(h))
+        if rc != nat.VS_OK:
+            raise nat.NativeError(rc, L.vs_last_error(ctx._h if ctx is not None else None).decode("utf-8", "replace"))
+        self._h = h
+        self.n_pairs = last - first
+        self.lines = tuple(lines)
+        self.total_pairs, self.first, self.block_offset, self.whole = total, first, 0, False
+        return self
+
+    @property
+    def bytes_indexed(self) -> int:
+        return int(nat.lib().vs_fastq_bytes_indexed(self._h))
+
     def __len__(self):
         return self.n_pairs
 

@@ -11,7 +11,6 @@ import sys
 import time
 
 from . import pe as host
-from .dist import shard_range
 
 BATCH_PAIRS = 1 << 20
 
@@ -35,13 +34,17 @@ def count_links(ctx, gfa: str, fwd: str, rve: str, kmer_size: int):
     counter = host.PeCounter(ctx)
 
     print("Start aligning reads to gfa nodes")  # :146
-    fq = host.FastqPair(fwd, rve, ctx)  # :146-154, native multi-threaded ingest
-    total = len(fq)
     # one process per GPU (torchrun): this rank counts its contiguous block of the pairs and the
     # counters are summed over ranks afterwards (RCCL all-reduce); a single process takes everything
     rank, world = _rank_world()
-    first, last = shard_range(total, rank, world)
-    count_fastq(ctx, fq, counter, first, last, progress=(rank == 0))
+    if world > 1:
+        # nobody reads a whole file: every rank counts the lines of its byte range, the ranks exchange the counts and
+        # each indexes only the bytes of its own records (:154's total follows from the counts)
+        fq = host.FastqPair.open_shard(fwd, rve, ctx, rank, world)
+        count_fastq(ctx, fq, counter, fq.block_offset, fq.block_offset + len(fq), progress=(rank == 0))
+    else:
+        fq = host.FastqPair(fwd, rve, ctx)  # :146-154, native multi-threaded ingest
+        count_fastq(ctx, fq, counter, 0, len(fq), progress=True)
     fq.close()
     if world > 1:
         counter.all_reduce()
