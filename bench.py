@@ -95,6 +95,7 @@ def strain_extract(ctx, counter, pre, names, logger, out_dir):
     from vstrains_amd import graph as graph_pkg
 
     return {"seconds": secs, "strains": len(strains), "stage_graphs_written": n_stage_graphs,
+            "stages": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in getattr(pipeline.extract_strains, "last_stages", {}).items()},
             "host_modules": graph_pkg.host_modules(),
             "graph_refresh_launches": backend.graph_ops.calls, "link_table_launches": table.calls,
             "longest_strain_bp": max([rec[1] for rec in strains.values()] or [0])}

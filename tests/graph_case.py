@@ -33,6 +33,34 @@ class Case:
             with open(os.path.join(self.dir, "out", rel)) as fh:
                 self.expected[rel] = fh.read()
 
+    # Files of this case that do not pin the build to the reference: the reference itself writes them differently under
+    # another PYTHONHASHSEED (it iterates sets of names), or the stand-in writes them differently under another of its
+    # models of graph-tool's adjacency container (in-edge placement, edge-index reuse, remove_edge: the rules recalled,
+    # not read -- tests/golden/gt_standin).  They are still compared and reported; only the others are binding.
+    MODEL_FIELDS = ("differs_under_plain_inedge_order", "differs_under_lifo_index_reuse", "differs_under_swap_pop_removal")
+
+    def model_dependent(self):
+        dep = set()
+        for field in self.MODEL_FIELDS:
+            dep.update(self.meta.get(field, []))
+        return dep
+
+    def non_binding(self):
+        return set(self.meta["differs_under_other_hashseeds"]) | self.model_dependent()
+
+    def binding(self, problems, report=None):
+        """``problems`` of ``compare`` without the ones in non-binding files (those go to ``report``, if given)."""
+        skip = self.non_binding()
+        out = []
+        for p in problems:
+            rel = p.split(" ", 1)[1]
+            if rel in skip:
+                if report is not None:
+                    report.append("%s: %s (non-binding)" % (self.name, p))
+            else:
+                out.append(p)
+        return out
+
     def inputs(self, tmp, with_reads=False):
         """Re-derive the inputs from the seed and check them against the pinned digests."""
         pc = synth.make_pipeline_case(**self.meta["synth"])

@@ -201,7 +201,7 @@ def test_full_cli_on_device_matches_reference(backend, name, tmp_path):
     else:
         cli.main(argv, backend=backend)
     problems, _ = compare(case, out)
-    binding = [p for p in problems if p.split(" ", 1)[1] not in case.meta["differs_under_other_hashseeds"]]
+    binding = case.binding(problems)
     assert not binding, binding
 
 
@@ -343,7 +343,7 @@ def test_reference_shaped_driver_on_the_device(backend, name, tmp_path):
     finally:
         api.set_backend(None)
     problems, _ = compare(case, out)
-    binding = [p for p in problems if p.split(" ", 1)[1] not in case.meta["differs_under_other_hashseeds"]]
+    binding = case.binding(problems)
     assert not binding, binding
 
 

@@ -74,7 +74,7 @@ def test_reference_shaped_driver_reproduces_the_golden_run(name, tmp_path):
     finally:
         api.set_backend(None)
     problems, _ = compare(case, out)
-    binding = [p for p in problems if p.split(" ", 1)[1] not in case.meta["differs_under_other_hashseeds"]]
+    binding = case.binding(problems)
     assert not binding, binding
 
 

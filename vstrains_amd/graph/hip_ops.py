@@ -26,6 +26,9 @@ class HipGraphOps(GraphOps):
     def __init__(self, ctx):
         self.ctx = ctx
         self.calls = 0
+        self.reinit_s = 0.0     # seconds spent in reinit() since the object was made, of which in the library call:
+        self.native_s = 0.0
+        self.reinit_calls = 0
         self._seg_lines: Dict[str, tuple] = {}   # id -> (depth, "S ..." line)
         self._link_lines: Dict[tuple, tuple] = {}  # (id, id) -> (overlap, "L ..." line)
         from . import fast_module
@@ -75,6 +78,16 @@ class HipGraphOps(GraphOps):
                          rank[:nv].tolist())
 
     def reinit(self, g: AsmGraph, nodes, edges, gfa_path: str):
+        import time
+
+        t0 = time.perf_counter()
+        try:
+            return self._reinit(g, nodes, edges, gfa_path)
+        finally:
+            self.reinit_s += time.perf_counter() - t0
+            self.reinit_calls += 1
+
+    def _reinit(self, g: AsmGraph, nodes, edges, gfa_path: str):
         """``formats.stage_graph_from_state`` + ``refresh`` with the per-edge work in the library
         (``vs_stage_rebuild``): this side filters the surviving vertices and edges (map order, by
         name, as the reference's ``graph_to_gfa`` does, IO.py:345-369), writes the stage GFA, and
@@ -166,10 +179,14 @@ class HipGraphOps(GraphOps):
         top = np.zeros(max(nv, 1), dtype=np.int32)
         rank = np.zeros(max(nv, 1), dtype=np.int32)
         bad = C.c_uint32(0xFFFFFFFF)
+        import time
+
+        t0 = time.perf_counter()
         nat.check(self.ctx._h, nat.lib().vs_stage_rebuild(
             self.ctx._h, nv, n_e, _ptr(a_src), _ptr(a_tgt), _ptr(a_dp), row_ptr.ctypes.data, n_out.ctypes.data,
             nbr.ctypes.data, eidx.ctypes.data, flow.ctypes.data, nt.ctypes.data, fk.ctypes.data, nxt.ctypes.data,
             top.ctypes.data, rank.ctypes.data, C.byref(bad)))
+        self.native_s += time.perf_counter() - t0
         self.calls += 1
         ng = AsmGraph()
         ng.vid, ng.vdp, ng.vseq = n_vid, n_vdp, n_vseq

@@ -102,24 +102,35 @@ def _extract_strains(pre: Prepared, table, backend, logger, out: str):
     ops = backend.graph_ops
     contigs = pre.contigs
     links = backend.live_links(table)
+    # where the leg's time goes (seconds per part; `reinit_s` / `native_s` of the graph ops, where they keep them, say how
+    # much of it is re-initialisation and how much of that the library call): extract_strains.last_stages
+    marks = [("start", time.perf_counter())]
     stage1 = dis.Stage(pre.g1, pre.nodes1, pre.edges1)
     dis.edge_cleaning(pre.g1, pre.edges1, contigs, links, logger)
     stage2 = dis.reinit(stage1, ops, logger, "{0}/gfa/es_graph_L2.gfa".format(out))
     write_contig_paths(contigs, "{0}/tmp/pre_contigs.paths".format(out))
     write_contig_fasta(stage2.g, stage2.nodes, contigs, "{0}/tmp/pre_contigs.fasta".format(out))
+    marks.append(("edge_cleaning_s", time.perf_counter()))
 
     delta = 0.05 * numpy.median([stage2.g.vdp[v] for v in range(stage2.g.num_vertices())])
     stagef = dis.iter_graph_disentanglement(stage2, contigs, links, ops, logger, delta, out)
     write_contig_paths(contigs, "{0}/tmp/post_contigs.paths".format(out))
     write_contig_fasta(stagef.g, stagef.nodes, contigs, "{0}/tmp/post_contigs.fasta".format(out))
+    marks.append(("disentanglement_s", time.perf_counter()))
 
     logger.info(">>>STAGE: contig path extension")
     full_link = ext.best_matching(stagef, contigs, links, logger)
     ext.increment_nt_branch_coverage(stagef, logger)
     write_stage_gfa(stagef.g, stagef.nodes, stagef.edges, "{0}/gfa/split_graph_final.gfa".format(out))
     _stored(logger, "{0}/gfa/split_graph_final.gfa".format(out))
+    marks.append(("best_matching_s", time.perf_counter()))
     p_delta = 0.05 * numpy.median([stagef.g.vdp[v] for v in range(stagef.g.num_vertices())])
     strains, usages = ext.path_extension(stagef, contigs, full_link, table, ops, logger, p_delta, out)
+    marks.append(("path_extension_s", time.perf_counter()))
+    extract_strains.last_stages = {name: t - marks[i][1] for i, (name, t) in enumerate(marks[1:])}
+    for attr in ("reinit_s", "native_s", "reinit_calls", "reinit_reused"):
+        if hasattr(ops, attr):
+            extract_strains.last_stages[attr] = getattr(ops, attr)
 
     logger.info(">>>STAGE: final process")
     resolve_contigs(strains)
