@@ -19,7 +19,7 @@ import numpy as np  # noqa: E402
 from oracle import pe_oracle_c  # noqa: E402  (the checker)
 from vstrains_amd import pe as host, synth  # noqa: E402
 
-K_EDGE = [3, 5, 15, 21, 29, 30, 31, 32, 33, 54, 55, 56, 61, 62, 63, 84, 85, 86, 87, 100, 125, 126, 127]
+K_EDGE = [3, 5, 15, 21, 29, 30, 31, 32, 33, 54, 55, 56, 61, 62, 63, 84, 85, 86, 87, 94, 95, 96, 100, 125, 126, 127, 128, 150]
 DIRTY = np.frombuffer(b"acgtnRYKMSWBDHV.-*", dtype=np.uint8)
 
 

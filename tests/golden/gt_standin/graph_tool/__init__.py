@@ -23,7 +23,7 @@ import os
 from collections import deque
 
 MODEL = os.environ.get("GT_STANDIN_INEDGE", "rotate")
-INEDGE_ROTATION = MODEL == "rotate"
+INEDGE_ROTATION = MODEL in ("rotate", "lifo", "swappop")  # (lifo / swappop vary ONE other rule each, on top of the default)
 # Two further models vary the OTHER recalled rules (fixtures count as "adjacency invariant" only if they survive all of
 # rotate / plain / lifo / swappop): "lifo" reuses the index of the edge removed LAST (the free list as a stack instead of
 # a queue: changes hash(Edge), hence the order of the sets of edges the reference builds, IO.py:207, and which stale

@@ -90,6 +90,19 @@ INVARIANT_CASES = {
     "inv5_k21_s201": (dict(n_strains=5, genome_len=3200, snp_rate=0.012, k=21, n_pairs=9000, read_len=100,
                            abundance_ratio=0.7, seed=201), []),
 }
+# round 3: found under four models (rotate, plain, lifo, swappop -- see gt_standin); with -mc, k = 31 and k = 55 among them
+INVARIANT_CASES.update({
+    "inv4_k21_mc_s200": (dict(n_strains=4, genome_len=3000, snp_rate=0.01, k=21, n_pairs=7000, read_len=100, abundance_ratio=0.6, seed=200), ["-mc", "15"]),
+    "inv4_k21_mc_s216": (dict(n_strains=4, genome_len=3000, snp_rate=0.01, k=21, n_pairs=7000, read_len=100, abundance_ratio=0.6, seed=216), ["-mc", "15"]),
+    "inv5_k31_mc_s211": (dict(n_strains=5, genome_len=3600, snp_rate=0.012, k=31, n_pairs=9000, read_len=120, abundance_ratio=0.7, seed=211), ["-mc", "12"]),
+    "inv5_k31_mc_s219": (dict(n_strains=5, genome_len=3600, snp_rate=0.012, k=31, n_pairs=9000, read_len=120, abundance_ratio=0.7, seed=219), ["-mc", "12"]),
+    "inv5_k21_s239": (dict(n_strains=5, genome_len=3200, snp_rate=0.012, k=21, n_pairs=9000, read_len=100, abundance_ratio=0.7, seed=239), []),
+    "inv5_k21_s259": (dict(n_strains=5, genome_len=3200, snp_rate=0.012, k=21, n_pairs=9000, read_len=100, abundance_ratio=0.7, seed=259), []),
+    "inv4_k31_s250": (dict(n_strains=4, genome_len=3600, snp_rate=0.012, k=31, n_pairs=8000, read_len=120, abundance_ratio=0.65, seed=250), []),
+    "inv4_k31_s252": (dict(n_strains=4, genome_len=3600, snp_rate=0.012, k=31, n_pairs=8000, read_len=120, abundance_ratio=0.65, seed=252), []),
+    "inv3_k55s_s209": (dict(n_strains=3, genome_len=3500, snp_rate=0.006, k=55, n_pairs=6000, read_len=150, abundance_ratio=0.55, seed=209), []),
+    "inv3_k55t_s201": (dict(n_strains=3, genome_len=2600, snp_rate=0.009, k=55, n_pairs=5000, read_len=150, abundance_ratio=0.55, seed=201), []),
+})
 CASES.update(INVARIANT_CASES)
 
 
@@ -268,6 +281,9 @@ def search_invariant(n_seeds):
         ("inv5_k21", dict(n_strains=5, genome_len=3200, snp_rate=0.012, k=21, n_pairs=9000, read_len=100, abundance_ratio=0.7), []),
         ("inv4_k55", dict(n_strains=4, genome_len=5000, snp_rate=0.012, k=55, n_pairs=9000, read_len=150, abundance_ratio=0.65), []),
         ("inv3_k55", dict(n_strains=3, genome_len=4500, snp_rate=0.01, k=55, n_pairs=7000, read_len=150, abundance_ratio=0.55), []),
+        ("inv3_k55s", dict(n_strains=3, genome_len=3500, snp_rate=0.006, k=55, n_pairs=6000, read_len=150, abundance_ratio=0.55), []),
+        ("inv2_k55s", dict(n_strains=2, genome_len=4000, snp_rate=0.008, k=55, n_pairs=6000, read_len=150, abundance_ratio=0.45), []),
+        ("inv3_k55t", dict(n_strains=3, genome_len=2600, snp_rate=0.009, k=55, n_pairs=5000, read_len=150, abundance_ratio=0.55), []),
         ("inv4_k21_mc", dict(n_strains=4, genome_len=3000, snp_rate=0.01, k=21, n_pairs=7000, read_len=100, abundance_ratio=0.6), ["-mc", "15"]),
         ("inv5_k31_mc", dict(n_strains=5, genome_len=3600, snp_rate=0.012, k=31, n_pairs=9000, read_len=120, abundance_ratio=0.7), ["-mc", "12"]),
         ("inv4_k21_scr", dict(n_strains=4, genome_len=3000, snp_rate=0.01, k=21, n_pairs=7000, read_len=100, abundance_ratio=0.6, scramble=True), []),

@@ -58,9 +58,8 @@ k_seed_insert(VsIndexDev idx, const uint64_t *__restrict__ seed_off, uint64_t n_
     uint32_t node = vs_upper_idx(seed_off, idx.n_nodes + 1, g);
     uint32_t p = (uint32_t)(g - seed_off[node]);
     VsNodeMeta m = idx.meta[node];
-    uint64_t f = vs_win64(idx.fwd_words, (uint64_t)m.woff * 16u + p) & vs_lowmask(2u * idx.w);
-    uint64_t r = vs_rc(f, idx.w);
-    uint64_t key = f < r ? f : r;
+    uint32_t strand;
+    uint64_t key = vs_seed_key(idx.fwd_words, (uint64_t)m.woff * 16u + p, idx.w, &strand);
     uint32_t mask = (1u << idx.table_bits) - 1u;
     uint32_t sl = vs_slot_of(key, idx.table_bits);
     for (;;) {
@@ -81,9 +80,8 @@ k_seed_fill(VsIndexDev idx, const uint64_t *__restrict__ seed_off, uint64_t n_po
     uint32_t node = vs_upper_idx(seed_off, idx.n_nodes + 1, g);
     uint32_t p = (uint32_t)(g - seed_off[node]);
     VsNodeMeta m = idx.meta[node];
-    uint64_t f = vs_win64(idx.fwd_words, (uint64_t)m.woff * 16u + p) & vs_lowmask(2u * idx.w);
-    uint64_t r = vs_rc(f, idx.w);
-    uint32_t strand = r < f ? 1u : 0u;  // 1: the stored key is the reverse complement of the node text
+    uint32_t strand;  // 1: the stored key is the reverse complement of the node text
+    (void)vs_seed_key(idx.fwd_words, (uint64_t)m.woff * 16u + p, idx.w, &strand);
     uint32_t sl = pos_slot[g];
     uint32_t at = offs[sl] + atomicAdd(&cursor[sl], 1u);
     VsPosting rec;  // (carries the node header: the mapping kernel needs no second load for it)
@@ -116,6 +114,10 @@ k_table_finalize(const unsigned long long *__restrict__ keys, const uint32_t *__
 
 static void seed_geometry(uint32_t K, uint32_t *w, uint32_t *s) {
     uint32_t ww = K < 31u ? K : 31u;
+    // Long overlaps (k >= 95) put a 31-mer into every node that shares the overlap it lies in: 15.7 postings per seed
+    // at configs[3] (k = 127).  A 63-mer lies in a third fewer nodes and a 2 x 250 end still needs three probes
+    // (stride K - 62); its key is a mix of the 126 bits, the comparison covers the seed's own bases (vs_seed_key).
+    if (K >= 96u) ww = 63u;
     if ((ww & 1u) == 0u) ww -= 1u;  // K >= 2 here, so ww >= 1
     *w = ww;
     *s = K - ww + 1u;

@@ -269,6 +269,39 @@ __device__ __forceinline__ uint64_t vs_rc(uint64_t x, uint32_t w) {
     return (~x) >> (64u - 2u * w);
 }
 
+__device__ __forceinline__ uint64_t vs_mix64(uint64_t z);
+// Key of the seed (w-mer, w <= 63) at base offset `base` of a packed text, and which strand it is the smaller on.
+// w <= 31: the canonical w-mer itself.  Longer seeds (k >= 95: w = 63) do not fit a 62-bit key: the key is a mix of the
+// canonical 2w bits, so two different seeds may share a key -- which is why, for those indexes, the comparison that
+// follows a probe starts at the seed's FIRST base instead of behind it (VS_SEED_VERIFIED below): a posting is credited
+// on compared text only, the key merely nominates it.
+template <typename B>
+__device__ __forceinline__ uint64_t vs_seed_key(const uint32_t *words, B base, uint32_t w, uint32_t *strand) {
+    if (w <= 31u) {
+        const uint64_t f = vs_win(words, base) & vs_lowmask(2u * w);
+        const uint64_t r = vs_rc(f, w);
+        *strand = r < f ? 1u : 0u;
+        return r < f ? r : f;
+    }
+    const uint32_t sh = 2u * (w - 32u);  // bits of the seed in the second word pair (w = 63: 62)
+    const uint64_t lo = vs_win(words, base), hi = vs_win(words, base + (B)32) & vs_lowmask(sh);
+    // reverse complement of the 2w bits (hi:lo): the first 32 bases reversed go to the top
+    const uint64_t rl = vs_rc(lo, 32u), rh = vs_rc(hi, w - 32u);
+    const uint64_t rc_lo = (rl << sh) | rh, rc_hi = sh ? rl >> (64u - sh) : 0ull;
+    const bool rev = rc_hi < hi || (rc_hi == hi && rc_lo < lo);
+    *strand = rev ? 1u : 0u;
+    const uint64_t a = rev ? rc_lo : lo, b = rev ? rc_hi : hi;
+    return vs_mix64(a ^ vs_mix64(b + 0x632BE59BD9B4E019ull)) >> 2;  // 62 bits: neither the empty key nor the multi flag
+}
+// does the seed at `base` hold a byte outside ACGT?  (mask: 0b11 per such byte)
+template <typename B>
+__device__ __forceinline__ bool vs_seed_dirty(const uint32_t *mask, B base, uint32_t w) {
+    if (w <= 32u) return (vs_win(mask, base) & vs_lowmask(2u * w)) != 0ull;
+    return vs_win(mask, base) != 0ull || (vs_win(mask, base + (B)32) & vs_lowmask(2u * (w - 32u))) != 0ull;
+}
+// bases of the seed the comparison may take for granted: all of them for exact keys, none for mixed ones
+#define VS_SEED_VERIFIED(w) ((w) <= 31u ? (w) : 0u)
+
 __device__ __forceinline__ uint32_t vs_slot_of(uint64_t key, uint32_t bits) {
     return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64u - bits));
 }

@@ -342,10 +342,7 @@ __device__ __forceinline__ bool vs_accept32(uint32_t v, uint32_t coord, uint32_t
 }
 
 // Probe the table for the seed at read offset j.  Returns posting count (0 = miss) and payload.
-__device__ __forceinline__ uint32_t vs_probe(const VsIndexDev &idx, uint64_t f, uint32_t *pa, uint32_t *pb) {
-    uint64_t r = vs_rc(f, idx.w);
-    uint32_t sr = r < f ? 1u : 0u;
-    uint64_t key = sr ? r : f;
+__device__ __forceinline__ uint32_t vs_probe(const VsIndexDev &idx, uint64_t key, uint32_t sr, uint32_t *pa, uint32_t *pb) {
     uint32_t mask = (1u << idx.table_bits) - 1u;
     uint32_t sl = vs_slot_of(key, idx.table_bits);
     const uint4 *tab = (const uint4 *)idx.table;
@@ -431,6 +428,7 @@ k_pe_tiles(PeParams P) {
     const uint32_t ept = STD ? STD_EPT : P.ept, pmax = STD ? STD_PMAX : P.pmax;
     const uint32_t NI = ept * pmax;
     const uint32_t w = STD ? STD_W : P.idx.w, s = STD ? STD_S : P.idx.s, K = STD ? STD_K : P.idx.K;
+    const uint32_t wv = VS_SEED_VERIFIED(w);  // seed bases the comparison skips (0: seeds with mixed keys, vs_seed_key)
     const uint32_t pool = STD ? (1u << STD_POOL_BITS) : P.pool, pool_shift = 32u - (STD ? STD_POOL_BITS : P.pool_bits);
     const uint32_t words_cap = STD ? STD_EPT * STD_WPE : P.words_cap;
     const TileLayout T = tile_layout(ept, pmax, words_cap, pool);
@@ -607,17 +605,18 @@ k_pe_tiles(PeParams P) {
                 uint32_t rlen = meta & VS_LEN_MASK;
                 uint32_t j = pi * s;
                 if (j + w <= rlen) {
-                    uint64_t f = vs_win64_u32(s_words, e * wpe * 16u + j) & vs_lowmask(2u * w);
+                    uint32_t sr;
+                    const uint64_t key = vs_seed_key(s_words, e * wpe * 16u + j, w, &sr);
                     bool ok = true;
                     if ((meta >> 24) & VS_FLAG_INVALID) {
                         if (FAST) {
                             uint32_t lo, hi;
                             ok = vs_seed_limits(s_inv[e], j, w, rlen, &lo, &hi);
                         } else {
-                            ok = (vs_win64(P.rd.mask, (uint64_t)s_gwoff[e] * 16u + j) & vs_lowmask(2u * w)) == 0ull;
+                            ok = !vs_seed_dirty(P.rd.mask, (uint64_t)s_gwoff[e] * 16u + j, w);
                         }
                     }
-                    if (ok) cnt = vs_probe(P.idx, f, &pa, &pb);
+                    if (ok) cnt = vs_probe(P.idx, key, sr, &pa, &pb);
                 }
             }
             s_pcnt[it] = cnt;
@@ -755,19 +754,19 @@ k_pe_tiles(PeParams P) {
                     if ((meta >> 24) & VS_FLAG_INVALID) vs_seed_limits(s_inv[e], j, w, rlen, &lo, &hi);
                     uint32_t cl = s < j - lo ? s : j - lo;
                     cl = cl < q ? cl : q;
-                    uint32_t rem = hi - j - w;
-                    const uint32_t dr = nm.len - q - w;
+                    uint32_t rem = hi - j - wv;
+                    const uint32_t dr = nm.len - q - wv;
                     rem = rem < dr ? rem : dr;
                     uint32_t left, ext;
-                    if (MODE == 2) vs_agree_long(s_words, e * wpe * 16u, tw, tb + q, cl, tb + q + w, rem, j, w, &left, &ext);
-                    else vs_agree_fast<STD>(s_words, e * wpe * 16u, tw, tb + q, cl, tb + q + w, rem, j, w, &left, &ext);
-                    len = left + w + ext;
+                    if (MODE == 2) vs_agree_long(s_words, e * wpe * 16u, tw, tb + q, cl, tb + q + wv, rem, j, wv, &left, &ext);
+                    else vs_agree_fast<STD>(s_words, e * wpe * 16u, tw, tb + q, cl, tb + q + wv, rem, j, wv, &left, &ext);
+                    len = left + wv + ext;
                     if (left >= s || len < K) continue;  // an earlier probe lies inside this match and owns it / too short
                     a = j - left;
                     qa = q - left;
                 } else {
                     const uint32_t *mk = ((meta >> 24) & VS_FLAG_INVALID) ? P.rd.mask : nullptr;
-                    if (!vs_extend(s_words, e * wpe * 16u, rlen, tw, tb, nm.len, j, q, w, s, K, mk, (uint64_t)s_gwoff[e] * 16u, &a, &qa, &len))
+                    if (!vs_extend(s_words, e * wpe * 16u, rlen, tw, tb, nm.len, j, q, wv, s, K, mk, (uint64_t)s_gwoff[e] * 16u, &a, &qa, &len))
                         continue;
                 }
                 credit(e, node, nm.len, len - K + 1u, opp ? nm.len - qa - len : qa, a);
@@ -1221,9 +1220,10 @@ __device__ __forceinline__ uint32_t vs_locus_key(const VsIndexDev &idx, const Vs
     const uint64_t base = (uint64_t)rd.woff[2 * p] * 16u;
     const bool inv = (mf >> 24) & VS_FLAG_INVALID;
     for (uint32_t j = 0; j + w <= rlen; j += s) {
-        if (inv && (vs_win64(rd.mask, base + j) & vs_lowmask(2u * w))) continue;
-        uint32_t pa, pb;
-        const uint32_t c = vs_probe(idx, vs_win64(rd.words, base + j) & vs_lowmask(2u * w), &pa, &pb);
+        if (inv && vs_seed_dirty(rd.mask, base + j, w)) continue;
+        uint32_t pa, pb, sr;
+        const uint64_t key = vs_seed_key(rd.words, base + j, w, &sr);
+        const uint32_t c = vs_probe(idx, key, sr, &pa, &pb);
         if (c) return c == 1u ? pa : (idx.postings[pa].x & 0x01FFFFFFu);
     }
     return N;
@@ -1323,8 +1323,11 @@ k_pe_slow(PeParams P, uint32_t *dense, uint32_t n_slow_cap) {
                 const uint32_t pi = p0 + tid;
                 if (pi < nprobe) {
                     const uint32_t j = pi * s;
-                    if (!(mk && (vs_win64(mk, rbase + j) & vs_lowmask(2u * w))))
-                        c = vs_probe(P.idx, vs_win64(P.rd.words, rbase + j) & vs_lowmask(2u * w), &pa, &pb);
+                    if (!(mk && vs_seed_dirty(mk, rbase + j, w))) {
+                        uint32_t sr;
+                        const uint64_t key = vs_seed_key(P.rd.words, rbase + j, w, &sr);
+                        c = vs_probe(P.idx, key, sr, &pa, &pb);
+                    }
                 }
                 s_pa[tid] = pa;
                 s_pb[tid] = pb;
@@ -1363,7 +1366,7 @@ k_pe_slow(PeParams P, uint32_t *dense, uint32_t n_slow_cap) {
                     const uint32_t *tw = opp ? P.idx.rc_words : P.idx.fwd_words;
                     const uint32_t q = opp ? nm.len - pos - w : pos;
                     uint32_t a, qa, len;
-                    if (!vs_extend(P.rd.words, rbase, rlen, tw, nm.woff * 16u, nm.len, j, q, w, s, K, mk, rbase, &a, &qa, &len))
+                    if (!vs_extend(P.rd.words, rbase, rlen, tw, nm.woff * 16u, nm.len, j, q, VS_SEED_VERIFIED(w), s, K, mk, rbase, &a, &qa, &len))
                         continue;
                     if (atomicAdd(&cnt[node], len - K + 1u) == 0u) touched[atomicAdd(&s_nt, 1u)] = node;
                     atomicMin(&minp[node], opp ? nm.len - qa - len : qa);
@@ -1596,7 +1599,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         else if (wpe == 7u && pmax == 3u) std_shape = 3;
     }
     // longer strides and reads (k = 127 with 2 x 250 bases): the straight-line kernel with more windows
-    const bool fast_long = !fast && (!reads->d_mask || reads->d_inv4) && idx.s <= 128u && maxlen <= idx.w + 256u &&
+    const bool fast_long = !fast && (!reads->d_mask || reads->d_inv4) && idx.s <= 128u && maxlen <= VS_SEED_VERIFIED(idx.w) + 256u &&
                            ctx->max_node_len < (1u << 23) && !tn.no_fast;
     const void *tiles_fn = std_shape == 1   ? (const void *)k_pe_tiles<1, 10u, 5u>
                            : std_shape == 2 ? (const void *)k_pe_tiles<1, 8u, 4u>
