@@ -339,7 +339,7 @@ def test_device_read_generator_equals_cpu_twin(host, ctx):
     {"VS_ACC_QUEUE": "0"}, {"VS_ACC_GRID_PER_CU": "1", "VS_ACC_QUEUE": "0"}, {"VS_NO_XCD_MAP": "1"}, {"VS_GRID_PER_CU": "8"}, {"VS_NO_STD": "1"}, {"VS_SHORTCUT": "1"}, {"VS_SHORTCUT": "0"},
     {"VS_ACC_MERGE": "1"}, {"VS_ACC_MERGE": "1", "VS_NO_AGG": "1"}, {"VS_ACC_MERGE": "1", "VS_ACC_WIDE": "1", "VS_ACC_FILL": "1"},
     {"VS_ACC_WIDE": "2"}, {"VS_ACC_WIDE": "2", "VS_ACC_FILL": "1"}, {"VS_ACC_WIDE": "2", "VS_ACC_FILL": "100", "VS_ACC_MERGE": "1"},
-    {"VS_WALK": "1"}, {"VS_WALK": "1", "VS_NO_SORT": "1"}, {"VS_WALK": "1", "VS_NO_XCD_MAP": "1", "VS_GRID_PER_CU": "1"}, {"VS_WALK": "1", "VS_ACC_WIDE": "2"},
+    {"VS_INLINE": "1"}, {"VS_INLINE": "1", "VS_NO_STD": "1"}, {"VS_WALK": "1"}, {"VS_WALK": "1", "VS_NO_SORT": "1"}, {"VS_WALK": "1", "VS_NO_XCD_MAP": "1", "VS_GRID_PER_CU": "1"}, {"VS_WALK": "1", "VS_ACC_WIDE": "2"},
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_every_kernel_variant_gives_the_same_counters(host, ctx, env, monkeypatch):
     """The tuning switches select other code paths (input order instead of locus order, global
@@ -361,6 +361,8 @@ def test_every_kernel_variant_gives_the_same_counters(host, ctx, env, monkeypatc
     assert np.array_equal(short_mat, want[1])
     assert stats == tuple(int(x) for x in want[2])
     assert ctx.last_kernel.startswith("k_pe_walk") == ("VS_WALK" in env), ctx.last_kernel
+    if "VS_INLINE" in env and "VS_WALK" not in env:
+        assert ctx.last_kernel.endswith("true>"), ctx.last_kernel  # (this graph's nodes are short: the 32-byte records are taken)
 
 
 def test_switches_do_not_exist_outside_experiment_mode(tmp_path):

@@ -74,7 +74,7 @@ k_seed_insert(VsIndexDev idx, const uint64_t *__restrict__ seed_off, uint64_t n_
 __global__ void __launch_bounds__(TPB)
 k_seed_fill(VsIndexDev idx, const uint64_t *__restrict__ seed_off, uint64_t n_pos,
             const uint32_t *__restrict__ pos_slot, const uint32_t *__restrict__ offs,
-            uint32_t *__restrict__ cursor, uint4 *__restrict__ postings) {
+            uint32_t *__restrict__ cursor, uint4 *__restrict__ postings, uint4 *__restrict__ postings32, uint32_t *__restrict__ n_long) {
     uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
     if (g >= n_pos) return;
     uint32_t node = vs_upper_idx(seed_off, idx.n_nodes + 1, g);
@@ -87,6 +87,30 @@ k_seed_fill(VsIndexDev idx, const uint64_t *__restrict__ seed_off, uint64_t n_po
     VsPosting rec;  // (carries the node header: the mapping kernel needs no second load for it)
     rec.node = node; rec.pos = p; rec.strand = strand; rec.len = m.len; rec.woff = m.woff;
     postings[at] = vs_posting_pack(rec);
+    if (postings32) {
+        // the same posting with VS_FLANK bases of node text on either side of the seed, nearest first (VsIndexDev::postings32)
+        const uint32_t *tw = idx.fwd_words;
+        const uint64_t tb = (uint64_t)m.woff * 16u;
+        const uint32_t nl = p < VS_FLANK ? p : VS_FLANK, rfree = m.len - p - idx.w, nr = rfree < VS_FLANK ? rfree : VS_FLANK;
+        uint32_t a[3] = {0u, 0u, 0u}, b[3] = {0u, 0u, 0u};
+        for (uint32_t i = 0; i < nl; i++) {
+            const uint64_t at2 = tb + p - 1u - i;
+            a[i >> 4] |= ((tw[at2 >> 4] >> (2u * (uint32_t)(at2 & 15u))) & 3u) << (2u * (i & 15u));
+        }
+        for (uint32_t i = 0; i < nr; i++) {
+            const uint64_t at2 = tb + p + idx.w + i;
+            b[i >> 4] |= ((tw[at2 >> 4] >> (2u * (uint32_t)(at2 & 15u))) & 3u) << (2u * (i & 15u));
+        }
+        uint4 h0, h1;
+        h0.x = node | (strand << 31); h0.y = p; h0.z = m.len; h0.w = a[0];
+        h1.x = a[1];
+        h1.y = (a[2] & 0xFFFFu) | (b[0] << 16);
+        h1.z = (b[0] >> 16) | (b[1] << 16);
+        h1.w = (b[1] >> 16) | (b[2] << 16);
+        postings32[2ull * at] = h0;
+        postings32[2ull * at + 1u] = h1;
+        if ((p > VS_FLANK || rfree > VS_FLANK) && n_long) atomicAdd(n_long, 1u);
+    }
 }
 
 __global__ void __launch_bounds__(TPB)
@@ -170,7 +194,12 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
     ctx->d_rc = nullptr;
     VS_HIP(ctx, hipMalloc(&ctx->d_table, b_table));
     VS_HIP(ctx, hipMalloc(&ctx->d_post, b_post));
-    ctx->index_bytes = b_meta + 2 * b_words + b_table + b_post;
+    // 32-byte postings with the text around the seed (VsIndexDev::postings32) for the seed geometry of k <= 85 (stride
+    // <= 32: the straight-line kernel k_pe_tiles<1>, the only one that reads them)
+    if (ctx->experiment_level) vs_tuning_load(ctx->tune, ctx->experiment_level);
+    const bool want32 = ctx->tune.use_inline && s <= 32u && w <= 31u;  // (VS_INLINE=1 only: DESIGN 11)
+    if (want32) VS_HIP(ctx, hipMalloc(&ctx->d_post32, 2 * b_post));
+    ctx->index_bytes = b_meta + 2 * b_words + b_table + b_post + (want32 ? 2 * b_post : 0);
     // temporaries
     uint8_t *d_ascii = nullptr;
     uint64_t *d_aoff = nullptr, *d_seed_off = nullptr, *d_tmp = nullptr;
@@ -218,6 +247,7 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
         d.rc_words = d.fwd_words + d.rc_delta;
         d.table = (const VsSlot *)ctx->d_table;
         d.postings = (const uint4 *)ctx->d_post;
+        d.postings32 = (const uint4 *)ctx->d_post32;
 
         if (words)
             hipLaunchKernelGGL(k_pack_nodes, dim3((unsigned)((words + TPB - 1) / TPB)), dim3(TPB), 0, st, d_ascii, d_aoff,
@@ -248,7 +278,7 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
             rc = vs_scan_u32(ctx, d_cnts, d_offs, n_slots, d_tmp, nullptr);
             if (rc) goto done;
             hipLaunchKernelGGL(k_seed_fill, dim3(nb), dim3(TPB), 0, st, d, d_seed_off, npos, d_pos_slot, d_offs, d_cursor,
-                               (uint4 *)ctx->d_post);
+                               (uint4 *)ctx->d_post, (uint4 *)ctx->d_post32, d_flags + 2);
         }
         hipLaunchKernelGGL(k_table_finalize, dim3((unsigned)((n_slots + TPB - 1) / TPB)), dim3(TPB), 0, st, d_keys, d_cnts,
                            d_offs, (const uint4 *)ctx->d_post, (uint32_t)n_slots, (VsSlot *)ctx->d_table, d_flags + 1);
@@ -261,6 +291,7 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
         for (uint32_t i = 0; i < n_nodes; i++) ctx->max_node_len = meta[i].len > ctx->max_node_len ? meta[i].len : ctx->max_node_len;
         ctx->n_slots = n_slots;
         ctx->n_distinct = h_flags[1];
+        ctx->n_long_flank = h_flags[2];
         ctx->has_index = true;
         // walk index (vs_walk.h): certified on the host, tables uploaded; a node set that fails keeps the seed kernels
         if (ctx->experiment_level) vs_tuning_load(ctx->tune, ctx->experiment_level);

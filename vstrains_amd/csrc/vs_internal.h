@@ -74,7 +74,17 @@ struct VsIndexDev {
     uint32_t rc_delta;          // so that a kernel can address either strand off one uniform base)
     const VsSlot *table;        // [1 << table_bits]
     const uint4 *postings;      // VsPosting records, the postings of one seed contiguous
+    // The same postings with the node text around the seed inside the record (32 B = two uint4; same index as
+    // `postings`), so that the mapping kernel compares most postings without a third dependent load:
+    //   w0 node | strand << 31   w1 pos   w2 node length
+    //   A = the 40 bases LEFT of the seed, nearest first (A[i] = base pos - 1 - i), B = the 40 bases RIGHT of it, nearest
+    //   first; w3 = A[0..15], w4 = A[16..31], w5 = A[32..39] | B[0..7] << 16, w6 = B[8..23], w7 = B[24..39]
+    // Stored nearest-first on both sides, the flanks of the OTHER strand are the complements with the sides swapped (no
+    // reversal): left' = ~B, right' = ~A.  Bases beyond the node's ends are zero and never looked at (clipped by the
+    // node length).  NULL when the index was built without them.
+    const uint4 *postings32;
 };
+#define VS_FLANK 40u  // bases of node text a 32-byte posting holds on either side of its seed
 
 struct VsReadsDev {
     uint64_t n_ends;
@@ -113,6 +123,8 @@ struct VsTuning {
     int shortcut = -1;              // VS_SHORTCUT (-1 = by index statistics)
     bool no_sort = false, locus_global = false, no_xcd_map = false, no_fast = false, no_std = false, no_agg = false;
     bool acc_queue = true, acc_merge = false;
+    bool use_inline = false;        // VS_INLINE=1: 32-byte postings that hold the node text around the seed (k_pe_tiles<.., true>) --
+                                    // exact, but 7.2 ms against 5.8 ms at configs[2]: not the default
     bool walk = false;              // VS_WALK=1: certified graphs (vs_walk.h) through k_pe_walk instead of the seed kernels --
                                     // exact and tested, but slower on every bench config, hence not the default
     bool debug_postings = false, debug_occ = false, debug_acc = false;
@@ -133,7 +145,8 @@ struct vs_ctx {
     bool has_index = false;
     VsIndexDev idx{};
     // owned device allocations of the index
-    void *d_meta = nullptr, *d_fwd = nullptr, *d_rc = nullptr, *d_table = nullptr, *d_post = nullptr;
+    void *d_meta = nullptr, *d_fwd = nullptr, *d_rc = nullptr, *d_table = nullptr, *d_post = nullptr, *d_post32 = nullptr;
+    uint64_t n_long_flank = 0;  // postings with more than VS_FLANK bases of node text on some side of the seed
     uint64_t n_seed_pos = 0, n_slots = 0, n_distinct = 0, index_bytes = 0;
     uint32_t max_node_len = 0;
     // walk index (vs_walk.h): present when the node set passed the certification

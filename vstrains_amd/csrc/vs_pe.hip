@@ -411,11 +411,15 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
 #define STD_S 26u
 // MODE 0: generic loops (masked reads through the validity mask, any stride / read length);
 //      1: straight-line comparison, stride <= 32, reads <= w + 160; 2: the same for stride <= 128, reads <= w + 256.
-template <int MODE, uint32_t SW, uint32_t SP>
+// INL (MODE 1 only): multi-posting seeds are read as 32-byte records that hold the node text around the seed
+// (VsIndexDev::postings32): a posting whose match cannot leave those VS_FLANK bases is compared without touching the node
+// text -- one dependent load less, no alignment of the text side -- and only the others (long nodes) take the text.
+template <int MODE, uint32_t SW, uint32_t SP, bool INL = false>
 __global__ void __launch_bounds__(TTPB)
 __attribute__((amdgpu_waves_per_eu(MODE == 2 ? TILES_WAVES_LONG : TILES_WAVES, MODE == 2 ? TILES_WAVES_LONG : TILES_WAVES)))
 k_pe_tiles(PeParams P) {
     constexpr bool FAST = MODE != 0;
+    static_assert(!INL || MODE == 1, "inline flanks: straight-line kernel of k <= 85 only");
     constexpr uint32_t AB = MODE == 2 ? 9u : 8u;  // bits of the read offset packed under the node length (credit / P4)
     constexpr bool STD = SW != 0u;
     constexpr uint32_t STD_WPE = SW, STD_PMAX = SP;
@@ -703,6 +707,9 @@ k_pe_tiles(PeParams P) {
             bool live[PPT];
             uint32_t p_e[PPT], p_j[PPT], p_node[PPT], p_pos[PPT], p_opp[PPT];
             VsNodeMeta p_nm[PPT];
+            // INL: the flanks of the posting (A leftwards, B rightwards, nearest first), woff = ~0 marks "record with flanks"
+            uint64_t p_fa[INL ? PPT : 1u], p_fb[INL ? PPT : 1u];
+            uint32_t p_fa1[INL ? PPT : 1u], p_fb1[INL ? PPT : 1u];
 #pragma unroll
             for (uint32_t k2 = 0; k2 < PPT; k2++) {
                 const uint32_t t = c0 + tid * PPT + k2;
@@ -716,7 +723,16 @@ k_pe_tiles(PeParams P) {
                 p_j[k2] = pi * s;
                 uint32_t node = pa, pos = pb & 0x7FFFFFFFu, opp = pb >> 31;
                 p_nm[k2].woff = 0; p_nm[k2].len = 0;
-                if (live[k2] && cnt != 1u) {  // (the record carries the node header: no second round trip)
+                if (INL) { p_fa[k2] = 0ull; p_fb[k2] = 0ull; p_fa1[k2] = 0u; p_fb1[k2] = 0u; }
+                if (INL && live[k2] && cnt != 1u) {
+                    const uint4 h0 = P.idx.postings32[2u * (pa + (t - excl))], h1 = P.idx.postings32[2u * (pa + (t - excl)) + 1u];
+                    node = h0.x & 0x01FFFFFFu; pos = h0.y; opp = (h0.x >> 31) ^ (pb >> 31);
+                    p_nm[k2].woff = 0xFFFFFFFFu; p_nm[k2].len = h0.z;
+                    p_fa[k2] = (uint64_t)h0.w | ((uint64_t)h1.x << 32);
+                    p_fa1[k2] = h1.y & 0xFFFFu;
+                    p_fb[k2] = (uint64_t)(h1.y >> 16) | ((uint64_t)h1.z << 16) | ((uint64_t)(h1.w & 0xFFFFu) << 48);
+                    p_fb1[k2] = h1.w >> 16;
+                } else if (live[k2] && cnt != 1u) {  // (the record carries the node header: no second round trip)
                     const VsPosting po = vs_posting_unpack(P.idx.postings[pa + (t - excl)]);
                     node = po.node; pos = po.pos; opp = po.strand ^ (pb >> 31);
                     p_nm[k2].woff = po.woff; p_nm[k2].len = po.len;
@@ -740,12 +756,11 @@ k_pe_tiles(PeParams P) {
             for (uint32_t k2 = 0; k2 < PPT; k2++) {
                 if (!live[k2]) continue;
                 const uint32_t e = p_e[k2], j = p_j[k2], node = p_node[k2], opp = p_opp[k2];
-                const VsNodeMeta nm = p_nm[k2];
+                VsNodeMeta nm = p_nm[k2];
                 const uint32_t meta = s_meta[e];
                 const uint32_t rlen = meta & VS_LEN_MASK;
                 // either strand off the one (wave-uniform) text base: the reverse complements lie rc_delta words on
                 const uint32_t *tw = P.idx.fwd_words;
-                const uint32_t tb = (nm.woff + (opp ? P.idx.rc_delta : 0u)) * 16u;
                 const uint32_t q = opp ? nm.len - p_pos[k2] - w : p_pos[k2];
                 uint32_t a, qa, len;
                 if (FAST) {
@@ -757,14 +772,44 @@ k_pe_tiles(PeParams P) {
                     uint32_t rem = hi - j - wv;
                     const uint32_t dr = nm.len - q - wv;
                     rem = rem < dr ? rem : dr;
-                    uint32_t left, ext;
-                    if (MODE == 2) vs_agree_long(s_words, e * wpe * 16u, tw, tb + q, cl, tb + q + wv, rem, j, wv, &left, &ext);
+                    uint32_t left = 0u, ext = 0u;
+                    bool done = false;
+                    if (INL && nm.woff == 0xFFFFFFFFu) {
+                        if (rem <= VS_FLANK) {
+                            // the match cannot leave the text the record holds (cl <= s <= 32 on the left): on the read's
+                            // strand the flanks are A / B as stored, on the other one their complements with the sides swapped
+                            const uint64_t lf = opp ? ~p_fb[k2] : p_fa[k2], rf = opp ? ~p_fa[k2] : p_fb[k2];
+                            const uint32_t rf1 = (opp ? ~p_fa1[k2] : p_fb1[k2]) & 0xFFFFu;
+                            const uint32_t rbase = e * wpe * 16u;
+                            left = cl;
+                            if (cl) {  // the cl read bases before the seed, nearest first
+                                uint64_t x = __builtin_bitreverse64(vs_win(s_words, rbase + j - cl));
+                                x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+                                x = ((x >> (64u - 2u * cl)) ^ lf) & vs_lowmask(2u * cl);
+                                if (x) left = (uint32_t)(__ffsll((long long)x) - 1) >> 1;
+                            }
+                            const uint64_t x0 = vs_win(s_words, rbase + j + w) ^ rf;
+                            ext = x0 ? (uint32_t)(__ffsll((long long)x0) - 1) >> 1 : 32u;
+                            if (ext == 32u && rem > 32u) {
+                                const uint32_t x1 = ((uint32_t)vs_win(s_words, rbase + j + w + 32u) ^ rf1) & 0xFFFFu;
+                                ext = x1 ? 32u + ((uint32_t)(__ffs((int)x1) - 1) >> 1) : VS_FLANK;
+                            }
+                            ext = ext < rem ? ext : rem;
+                            done = true;
+                        } else {
+                            nm.woff = P.idx.meta[node].woff;  // a long node: its text after all
+                        }
+                    }
+                    const uint32_t tb = (nm.woff + (opp ? P.idx.rc_delta : 0u)) * 16u;
+                    if (done) {
+                    } else if (MODE == 2) vs_agree_long(s_words, e * wpe * 16u, tw, tb + q, cl, tb + q + wv, rem, j, wv, &left, &ext);
                     else vs_agree_fast<STD>(s_words, e * wpe * 16u, tw, tb + q, cl, tb + q + wv, rem, j, wv, &left, &ext);
                     len = left + wv + ext;
                     if (left >= s || len < K) continue;  // an earlier probe lies inside this match and owns it / too short
                     a = j - left;
                     qa = q - left;
                 } else {
+                    const uint32_t tb = (nm.woff + (opp ? P.idx.rc_delta : 0u)) * 16u;
                     const uint32_t *mk = ((meta >> 24) & VS_FLAG_INVALID) ? P.rd.mask : nullptr;
                     if (!vs_extend(s_words, e * wpe * 16u, rlen, tw, tb, nm.len, j, q, wv, s, K, mk, (uint64_t)s_gwoff[e] * 16u, &a, &qa, &len))
                         continue;
@@ -1601,7 +1646,15 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     // longer strides and reads (k = 127 with 2 x 250 bases): the straight-line kernel with more windows
     const bool fast_long = !fast && (!reads->d_mask || reads->d_inv4) && idx.s <= 128u && maxlen <= VS_SEED_VERIFIED(idx.w) + 256u &&
                            ctx->max_node_len < (1u << 23) && !tn.no_fast;
-    const void *tiles_fn = std_shape == 1   ? (const void *)k_pe_tiles<1, 10u, 5u>
+    // VS_INLINE=1 (experiment mode): 32-byte postings with the text around the seed, where most postings fit their flanks
+    // (graphs of short nodes).  Exact, but slower than the 16-byte records: a wavefront nearly always holds
+    // SOME posting that needs the node text after all, so it runs both comparisons.
+    const bool inl = fast && idx.postings32 && tn.use_inline && 2u * ctx->n_long_flank <= ctx->n_seed_pos;
+    const void *tiles_fn = inl && std_shape == 1   ? (const void *)k_pe_tiles<1, 10u, 5u, true>
+                           : inl && std_shape == 2 ? (const void *)k_pe_tiles<1, 8u, 4u, true>
+                           : inl && std_shape == 3 ? (const void *)k_pe_tiles<1, 7u, 3u, true>
+                           : inl && fast           ? (const void *)k_pe_tiles<1, 0u, 0u, true>
+                           : std_shape == 1 ? (const void *)k_pe_tiles<1, 10u, 5u>
                            : std_shape == 2 ? (const void *)k_pe_tiles<1, 8u, 4u>
                            : std_shape == 3 ? (const void *)k_pe_tiles<1, 7u, 3u>
                            : fast           ? (const void *)k_pe_tiles<1, 0u, 0u>
@@ -1685,13 +1738,25 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         int wrc = vs_walk_launch(ctx, W, (uint32_t)wgrid, st);
         if (wrc) return wrc;
     } else {
-    ctx->last_kernel = std_shape == 1   ? "k_pe_tiles<1, 10u, 5u>"
+    ctx->last_kernel = inl && std_shape == 1   ? "k_pe_tiles<1, 10u, 5u, true>"
+                       : inl && std_shape == 2 ? "k_pe_tiles<1, 8u, 4u, true>"
+                       : inl && std_shape == 3 ? "k_pe_tiles<1, 7u, 3u, true>"
+                       : inl && fast           ? "k_pe_tiles<1, 0u, 0u, true>"
+                       : std_shape == 1 ? "k_pe_tiles<1, 10u, 5u>"
                        : std_shape == 2 ? "k_pe_tiles<1, 8u, 4u>"
                        : std_shape == 3 ? "k_pe_tiles<1, 7u, 3u>"
                        : fast           ? "k_pe_tiles<1, 0u, 0u>"
                        : fast_long      ? "k_pe_tiles<2, 0u, 0u>"
                                         : "k_pe_tiles<0, 0u, 0u>";
-    if (std_shape == 1)
+    if (inl && std_shape == 1)
+        hipLaunchKernelGGL((k_pe_tiles<1, 10u, 5u, true>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
+    else if (inl && std_shape == 2)
+        hipLaunchKernelGGL((k_pe_tiles<1, 8u, 4u, true>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
+    else if (inl && std_shape == 3)
+        hipLaunchKernelGGL((k_pe_tiles<1, 7u, 3u, true>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
+    else if (inl && fast)
+        hipLaunchKernelGGL((k_pe_tiles<1, 0u, 0u, true>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
+    else if (std_shape == 1)
         hipLaunchKernelGGL((k_pe_tiles<1, 10u, 5u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
     else if (std_shape == 2)
         hipLaunchKernelGGL((k_pe_tiles<1, 8u, 4u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
