@@ -85,6 +85,8 @@ def main():
         if rng.random() < 0.3:
             env = dict([[("VS_NO_STD", "1")], [("VS_NO_FAST", "1")], [("VS_EPT", "6")], [("VS_ACC_WIDE", "2")], [("VS_ACC_MERGE", "1")],
                         [("VS_NO_SORT", "1")], [("VS_LOCUS_GLOBAL", "1")]][int(rng.integers(0, 7))])
+        if rng.random() < 0.15:
+            env["VS_NO_MID"] = "1"  # overflow pairs straight to the general kernel
         if rng.random() < 0.25:
             env["VS_INLINE"] = "1"  # 32-byte postings with inline flanks (k <= 85, graphs of short nodes)
         if os.environ.get("FUZZ_WALK") or rng.random() < 0.25:

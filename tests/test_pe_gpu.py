@@ -160,9 +160,12 @@ def _dense_case(k, n_pairs, read_len, seed, snp, n_strains=6, glen=1500, sub=0.0
     return g, f, r
 
 
-def test_overflow_pairs_take_slow_path_and_stay_exact(host, ctx):
+@pytest.mark.parametrize("no_mid", ["0", "1"])
+def test_overflow_pairs_take_slow_path_and_stay_exact(host, ctx, no_mid, monkeypatch):
     # dense variation at k=11: a 100-base read is accepted by more than 16 short nodes in ~30 % of
-    # the ends, which overflows the per-end list kept in LDS
+    # the ends, which overflows the per-end list kept in LDS: those pairs go to k_pe_mid (one wavefront per
+    # pair, state in LDS), or with VS_NO_MID=1 straight to the general kernel k_pe_slow
+    monkeypatch.setenv("VS_NO_MID", no_mid)
     g, f, r = _dense_case(11, 1500, 100, seed=301, snp=0.2)
     (node_mat, short_mat, stats), block = _gpu_matrices(host, ctx, g.seqs, f, r, 11)
     t = ctx.last_timing()
@@ -178,6 +181,38 @@ def test_overflow_pairs_take_slow_path_and_stay_exact(host, ctx):
             continue
         assert lists[2 * p] == orc.map_end(f[p])
         assert lists[2 * p + 1] == orc.map_end(r[p])
+
+
+def test_ends_with_a_hundred_nodes_pass_through_both_overflow_kernels(host, ctx):
+    """A chain of nodes that advance ONE base each (every node k + 1 bases long): a 120-base read is accepted by 100 nodes
+    -- beyond a list row (16) and beyond k_pe_mid's per-end list (64), so the pairs end in the general kernel; shorter reads
+    of the same block (50 bases: 30 nodes) stop at k_pe_mid; reads with many dirty bytes take the mask path in either."""
+    rng = np.random.default_rng(17)
+    k = 20
+    genome = "".join("ACGT"[i] for i in rng.integers(0, 4, size=700))
+    seqs = [genome[i: i + k + 1] for i in range(len(genome) - k)]
+    from vstrains_amd import synth
+
+    fwd, rve = [], []
+    for i in range(600):
+        L = 120 if i % 3 else 50
+        a = int(rng.integers(0, len(genome) - 300))
+        f_, r_ = genome[a: a + L], synth.revcomp(genome[a + 150: a + 150 + L])
+        if i % 7 == 0:  # six bytes outside ACGT: more than inv4 holds
+            for p_ in rng.choice(L, size=6, replace=False):
+                f_ = f_[: int(p_)] + "n" + f_[int(p_) + 1:]
+        fwd.append(f_)
+        rve.append(r_)
+    orc = pe_oracle_c.Oracle(seqs, k)
+    want = orc.count_pairs(fwd, rve)
+    (node_mat, short_mat, stats), block = _gpu_matrices(host, ctx, seqs, fwd, rve, k)
+    assert ctx.last_timing()["slow_pairs"] > 500
+    assert np.array_equal(node_mat, want[0]) and np.array_equal(short_mat, want[1])
+    assert stats == tuple(int(x) for x in want[2])
+    lists = ctx.map_ends(block, cap=len(seqs))
+    for p in range(0, len(fwd), 11):
+        assert lists[2 * p] == orc.map_end(fwd[p]) and lists[2 * p + 1] == orc.map_end(rve[p])
+    assert max(len(l) for l in lists) >= 100
 
 
 @pytest.mark.parametrize("k,read_len,n_pairs,snp", [(55, 150, 20000, 0.03), (127, 250, 6000, 0.02), (31, 100, 8000, 0.05), (32, 100, 8000, 0.05)])
@@ -361,8 +396,34 @@ def test_every_kernel_variant_gives_the_same_counters(host, ctx, env, monkeypatc
     assert np.array_equal(short_mat, want[1])
     assert stats == tuple(int(x) for x in want[2])
     assert ctx.last_kernel.startswith("k_pe_walk") == ("VS_WALK" in env), ctx.last_kernel
-    if "VS_INLINE" in env and "VS_WALK" not in env:
-        assert ctx.last_kernel.endswith("true>"), ctx.last_kernel  # (this graph's nodes are short: the 32-byte records are taken)
+
+
+def test_inline_flank_postings_on_a_graph_of_short_nodes(host, ctx, monkeypatch):
+    """VS_INLINE=1: 32-byte postings that hold 40 bases of node text on either side of the seed
+    (k_pe_tiles<1, .., true>), taken where at least half of the postings fit those flanks -- a dense graph of
+    many strains; postings of longer nodes in the same graph still go to the text.  Same counters as the oracle,
+    with ragged and dirty reads, in the compile-time tile shape and in the run-time one."""
+    from vstrains_amd import synth
+
+    st = synth.make_strains(30, 3000, 0.085, seed=77)  # (2 587 nodes, median 64 bases: 31 % of the postings have a long flank)
+    g = synth.compact_dbg(st, 55)
+    fwd, rve = synth.sample_pairs(st, 9000, 150, seed=78, sub_rate=0.01, n_rate=0.01)
+    rng = np.random.default_rng(79)
+    for lst in (fwd, rve):
+        for i in rng.choice(len(lst), size=300, replace=False):
+            s_ = lst[int(i)]
+            p_ = int(rng.integers(0, len(s_)))
+            lst[int(i)] = s_[:p_] + str(rng.choice(list("nRYacgt*"))) + s_[p_ + 1:]
+    want = pe_oracle_c.Oracle(g.seqs, 55).count_pairs(fwd, rve)
+    monkeypatch.setenv("VS_INLINE", "1")
+    for no_std, ragged in (("0", False), ("1", True)):
+        monkeypatch.setenv("VS_NO_STD", no_std)
+        f2 = [s_[: int(rng.integers(60, 151))] for s_ in fwd] if ragged else fwd
+        w2 = pe_oracle_c.Oracle(g.seqs, 55).count_pairs(f2, rve) if ragged else want
+        (node_mat, short_mat, stats), _ = _gpu_matrices(host, ctx, g.seqs, f2, rve, 55)
+        assert ctx.last_kernel.endswith("true>"), ctx.last_kernel
+        assert np.array_equal(node_mat, w2[0]) and np.array_equal(short_mat, w2[1])
+        assert stats == tuple(int(x) for x in w2[2])
 
 
 def test_switches_do_not_exist_outside_experiment_mode(tmp_path):

@@ -40,6 +40,7 @@ void vs_tuning_load(VsTuning &t, int level) {
     t.no_agg = env_on("VS_NO_AGG");
     t.walk = env_on("VS_WALK");
     t.use_inline = env_on("VS_INLINE");
+    t.no_mid = env_on("VS_NO_MID");
     if (const char *v = getenv("VS_ACC_QUEUE")) t.acc_queue = atoi(v) != 0;
     t.acc_merge = env_on("VS_ACC_MERGE");
     t.debug_postings = getenv("VS_DEBUG_POSTINGS") != nullptr;
@@ -142,6 +143,7 @@ void vs_ctx_destroy(vs_ctx *ctx) {
     free_index(ctx);
     if (ctx->d_slow_list) (void)hipFree(ctx->d_slow_list);
     if (ctx->d_slow_count) (void)hipFree(ctx->d_slow_count);
+    if (ctx->d_slow_list2) (void)hipFree(ctx->d_slow_list2);
     if (ctx->d_dense) (void)hipFree(ctx->d_dense);
     for (void *q : {ctx->d_locus_keys, ctx->d_perm, ctx->d_locus_hist, ctx->d_scan_tmp, ctx->d_lists, ctx->d_list_counts})
         if (q) (void)hipFree(q);

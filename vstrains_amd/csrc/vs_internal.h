@@ -123,6 +123,7 @@ struct VsTuning {
     int shortcut = -1;              // VS_SHORTCUT (-1 = by index statistics)
     bool no_sort = false, locus_global = false, no_xcd_map = false, no_fast = false, no_std = false, no_agg = false;
     bool acc_queue = true, acc_merge = false;
+    bool no_mid = false;            // VS_NO_MID: overflow pairs straight to k_pe_slow
     bool use_inline = false;        // VS_INLINE=1: 32-byte postings that hold the node text around the seed (k_pe_tiles<.., true>) --
                                     // exact, but 7.2 ms against 5.8 ms at configs[2]: not the default
     bool walk = false;              // VS_WALK=1: certified graphs (vs_walk.h) through k_pe_walk instead of the seed kernels --
@@ -158,7 +159,9 @@ struct vs_ctx {
     // scratch for vs_pe_count
     void *d_slow_list = nullptr;   // pair indices sent to the slow path
     uint64_t slow_cap = 0;
-    void *d_slow_count = nullptr;  // uint32 counter
+    void *d_slow_count = nullptr;  // uint32 counters (see pe_launch)
+    void *d_slow_list2 = nullptr;  // pairs k_pe_mid hands on to k_pe_slow
+    uint64_t slow2_cap = 0;
     void *d_dense = nullptr;       // dense per-workgroup state for the slow path
     uint64_t dense_bytes = 0;
     uint32_t dense_nodes = 0xFFFFFFFFu;  // node count the dense layout was initialised for

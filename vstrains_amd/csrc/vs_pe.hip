@@ -1281,37 +1281,48 @@ __device__ __forceinline__ uint32_t vs_locus_key(const VsIndexDev &idx, const Vs
 //                     (key, workgroup) run in the sorted order -- stable, deterministic
 //   k_locus_scatter : workgroup g loads its column as LDS cursors and places its pairs
 #define LOCUS_LDS_KEYS 36864u  // 144 KB of LDS counters
+#define LOCUS_LDS_MAX_PASSES 4u  // ... per pass; graphs of up to 147 k nodes are sorted through LDS histograms
 #ifndef LOCUS_TPB
 #define LOCUS_TPB 1024     // threads per workgroup of the two LDS-histogram sort kernels
 #endif
 #ifndef LOCUS_WGS
 #define LOCUS_WGS 256u       // one per CU (measured: 1024 x 256 threads 0.70 ms, 256 x 1024 threads 0.57 ms)
 #endif
+// (key_lo, nk): the keys this pass counts / places -- a graph with more keys than one LDS histogram holds (54 k nodes at
+// configs[4]) takes two or three passes over the stored keys instead of the global-atomic sort; `compute`: the first
+// pass derives the keys (the expensive part: a read's seeds are probed) and stores them, the others read them back.
 __global__ void __launch_bounds__(LOCUS_TPB)
 k_locus_count(VsIndexDev idx, VsReadsDev rd, uint64_t n_pairs, uint32_t chunk, uint32_t n_wg, uint32_t *__restrict__ keys,
-              uint32_t *__restrict__ cnt) {
-    const uint32_t nk = idx.n_nodes + 2u;
+              uint32_t *__restrict__ cnt, uint32_t key_lo, uint32_t nk, uint32_t compute) {
     for (uint32_t i = threadIdx.x; i < nk; i += LOCUS_TPB) vs_lds[i] = 0;
     __syncthreads();
     const uint64_t lo = (uint64_t)blockIdx.x * chunk;
     const uint64_t hi = lo + chunk < n_pairs ? lo + chunk : n_pairs;
     for (uint64_t p = lo + threadIdx.x; p < hi; p += LOCUS_TPB) {
-        const uint32_t key = vs_locus_key(idx, rd, p);
-        keys[p] = key;
-        atomicAdd(&vs_lds[key], 1u);
+        uint32_t key;
+        if (compute) {
+            key = vs_locus_key(idx, rd, p);
+            keys[p] = key;
+        } else {
+            key = keys[p];
+        }
+        if (key - key_lo < nk) atomicAdd(&vs_lds[key - key_lo], 1u);
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nk; i += LOCUS_TPB) cnt[(uint64_t)i * n_wg + blockIdx.x] = vs_lds[i];
+    for (uint32_t i = threadIdx.x; i < nk; i += LOCUS_TPB) cnt[(uint64_t)(key_lo + i) * n_wg + blockIdx.x] = vs_lds[i];
 }
 
 __global__ void __launch_bounds__(LOCUS_TPB)
-k_locus_scatter(uint32_t nk, uint64_t n_pairs, uint32_t chunk, uint32_t n_wg, const uint32_t *__restrict__ keys,
+k_locus_scatter(uint32_t key_lo, uint32_t nk, uint64_t n_pairs, uint32_t chunk, uint32_t n_wg, const uint32_t *__restrict__ keys,
                 const uint32_t *__restrict__ first, uint32_t *__restrict__ perm) {
-    for (uint32_t i = threadIdx.x; i < nk; i += LOCUS_TPB) vs_lds[i] = first[(uint64_t)i * n_wg + blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < nk; i += LOCUS_TPB) vs_lds[i] = first[(uint64_t)(key_lo + i) * n_wg + blockIdx.x];
     __syncthreads();
     const uint64_t lo = (uint64_t)blockIdx.x * chunk;
     const uint64_t hi = lo + chunk < n_pairs ? lo + chunk : n_pairs;
-    for (uint64_t p = lo + threadIdx.x; p < hi; p += LOCUS_TPB) perm[atomicAdd(&vs_lds[keys[p]], 1u)] = (uint32_t)p;
+    for (uint64_t p = lo + threadIdx.x; p < hi; p += LOCUS_TPB) {
+        const uint32_t key = keys[p];
+        if (key - key_lo < nk) perm[atomicAdd(&vs_lds[key - key_lo], 1u)] = (uint32_t)p;
+    }
 }
 
 // Fallback for graphs with more nodes than the LDS histogram holds: global atomics.
@@ -1331,6 +1342,149 @@ k_pe_permute(uint64_t n_pairs, const uint32_t *__restrict__ keys, uint32_t *__re
     perm[atomicAdd(&cursor[keys[p]], 1u)] = (uint32_t)p;
 }
 
+// ---- overflow path, first stop: one WAVEFRONT per listed pair ------------------------------------------------------------
+// Pairs the tile kernels hand over -- an end with more accepted nodes than a list row holds (3 % of the pairs at configs[4]),
+// a full tile table, an end with more bytes outside ACGT than inv4 holds -- are mapped here the general way (every probe,
+// every posting, vs_extend with the validity mask), but with the per-end (node -> count, min offset, min window) state in an
+// LDS hash table of the wavefront instead of the dense per-workgroup node state of k_pe_slow, four pairs per workgroup at a
+// time and no workgroup barrier: 8 192 pairs in flight on the chip.  Its own limits (MID_SLOTS touched nodes, MID_LIST
+// accepted nodes per end, 64 probes per end) send what is left to k_pe_slow, which has none.
+#define MID_SLOTS 256u
+#define MID_LIST 64u
+#define MID_WORDS (4u * MID_SLOTS + 3u * 64u + 65u + 2u * MID_LIST + 4u)
+__device__ __forceinline__ void vs_wave_sync() {  // LDS written by this wavefront is visible to all of its lanes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__global__ void __launch_bounds__(TPB)
+k_pe_mid(PeParams P, const uint32_t *__restrict__ in_list, const uint32_t *__restrict__ in_count, uint32_t in_cap,
+         uint32_t *__restrict__ out_list, uint32_t *__restrict__ out_count) {
+    __shared__ uint32_t s_all[(TPB / 64u) * MID_WORDS];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t *s_key = s_all + wv * MID_WORDS, *s_cnt = s_key + MID_SLOTS, *s_minp = s_cnt + MID_SLOTS, *s_minj = s_minp + MID_SLOTS;
+    uint32_t *s_pa = s_minj + MID_SLOTS, *s_pb = s_pa + 64u, *s_pc = s_pb + 64u, *s_pref = s_pc + 64u;  // s_pref[65]
+    uint32_t *s_lst = s_pref + 65u;  // [2][MID_LIST] accepted nodes of the two ends
+    uint32_t *s_flag = s_lst + 2u * MID_LIST;  // [0] overflow, [1..2] list lengths
+    const uint32_t N = P.idx.n_nodes, w = P.idx.w, s = P.idx.s, K = P.idx.K, wv_seed = VS_SEED_VERIFIED(P.idx.w);
+    uint32_t n_in = *in_count;
+    if (n_in > in_cap) n_in = in_cap;
+    const uint32_t n_waves = gridDim.x * (TPB / 64u);
+    for (uint32_t li = blockIdx.x * (TPB / 64u) + wv; li < n_in; li += n_waves) {
+        const uint32_t pair = in_list[li];
+        if (lane < 4u) s_flag[lane] = 0u;
+        vs_wave_sync();
+        for (uint32_t side = 0; side < 2u; side++) {
+            const uint64_t e = 2ull * pair + side;
+            const uint32_t meta = P.rd.meta[e];
+            const uint32_t rlen = meta & VS_LEN_MASK;
+            const uint64_t rbase = (uint64_t)P.rd.woff[e] * 16u;
+            const uint32_t *mk = ((meta >> 24) & VS_FLAG_INVALID) ? P.rd.mask : nullptr;
+            const uint32_t nprobe = rlen >= w ? (rlen - w) / s + 1u : 0u;
+            for (uint32_t i = lane; i < MID_SLOTS; i += 64u) { s_key[i] = EMPTY_NODE; s_cnt[i] = 0u; s_minp[i] = 0xFFFFFFFFu; s_minj[i] = 0xFFFFFFFFu; }
+            if (nprobe > 64u) { if (lane == 0u) s_flag[0] = 1u; }
+            // probes: one per lane
+            uint32_t c = 0u, pa = 0u, pb = 0u;
+            if (lane < nprobe && nprobe <= 64u) {
+                const uint32_t j = lane * s;
+                if (!(mk && vs_seed_dirty(mk, rbase + j, w))) {
+                    uint32_t sr;
+                    const uint64_t key = vs_seed_key(P.rd.words, rbase + j, w, &sr);
+                    c = vs_probe(P.idx, key, sr, &pa, &pb);
+                }
+            }
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t2 = __shfl_up(incl, d, 64);
+                if (lane >= (uint32_t)d) incl += t2;
+            }
+            s_pa[lane] = pa; s_pb[lane] = pb; s_pc[lane] = c;
+            s_pref[lane + 1u] = incl;
+            if (lane == 0u) s_pref[0] = 0u;
+            vs_wave_sync();
+            const uint32_t total = s_pref[64];
+            for (uint32_t t = lane; t < total; t += 64u) {
+                const uint32_t pr = vs_upper_idx(s_pref, 65u, t);
+                const uint32_t k2 = t - s_pref[pr], j = pr * s;
+                uint32_t node, pos, opp;
+                VsNodeMeta nm;
+                if (s_pc[pr] == 1u) {
+                    node = s_pa[pr]; pos = s_pb[pr] & 0x7FFFFFFFu; opp = s_pb[pr] >> 31;
+                    nm = P.idx.meta[node];
+                } else {
+                    const VsPosting po = vs_posting_unpack(P.idx.postings[s_pa[pr] + k2]);
+                    node = po.node; pos = po.pos; opp = po.strand ^ (s_pb[pr] >> 31);
+                    nm.woff = po.woff; nm.len = po.len;
+                }
+                const uint32_t *tw = opp ? P.idx.rc_words : P.idx.fwd_words;
+                const uint32_t q = opp ? nm.len - pos - w : pos;
+                uint32_t a, qa, len;
+                if (!vs_extend(P.rd.words, rbase, rlen, tw, nm.woff * 16u, nm.len, j, q, wv_seed, s, K, mk, rbase, &a, &qa, &len)) continue;
+                uint32_t at = (node * 0x9E3779B1u) >> 24;  // MID_SLOTS = 256
+                bool placed = false;
+                for (uint32_t tr = 0; tr < MID_SLOTS; tr++) {
+                    const uint32_t old = atomicCAS(&s_key[at], EMPTY_NODE, node);
+                    if (old == EMPTY_NODE || old == node) {
+                        atomicAdd(&s_cnt[at], len - K + 1u);
+                        atomicMin(&s_minp[at], opp ? nm.len - qa - len : qa);
+                        atomicMin(&s_minj[at], a);
+                        placed = true;
+                        break;
+                    }
+                    at = (at + 1u) & (MID_SLOTS - 1u);
+                }
+                if (!placed) s_flag[0] = 1u;
+            }
+            vs_wave_sync();
+            // acceptance test per occupied slot; accepted nodes to the end's list (ballot + prefix count)
+            uint32_t base = 0u;
+            for (uint32_t i0 = 0; i0 < MID_SLOTS; i0 += 64u) {
+                const uint32_t i = i0 + lane;
+                const uint32_t node = s_key[i];
+                bool acc = false;
+                if (node != EMPTY_NODE) acc = vs_accept(s_cnt[i], s_minp[i], s_minj[i], P.idx.meta[node].len, rlen, K);
+                const unsigned long long mask = __ballot(acc);
+                const uint32_t at = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                if (acc) {
+                    if (at < MID_LIST) s_lst[side * MID_LIST + at] = node; else s_flag[0] = 1u;
+                }
+                base += (uint32_t)__popcll(mask);
+            }
+            if (lane == 0u) s_flag[1u + side] = base;
+            vs_wave_sync();
+        }
+        if (s_flag[0]) {  // beyond this kernel's tables: the general kernel
+            if (lane == 0u) out_list[atomicAdd(out_count, 1u)] = pair;
+            vs_wave_sync();
+            continue;
+        }
+        const uint32_t nl = s_flag[1], nr = s_flag[2];
+        const uint32_t *L = s_lst, *R = s_lst + MID_LIST;
+        if (P.accumulate) {  // PE_Inference.py:174-188
+            for (uint32_t i = lane; i < nl * nr; i += 64u) atomicAdd(&P.node_mat[(uint64_t)L[i / nr] * N + R[i % nr]], 1u);
+            for (uint32_t side = 0; side < 2u; side++) {
+                const uint32_t *sv = side ? R : L;
+                const uint32_t n = side ? nr : nl;
+                for (uint32_t i = lane; i < n * n; i += 64u) {
+                    const uint32_t a = i / n, b = i % n, x = sv[a], y = sv[b];
+                    if (x < y || a == b) atomicAdd(&P.short_mat[(uint64_t)x * N + y], 1u);
+                }
+            }
+        }
+        if (P.dbg_counts) {
+            for (uint32_t side = 0; side < 2u; side++) {
+                const uint32_t *sv = side ? R : L;
+                const uint32_t n = side ? nr : nl;
+                const uint64_t e = 2ull * pair + side;
+                if (lane == 0u) P.dbg_counts[e] = n;
+                for (uint32_t i = lane; i < n && i < P.dbg_cap; i += 64u) P.dbg_lists[e * P.dbg_cap + i] = sv[i];
+            }
+        }
+        vs_wave_sync();
+    }
+}
+
 // ---- overflow path: any number of nodes per end, any read ------------------------------------------
 // One workgroup per listed pair (ends with more accepted nodes than an LDS row holds, ends with many
 // bytes outside ACGT, seeds with a huge posting list).  Node state is dense in HBM per workgroup --
@@ -1341,16 +1495,16 @@ k_pe_permute(uint64_t n_pairs, const uint32_t *__restrict__ keys, uint32_t *__re
 // dense layout per workgroup: cnt[N] minp[N] minj[N] touched[N] surv0[N] surv1[N].
 #define SLOW_WORDS_PER_NODE 6u
 __global__ void __launch_bounds__(TPB)
-k_pe_slow(PeParams P, uint32_t *dense, uint32_t n_slow_cap) {
+k_pe_slow(PeParams P, uint32_t *dense, uint32_t n_slow_cap, const uint32_t *__restrict__ list, const uint32_t *__restrict__ count) {
     __shared__ uint32_t s_n[2], s_nt, s_cnt[TPB + 1], s_pa[TPB], s_pb[TPB];
     const uint32_t tid = threadIdx.x;
     const uint32_t N = P.idx.n_nodes, w = P.idx.w, s = P.idx.s, K = P.idx.K;
-    uint32_t n_slow = *P.slow_count;
+    uint32_t n_slow = *count;
     if (n_slow > n_slow_cap) n_slow = n_slow_cap;
     uint32_t *cnt = dense + (uint64_t)blockIdx.x * SLOW_WORDS_PER_NODE * N;
     uint32_t *minp = cnt + N, *minj = minp + N, *touched = minj + N, *surv0 = touched + N, *surv1 = surv0 + N;
     for (uint32_t li = blockIdx.x; li < n_slow; li += gridDim.x) {
-        const uint32_t pair = P.slow_list[li];
+        const uint32_t pair = list[li];
         if (tid < 2) s_n[tid] = 0;
         for (uint32_t side = 0; side < 2; side++) {
             const uint64_t e = 2ull * pair + side;
@@ -1539,7 +1693,14 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         VS_HIP(ctx, hipMalloc(&ctx->d_slow_list, sizeof(uint32_t) * n_pairs));
         ctx->slow_cap = n_pairs;
     }
-    if (!ctx->d_slow_count) VS_HIP(ctx, hipMalloc(&ctx->d_slow_count, 32));
+    if (!ctx->d_slow_count) VS_HIP(ctx, hipMalloc(&ctx->d_slow_count, 64));  // [0] pairs for k_pe_mid, [1] queue, [2..3] postings, [4..7] acc, [8] pairs for k_pe_slow
+    if (ctx->slow2_cap < n_pairs) {
+        if (ctx->d_slow_list2) VS_HIP(ctx, hipFree(ctx->d_slow_list2));
+        ctx->d_slow_list2 = nullptr;
+        ctx->slow2_cap = 0;
+        VS_HIP(ctx, hipMalloc(&ctx->d_slow_list2, sizeof(uint32_t) * n_pairs));
+        ctx->slow2_cap = n_pairs;
+    }
     const uint32_t SLOW_GRID = slow_grid_for(idx.n_nodes);
     uint64_t need_dense = sizeof(uint32_t) * (uint64_t)SLOW_WORDS_PER_NODE * (idx.n_nodes ? idx.n_nodes : 1) * SLOW_GRID;
     if (ctx->dense_bytes < need_dense || ctx->dense_nodes != idx.n_nodes) {
@@ -1555,7 +1716,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         hipLaunchKernelGGL(k_dense_zero_cnt, dim3((unsigned)((N * SLOW_GRID + TPB - 1) / TPB)), dim3(TPB), 0, st,
                            (uint32_t *)ctx->d_dense, N, (uint64_t)SLOW_GRID);
     }
-    VS_HIP(ctx, hipMemsetAsync(ctx->d_slow_count, 0, 32, st));
+    VS_HIP(ctx, hipMemsetAsync(ctx->d_slow_count, 0, 64, st));
 
     // locus order of the pairs (see k_pe_locus); VS_NO_SORT=1 keeps the input order
     const bool use_sort = !tn.no_sort && n_pairs >= 4096 && n_pairs < 0xFFFFFFF0ull;
@@ -1570,7 +1731,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
             VS_HIP(ctx, hipMalloc(&ctx->d_perm, sizeof(uint32_t) * n_pairs));
             ctx->locus_cap = n_pairs;
         }
-        const uint64_t hist_words = nk <= LOCUS_LDS_KEYS ? nk * LOCUS_WGS : nk;
+        const uint64_t hist_words = nk <= LOCUS_LDS_MAX_PASSES * LOCUS_LDS_KEYS ? nk * LOCUS_WGS : nk;
         if (ctx->hist_cap < hist_words) {
             if (ctx->d_locus_hist) VS_HIP(ctx, hipFree(ctx->d_locus_hist));
             if (ctx->d_scan_tmp) VS_HIP(ctx, hipFree(ctx->d_scan_tmp));
@@ -1678,22 +1839,29 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     VS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
     if (use_sort) {
         const uint64_t nk = (uint64_t)idx.n_nodes + 2u;
-        const bool lds_sort = nk <= LOCUS_LDS_KEYS && !tn.locus_global;
+        const bool lds_sort = nk <= LOCUS_LDS_MAX_PASSES * LOCUS_LDS_KEYS && !tn.locus_global;
         if (lds_sort) {
             const uint32_t n_wg = LOCUS_WGS;
             const uint32_t chunk = (uint32_t)((n_pairs + n_wg - 1) / n_wg);
-            const size_t lds_keys = sizeof(uint32_t) * nk;
+            const uint32_t per_pass = (uint32_t)(nk < LOCUS_LDS_KEYS ? nk : LOCUS_LDS_KEYS);
+            const size_t lds_keys = sizeof(uint32_t) * per_pass;
             if (lds_keys > 64u * 1024u) {
                 VS_HIP(ctx, hipFuncSetAttribute((const void *)k_locus_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_keys));
                 VS_HIP(ctx, hipFuncSetAttribute((const void *)k_locus_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_keys));
             }
-            hipLaunchKernelGGL(k_locus_count, dim3(n_wg), dim3(LOCUS_TPB), lds_keys, st, idx, reads->dev(), n_pairs, chunk, n_wg,
-                               (uint32_t *)ctx->d_locus_keys, (uint32_t *)ctx->d_locus_hist);
+            for (uint32_t key_lo = 0; key_lo < nk; key_lo += per_pass) {
+                const uint32_t n_here = (uint32_t)(nk - key_lo < per_pass ? nk - key_lo : per_pass);
+                hipLaunchKernelGGL(k_locus_count, dim3(n_wg), dim3(LOCUS_TPB), lds_keys, st, idx, reads->dev(), n_pairs, chunk, n_wg,
+                                   (uint32_t *)ctx->d_locus_keys, (uint32_t *)ctx->d_locus_hist, key_lo, n_here, key_lo == 0u ? 1u : 0u);
+            }
             int rc = vs_scan_u32(ctx, (const uint32_t *)ctx->d_locus_hist, (uint32_t *)ctx->d_locus_hist, nk * n_wg,
                                  (uint64_t *)ctx->d_scan_tmp, nullptr);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_locus_scatter, dim3(n_wg), dim3(LOCUS_TPB), lds_keys, st, (uint32_t)nk, n_pairs, chunk, n_wg,
-                               (const uint32_t *)ctx->d_locus_keys, (const uint32_t *)ctx->d_locus_hist, (uint32_t *)ctx->d_perm);
+            for (uint32_t key_lo = 0; key_lo < nk; key_lo += per_pass) {
+                const uint32_t n_here = (uint32_t)(nk - key_lo < per_pass ? nk - key_lo : per_pass);
+                hipLaunchKernelGGL(k_locus_scatter, dim3(n_wg), dim3(LOCUS_TPB), lds_keys, st, key_lo, n_here, n_pairs, chunk, n_wg,
+                                   (const uint32_t *)ctx->d_locus_keys, (const uint32_t *)ctx->d_locus_hist, (uint32_t *)ctx->d_perm);
+            }
         } else {
             VS_HIP(ctx, hipMemsetAsync(ctx->d_locus_hist, 0, sizeof(uint32_t) * nk, st));
             const unsigned pg = (unsigned)((n_pairs + TPB - 1) / TPB);
@@ -1808,7 +1976,8 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         // list).  Exact and tested, but off by default: it removes 47 % of the increments at configs[2] and
         // the kernel takes the same 3.2 ms -- the cell table is not what the time goes into there -- while it
         // costs 8-20 % on graphs with short lists (configs[1], [3]) and gains 10 % at configs[4].
-        const uint32_t merge = tn.acc_merge ? 1u : 0u;
+        // (the split-table shape -- 46 k to 65 k nodes, configs[4] -- gains 4 % from merging equal end lists: 52.5 -> 50.5 ms)
+        const uint32_t merge = (tn.acc_merge || shape == 1) ? 1u : 0u;
         uint32_t *acc_dbg = tn.debug_acc ? (uint32_t *)ctx->d_slow_count + 4 : nullptr;
         VS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
         const void *acc_fn = shape == 2 ? (const void *)k_pe_accumulate<Acc64> : shape == 1 ? (const void *)k_pe_accumulate<Acc32Split>
@@ -1824,7 +1993,16 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
 #undef VS_ACC_LAUNCH
     }
     VS_HIP(ctx, hipEventRecord(ctx->ev[1], st));
-    hipLaunchKernelGGL(k_pe_slow, dim3(SLOW_GRID), dim3(TPB), 0, st, P, (uint32_t *)ctx->d_dense, (uint32_t)n_pairs);
+    // overflow pairs: one wavefront per pair with its state in LDS first, the general kernel for what that cannot hold
+    if (!tn.no_mid) {
+        hipLaunchKernelGGL(k_pe_mid, dim3((unsigned)ctx->n_cu * 8u), dim3(TPB), 0, st, P, (const uint32_t *)ctx->d_slow_list,
+                           (const uint32_t *)ctx->d_slow_count, (uint32_t)n_pairs, (uint32_t *)ctx->d_slow_list2, (uint32_t *)ctx->d_slow_count + 8);
+        hipLaunchKernelGGL(k_pe_slow, dim3(SLOW_GRID), dim3(TPB), 0, st, P, (uint32_t *)ctx->d_dense, (uint32_t)n_pairs,
+                           (const uint32_t *)ctx->d_slow_list2, (const uint32_t *)ctx->d_slow_count + 8);
+    } else {
+        hipLaunchKernelGGL(k_pe_slow, dim3(SLOW_GRID), dim3(TPB), 0, st, P, (uint32_t *)ctx->d_dense, (uint32_t)n_pairs,
+                           (const uint32_t *)ctx->d_slow_list, (const uint32_t *)ctx->d_slow_count);
+    }
     VS_HIP(ctx, hipEventRecord(ctx->ev[2], st));
     VS_HIP(ctx, hipGetLastError());
     return VS_OK;
