@@ -181,3 +181,21 @@ def test_hip_path_reproduces_the_files_of_the_real_reference_script(host, ctx, t
         host.write_matrix_text(path, ids, mat)
         assert os.path.getsize(path) == want[name + "_bytes"]
         assert sha(path) == want[name + "_sha256"], name
+
+
+def test_second_sort_key_with_loci_longer_than_its_workgroup_buffer(host, ctx, tmp_path, monkeypatch):
+    """VS_REFINE=1 (the default for graphs beyond 46 k nodes: inside a forward-read locus the pairs are ordered by the
+    reverse read's locus, one workgroup per locus with a bitonic sort in LDS) on configs[0]'s 216-node graph with 1.2 M
+    pairs: most loci hold more pairs than the 4 096 the workgroup buffer takes and stay in first-key order, the others are
+    re-ordered -- the counters equal the oracle's either way (any order gives the same sums)."""
+    from vstrains_amd.workloads import CONFIGS, workload_for
+
+    cfg = CONFIGS[0]
+    st, pre, names, seqs, cum, logger, n_in = workload_for(0, str(tmp_path))
+    ctx.build_index(seqs, cfg["k"])
+    L, seed, R = cfg["read_len"], 5151, 1_200_000
+    sub, nth = int(0.005 * 2 ** 32), int(0.001 * 2 ** 32)
+    monkeypatch.setenv("VS_REFINE", "1")
+    refined = _count(host, ctx, st, cum, seed, L, [(0, R)], sub, nth)
+    orc = pe_oracle_c.Oracle(seqs, cfg["k"])
+    _assert_equals_oracle(refined, orc, st, cum, seed, L, R, sub, nth)

@@ -374,6 +374,7 @@ def test_device_read_generator_equals_cpu_twin(host, ctx):
     {"VS_ACC_QUEUE": "0"}, {"VS_ACC_GRID_PER_CU": "1", "VS_ACC_QUEUE": "0"}, {"VS_NO_XCD_MAP": "1"}, {"VS_GRID_PER_CU": "8"}, {"VS_NO_STD": "1"}, {"VS_SHORTCUT": "1"}, {"VS_SHORTCUT": "0"},
     {"VS_ACC_MERGE": "1"}, {"VS_ACC_MERGE": "1", "VS_NO_AGG": "1"}, {"VS_ACC_MERGE": "1", "VS_ACC_WIDE": "1", "VS_ACC_FILL": "1"},
     {"VS_ACC_WIDE": "2"}, {"VS_ACC_WIDE": "2", "VS_ACC_FILL": "1"}, {"VS_ACC_WIDE": "2", "VS_ACC_FILL": "100", "VS_ACC_MERGE": "1"},
+    {"VS_REFINE": "1"}, {"VS_REFINE": "1", "VS_EPT": "32", "VS_ACC_WIDE": "2"}, {"VS_NO_MID": "1"},
     {"VS_INLINE": "1"}, {"VS_INLINE": "1", "VS_NO_STD": "1"}, {"VS_WALK": "1"}, {"VS_WALK": "1", "VS_NO_SORT": "1"}, {"VS_WALK": "1", "VS_NO_XCD_MAP": "1", "VS_GRID_PER_CU": "1"}, {"VS_WALK": "1", "VS_ACC_WIDE": "2"},
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_every_kernel_variant_gives_the_same_counters(host, ctx, env, monkeypatch):

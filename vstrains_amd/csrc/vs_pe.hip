@@ -1274,6 +1274,61 @@ __device__ __forceinline__ uint32_t vs_locus_key(const VsIndexDev &idx, const Vs
     return N;
 }
 
+// The first node a seed of read end e hits (N = none): the locus of that end.
+__device__ __forceinline__ uint32_t vs_locus_key_end(const VsIndexDev &idx, const VsReadsDev &rd, uint64_t e) {
+    const uint32_t m = rd.meta[e];
+    const uint32_t N = idx.n_nodes, w = idx.w, s = idx.s, rlen = m & VS_LEN_MASK;
+    const uint64_t base = (uint64_t)rd.woff[e] * 16u;
+    const bool inv = (m >> 24) & VS_FLAG_INVALID;
+    for (uint32_t j = 0; j + w <= rlen; j += s) {
+        if (inv && vs_seed_dirty(rd.mask, base + j, w)) continue;
+        uint32_t pa, pb, sr;
+        const uint64_t key = vs_seed_key(rd.words, base + j, w, &sr);
+        const uint32_t c = vs_probe(idx, key, sr, &pa, &pb);
+        if (c) return c == 1u ? pa : (idx.postings[pa].x & 0x01FFFFFFu);
+    }
+    return N;
+}
+
+// Second sort key (large graphs): inside the run of pairs that share the forward read's locus, order by the REVERSE read's
+// locus.  Pairs that are neighbours in that order come from the same strain and insert size far more often, hit the same
+// counter cells, and the cell table of k_pe_accumulate sums them before they become global atomics.  One workgroup per
+// locus: its pairs and their second keys go to LDS, a bitonic sort orders them, the run of `perm` is rewritten in place
+// (runs longer than REFINE_CAP stay as they are).  Any order gives the same counters.
+#define REFINE_CAP 4096u
+__global__ void __launch_bounds__(TPB)
+k_locus_refine(VsIndexDev idx, VsReadsDev rd, uint32_t n_wg, uint64_t n_pairs, const uint32_t *__restrict__ first, uint32_t *__restrict__ perm) {
+    __shared__ unsigned long long s_kv[REFINE_CAP];
+    const uint32_t key = blockIdx.x;  // 0 .. N-1 (the runs of unmapped / dropped pairs are left alone)
+    const uint64_t lo = first[(uint64_t)key * n_wg];
+    const uint64_t hi = first[(uint64_t)(key + 1u) * n_wg];  // (key + 1 <= N: the table holds N + 2 keys)
+    const uint32_t n = (uint32_t)(hi - lo);
+    if (n < 2u || n > REFINE_CAP) return;
+    uint32_t m = 1u;
+    while (m < n) m <<= 1;
+    for (uint32_t i = threadIdx.x; i < m; i += TPB) {
+        unsigned long long kv = ~0ull;  // padding sorts to the end
+        if (i < n) {
+            const uint32_t pair = perm[lo + i];
+            kv = ((unsigned long long)vs_locus_key_end(idx, rd, 2ull * pair + 1u) << 32) | pair;
+        }
+        s_kv[i] = kv;
+    }
+    __syncthreads();
+    for (uint32_t size = 2u; size <= m; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0u; stride >>= 1) {
+            for (uint32_t i = threadIdx.x; i < (m >> 1); i += TPB) {
+                const uint32_t a = 2u * i - (i & (stride - 1u)), b = a + stride;
+                const bool up = (a & size) == 0u;
+                const unsigned long long x = s_kv[a], y = s_kv[b];
+                if ((x > y) == up) { s_kv[a] = y; s_kv[b] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += TPB) perm[lo + i] = (uint32_t)s_kv[i];
+}
+
 // Counting sort without global atomics (used while the N+2 keys fit an LDS histogram):
 //   k_locus_count   : workgroup g takes pairs [g*chunk, (g+1)*chunk): keys -> keys[], LDS histogram
 //                     -> column g of cnt[key][g]  (key-major so that the scan below is contiguous)
@@ -1840,6 +1895,9 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     if (use_sort) {
         const uint64_t nk = (uint64_t)idx.n_nodes + 2u;
         const bool lds_sort = nk <= LOCUS_LDS_MAX_PASSES * LOCUS_LDS_KEYS && !tn.locus_global;
+        // second key (the reverse read's locus) where the counter kernel is bound by global atomics: graphs beyond the
+        // one-table shape of its cell table (VS_REFINE=0 / 1 overrides)
+        const bool refine = tn.refine >= 0 ? tn.refine != 0 : 2ull * idx.n_nodes * idx.n_nodes >= 0xFFFFFFFFull;
         if (lds_sort) {
             const uint32_t n_wg = LOCUS_WGS;
             const uint32_t chunk = (uint32_t)((n_pairs + n_wg - 1) / n_wg);
@@ -1862,6 +1920,9 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
                 hipLaunchKernelGGL(k_locus_scatter, dim3(n_wg), dim3(LOCUS_TPB), lds_keys, st, key_lo, n_here, n_pairs, chunk, n_wg,
                                    (const uint32_t *)ctx->d_locus_keys, (const uint32_t *)ctx->d_locus_hist, (uint32_t *)ctx->d_perm);
             }
+            if (refine && idx.n_nodes)
+                hipLaunchKernelGGL(k_locus_refine, dim3(idx.n_nodes), dim3(TPB), 0, st, idx, reads->dev(), n_wg, n_pairs,
+                                   (const uint32_t *)ctx->d_locus_hist, (uint32_t *)ctx->d_perm);
         } else {
             VS_HIP(ctx, hipMemsetAsync(ctx->d_locus_hist, 0, sizeof(uint32_t) * nk, st));
             const unsigned pg = (unsigned)((n_pairs + TPB - 1) / TPB);
