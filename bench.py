@@ -295,6 +295,7 @@ def main():
                                "read-block sharding x%d + all-reduce of [2,N,N] counters (RCCL, overlapped with the next block)" % world,
                 "rccl_ranks": rccl_ranks, "collective_backend": coll_backend,
                 "index": ctx.index_info, "index_build_s": index_s, "workload_build_s": workload_s,
+                "node_numbering": "along the graph's paths (vs_node_order_host), results mapped back" if ctx.node_order is not None else "as given",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -507,6 +508,8 @@ def cpu_baseline(ctx, host, st, g, cum, seed, L, k, sub_thresh, n_thresh, R, tar
     same = tuple(int(x) for x in chk.stats.cpu().tolist()) == tuple(int(x) for x in ref_stats)
     for mat, cells, counts in ((0, node_cells, node_counts), (1, short_cells, short_counts)):
         flat = chk.mats[mat].reshape(-1)
+        # (the oracle numbers the nodes as the GFA does, the device as the index was built: Context.build_index)
+        cells = ctx.internal_cells(mat, cells.astype(np.int64) // chk.n, cells.astype(np.int64) % chk.n)
         got = flat[torch.from_numpy(cells).to(flat.device)].cpu().numpy().view(np.uint32).astype(np.int64)
         same = same and bool(np.array_equal(got, counts)) and int(flat.sum(dtype=torch.int64).item()) == int(counts.sum())
     out = {

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VS_ABI_VERSION 4
+#define VS_ABI_VERSION 5
 
 enum {
     VS_OK = 0,
@@ -60,6 +60,16 @@ int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint64_t *node_
 /* Index facts for reporting: info[0]=seed length w, [1]=probe stride s, [2]=seed positions
  * indexed, [3]=hash slots, [4]=distinct seeds, [5]=bytes of device memory held by the index. */
 int vs_index_info(const vs_ctx *ctx, uint64_t info[6]);
+
+/* A numbering of the nodes that runs along the graph's paths (host only; depth-first over k-base overlaps, either strand).
+ * order_out[n_nodes]: order_out[r] = the node (position in node_off) that should be handed to vs_index_build as number r.
+ * Optional, for speed only: the matrices vs_pe_count fills are indexed by the numbering vs_index_build was given
+ * (PE_Inference.py:139-140 indexes them by GFA position), and every result is the same sum under any numbering -- but
+ * pairs are processed in the order of the node their forward read starts in, a slice per XCD, and a numbering that
+ * scatters the neighbours of a path costs 20-25 % of the step (csrc/vs_order_host.cpp).  The Python host side does this
+ * by default and maps the matrices back (vstrains_amd/pe.py). */
+int vs_node_order_host(const uint8_t *node_ascii, const uint64_t *node_off, uint32_t n_nodes, uint32_t ksize,
+                       uint32_t *order_out);
 
 /* Walk index (built by vs_index_build next to the seed index): node sets that certify as proper overlap graphs of
  * (k+1)-mers -- every (k+1)-mer of PE_Inference.py:116-135's table has ONE entry, nodes continue into each other only

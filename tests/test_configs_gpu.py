@@ -47,6 +47,8 @@ def _assert_equals_oracle(counter, orc, st, cum, seed, L, M, sub, nth):
     assert tuple(int(x) for x in counter.stats.cpu().tolist()) == tuple(int(x) for x in ref_stats)
     for mat, cells, counts in ((0, node_cells, node_counts), (1, short_cells, short_counts)):
         flat = counter.mats[mat].reshape(-1)
+        n = counter.n
+        cells = counter.ctx.internal_cells(mat, cells.astype(np.int64) // n, cells.astype(np.int64) % n)  # (the index's numbering)
         got = flat[torch.from_numpy(cells).to(flat.device)].cpu().numpy().view(np.uint32).astype(np.int64)
         assert np.array_equal(got, counts), "mat %d: %d cells differ" % (mat, int((got != counts).sum()))
         # no count anywhere else: the totals agree

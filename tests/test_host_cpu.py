@@ -21,7 +21,7 @@ def test_library_exports_every_symbol_of_the_header():
     assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
     for name in declared:
         assert hasattr(L, name)
-    assert L.vs_abi_version() == 4
+    assert L.vs_abi_version() == 5
 
 
 def test_no_device_means_loud_failure_not_fallback():
@@ -608,3 +608,58 @@ def test_cooperative_fastq_open_two_ranks_gloo(tmp_path):
     assert [x[1] for x in res] == [0, 1500] and all(x[2] == 3001 for x in res)
     assert all(x[3] <= total_bytes * 0.51 for x in res), [x[3] for x in res]  # each rank went through about half the text
     assert res[0][4] + res[1][4] == [a + "|" + b for a, b in zip(f, r)]
+
+
+def test_node_order_runs_along_paths_and_equals_its_python_statement():
+    """vs_node_order_host (csrc/vs_order_host.cpp) against vstrains_amd/node_order.py:path_order: a permutation, the same
+    one, on the bench graph of configs[1], on the same nodes shuffled / partly reverse-complemented / with odd members
+    (empty, shorter than k, bytes outside ACGT), and along a chain cut into shuffled pieces."""
+    import random
+    import tempfile
+
+    from vstrains_amd import pe as host
+    from vstrains_amd.node_order import _revcomp, path_order
+    from vstrains_amd.workloads import CONFIGS, workload_for
+
+    st, pre, names, seqs, cum, logger, n_in = workload_for(1, tempfile.mkdtemp(prefix="order_"))
+    k = CONFIGS[1]["k"]
+    rnd = random.Random(11)
+    mixed = list(seqs)
+    rnd.shuffle(mixed)
+    mixed = [s if rnd.random() < 0.5 else _revcomp(s) for s in mixed] + ["AC", "", "N" * 80, "acgt" * 20]
+    for nodes in (seqs, mixed):
+        got = host.node_order(nodes, k)
+        assert sorted(got.tolist()) == list(range(len(nodes)))
+        assert got.tolist() == path_order(nodes, k)
+    # neighbours along a path are neighbours in the numbering: the nodes under a 150-base window of a strain
+    home = {}
+    K = k + 1
+    for i, s in enumerate(mixed):
+        for strand in (s, _revcomp(s)):
+            for o in range(len(strand) - K + 1):
+                home[strand[o:o + K]] = i
+    rank = np.empty(len(mixed), dtype=np.int64)
+    rank[host.node_order(mixed, k)] = np.arange(len(mixed))
+    spans_given, spans_ordered = [], []
+    for g in st.genomes[:4]:
+        for p in range(0, len(g) - 150, 97):
+            ns = {home.get(g[q:q + K]) for q in range(p, p + 150 - K + 1)} - {None}
+            if len(ns) > 1:
+                ids = np.array(sorted(ns))
+                spans_given.append(ids.max() - ids.min())
+                spans_ordered.append(rank[ids].max() - rank[ids].min())
+    assert np.median(spans_ordered) * 4 < np.median(spans_given), (np.median(spans_ordered), np.median(spans_given))
+    # a chain in shuffled pieces, mixed strands: one walk forwards from where it starts, then the rest backwards
+    g = "".join(rnd.choice("ACGT") for _ in range(1500))
+    cuts = sorted(rnd.sample(range(40, len(g) - 40), 30))
+    pieces, a = [], 0
+    for c in cuts + [len(g)]:
+        pieces.append(g[a:c + 21] if c < len(g) else g[a:])
+        a = c
+    idx = list(range(len(pieces)))
+    rnd.shuffle(idx)
+    chain = [pieces[i] if rnd.random() < 0.5 else _revcomp(pieces[i]) for i in idx]
+    walk = [idx[o] for o in host.node_order(chain, 21).tolist()]
+    first, m = walk[0], len(pieces)
+    assert walk in (list(range(first, m)) + list(range(first - 1, -1, -1)), list(range(first, -1, -1)) + list(range(first + 1, m))), walk
+    assert host.node_order([], 5).tolist() == [] and host.node_order(["ACGT"], 0).tolist() == [0]

@@ -331,6 +331,46 @@ def test_blocks_add_up_and_swapping_ends_transposes(host, ctx):
     assert np.array_equal(c[0], a[0].T) and np.array_equal(c[1], a[1])
 
 
+def test_results_do_not_depend_on_the_internal_numbering(host, ctx):
+    """The index numbers the nodes along the graph's paths (Context.build_index, csrc/vs_order_host.cpp) and every
+    result is handed out in the caller's numbering: matrices, per-end lists and the PE-link table of a graph whose
+    nodes were shuffled and partly reverse-complemented equal the oracle's, with the renumbering on and off."""
+    import random
+
+    from vstrains_amd.graph.hip_ops import HipPeLinks
+    from vstrains_amd.node_order import _revcomp
+
+    g, f, r = _dense_case(55, 9000, 150, seed=733, snp=0.04, glen=5000)
+    rnd = random.Random(5)
+    seqs = [s if rnd.random() < 0.6 else _revcomp(s) for s in g.seqs]
+    rnd.shuffle(seqs)
+    names = ["n%d" % i for i in range(len(seqs))]
+    orc = pe_oracle_c.Oracle(seqs, 55)
+    ref_node, ref_short, ref_stats = orc.count_pairs(f, r)
+    want_links = ref_node + ref_short
+    want_links = want_links + want_links.T - np.diag(np.diag(want_links))  # (IO.py:598-627: both orders, the diagonal once)
+    got = {}
+    for renumber in (True, False):
+        ctx.build_index(seqs, 55, renumber=renumber)
+        assert (ctx.node_order is not None) == renumber
+        counter = host.PeCounter(ctx)
+        block = ctx.pack_pairs(f, r)
+        counter.add(block)
+        node_mat, short_mat, stats = counter.result()
+        assert np.array_equal(node_mat, ref_node) and np.array_equal(short_mat, ref_short)
+        assert stats == tuple(int(x) for x in ref_stats)
+        lists = ctx.map_ends(block)
+        table = HipPeLinks.from_counter(ctx, counter, names)
+        assert np.array_equal(table.to_numpy(), want_links)
+        u, v = 3, len(seqs) // 2
+        assert table.block_sums([([table.index_of(names[u])], [table.index_of(names[v])])])[0] == int(want_links[u, v])
+        table.close()
+        got[renumber] = lists
+    assert got[True] == got[False]
+    ctx.build_index(seqs, 55)  # default: on
+    assert ctx.node_order is not None and sorted(ctx.node_order.tolist()) == list(range(len(seqs)))
+
+
 def test_device_read_generator_equals_cpu_twin(host, ctx):
     from vstrains_amd import synth
 

@@ -28,14 +28,20 @@ t0 = time.time()
 loc = locality_order(seqs, k)
 print("locality_order: %.2f s for %d nodes" % (time.time() - t0, n), flush=True)
 rng = np.random.default_rng(5)
-orders = {"gfa": list(range(n)), "locality": loc, "random": [int(x) for x in rng.permutation(n)]}
+from vstrains_amd.node_order import path_order
+orders = {"gfa": list(range(n)), "locality": loc, "path": path_order(seqs, k), "native path": host.node_order(seqs, k).tolist(), "random": [int(x) for x in rng.permutation(n)]}
+if os.environ.get("ORDER_FROM_RANDOM") == "1":  # the orders computed from a randomly numbered graph, as an assembler would hand it over
+    rp = orders["random"]
+    sq = [seqs[i] for i in rp]
+    orders["locality(random)"] = [rp[j] for j in locality_order(sq, k)]
+    orders["path(random)"] = [rp[j] for j in path_order(sq, k)]
 seed = 20250000 + config
 sums = {}
 ref = None
 for tag, order in orders.items():
     ctx = host.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    ctx.build_index([seqs[i] for i in order], k)
+    ctx.build_index([seqs[i] for i in order], k, renumber=False)
     reads = ctx.synth_pairs(st.genomes, cum, seed, 0, R, L, int(0.005 * 2 ** 32), int(0.001 * 2 ** 32))
     c = host.PeCounter(ctx)
     rows = []
@@ -47,7 +53,7 @@ for tag, order in orders.items():
     t = rows[-1]
     torch.cuda.synchronize()
     print("%-9s main %.2f  counters %.2f  sort %.2f  overflow %.2f  (%s)" % (
-        tag, t["main_ms"], t["accumulate_ms"], t["sort_ms"], t["slow_ms"], ctx.last_kernel()), flush=True)
+        tag, t["main_ms"], t["accumulate_ms"], t["sort_ms"], t["slow_ms"], ctx.last_kernel), flush=True)
     tot = (int(c.mats[0].sum(dtype=torch.int64)), int(c.mats[1].sum(dtype=torch.int64)), tuple(c.stats.cpu().tolist()))
     # the permuted matrices, sampled: 2 000 random rows against the gfa numbering
     rank = torch.empty(n, dtype=torch.int64)

@@ -25,6 +25,7 @@ SYMBOLS = {
     "vs_index_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                  C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]),
     "vs_index_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "vs_node_order_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "vs_walk_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]),
     "vs_walk_map_ends_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                         C.c_void_p, C.c_void_p]),

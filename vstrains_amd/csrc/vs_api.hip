@@ -32,6 +32,7 @@ void vs_tuning_load(VsTuning &t, int level) {
     if (const char *v = getenv("VS_ACC_FILL")) t.acc_fill_pct = atoi(v);
     if (const char *v = getenv("VS_ACC_WIDE")) t.acc_wide = atoi(v);
     if (const char *v = getenv("VS_SHORTCUT")) t.shortcut = atoi(v) != 0 ? 1 : 0;
+    if (const char *v = getenv("VS_TABLE_SHIFT")) t.table_shift = atoi(v) < 1 ? 1u : atoi(v) > 8 ? 8u : (uint32_t)atoi(v);
     if (const char *v = getenv("VS_REFINE")) t.refine = atoi(v) != 0 ? 1 : 0;
     t.no_sort = env_on("VS_NO_SORT");
     t.locus_global = env_on("VS_LOCUS_GLOBAL");

@@ -52,7 +52,7 @@ k_pack_nodes(const uint8_t *__restrict__ ascii, const uint64_t *__restrict__ aof
 __global__ void __launch_bounds__(TPB)
 k_seed_insert(VsIndexDev idx, const uint64_t *__restrict__ seed_off, uint64_t n_pos,
               unsigned long long *__restrict__ keys, uint32_t *__restrict__ cnts,
-              uint32_t *__restrict__ pos_slot) {
+              uint32_t *__restrict__ pos_slot, uint32_t *__restrict__ n_claimed) {
     uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
     if (g >= n_pos) return;
     uint32_t node = vs_upper_idx(seed_off, idx.n_nodes + 1, g);
@@ -64,11 +64,12 @@ k_seed_insert(VsIndexDev idx, const uint64_t *__restrict__ seed_off, uint64_t n_
     uint32_t sl = vs_slot_of(key, idx.table_bits);
     for (;;) {
         unsigned long long old = atomicCAS(&keys[sl], (unsigned long long)VS_EMPTY_KEY, (unsigned long long)key);
+        if (old == VS_EMPTY_KEY && n_claimed) atomicAdd(n_claimed, 1u);
         if (old == VS_EMPTY_KEY || old == key) break;
         sl = (sl + 1u) & mask;
     }
-    atomicAdd(&cnts[sl], 1u);
-    pos_slot[g] = sl;
+    if (cnts) atomicAdd(&cnts[sl], 1u);
+    if (pos_slot) pos_slot[g] = sl;
 }
 
 __global__ void __launch_bounds__(TPB)
@@ -187,19 +188,17 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
     // device buffers: permanent
     size_t b_meta = sizeof(VsNodeMeta) * (n_nodes ? n_nodes : 1);
     size_t b_words = sizeof(uint32_t) * (words + VS_PAD_WORDS);
-    size_t b_table = sizeof(VsSlot) * n_slots;
     size_t b_post = sizeof(uint4) * (npos ? npos : 1);
     VS_HIP(ctx, hipMalloc(&ctx->d_meta, b_meta));
     VS_HIP(ctx, hipMalloc(&ctx->d_fwd, 2 * b_words));  // forward text, then the reverse complements
     ctx->d_rc = nullptr;
-    VS_HIP(ctx, hipMalloc(&ctx->d_table, b_table));
     VS_HIP(ctx, hipMalloc(&ctx->d_post, b_post));
     // 32-byte postings with the text around the seed (VsIndexDev::postings32) for the seed geometry of k <= 85 (stride
     // <= 32: the straight-line kernel k_pe_tiles<1>, the only one that reads them)
     if (ctx->experiment_level) vs_tuning_load(ctx->tune, ctx->experiment_level);
     const bool want32 = ctx->tune.use_inline && s <= 32u && w <= 31u;  // (VS_INLINE=1 only: DESIGN 11)
     if (want32) VS_HIP(ctx, hipMalloc(&ctx->d_post32, 2 * b_post));
-    ctx->index_bytes = b_meta + 2 * b_words + b_table + b_post + (want32 ? 2 * b_post : 0);
+    ctx->index_bytes = b_meta + 2 * b_words + b_post + (want32 ? 2 * b_post : 0);  // (+ the table, sized below)
     // temporaries
     uint8_t *d_ascii = nullptr;
     uint64_t *d_aoff = nullptr, *d_seed_off = nullptr, *d_tmp = nullptr;
@@ -221,11 +220,7 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
         TRY(hipMalloc((void **)&d_seed_off, sizeof(uint64_t) * (n_nodes + 1)));
         TRY(hipMalloc((void **)&d_woff, sizeof(uint32_t) * (n_nodes + 1)));
         TRY(hipMalloc((void **)&d_keys, sizeof(unsigned long long) * n_slots));
-        TRY(hipMalloc((void **)&d_cnts, sizeof(uint32_t) * n_slots));
-        TRY(hipMalloc((void **)&d_offs, sizeof(uint32_t) * n_slots));
-        TRY(hipMalloc((void **)&d_cursor, sizeof(uint32_t) * n_slots));
         TRY(hipMalloc((void **)&d_pos_slot, sizeof(uint32_t) * (npos ? npos : 1)));
-        TRY(hipMalloc((void **)&d_tmp, sizeof(uint64_t) * (n_slots / 2048 + 4)));
         TRY(hipMalloc((void **)&d_flags, sizeof(uint32_t) * 4));
         if (total_ascii) TRY(hipMemcpyAsync(d_ascii, node_ascii, total_ascii, hipMemcpyHostToDevice, st));
         TRY(hipMemcpyAsync(d_aoff, node_off, sizeof(uint64_t) * (n_nodes + 1), hipMemcpyHostToDevice, st));
@@ -234,8 +229,6 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
         TRY(hipMemcpyAsync(ctx->d_meta, meta.data(), b_meta, hipMemcpyHostToDevice, st));
         TRY(hipMemsetAsync(ctx->d_fwd, 0, 2 * b_words, st));
         TRY(hipMemsetAsync(d_keys, 0xFF, sizeof(unsigned long long) * n_slots, st));
-        TRY(hipMemsetAsync(d_cnts, 0, sizeof(uint32_t) * n_slots, st));
-        TRY(hipMemsetAsync(d_cursor, 0, sizeof(uint32_t) * n_slots, st));
         uint32_t init_flags[4] = {0xFFFFFFFFu, 0, 0, 0};
         TRY(hipMemcpyAsync(d_flags, init_flags, sizeof init_flags, hipMemcpyHostToDevice, st));
 
@@ -272,16 +265,52 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
             rc = vs_fail(ctx, VS_E_NODE_BASE, "node %u holds byte 0x%02x outside ACGT", nd, last);
             goto done;
         }
+        // The table is sized by the DISTINCT seeds, which only an insertion pass can count: a graph whose nodes overlap
+        // by k bases holds every seed of an overlap once per node that shares it (3.6 positions per distinct seed at
+        // configs[2], 8.9 at configs[4]), and a table sized by positions is 5-12 % full -- every occupied 16-byte slot
+        // alone in its 128-byte line, 8 MB where 2 MB do, and the probes of seeds that are in no node (every read
+        // error makes some) land anywhere in it.  First pass: claim slots in the scratch table only to count.
+        uint64_t n_slots_final = n_slots;
+        uint32_t bits_final = bits;
         if (npos) {
             unsigned nb = (unsigned)((npos + TPB - 1) / TPB);
-            hipLaunchKernelGGL(k_seed_insert, dim3(nb), dim3(TPB), 0, st, d, d_seed_off, npos, d_keys, d_cnts, d_pos_slot);
-            rc = vs_scan_u32(ctx, d_cnts, d_offs, n_slots, d_tmp, nullptr);
+            hipLaunchKernelGGL(k_seed_insert, dim3(nb), dim3(TPB), 0, st, d, d_seed_off, npos, d_keys, (uint32_t *)nullptr,
+                               (uint32_t *)nullptr, d_flags + 3);
+            TRY(hipMemcpyAsync(h_flags, d_flags, sizeof h_flags, hipMemcpyDeviceToHost, st));
+            TRY(hipStreamSynchronize(st));
+            const uint64_t want = ((uint64_t)h_flags[3] << ctx->tune.table_shift) + 2u;
+            bits_final = 4;
+            while ((1ull << bits_final) < want) bits_final++;
+            if (bits_final > 30u) bits_final = 30u;
+            n_slots_final = 1ull << bits_final;
+            d.table_bits = bits_final;
+            if (bits_final > bits) {
+                (void)hipFree(d_keys);
+                d_keys = nullptr;
+                TRY(hipMalloc((void **)&d_keys, sizeof(unsigned long long) * n_slots_final));
+            }
+            TRY(hipMemsetAsync(d_keys, 0xFF, sizeof(unsigned long long) * n_slots_final, st));
+        }
+        TRY(hipMalloc((void **)&d_cnts, sizeof(uint32_t) * n_slots_final));
+        TRY(hipMalloc((void **)&d_offs, sizeof(uint32_t) * n_slots_final));
+        TRY(hipMalloc((void **)&d_cursor, sizeof(uint32_t) * n_slots_final));
+        TRY(hipMalloc((void **)&d_tmp, sizeof(uint64_t) * (n_slots_final / 2048 + 4)));
+        TRY(hipMemsetAsync(d_cnts, 0, sizeof(uint32_t) * n_slots_final, st));
+        TRY(hipMemsetAsync(d_cursor, 0, sizeof(uint32_t) * n_slots_final, st));
+        TRY(hipMalloc(&ctx->d_table, sizeof(VsSlot) * n_slots_final));
+        d.table = (const VsSlot *)ctx->d_table;
+        ctx->index_bytes += sizeof(VsSlot) * n_slots_final;
+        if (npos) {
+            unsigned nb = (unsigned)((npos + TPB - 1) / TPB);
+            hipLaunchKernelGGL(k_seed_insert, dim3(nb), dim3(TPB), 0, st, d, d_seed_off, npos, d_keys, d_cnts, d_pos_slot,
+                               (uint32_t *)nullptr);
+            rc = vs_scan_u32(ctx, d_cnts, d_offs, n_slots_final, d_tmp, nullptr);
             if (rc) goto done;
             hipLaunchKernelGGL(k_seed_fill, dim3(nb), dim3(TPB), 0, st, d, d_seed_off, npos, d_pos_slot, d_offs, d_cursor,
                                (uint4 *)ctx->d_post, (uint4 *)ctx->d_post32, d_flags + 2);
         }
-        hipLaunchKernelGGL(k_table_finalize, dim3((unsigned)((n_slots + TPB - 1) / TPB)), dim3(TPB), 0, st, d_keys, d_cnts,
-                           d_offs, (const uint4 *)ctx->d_post, (uint32_t)n_slots, (VsSlot *)ctx->d_table, d_flags + 1);
+        hipLaunchKernelGGL(k_table_finalize, dim3((unsigned)((n_slots_final + TPB - 1) / TPB)), dim3(TPB), 0, st, d_keys, d_cnts,
+                           d_offs, (const uint4 *)ctx->d_post, (uint32_t)n_slots_final, (VsSlot *)ctx->d_table, d_flags + 1);
         TRY(hipGetLastError());
         TRY(hipMemcpyAsync(h_flags, d_flags, sizeof h_flags, hipMemcpyDeviceToHost, st));
         TRY(hipStreamSynchronize(st));
@@ -289,7 +318,7 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
         ctx->n_seed_pos = npos;
         ctx->max_node_len = 0;
         for (uint32_t i = 0; i < n_nodes; i++) ctx->max_node_len = meta[i].len > ctx->max_node_len ? meta[i].len : ctx->max_node_len;
-        ctx->n_slots = n_slots;
+        ctx->n_slots = n_slots_final;
         ctx->n_distinct = h_flags[1];
         ctx->n_long_flank = h_flags[2];
         ctx->has_index = true;

@@ -121,6 +121,7 @@ struct VsTuning {
     int acc_fill_pct = -1;          // VS_ACC_FILL (-1 = 1/16 of the slots)
     int acc_wide = 0;               // VS_ACC_WIDE (1: 64-bit keys, 2: split tables)
     int shortcut = -1;              // VS_SHORTCUT (-1 = by index statistics)
+    uint32_t table_shift = 3;       // VS_TABLE_SHIFT: seed table of >= (distinct seeds << shift) slots (3: at most an eighth full)
     int refine = -1;                // VS_REFINE (-1 = by graph size): second sort key, the reverse read's locus
     bool no_sort = false, locus_global = false, no_xcd_map = false, no_fast = false, no_std = false, no_agg = false;
     bool acc_queue = true, acc_merge = false;

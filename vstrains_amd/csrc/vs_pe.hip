@@ -342,25 +342,42 @@ __device__ __forceinline__ bool vs_accept32(uint32_t v, uint32_t coord, uint32_t
 }
 
 // Probe the table for the seed at read offset j.  Returns posting count (0 = miss) and payload.
+// -DVS_PROBE_PAIR=1 requests two neighbouring slots together (at an eighth fill one lane in ten needs the second slot,
+// so nearly every wavefront does, as a second dependent round trip): measured equal within noise at configs[2..4]
+// (5.97 / 30.2 / 11.7 ms against 5.99 / 30.6 / 11.5), like tables of 1/16 .. 1/64 fill -- the probes are not where
+// k_pe_tiles waits.  Fuller tables lose: 1/4 fill +3 %, 1/2 fill +13 % (tools/r3_table.sh).
+#ifndef VS_PROBE_PAIR
+#define VS_PROBE_PAIR 0
+#endif
 __device__ __forceinline__ uint32_t vs_probe(const VsIndexDev &idx, uint64_t key, uint32_t sr, uint32_t *pa, uint32_t *pb) {
     uint32_t mask = (1u << idx.table_bits) - 1u;
     uint32_t sl = vs_slot_of(key, idx.table_bits);
     const uint4 *tab = (const uint4 *)idx.table;
     for (;;) {
-        uint4 raw = tab[sl];
-        uint64_t k = (uint64_t)raw.x | ((uint64_t)raw.y << 32);
-        if (k == VS_EMPTY_KEY) return 0u;
-        if ((k & ~VS_MULTI_BIT) == key) {
-            if (k & VS_MULTI_BIT) {
+        const uint4 r0 = tab[sl];
+#if VS_PROBE_PAIR
+        const uint4 r1 = tab[(sl + 1u) & mask];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint4 raw = h ? r1 : r0;
+#else
+        {
+            const uint4 raw = r0;
+#endif
+            uint64_t k = (uint64_t)raw.x | ((uint64_t)raw.y << 32);
+            if (k == VS_EMPTY_KEY) return 0u;
+            if ((k & ~VS_MULTI_BIT) == key) {
+                if (k & VS_MULTI_BIT) {
+                    *pa = raw.z;
+                    *pb = raw.w | (sr << 31);
+                    return raw.w;
+                }
                 *pa = raw.z;
-                *pb = raw.w | (sr << 31);
-                return raw.w;
+                *pb = raw.w ^ (sr << 31);
+                return 1u;
             }
-            *pa = raw.z;
-            *pb = raw.w ^ (sr << 31);
-            return 1u;
         }
-        sl = (sl + 1u) & mask;
+        sl = (sl + (VS_PROBE_PAIR ? 2u : 1u)) & mask;
     }
 }
 
@@ -903,13 +920,26 @@ k_pe_tiles(PeParams P) {
 //   Acc32Split one 8 k-slot table per matrix, 32-bit keys x * N + y, while N*N fits (N <= 65535): the matrix is
 //              the upper bit of the slot index, a probe sequence stays inside its half
 //   Acc64      8 k slots, 64-bit keys mat << 60 | x * N + y, above that
+// (r3) ACC_SEG: the 16 cells of one 64-byte stretch of a matrix row sit in 16 NEIGHBOURING slots (the hash picks a
+// group of 16 slots from the cell index >> 4, the low four bits pick the slot inside it; a taken slot sends the probe to
+// the same position of the next group).  A write-out walks the slots in order, a lane per slot, so the lanes of a
+// wavefront that hold cells of one stretch issue their atomics side by side -- and integer atomics, like the float
+// ones of MI355X_MICROARCH.md, leave the L2 as one memory-side request per 64-byte stretch a wave instruction touches.
+#ifndef ACC_SEG
+#define ACC_SEG 1
+#endif
 struct Acc32 {
     typedef uint32_t KT;
     static constexpr uint32_t BITS = ACC_BITS;
     static constexpr uint32_t EMPTY = 0xFFFFFFFFu;
     __device__ static uint32_t key(uint32_t mat, uint32_t x, uint32_t y, uint32_t N) { return (mat * N + x) * N + y; }
+#if ACC_SEG
+    __device__ static uint32_t slot(uint32_t, uint32_t k) { return ((((k >> 4) * 0x9E3779B1u) >> (36u - BITS)) << 4) | (k & 15u); }
+    __device__ static uint32_t next(uint32_t at) { return (at + 16u) & ((1u << BITS) - 1u); }
+#else
     __device__ static uint32_t slot(uint32_t, uint32_t k) { return (k * 0x9E3779B1u) >> (32u - BITS); }
     __device__ static uint32_t next(uint32_t at) { return (at + 1u) & ((1u << BITS) - 1u); }
+#endif
     __device__ static uint32_t mat_of(uint32_t k, uint32_t N, uint32_t) { return k >= N * N ? 1u : 0u; }
     __device__ static uint64_t cell_of(uint32_t k, uint32_t N) { return k >= N * N ? (uint64_t)(k - N * N) : (uint64_t)k; }
 };
@@ -919,8 +949,13 @@ struct Acc32Split {
     static constexpr uint32_t HALF = 1u << (ACC_BITS - 1u);
     static constexpr uint32_t EMPTY = 0xFFFFFFFFu;  // (N <= 65535: the largest cell is N*N - 1 < 2^32 - 1)
     __device__ static uint32_t key(uint32_t, uint32_t x, uint32_t y, uint32_t N) { return x * N + y; }
+#if ACC_SEG
+    __device__ static uint32_t slot(uint32_t mat, uint32_t k) { return (mat ? HALF : 0u) | ((((k >> 4) * 0x9E3779B1u) >> (37u - BITS)) << 4) | (k & 15u); }
+    __device__ static uint32_t next(uint32_t at) { return (at & HALF) | ((at + 16u) & (HALF - 1u)); }
+#else
     __device__ static uint32_t slot(uint32_t mat, uint32_t k) { return (mat ? HALF : 0u) | ((k * 0x9E3779B1u) >> (33u - BITS)); }
     __device__ static uint32_t next(uint32_t at) { return (at & HALF) | ((at + 1u) & (HALF - 1u)); }
+#endif
     __device__ static uint32_t mat_of(uint32_t, uint32_t, uint32_t i) { return i >> (BITS - 1u); }
     __device__ static uint64_t cell_of(uint32_t k, uint32_t) { return (uint64_t)k; }
 };
@@ -931,8 +966,15 @@ struct Acc64 {
     __device__ static unsigned long long key(uint32_t mat, uint32_t x, uint32_t y, uint32_t N) {
         return ((unsigned long long)mat << 60) | ((unsigned long long)x * N + y);
     }
+#if ACC_SEG
+    __device__ static uint32_t slot(uint32_t, unsigned long long k) {
+        return ((uint32_t)(((k >> 4) * 0x9E3779B97F4A7C15ull) >> (68u - BITS)) << 4) | ((uint32_t)k & 15u);
+    }
+    __device__ static uint32_t next(uint32_t at) { return (at + 16u) & ((1u << BITS) - 1u); }
+#else
     __device__ static uint32_t slot(uint32_t, unsigned long long k) { return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> (64u - BITS)); }
     __device__ static uint32_t next(uint32_t at) { return (at + 1u) & ((1u << BITS) - 1u); }
+#endif
     __device__ static uint32_t mat_of(unsigned long long k, uint32_t, uint32_t) { return (uint32_t)(k >> 60); }
     __device__ static uint64_t cell_of(unsigned long long k, uint32_t) { return k & ((1ull << 60) - 1ull); }
 };

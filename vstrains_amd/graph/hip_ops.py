@@ -5,7 +5,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -222,11 +222,14 @@ class HipGraphOps(GraphOps):
 class HipPeLinks(PeLinks):
     """K5: the symmetrised PE-link matrix, resident in HBM."""
 
-    def __init__(self, ctx, handle, names: Sequence[str]):
+    def __init__(self, ctx, handle, names: Sequence[str], caller_names: Optional[Sequence[str]] = None):
+        """``names``: row i of the device table belongs to names[i]; ``caller_names``: the same names in the order the
+        caller knows them (``to_numpy`` answers in that order), when the two differ."""
         self.ctx = ctx
         self._h = handle
         self.names = list(names)
         self._index = {n: i for i, n in enumerate(self.names)}
+        self._caller_rows = None if caller_names is None else np.asarray([self._index[n] for n in caller_names], dtype=np.int64)
         self.calls = 0
 
     @classmethod
@@ -245,6 +248,11 @@ class HipPeLinks(PeLinks):
             nat.check(ctx._h, nat.lib().vs_links_from_counts(ctx._h, C.c_void_p(counter.mats[0].data_ptr()),
                                                              C.c_void_p(counter.mats[1].data_ptr()), n, C.byref(h)))
         ctx.sync()
+        # (the counters are in the numbering the index was built in -- pe.Context.build_index -- and so is the table
+        # made from them: rows are found by name, so only the name list has to follow)
+        order = getattr(getattr(counter, "ctx", None), "node_order", None)  # (the context that counted into it)
+        if order is not None:
+            return cls(ctx, h, [names[i] for i in order.tolist()], caller_names=names)
         return cls(ctx, h, names)
 
     @classmethod
@@ -290,7 +298,10 @@ class HipPeLinks(PeLinks):
         out = np.zeros((max(n, 1), max(n, 1)), dtype=np.int64)
         if n:
             nat.check(self.ctx._h, nat.lib().vs_links_to_host(self.ctx._h, self._h, out.ctypes.data))
-        return out[:n, :n]
+        out = out[:n, :n]
+        if self._caller_rows is not None:
+            out = out[np.ix_(self._caller_rows, self._caller_rows)]
+        return out
 
     @staticmethod
     def _pool(lists: Sequence[Sequence[int]]):

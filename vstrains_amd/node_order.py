@@ -57,3 +57,42 @@ def locality_order(seqs: Sequence[str], k: int) -> List[int]:
                     comp[j], coord[j], flip[j] = start, x - (len(seqs[j]) - k), (t & 1) ^ 1
                     queue.append(j)
     return sorted(range(n), key=lambda i: (comp[i], coord[i], i))
+
+
+def path_order(seqs: Sequence[str], k: int) -> List[int]:
+    """Depth-first variant: a node is followed by one of its successors, so the numbering runs along paths
+    (the first one a whole walk through the component, the later ones the branches it left out, each next to
+    where it rejoins).  Pairs sorted by the number of the node their read starts in then meet the pairs of the
+    NEXT node of the same path, whose cells are mostly the same."""
+    n = len(seqs)
+    rc = [_revcomp(s) for s in seqs]
+    heads = {}
+    for i, s in enumerate(seqs):
+        if len(s) < k or k <= 0:
+            continue
+        heads.setdefault(s[:k], []).append(2 * i)
+        heads.setdefault(rc[i][:k], []).append(2 * i + 1)
+    seen = [False] * n
+    order: List[int] = []
+    for start in range(n):
+        if seen[start]:
+            continue
+        stack = [2 * start]
+        while stack:
+            t = stack.pop()
+            i = t >> 1
+            if seen[i]:
+                continue
+            seen[i] = True
+            order.append(i)
+            fw, bw = (seqs[i], rc[i]) if not (t & 1) else (rc[i], seqs[i])
+            if len(fw) < k or k <= 0:
+                continue
+            # what precedes goes under what follows: the walk continues forwards first
+            for u in reversed(heads.get(bw[-k:], ())):
+                if not seen[u >> 1]:
+                    stack.append(u ^ 1)
+            for u in reversed(heads.get(fw[-k:], ())):
+                if not seen[u >> 1]:
+                    stack.append(u)
+    return order

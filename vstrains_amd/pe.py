@@ -188,6 +188,17 @@ def encode_seqs(seqs: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
     return np.ascontiguousarray(data), off
 
 
+def node_order(seqs: Sequence[str], ksize: int, _encoded=None) -> np.ndarray:
+    """Numbering of the nodes along the graph's paths (``vs_node_order_host``, csrc/vs_order_host.cpp):
+    ``order[r]`` = position in ``seqs`` of the node that gets number r."""
+    data, off = _encoded if _encoded is not None else encode_seqs(seqs)
+    order = np.zeros(max(len(seqs), 1), dtype=np.uint32)
+    rc = nat.lib().vs_node_order_host(data.ctypes.data, off.ctypes.data, len(seqs), ksize, order.ctypes.data)
+    if rc != nat.VS_OK:
+        raise nat.NativeError(rc, "vs_node_order_host")
+    return order[: len(seqs)].astype(np.int64)
+
+
 def certify_walk_host(seqs: Sequence[str], ksize: int) -> dict:
     """Host-only run of the walk-index certification (no device): what ``Context.build_index`` would decide."""
     data, off = encode_seqs(seqs)
@@ -265,6 +276,8 @@ class Context:
         self.device = device
         self.n_nodes = 0
         self.ksize = 0
+        self.node_order = None  # internal number -> position in the caller's node list (None: identical)
+        self.node_rank = None   # the inverse
 
     def close(self):
         if self._h:
@@ -283,19 +296,53 @@ class Context:
     def sync(self):
         nat.check(self._h, nat.lib().vs_ctx_sync(self._h))
 
-    def build_index(self, seqs: Sequence[str], ksize: int):
+    def build_index(self, seqs: Sequence[str], ksize: int, renumber: Optional[bool] = None):
         """KeyError(char) if a node of length >= ksize+1 holds a byte outside ACGT, as the
-        reference's reverse_seq raises (PE_Inference.py:12-13)."""
+        reference's reverse_seq raises (PE_Inference.py:12-13).
+
+        ``renumber`` (default on; ``VS_RENUMBER=0`` turns the default off): the index is built over the nodes in an
+        order that runs along the graph's paths (``node_order``, csrc/vs_order_host.cpp) instead of the GFA's -- the
+        device's matrices are then in that INTERNAL numbering (``node_order[internal] = position in seqs``), and
+        everything that hands results out maps back: ``PeCounter.result``, ``map_ends``, ``HipPeLinks``.  Sums do not
+        depend on the numbering; the time does (20-25 % of the step on a graph whose numbering scatters neighbours)."""
+        if renumber is None:
+            renumber = os.environ.get("VS_RENUMBER", "1") != "0"
         data, off = encode_seqs(seqs)
+        order = None
+        if renumber and len(seqs) > 1:
+            order = node_order(seqs, ksize, _encoded=(data, off))
+            if np.array_equal(order, np.arange(len(seqs), dtype=order.dtype)):
+                order = None
+        if order is not None:
+            data, off = encode_seqs([seqs[i] for i in order.tolist()])
         bad_node = C.c_uint32(0)
         bad_char = C.c_uint8(0)
         rc = nat.lib().vs_index_build(self._h, data.ctypes.data, off.ctypes.data, len(seqs), ksize,
                                       C.byref(bad_node), C.byref(bad_char))
         if rc == nat.VS_E_NODE_BASE:
+            if order is not None:  # (the byte the reference names is the first one in GFA order: ask again in that order)
+                return self.build_index(seqs, ksize, renumber=False)
             raise KeyError(chr(bad_char.value))
         nat.check(self._h, rc)
         self.n_nodes = len(seqs)
         self.ksize = ksize
+        self.node_order = order  # None: the numbering of ``seqs``
+        self.node_rank = None
+        if order is not None:
+            self.node_rank = np.empty(len(seqs), dtype=np.int64)
+            self.node_rank[order] = np.arange(len(seqs), dtype=np.int64)
+
+    def internal_cells(self, mat: int, u, v) -> np.ndarray:
+        """Flat cell index inside ``PeCounter.mats[mat]`` (internal numbering) of the cells (u, v) given in the
+        numbering of ``build_index``'s ``seqs``; ``mat`` 1 = short_mat, whose cell is (smaller, larger) index
+        (PE_Inference.py:174-184) in the numbering it was counted in."""
+        u = np.asarray(u, dtype=np.int64)
+        v = np.asarray(v, dtype=np.int64)
+        if self.node_rank is not None:
+            u, v = self.node_rank[u], self.node_rank[v]
+            if mat == 1:
+                u, v = np.minimum(u, v), np.maximum(u, v)
+        return u * self.n_nodes + v
 
     @property
     def index_info(self):
@@ -363,7 +410,8 @@ class Context:
             c = int(counts[e])
             if c > cap:
                 raise ValueError("end %d has %d nodes, cap %d" % (e, c, cap))
-            out.append(sorted(int(x) for x in lists[e, :c]))
+            ids = lists[e, :c] if self.node_order is None else self.node_order[lists[e, :c]]
+            out.append(sorted(int(x) for x in ids))
         return out
 
 
@@ -480,14 +528,31 @@ class PeCounter:
         self.pairs_in_buffer *= world
         return work
 
+    def user_order(self, t):
+        """[2,N,N] device tensor in the index's internal numbering -> the caller's (``Context.build_index``):
+        node_mat rows and columns permuted; short_mat, which holds a pair of nodes at (smaller, larger) number
+        (PE_Inference.py:174-184: ``i <= i2`` over ascending indices), mirrored first and cut back to the upper
+        triangle of the caller's numbering after."""
+        torch = self.torch
+        rank = getattr(self.ctx, "node_rank", None)
+        if rank is None:
+            return t
+        r = torch.from_numpy(rank).to(t.device)
+        node = t[0].index_select(0, r).index_select(1, r)
+        s = t[1]
+        s = s + s.t() - torch.diag(torch.diagonal(s))
+        short = torch.triu(s.index_select(0, r).index_select(1, r))
+        return torch.stack([node, short])
+
     def result(self):
-        """-> (node_mat int64 [N,N], short_mat int64 [N,N], (n_reads, short_reads, used_reads))"""
-        m = self.mats.cpu().numpy().view(np.uint32).astype(np.int64)
-        if self.wide is not None:
-            m += self.wide.cpu().numpy()
-        s = self.stats.cpu().numpy()
+        """-> (node_mat int64 [N,N], short_mat int64 [N,N], (n_reads, short_reads, used_reads)), in the numbering of
+        the node list ``Context.build_index`` was given."""
         n = self.n
-        return m[0, :n, :n], m[1, :n, :n], (int(s[0]), int(s[1]), int(s[2]))
+        m = self.user_order(self.mats[:, :n, :n]).cpu().numpy().view(np.uint32).astype(np.int64)
+        if self.wide is not None:
+            m += self.user_order(self.wide[:, :n, :n]).cpu().numpy()
+        s = self.stats.cpu().numpy()
+        return m[0], m[1], (int(s[0]), int(s[1]), int(s[2]))
 
 
 # ---- outputs -------------------------------------------------------------------------------------
