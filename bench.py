@@ -350,15 +350,22 @@ def launch_ranks(n):
     import socket
     import subprocess
 
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    for attempt in range(3):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+        # (the port was free when asked for and may be taken a moment later: the rendezvous then fails before any rank
+        # has started -- ask for another one)
+        if proc.returncode != 0 and not lines and "address already in use" in proc.stderr and attempt < 2:
+            continue
+        break
+    sys.stderr.write(proc.stderr)
     for l in proc.stdout.splitlines():
         if not l.startswith("{"):
             print(l, file=sys.stderr)

@@ -83,8 +83,8 @@ def main():
         want = pe_oracle_c.Oracle(g.seqs, p["k"]).count_pairs(fwd, rve)
         env = {}
         if rng.random() < 0.3:
-            env = dict([[("VS_NO_STD", "1")], [("VS_NO_FAST", "1")], [("VS_EPT", "6")], [("VS_ACC_WIDE", "2")], [("VS_ACC_MERGE", "1")],
-                        [("VS_NO_SORT", "1")], [("VS_LOCUS_GLOBAL", "1")]][int(rng.integers(0, 7))])
+            env = dict([[("VS_NO_STD", "1")], [("VS_NO_FAST", "1")], [("VS_EPT", "6")], [("VS_ACC_WIDE", "2")], [("VS_ACC_WIDE", "4")], [("VS_ACC_WIDE", "1")], [("VS_ACC_MERGE", "1")], [("VS_ACC_FILL", "100")],
+                        [("VS_NO_SORT", "1")], [("VS_LOCUS_GLOBAL", "1")]][int(rng.integers(0, 10))])
         if rng.random() < 0.15:
             env["VS_NO_MID"] = "1"  # overflow pairs straight to the general kernel
         if rng.random() < 0.25:

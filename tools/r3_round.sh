@@ -1,0 +1,11 @@
+#!/bin/bash
+# GPU-side: pairs per round of the counter kernel (VS_ACC_ROUND) x fill limit, after ACC_SEG
+R="$GRAFT_REPO_ROOT"; cd "$R"; mkdir -p gpurun_out
+export VS_EXPERIMENT=1
+python -m pytest tests/test_pe_gpu.py tests/test_configs_gpu.py -m gpu -x -q 2>&1 | tail -5 > gpurun_out/r3_round_tests.log; tail -3 gpurun_out/r3_round_tests.log
+P='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d["roofline"]; print("tiles %.3f counters %.3f sort %.3f overflow %.3f step %.3f" % (r["kernel_ms_avg"], r["accumulate_ms_avg"], r["locus_sort_ms_avg"], r["slow_kernel_ms_avg"], d["ms_per_step"]))'
+for c in 4 2 3 1; do
+  for env in "X=0" "VS_ACC_ROUND=512" "VS_ACC_ROUND=256" "VS_ACC_ROUND=128" "VS_ACC_ROUND=64" "VS_ACC_ROUND=256 VS_ACC_FILL=25" "VS_ACC_ROUND=128 VS_ACC_FILL=25" "VS_ACC_ROUND=128 VS_ACC_FILL=50" "VS_ACC_ROUND=64 VS_ACC_FILL=50"; do
+    echo -n "config $c [$env]: "; env $env timeout 600 python bench.py --config $c --steps 5 --warmup 1 --cpu-seconds 0 --ingest-pairs 0 --no-extract 2>/dev/null | python -c "$P"
+  done
+done 2>&1 | tee gpurun_out/r3_round.log

@@ -119,6 +119,7 @@ struct VsTuning {
     uint32_t grid_per_cu = 128;     // VS_GRID_PER_CU
     uint32_t acc_grid_per_cu = 32;  // VS_ACC_GRID_PER_CU
     int acc_fill_pct = -1;          // VS_ACC_FILL (-1 = 1/16 of the slots)
+    uint32_t acc_round = 0;         // VS_ACC_ROUND: pairs per round of the counter kernel (0 = automatic; 64 .. 1024, power of two)
     int acc_wide = 0;               // VS_ACC_WIDE (1: 64-bit keys, 2: split tables)
     int shortcut = -1;              // VS_SHORTCUT (-1 = by index statistics)
     uint32_t table_shift = 3;       // VS_TABLE_SHIFT: seed table of >= (distinct seeds << shift) slots (3: at most an eighth full)

@@ -930,6 +930,7 @@ k_pe_tiles(PeParams P) {
 #endif
 struct Acc32 {
     typedef uint32_t KT;
+    static constexpr bool GROUPED = false;
     static constexpr uint32_t BITS = ACC_BITS;
     static constexpr uint32_t EMPTY = 0xFFFFFFFFu;
     __device__ static uint32_t key(uint32_t mat, uint32_t x, uint32_t y, uint32_t N) { return (mat * N + x) * N + y; }
@@ -945,6 +946,7 @@ struct Acc32 {
 };
 struct Acc32Split {
     typedef uint32_t KT;
+    static constexpr bool GROUPED = false;
     static constexpr uint32_t BITS = ACC_BITS;
     static constexpr uint32_t HALF = 1u << (ACC_BITS - 1u);
     static constexpr uint32_t EMPTY = 0xFFFFFFFFu;  // (N <= 65535: the largest cell is N*N - 1 < 2^32 - 1)
@@ -961,6 +963,7 @@ struct Acc32Split {
 };
 struct Acc64 {
     typedef unsigned long long KT;
+    static constexpr bool GROUPED = false;
     static constexpr uint32_t BITS = ACC_BITS - 1u;
     static constexpr unsigned long long EMPTY = ~0ull;
     __device__ static unsigned long long key(uint32_t mat, uint32_t x, uint32_t y, uint32_t N) {
@@ -977,6 +980,22 @@ struct Acc64 {
 #endif
     __device__ static uint32_t mat_of(unsigned long long k, uint32_t, uint32_t) { return (uint32_t)(k >> 60); }
     __device__ static uint64_t cell_of(unsigned long long k, uint32_t) { return k & ((1ull << 60) - 1ull); }
+};
+
+// (r3) AccGrp (VS_ACC_WIDE=4 only -- measured slower than the tables above, see vs_pe_count): GROUPS of 16 cells -- one aligned 64-byte stretch of a matrix row --
+// under ONE tag (matrix << 28 | cell index >> 4), counts in 16 bits.  A group is 8 words of counts + 1 of tag where 16
+// cells of Acc32 take 32 words, so the same LDS holds 65 536 cells instead of 16 384; a look-up compares one tag; and a
+// write-out hands the 16 counts of a group to 16 neighbouring lanes, whose atomics leave the L2 as ONE memory-side
+// request.  A cell gets at most 2 per pair (short_mat's diagonal, PE_Inference.py:174-184), so 16 bits hold the rounds
+// between two write-outs as long as those are at most ACC_GRP_ROUNDS (31 x 1024 pairs x 2 < 65 536); two cells share a
+// word and are added to with one 32-bit LDS atomic (weight << 16 for the upper one: no carry can cross).
+#define ACC_GRP_ROUNDS 31u
+struct AccGrp {
+    typedef uint32_t KT;
+    static constexpr bool GROUPED = true;
+    static constexpr uint32_t BITS = ACC_BITS;  // (unused by the grouped paths: same LDS region)
+    static constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+    __device__ static uint32_t group(uint32_t seg, uint32_t n_groups) { return (uint32_t)(((uint64_t)(seg * 0x9E3779B1u) * n_groups) >> 32); }
 };
 
 // Slow side of vs_cell_add: the slot is empty or holds another cell.  Kept out of line so that
@@ -1023,7 +1042,7 @@ __global__ void __launch_bounds__(ACC_TPB)
 k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_slots_pairs,
                 uint32_t pairs_per_wg, uint32_t N, uint32_t use_table, uint32_t fill_limit,
                 uint32_t *__restrict__ node_mat, uint32_t *__restrict__ short_mat, uint32_t *__restrict__ queue, uint32_t merge,
-                uint32_t *__restrict__ dbg) {  // VS_DEBUG_ACC: [0] increments past the table, [1] write-outs, [2] cells written, [3] rounds
+                uint32_t *__restrict__ dbg, uint32_t ppw, uint32_t n_groups, uint32_t off0, uint32_t off1) {  // VS_DEBUG_ACC: [0] increments past the table, [1] write-outs, [2] cells written, [3] rounds
     using KT = typename TB::KT;
     constexpr uint32_t SLOTS = 1u << TB::BITS;
     KT *s_key = (KT *)vs_lds;                      // [SLOTS] keys: ACC_SLOTS words either way
@@ -1042,7 +1061,17 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
     uint32_t *s_down = s_ua + (LC + 1u) * ACC_GMAX + 4u;  // [ACC_DEDUP_SLOTS]
     uint32_t *s_dmul = s_down + ACC_DEDUP_SLOTS;          // [ACC_DEDUP_SLOTS]
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    for (uint32_t i = tid; i < SLOTS; i += ACC_TPB) { s_key[i] = TB::EMPTY; s_cnt[i] = 0; }
+    // grouped table (AccGrp): counts = 8 words per group from the start of LDS, tags behind them -- in the dedup area when
+    // that is unused (4096 groups), else inside the table region (3584 groups: the host picks n_groups accordingly)
+    uint32_t *g_cnt = vs_lds;
+    uint32_t *g_tag = merge ? vs_lds + 8u * n_groups : s_down;
+    uint32_t rounds_since = 0;  // (uniform over the workgroup)
+    if constexpr (TB::GROUPED) {
+        for (uint32_t i = tid; i < 8u * n_groups; i += ACC_TPB) g_cnt[i] = 0u;
+        for (uint32_t i = tid; i < n_groups; i += ACC_TPB) g_tag[i] = TB::EMPTY;
+    } else {
+        for (uint32_t i = tid; i < SLOTS; i += ACC_TPB) { s_key[i] = TB::EMPTY; s_cnt[i] = 0; }
+    }
     if (tid <= LC) {
         uint32_t gsum = 0;
         for (uint32_t m = 1; m <= tid; m++) gsum += (m + ACC_RUN - 1u) / ACC_RUN;
@@ -1059,6 +1088,23 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
     uint32_t &s_chunk = s_ua[(LC + 1u) * ACC_GMAX + 2u];
     // every cell of the table to its counter (one global atomic per cell), the table emptied
     auto write_out = [&]() {
+        if constexpr (TB::GROUPED) {
+            // 16 lanes per group, a lane per cell: tag and counts are read by all 16 before any of them clears (one wavefront,
+            // program order), the atomics of a group are one 64-byte stretch
+            for (uint32_t i = tid; i < 16u * n_groups; i += ACC_TPB) {
+                const uint32_t g = i >> 4, sub = i & 15u;
+                const uint32_t tag = g_tag[g];
+                if (tag != TB::EMPTY) {
+                    const uint32_t w2 = g_cnt[8u * g + (sub >> 1)];
+                    const uint32_t c = (w2 >> ((sub & 1u) * 16u)) & 0xFFFFu;
+                    const uint32_t mat = tag >> 28;
+                    if (c && use_table != 3u)
+                        atomicAdd((mat ? short_mat : node_mat) + ((((uint64_t)(tag & 0x0FFFFFFFu)) << 4) + sub - (mat ? off1 : off0)), c);
+                    if ((sub & 1u) == 0u) g_cnt[8u * g + (sub >> 1)] = 0u;
+                    if (sub == 0u) g_tag[g] = TB::EMPTY;
+                }
+            }
+        } else {
         for (uint32_t i = tid; i < SLOTS; i += ACC_TPB) {
             const KT key = s_key[i];
             if (key != TB::EMPTY) {
@@ -1068,6 +1114,8 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
                 s_cnt[i] = 0;
             }
         }
+        }
+        rounds_since = 0;
         if (tid == 0) { s_used = 0; s_lost = 0; }
         __syncthreads();
     };
@@ -1082,12 +1130,14 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
     const uint64_t lo = chunk * pairs_per_wg;
     if (lo >= n_slots_pairs) break;
     const uint64_t hi = lo + pairs_per_wg < n_slots_pairs ? lo + pairs_per_wg : n_slots_pairs;
-    for (uint64_t base = lo; base < hi; base += ACC_TPB) {  // ACC_TPB pairs per round, 64 per wavefront
-        const uint64_t wbase = base + wv * 64u;             // wave-uniform
+    // a round = ppw pairs per wavefront (64: one per lane; fewer where the lists are long, so that a round's cells fit the
+    // table and leave it through a write-out, whose atomics travel a 64-byte stretch at a time, instead of one by one)
+    for (uint64_t base = lo; base < hi; base += (ACC_TPB / 64u) * ppw) {
+        const uint64_t wbase = base + wv * ppw;             // wave-uniform
         const uint32_t *wcounts = counts + 2u * wbase;
         const uint32_t *wlists = lists + 2u * wbase * LC;
         uint32_t nl = 0, nr = 0;
-        if (wbase + lane < hi) {
+        if (lane < ppw && wbase + lane < hi) {
             const uint2 c = *(const uint2 *)(wcounts + 2u * lane);
             nl = c.x; nr = c.y;
         }
@@ -1102,7 +1152,7 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
             for (uint32_t side = 0; side < 2u; side++) {
                 const uint32_t n = side ? nr : nl;
                 if (n == 0u) continue;
-                const uint32_t me = 2u * (wv * 64u + lane) + side;  // end index within the round
+                const uint32_t me = 2u * (wv * ppw + lane) + side;  // end index within the round
                 const uint32_t *row = wlists + (2u * lane + side) * LC;
                 uint32_t mine[LC];
                 {
@@ -1237,9 +1287,55 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
             if (use_table == 2u) {
                 if ((y0 ^ y1 ^ y2 ^ y3 ^ x) == 0xDEADBEEFu) atomicAdd(&s_lost, 1u);  // (timing experiment: decode only)
             } else if (use_table) {
+                const uint32_t ys[4] = {y0, y1, y2, y3};
+                if constexpr (TB::GROUPED) {
+                    // the four cells' group tags are read together (independent LDS loads), then counted; a group that
+                    // does not carry the cell's tag yet goes the slow way (claim / next group / global)
+                    uint32_t seg[4], sub[4], at[4], seen[4], cellv[4];
+                    bool live[4];
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; j++) {
+                        live[j] = bi + j < be;  // j = 0 always
+                        const uint32_t yv = ys[j];
+                        const uint32_t cx = (mat && yv < x) ? yv : x, cy = (mat && yv < x) ? x : yv;
+                        cellv[j] = cx * N + cy;  // (N <= 65535)
+                        const uint32_t c2 = cellv[j] + (mat ? off1 : off0);  // position counted from the 64-byte boundary before the matrix
+                        seg[j] = (c2 >> 4) | (mat << 28);
+                        sub[j] = c2 & 15u;
+                        at[j] = TB::group(seg[j], n_groups);
+                        seen[j] = g_tag[at[j]];
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; j++) {
+                        if (!live[j]) continue;
+                        const uint32_t add = wgt << ((sub[j] & 1u) * 16u);
+                        if (seen[j] == seg[j]) {
+                            atomicAdd(&g_cnt[8u * at[j] + (sub[j] >> 1)], add);
+                            continue;
+                        }
+                        uint32_t g = at[j];
+                        bool done = false;
+                        for (uint32_t pr = 0; pr < 8u; pr++) {
+                            uint32_t t2 = g_tag[g];
+                            if (t2 == TB::EMPTY) {
+                                t2 = atomicCAS(&g_tag[g], TB::EMPTY, seg[j]);
+                                if (t2 == TB::EMPTY) { atomicAdd(&s_used, 1u); t2 = seg[j]; }
+                            }
+                            if (t2 == seg[j]) {
+                                atomicAdd(&g_cnt[8u * g + (sub[j] >> 1)], add);
+                                done = true;
+                                break;
+                            }
+                            g = g + 1u == n_groups ? 0u : g + 1u;
+                        }
+                        if (!done) {
+                            atomicAdd(&s_lost, 1u);
+                            atomicAdd((mat ? short_mat : node_mat) + cellv[j], wgt);
+                        }
+                    }
+                } else {
                 // the four cells' slots are read together (independent LDS loads), then counted; a
                 // slot that does not hold the cell yet goes the slow way (claim / probe / global)
-                const uint32_t ys[4] = {y0, y1, y2, y3};
                 KT key[4], seen[4];
                 uint32_t at[4];
                 bool live[4];
@@ -1262,15 +1358,22 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
                         atomicAdd((mat ? short_mat : node_mat) + TB::cell_of(key[j], N), wgt);
                     }
                 }
+                }
             } else {
-                vs_cell_add<TB>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y0, N, node_mat, short_mat, wgt);  // bi < be always
-                if (bi + 1u < be) vs_cell_add<TB>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y1, N, node_mat, short_mat, wgt);
-                if (bi + 2u < be) vs_cell_add<TB>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y2, N, node_mat, short_mat, wgt);
-                if (bi + 3u < be) vs_cell_add<TB>(s_key, s_cnt, s_used, s_lost, 0u, mat, x, y3, N, node_mat, short_mat, wgt);
+                // (VS_NO_AGG=1: every increment a global atomic)
+                const uint32_t ys[4] = {y0, y1, y2, y3};
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++) {
+                    if (bi + j >= be) continue;
+                    const uint32_t yv = ys[j];
+                    const uint32_t cx = (mat && yv < x) ? yv : x, cy = (mat && yv < x) ? x : yv;
+                    atomicAdd((mat ? short_mat : node_mat) + (uint64_t)cx * N + cy, wgt);
+                }
             }
         }
         __syncthreads();
-        const bool spill = s_used > fill_limit || s_lost > 4096u;
+        rounds_since++;
+        const bool spill = s_used > fill_limit || s_lost > 4096u || (TB::GROUPED && rounds_since >= ACC_GRP_ROUNDS);
         if (dbg && tid == 0) {
             atomicAdd(dbg + 3, 1u);
             if (spill) { atomicAdd(dbg + 0, s_lost); atomicAdd(dbg + 1, 1u); atomicAdd(dbg + 2, s_used); }
@@ -1285,11 +1388,7 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
     }
     __syncthreads();
     if (dbg && tid == 0) atomicAdd(dbg + 0, s_lost);
-    for (uint32_t i = tid; i < SLOTS; i += ACC_TPB) {
-        const KT key = s_key[i];
-        if (key != TB::EMPTY)
-            atomicAdd((TB::mat_of(key, N, i) ? short_mat : node_mat) + TB::cell_of(key, N), s_cnt[i]);
-    }
+    write_out();
 }
 
 // ---- locus order -----------------------------------------------------------------------------------
@@ -1559,6 +1658,24 @@ k_pe_mid(PeParams P, const uint32_t *__restrict__ in_list, const uint32_t *__res
         const uint32_t nl = s_flag[1], nr = s_flag[2];
         const uint32_t *L = s_lst, *R = s_lst + MID_LIST;
         if (P.accumulate) {  // PE_Inference.py:174-188
+            // Both lists ascending first (one entry per lane, bitonic network over the wavefront): neighbouring lanes
+            // below then add to neighbouring cells of one matrix row, and the atomics of a wave instruction leave the L2
+            // as one memory-side request per 64-byte stretch they touch (r3: 7.5 -> 5.8 ms with the path numbering).
+            for (uint32_t side = 0; side < 2u; side++) {
+                uint32_t *sv = s_lst + side * MID_LIST;
+                const uint32_t n = side ? nr : nl;
+                uint32_t v = lane < n ? sv[lane] : 0xFFFFFFFFu;
+#pragma unroll
+                for (uint32_t k2 = 2u; k2 <= 64u; k2 <<= 1)
+#pragma unroll
+                    for (uint32_t j2 = k2 >> 1; j2 > 0u; j2 >>= 1) {
+                        const uint32_t o = (uint32_t)__shfl_xor((int)v, (int)j2, 64);
+                        const bool keep_min = ((lane & j2) == 0u) == ((lane & k2) == 0u);
+                        v = keep_min ? (v < o ? v : o) : (v > o ? v : o);
+                    }
+                if (lane < n) sv[lane] = v;
+            }
+            vs_wave_sync();
             for (uint32_t i = lane; i < nl * nr; i += 64u) atomicAdd(&P.node_mat[(uint64_t)L[i / nr] * N + R[i % nr]], 1u);
             for (uint32_t side = 0; side < 2u; side++) {
                 const uint32_t *sv = side ? R : L;
@@ -2064,33 +2181,40 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         // 32-bit cell keys while 2*N*N fits, 64-bit keys (half the slots) above; VS_ACC_WIDE=1 forces
         // the wide table, VS_NO_AGG=1 turns the table off (every increment a global atomic)
         // table shape (see Acc32 / Acc32Split / Acc64); VS_ACC_WIDE=1 forces the 64-bit keys, =2 the split tables
+        // VS_ACC_WIDE=1 forces the 64-bit keys, =2 the split 32-bit tables, =4 the grouped table (AccGrp, shape 3: exact,
+        // 65 536 cells in the same LDS, and slower -- 47 against 35 ms at configs[4], 3.5 against 2.3 at configs[2]: a group of
+        // 16 cells is claimed whole and a round's cells fill 1.5-2 of the 16, so it holds fewer cells, not more)
         const int force_shape = tn.acc_wide;
         const bool fits32 = 2ull * idx.n_nodes * idx.n_nodes < 0xFFFFFFFFull, fits_split = idx.n_nodes <= 65535u;
-        const int shape = force_shape == 1 ? 2 : (force_shape == 2 && fits_split) ? 1 : fits32 ? 0 : fits_split ? 1 : 2;
+        const int shape = force_shape == 1 ? 2 : (force_shape == 2 && fits_split) ? 1 : (force_shape == 4 && fits_split) ? 3 : fits32 ? 0 : fits_split ? 1 : 2;
         const bool wide = shape == 2;
-        const uint32_t slots = wide ? ACC_SLOTS / 2u : ACC_SLOTS;
-        // the table is written out once this many of its slots are taken: linear probing stays
+        const uint32_t merge = (tn.acc_merge || shape == 1) ? 1u : 0u;
+        const uint32_t n_groups = merge ? 3584u : 4096u;  // (with the dedup area in use the tags move into the table region)
+        const uint32_t slots = shape == 3 ? n_groups : wide ? ACC_SLOTS / 2u : ACC_SLOTS;
+        // the table is written out once this many of its slots (groups) are taken: probing stays
         // short at a low fill, and cells of loci the run has left do not pile up (VS_ACC_FILL: percent)
-        uint32_t fill_limit = slots / 16u;
+        uint32_t fill_limit = shape == 3 ? slots / 8u : slots / 16u;
         if (tn.acc_fill_pct >= 0) fill_limit = (uint32_t)((uint64_t)slots * (uint32_t)tn.acc_fill_pct / 100u);
         uint32_t use_table = tn.no_agg ? 0u : 1u;
         if (tn.acc_ablate >= 0) use_table = (uint32_t)tn.acc_ablate;  // 2: decode only, 3: no write-outs (VS_EXPERIMENT=timing only)
         // VS_ACC_MERGE=1: equal end lists of a round are merged (one weighted short_mat expansion per distinct
         // list).  Exact and tested, but off by default: it removes 47 % of the increments at configs[2] and
-        // the kernel takes the same 3.2 ms -- the cell table is not what the time goes into there -- while it
-        // costs 8-20 % on graphs with short lists (configs[1], [3]) and gains 10 % at configs[4].
-        // (the split-table shape -- 46 k to 65 k nodes, configs[4] -- gains 4 % from merging equal end lists: 52.5 -> 50.5 ms)
-        const uint32_t merge = (tn.acc_merge || shape == 1) ? 1u : 0u;
+        // the kernel takes the same time -- the cell table is not what the time goes into there -- while it
+        // costs 8-20 % on graphs with short lists (configs[1], [3]); the split-table shape (VS_ACC_WIDE=2) gains 4 % from it
+        // at configs[4] and turns it on by itself.
         uint32_t *acc_dbg = tn.debug_acc ? (uint32_t *)ctx->d_slow_count + 4 : nullptr;
+        const uint32_t acc_ppw = tn.acc_round ? tn.acc_round / (ACC_TPB / 64u) : 64u;  // VS_ACC_ROUND: pairs per round
         VS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
-        const void *acc_fn = shape == 2 ? (const void *)k_pe_accumulate<Acc64> : shape == 1 ? (const void *)k_pe_accumulate<Acc32Split>
-                                                                                              : (const void *)k_pe_accumulate<Acc32>;
+        const void *acc_fn = shape == 3 ? (const void *)k_pe_accumulate<AccGrp> : shape == 2 ? (const void *)k_pe_accumulate<Acc64>
+                             : shape == 1 ? (const void *)k_pe_accumulate<Acc32Split> : (const void *)k_pe_accumulate<Acc32>;
+        const uint32_t off0 = (uint32_t)(((uintptr_t)d_node_mat >> 2) & 15u), off1 = (uint32_t)(((uintptr_t)d_short_mat >> 2) & 15u);
         VS_HIP(ctx, hipFuncSetAttribute(acc_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES));
 #define VS_ACC_LAUNCH(TB)                                                                                                         \
     hipLaunchKernelGGL(k_pe_accumulate<TB>, dim3(acc_grid), dim3(ACC_TPB), ACC_LDS_BYTES, st, (const uint32_t *)ctx->d_lists,     \
                        (const uint32_t *)ctx->d_list_counts, slots_pairs, per_wg, idx.n_nodes, use_table, fill_limit, d_node_mat, \
-                       d_short_mat, acc_queue, merge, acc_dbg)
-        if (shape == 2) VS_ACC_LAUNCH(Acc64);
+                       d_short_mat, acc_queue, merge, acc_dbg, acc_ppw, n_groups, off0, off1)
+        if (shape == 3) VS_ACC_LAUNCH(AccGrp);
+        else if (shape == 2) VS_ACC_LAUNCH(Acc64);
         else if (shape == 1) VS_ACC_LAUNCH(Acc32Split);
         else VS_ACC_LAUNCH(Acc32);
 #undef VS_ACC_LAUNCH
