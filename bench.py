@@ -56,7 +56,8 @@ def pmc_traffic(config, pairs, kernel_name):
         if summary.get("_pairs_per_gpu") != pairs:
             return {"traffic": None}
         names = [name for name in summary if name.startswith("k_pe_tiles")]
-        if len(names) != 1 or (kernel_name and names[0].replace(" ", "") != kernel_name.replace(" ", "")):
+        norm = lambda n: n.replace(" ", "").replace(",false>", ">")  # (rocprofv3 prints the defaulted template argument)
+        if len(names) != 1 or (kernel_name and norm(names[0]) != norm(kernel_name)):
             return {"traffic": None, "traffic_note": "committed profile is of %s, this run launched %s" % (names, kernel_name)}
         k = summary[names[0]]
         fetch = k["FETCH_SIZE"]["per_dispatch_mean"] * 1024.0

@@ -944,21 +944,36 @@ struct Acc32 {
     __device__ static uint32_t mat_of(uint32_t k, uint32_t N, uint32_t) { return k >= N * N ? 1u : 0u; }
     __device__ static uint64_t cell_of(uint32_t k, uint32_t N) { return k >= N * N ? (uint64_t)(k - N * N) : (uint64_t)k; }
 };
+// ACC_NODE_GROUPS of the ACC_SLOTS / 16 groups of 16 slots belong to node_mat, the rest to short_mat (an even split by
+// default; short_mat's cells -- pairs of nodes under ONE read -- repeat far more than node_mat's)
+#ifndef ACC_NODE_GROUPS
+#define ACC_NODE_GROUPS (ACC_SLOTS / 32u)
+#endif
 struct Acc32Split {
     typedef uint32_t KT;
     static constexpr bool GROUPED = false;
     static constexpr uint32_t BITS = ACC_BITS;
     static constexpr uint32_t HALF = 1u << (ACC_BITS - 1u);
+    static constexpr uint32_t NG = ACC_NODE_GROUPS, SG = ACC_SLOTS / 16u - ACC_NODE_GROUPS;
     static constexpr uint32_t EMPTY = 0xFFFFFFFFu;  // (N <= 65535: the largest cell is N*N - 1 < 2^32 - 1)
     __device__ static uint32_t key(uint32_t, uint32_t x, uint32_t y, uint32_t N) { return x * N + y; }
 #if ACC_SEG
-    __device__ static uint32_t slot(uint32_t mat, uint32_t k) { return (mat ? HALF : 0u) | ((((k >> 4) * 0x9E3779B1u) >> (37u - BITS)) << 4) | (k & 15u); }
-    __device__ static uint32_t next(uint32_t at) { return (at & HALF) | ((at + 16u) & (HALF - 1u)); }
+    __device__ static uint32_t slot(uint32_t mat, uint32_t k) {
+        const uint32_t h = (k >> 4) * 0x9E3779B1u;
+        const uint32_t g = mat ? NG + (uint32_t)(((uint64_t)h * SG) >> 32) : (uint32_t)(((uint64_t)h * NG) >> 32);
+        return (g << 4) | (k & 15u);
+    }
+    __device__ static uint32_t next(uint32_t at) {
+        const uint32_t g = at >> 4, sub = at & 15u;
+        const uint32_t g2 = g + 1u == NG ? 0u : g + 1u == NG + SG ? NG : g + 1u;
+        return (g2 << 4) | sub;
+    }
+    __device__ static uint32_t mat_of(uint32_t, uint32_t, uint32_t i) { return (i >> 4) >= NG ? 1u : 0u; }
 #else
     __device__ static uint32_t slot(uint32_t mat, uint32_t k) { return (mat ? HALF : 0u) | ((k * 0x9E3779B1u) >> (33u - BITS)); }
     __device__ static uint32_t next(uint32_t at) { return (at & HALF) | ((at + 1u) & (HALF - 1u)); }
-#endif
     __device__ static uint32_t mat_of(uint32_t, uint32_t, uint32_t i) { return i >> (BITS - 1u); }
+#endif
     __device__ static uint64_t cell_of(uint32_t k, uint32_t) { return (uint64_t)k; }
 };
 struct Acc64 {
