@@ -663,3 +663,44 @@ def test_node_order_runs_along_paths_and_equals_its_python_statement():
     first, m = walk[0], len(pieces)
     assert walk in (list(range(first, m)) + list(range(first - 1, -1, -1)), list(range(first, -1, -1)) + list(range(first + 1, m))), walk
     assert host.node_order([], 5).tolist() == [] and host.node_order(["ACGT"], 0).tolist() == [0]
+
+
+def test_counter_matrices_come_back_in_the_callers_numbering():
+    """PeCounter.user_order / result with an index built in another numbering (Context.build_index renumber): node_mat is
+    permuted on both axes; short_mat holds a pair of nodes at (smaller, larger) INTERNAL number and must come back at
+    (smaller, larger) position of the caller's list (PE_Inference.py:174-184), the diagonal untouched; folded int64
+    totals take the same way; Context.internal_cells names the same cells from the other side."""
+    import torch
+
+    from vstrains_amd import pe as host
+
+    n = 7
+    rng = np.random.default_rng(4)
+    order = rng.permutation(n)            # order[internal] = caller position
+    rank = np.empty(n, dtype=np.int64)
+    rank[order] = np.arange(n)
+    c = _cpu_counter(n, 0)
+    c.ctx.node_order, c.ctx.node_rank = order, rank
+    c.ctx.internal_cells = host.Context.internal_cells.__get__(c.ctx)
+    # what the caller's numbering should show
+    want_node = rng.integers(0, 50, size=(n, n))
+    want_short = np.triu(rng.integers(0, 50, size=(n, n)))
+    want_node[1, 2] = 2 ** 31 + 7         # (uint32 cells above 2^31 stay positive on the way)
+    for u in range(n):
+        for v in range(n):
+            _set_cell(c, 0, rank[u], rank[v], int(want_node[u, v]))
+            if u <= v:
+                a, b = sorted((rank[u], rank[v]))
+                _set_cell(c, 1, a, b, int(want_short[u, v]))
+    node, short, _ = c.result()
+    assert np.array_equal(node, want_node) and np.array_equal(short, want_short)
+    uu, vv = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    for mat, want in ((0, want_node), (1, want_short)):
+        flat = c.mats[mat].reshape(-1).numpy().view(np.uint32).astype(np.int64)
+        sel = uu <= vv if mat else np.ones_like(uu, dtype=bool)
+        assert np.array_equal(flat[c.ctx.internal_cells(mat, uu[sel], vv[sel])], want[sel])
+    c.fold()
+    _set_cell(c, 1, *sorted((rank[0], rank[3])), 5)
+    want_short[0, 3] += 5
+    node, short, _ = c.result()
+    assert np.array_equal(node, want_node) and np.array_equal(short, want_short)
