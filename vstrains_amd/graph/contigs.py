@@ -105,11 +105,13 @@ def remap_contigs(g: AsmGraph, nodes: NodeMap, edges: EdgeMap, contigs: ContigDi
         return out
 
     logger.info("contig resolution..")
-    for name in prev_ids:
-        id_mapping[name]  # the reference indexes it directly: unknown ids are an error
+    known = set(prev_ids)
+    if not known <= id_mapping.keys():
+        for name in prev_ids:
+            id_mapping[name]  # the reference indexes it directly: unknown ids are an error
     # (the closure of an id is worked out when somebody asks for it: a pass forks a handful of the
     # thousands of ids, and the callers index by id only)
-    closure = _Closure(leaves, set(prev_ids))
+    closure = _Closure(leaves, known)
 
     def images(ids: List[str]) -> List[List[str]]:
         paths = [[s] for s in closure[ids[0]]]

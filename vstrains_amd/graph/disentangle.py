@@ -410,6 +410,17 @@ def global_trivial_split(stage: Stage, logger):
     # (one shared empty dict stands for "not forked" until a vertex really is: remap_contigs only reads)
     id_mapping: Dict[str, Dict[str, None]] = dict.fromkeys(nodes.keys(), _NO_KIDS)
     vblack, adj, nout = g.vblack, g.adj, g.nout
+    # A stage that is still the graph its scan looked at (path_extension calls this right after a re-initialisation) and
+    # in which no vertex has one black edge on one side and several on the other -- ``fork_kind``, worked out for every
+    # vertex by the scan -- has nothing to fork: the sweep below would look at every vertex to find that out (twice a
+    # strain, tens of thousands of vertices).  VS_CHECK_UNTOUCHED=1 sweeps anyway and insists on the outcome.
+    scan, snap = stage.scan, stage.snap
+    nothing_to_fork = (scan is not None and snap is not None and len(scan.fork_kind) == len(adj) and not any(scan.fork_kind)
+                       and snap.matches(g, nodes, edges))
+    if nothing_to_fork and not _CHECK_UNTOUCHED:
+        logger.debug("No of trivial branch be removed: 0")
+        logger.info("done")
+        return 0, id_mapping
     progressed = True
     while progressed and forks < bound:
         progressed = False
@@ -461,6 +472,7 @@ def global_trivial_split(stage: Stage, logger):
     if forks >= bound:
         logger.warning("Strange topology detected, exit trivial split immediately")
         return None, id_mapping
+    assert not (nothing_to_fork and forks), "the scan saw no fork candidate and the sweep forked %d" % forks
     logger.debug("No of trivial branch be removed: " + str(forks))
     logger.info("done")
     return forks, id_mapping

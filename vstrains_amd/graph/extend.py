@@ -18,7 +18,7 @@ import numpy
 
 from .asm_graph import GRAY, AsmGraph, NodeMap
 from .contigs import contigs_by_node, origin_ids, remap_contigs
-from .disentangle import Stage, _add_edge, _add_vertex, _retire_vertex, global_trivial_split, reinit
+from .disentangle import _CHECK_UNTOUCHED, Stage, _add_edge, _add_vertex, _retire_vertex, global_trivial_split, reinit
 from .formats import ContigDict, path_length, path_sequence
 from .ops import GraphOps, LiveLinks, PeLinks, nontrivial_ids
 
@@ -195,15 +195,23 @@ def _consume(g: AsmGraph, nodes: NodeMap, usages: Dict[str, int], table: LinkTab
              threshold, logger) -> None:
     """``reduce_graph``: subtract the path coverage; vertices at or under the threshold go gray
     and leave ``usages``; links touching a gray vertex are dropped."""
+    grayed = False
     for v in path:
         usages[g.vid[v]] += 1
         g.vdp[v] = float(g.vdp[v] - pcov)
         if g.vdp[v] <= threshold:
             g.vblack[v] = GRAY
             usages.pop(g.vid[v])
+            grayed = True
+    # (every linked vertex was black when the pass filtered the table against the re-initialised graph, a moment ago: only
+    # a vertex that went gray just now can cost a link, so a path that left all its vertices above the threshold needs no
+    # walk over the whole table; VS_CHECK_UNTOUCHED=1 walks anyway and insists that nothing goes)
+    if not grayed and not _CHECK_UNTOUCHED:
+        return
     for kept in table.values():
         for (u, w) in list(kept.keys()):
             if not g.vblack[nodes[u]] or not g.vblack[nodes[w]]:
+                assert grayed, "a link to a gray vertex outlived the table filter: %s %s" % (u, w)
                 kept.pop((u, w))
 
 
@@ -275,9 +283,10 @@ def path_extension(stage: Stage, contigs: ContigDict, table: LinkTable, frozen: 
                 table[no] = kept
         if n_forks == 0:  # nothing forked: every id stands for itself, and popping and re-inserting
             # every key in turn leaves the dict as it was
-            for no in usages:
-                if no not in closure.known:
-                    raise KeyError(no)
+            if not usages.keys() <= closure.known:  # (set comparison in C; the walk only to name the first offender)
+                for no in usages:
+                    if no not in closure.known:
+                        raise KeyError(no)
         else:
             for no, used in list(usages.items()):
                 usages.pop(no)
