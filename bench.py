@@ -98,6 +98,7 @@ def strain_extract(ctx, counter, pre, names, logger, out_dir):
     return {"seconds": secs, "strains": len(strains), "stage_graphs_written": n_stage_graphs,
             "stages": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in getattr(pipeline.extract_strains, "last_stages", {}).items()},
             "host_modules": graph_pkg.host_modules(),
+            "sections": {k: round(v, 4) for k, v in sorted(__import__("vstrains_amd.graph._timing", fromlist=["SECTIONS"]).SECTIONS.items())},
             "graph_refresh_launches": backend.graph_ops.calls, "link_table_launches": table.calls,
             "longest_strain_bp": max([rec[1] for rec in strains.values()] or [0])}
 

@@ -27,6 +27,8 @@ from .formats import (ContigDict, path_length, path_sequence, read_stage_gfa, st
 from .ops import GraphOps, GraphScan, LiveLinks, nontrivial_ids
 
 
+from . import _timing as _tm
+
 _CHECK_UNTOUCHED = os.environ.get("VS_CHECK_UNTOUCHED", "") not in ("", "0")
 
 
@@ -87,6 +89,8 @@ def reinit(stage: Stage, ops: GraphOps, logger, filename: str, untouched: bool =
     counts and sums (``_Snapshot.quick_matches``; VS_CHECK_UNTOUCHED=1 makes the full comparison anyway and
     insists; the test suites run with it)."""
     snap = stage.snap
+    if _tm.ON:
+        _tc = _tm.now()
     if untouched and snap is not None and _CHECK_UNTOUCHED:
         assert snap.matches(stage.g, stage.nodes, stage.edges), "stage changed behind an 'untouched' hint: " + filename
     # (a stage that was written to behind an 'untouched' hint fails the quick guard and takes the full comparison)
@@ -98,6 +102,8 @@ def reinit(stage: Stage, ops: GraphOps, logger, filename: str, untouched: bool =
             fh.write(snap.text)
         logger.info(filename + " is stored..")
         return Stage(stage.g, stage.nodes, stage.edges, stage.scan, snap)
+    if _tm.ON:
+        _tm.add("reinit.compare_with_snapshot", _tc)
     # one pass: the file write_stage_gfa would write, and the graph read_stage_gfa(filename) would
     # give back (float(repr(dp)) == dp), without the parse
     if hasattr(ops, "reinit"):  # the device backend does rebuild + flows + scan in one library call
@@ -107,6 +113,11 @@ def reinit(stage: Stage, ops: GraphOps, logger, filename: str, untouched: bool =
         g, nodes, edges, text = stage_graph_from_state(stage.g, stage.nodes, stage.edges, gfa_path=filename, want_text=True)
         logger.info(filename + " is stored..")
         scan = ops.refresh(g)
+    if _tm.ON:
+        _t = _tm.now()
+        snap2 = _Snapshot(g, nodes, edges, text)
+        _tm.add("reinit.snapshot", _t)
+        return Stage(g, nodes, edges, scan, snap2)
     return Stage(g, nodes, edges, scan, _Snapshot(g, nodes, edges, text))
 
 

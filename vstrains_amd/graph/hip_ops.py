@@ -9,6 +9,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
+from . import _timing as _tm
+
 from .. import _native as nat
 from .asm_graph import AsmGraph
 from .ops import GraphOps, GraphScan, LiveLinks, PeLinks
@@ -96,6 +98,8 @@ class HipGraphOps(GraphOps):
         from .asm_graph import BLACK
 
         fast = self._fast
+        if _tm.ON:
+            _t0 = _tm.now()
         if fast is not None:
             try:
                 (n_vid, n_vdp, n_vseq, nn, kept_keys, src, tgt, ovl, a_src, a_tgt, a_dp, text) = fast.prepare(
@@ -106,8 +110,12 @@ class HipGraphOps(GraphOps):
             if len(self._dp_repr) > 1 << 20:
                 self._dp_repr.clear()
             nv, n_e = len(n_vid), len(src)
+            if _tm.ON:
+                _t = _tm.add("reinit.prepare", _t0)
             with open(gfa_path, "wb") as fh:
                 fh.write(text)
+            if _tm.ON:
+                _tm.add("reinit.write_file", _t)
             return self._rebuild(n_vid, n_vdp, n_vseq, nn, kept_keys, src, tgt, ovl, a_src, a_tgt, a_dp, text)
         vblack, vid, vdp, vseq = g.vblack, g.vid, g.vdp, g.vseq
         keep = [v for v in nodes.values() if vblack[v]]
@@ -168,6 +176,8 @@ class HipGraphOps(GraphOps):
         from .asm_graph import BLACK
 
         nv, n_e = len(n_vid), len(src)
+        if _tm.ON:
+            _tr = _tm.now()
         row_ptr = np.zeros(nv + 1, dtype=np.uint64)
         n_out = np.zeros(max(nv, 1), dtype=np.uint32)
         nbr = np.zeros(max(2 * n_e, 1), dtype=np.uint32)
@@ -188,6 +198,8 @@ class HipGraphOps(GraphOps):
             top.ctypes.data, rank.ctypes.data, C.byref(bad)))
         self.native_s += time.perf_counter() - t0
         self.calls += 1
+        if _tm.ON:
+            _t = _tm.add("reinit.arrays_and_native", _tr)
         ng = AsmGraph()
         ng.vid, ng.vdp, ng.vseq = n_vid, n_vdp, n_vseq
         ng.vblack = [BLACK] * nv
@@ -203,7 +215,10 @@ class HipGraphOps(GraphOps):
             raise FloatingPointError("divide by zero encountered in edge flow of edge %s -> %s"
                                      % (n_vid[src[bad.value]], n_vid[tgt[bad.value]]))
         ne = dict(zip(kept_keys, range(n_e)))
-        return ng, nn, ne, text, self._as_scan(ng, nt, fk, nxt, top, rank)
+        scan = self._as_scan(ng, nt, fk, nxt, top, rank)
+        if _tm.ON:
+            _tm.add("reinit.unpack", _t)
+        return ng, nn, ne, text, scan
 
     def edge_flows(self, g: AsmGraph) -> None:
         flow, _, _, _, _, _, bad = self._refresh(g)
