@@ -300,13 +300,13 @@ class Context:
         """KeyError(char) if a node of length >= ksize+1 holds a byte outside ACGT, as the
         reference's reverse_seq raises (PE_Inference.py:12-13).
 
-        ``renumber`` (default on; ``VS_RENUMBER=0`` turns the default off): the index is built over the nodes in an
+        ``renumber`` (default on; ``VS_EXPERIMENT=1 VS_RENUMBER=0`` turns the default off): the index is built over the nodes in an
         order that runs along the graph's paths (``node_order``, csrc/vs_order_host.cpp) instead of the GFA's -- the
         device's matrices are then in that INTERNAL numbering (``node_order[internal] = position in seqs``), and
         everything that hands results out maps back: ``PeCounter.result``, ``map_ends``, ``HipPeLinks``.  Sums do not
         depend on the numbering; the time does (20-25 % of the step on a graph whose numbering scatters neighbours)."""
-        if renumber is None:
-            renumber = os.environ.get("VS_RENUMBER", "1") != "0"
+        if renumber is None:  # (the switch exists in experiment mode only, like the library's: INTEGRATION.md)
+            renumber = not (os.environ.get("VS_EXPERIMENT") and os.environ.get("VS_RENUMBER", "1") == "0")
         data, off = encode_seqs(seqs)
         order = None
         if renumber and len(seqs) > 1:
