@@ -58,6 +58,15 @@ def make_reads(p, st):
                     b[int(h)] = int(DIRTY[int(rng.integers(0, len(DIRTY)))])
             res.append(b.decode())
         out.append(res)
+    # deep coverage: ends that repeat other ends letter for letter
+    n = len(out[0])
+    if n > 1 and rng.random() < 0.35:
+        for _ in range(n // 2 + 1):
+            i, j, which = int(rng.integers(0, n)), int(rng.integers(0, n)), int(rng.integers(0, 3))
+            if which != 2:
+                out[0][j] = out[0][i]
+            if which != 1:
+                out[1][j] = out[1][i]
     return out
 
 

@@ -371,6 +371,56 @@ def test_results_do_not_depend_on_the_internal_numbering(host, ctx):
     assert ctx.node_order is not None and sorted(ctx.node_order.tolist()) == list(range(len(seqs)))
 
 
+@pytest.mark.parametrize("k,read_len", [(55, 150), (127, 250), (21, 90)])
+def test_repeated_read_ends_are_counted_every_time(host, ctx, k, read_len):
+    """Deep coverage: most pairs of a locus repeat other pairs letter for letter (what the counter kernel's table and any
+    shortcut for repeated ends must get right).  A block made of a few hundred distinct pairs repeated forty times in random
+    order -- with copies that differ only in one end, only in lower-case / IUPAC bytes (same text once packed, other
+    positions outside ACGT), in an N, in their length -- against the oracle, matrices and per-end lists."""
+    import random
+
+    g, f, r = _dense_case(k, 300, read_len, seed=900 + k, snp=0.05, n_strains=8, glen=2500, sub=0.004, nrate=0.01)
+    rnd = random.Random(k)
+    fw, rv = [], []
+    for a, b in zip(f, r):
+        for _ in range(40):
+            fw.append(a)
+            rv.append(b)
+    for i in range(0, len(fw), 7):      # same forward read, another reverse read
+        rv[i] = r[rnd.randrange(len(r))]
+    for i in range(3, len(fw), 11):     # a byte outside ACGT: lower case here, IUPAC there, at this position or that
+        x = list(fw[i])
+        pos = rnd.randrange(len(x))
+        x[pos] = x[pos].lower() if rnd.random() < 0.5 else "R"
+        fw[i] = "".join(x)
+    for i in range(5, len(fw), 13):     # the same two positions in several copies: equal also in what is outside ACGT
+        x = list(rv[i])
+        x[10] = x[10].lower()
+        x[40] = "Y"
+        rv[i] = "".join(x)
+    for i in range(1, len(fw), 29):
+        fw[i] = fw[i][:-3]              # shorter copy
+    for i in range(2, len(fw), 97):
+        rv[i] = rv[i][:20] + "N" + rv[i][21:]
+    order = list(range(len(fw)))
+    rnd.shuffle(order)
+    fw = [fw[i] for i in order]
+    rv = [rv[i] for i in order]
+    (node_mat, short_mat, stats), block = _gpu_matrices(host, ctx, g.seqs, fw, rv, k)
+    orc = pe_oracle_c.Oracle(g.seqs, k)
+    ref_node, ref_short, ref_stats = orc.count_pairs(fw, rv)
+    assert np.array_equal(node_mat, ref_node) and np.array_equal(short_mat, ref_short)
+    assert stats == tuple(int(x) for x in ref_stats)
+    lists = ctx.map_ends(block, cap=len(g.seqs))
+    K = k + 1
+    tab = pe_oracle.build_table(g.seqs, K)
+    lens = [len(x) for x in g.seqs]
+    for p in rnd.sample(range(len(fw)), 400):
+        used = not (fw[p].count("N") or rv[p].count("N")) and len(fw[p]) >= K and len(rv[p]) >= K
+        assert lists[2 * p] == (pe_oracle.map_read_end(fw[p], tab, lens, K) if used else []), p
+        assert lists[2 * p + 1] == (pe_oracle.map_read_end(rv[p], tab, lens, K) if used else []), p
+
+
 def test_device_read_generator_equals_cpu_twin(host, ctx):
     from vstrains_amd import synth
 
