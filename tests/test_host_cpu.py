@@ -681,6 +681,7 @@ def test_counter_matrices_come_back_in_the_callers_numbering():
     rank[order] = np.arange(n)
     c = _cpu_counter(n, 0)
     c.ctx.node_order, c.ctx.node_rank = order, rank
+    c.node_order, c.node_rank = order, rank  # (what PeCounter.__init__ takes from a context whose index is numbered so)
     c.ctx.internal_cells = host.Context.internal_cells.__get__(c.ctx)
     # what the caller's numbering should show
     want_node = rng.integers(0, 50, size=(n, n))

@@ -265,7 +265,7 @@ class HipPeLinks(PeLinks):
         ctx.sync()
         # (the counters are in the numbering the index was built in -- pe.Context.build_index -- and so is the table
         # made from them: rows are found by name, so only the name list has to follow)
-        order = getattr(getattr(counter, "ctx", None), "node_order", None)  # (the context that counted into it)
+        order = getattr(counter, "node_order", None)  # (the numbering of the index it counted under)
         if order is not None:
             return cls(ctx, h, [names[i] for i in order.tolist()], caller_names=names)
         return cls(ctx, h, names)

@@ -442,6 +442,10 @@ class PeCounter:
         self.pairs_in_buffer = 0  # pairs counted into ``mats`` since it was last empty (all ranks, after a sum)
         self.pairs_seen = 0
         self.last_all_reduce = None  # "dense" / "sparse" after all_reduce()
+        # (the numbering of the index this counter counts under: kept here, so that a later build_index on the same context
+        # cannot change how these matrices are read)
+        self.node_order = getattr(ctx, "node_order", None)
+        self.node_rank = getattr(ctx, "node_rank", None)
 
     def reset(self):
         self.mats.zero_()
@@ -534,7 +538,7 @@ class PeCounter:
         (PE_Inference.py:174-184: ``i <= i2`` over ascending indices), mirrored first and cut back to the upper
         triangle of the caller's numbering after."""
         torch = self.torch
-        rank = getattr(self.ctx, "node_rank", None)
+        rank = self.node_rank
         if rank is None:
             return t
         r = torch.from_numpy(rank).to(t.device)
