@@ -25,6 +25,11 @@ DIRTY = np.frombuffer(b"acgtnRYKMSWBDHV.-*", dtype=np.uint8)
 
 def draw(rng):
     if os.environ.get("FUZZ_STD"):  # the compile-time tile shapes: k = 55, 2 x 97..159 bases; many strains -> long lists, overflow
+        if rng.random() < 0.25:  # ... and the one of the long-window kernel: k = 127, 2 x 241..256 (k_pe_tiles<2, 16, 3>)
+            return dict(k=127, L=int(rng.integers(238, 259)), n_strains=int(rng.integers(2, 12)), glen=int(rng.integers(900, 5000)),
+                        snp=float(rng.choice([0.01, 0.04, 0.1])), pairs=int(rng.integers(2000, 30000)),
+                        sub=float(rng.choice([0.0, 0.005, 0.02])), nrate=float(rng.choice([0.0, 0.01])),
+                        dirty=float(rng.choice([0.0, 0.0, 0.002, 0.03])), ragged=bool(rng.random() < 0.2), seed=int(rng.integers(0, 2 ** 31)))
         return dict(k=55, L=int(rng.integers(97, 161)), n_strains=int(rng.integers(2, 25)), glen=int(rng.integers(600, 5000)),
                     snp=float(rng.choice([0.01, 0.05, 0.12, 0.2])), pairs=int(rng.integers(3000, 60000)),
                     sub=float(rng.choice([0.0, 0.005, 0.02])), nrate=float(rng.choice([0.0, 0.01])),

@@ -426,6 +426,11 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
 #define STD_K 56u   // k + 1
 #define STD_W 31u   // seed length and probe stride that follow from it (seed_geometry)
 #define STD_S 26u
+#define STD2_EPT 58u  // the k = 127 shape (MODE 2): ends per tile, pool_for(58) = 1024 slots, k + 1, seed length, stride
+#define STD2_POOL_BITS 10u
+#define STD2_K 128u
+#define STD2_W 63u
+#define STD2_S 66u
 // MODE 0: generic loops (masked reads through the validity mask, any stride / read length);
 //      1: straight-line comparison, stride <= 32, reads <= w + 160; 2: the same for stride <= 128, reads <= w + 256.
 // INL (MODE 1 only): multi-posting seeds are read as 32-byte records that hold the node text around the seed
@@ -446,12 +451,17 @@ k_pe_tiles(PeParams P) {
     const uint32_t debug_stop = STD ? 0u : P.debug_stop;
     const bool count_postings = !STD && P.count_postings, want_dbg = !STD && P.dbg_counts != nullptr;
     const bool accumulate = STD || P.accumulate;
-    const uint32_t ept = STD ? STD_EPT : P.ept, pmax = STD ? STD_PMAX : P.pmax;
+    // (r3) MODE 2 has one compile-time shape too: k = 127 with 2 x 241..256 bases -- 63-base seeds, stride 66, 16 words and
+    // three probes per end, 58 ends per tile (what the host's LDS budget gives that shape)
+    constexpr uint32_t C_EPT = MODE == 2 ? STD2_EPT : STD_EPT, C_K = MODE == 2 ? STD2_K : STD_K;
+    constexpr uint32_t C_W = MODE == 2 ? STD2_W : STD_W, C_S = MODE == 2 ? STD2_S : STD_S;
+    constexpr uint32_t C_POOL_BITS = MODE == 2 ? STD2_POOL_BITS : STD_POOL_BITS;
+    const uint32_t ept = STD ? C_EPT : P.ept, pmax = STD ? STD_PMAX : P.pmax;
     const uint32_t NI = ept * pmax;
-    const uint32_t w = STD ? STD_W : P.idx.w, s = STD ? STD_S : P.idx.s, K = STD ? STD_K : P.idx.K;
+    const uint32_t w = STD ? C_W : P.idx.w, s = STD ? C_S : P.idx.s, K = STD ? C_K : P.idx.K;
     const uint32_t wv = VS_SEED_VERIFIED(w);  // seed bases the comparison skips (0: seeds with mixed keys, vs_seed_key)
-    const uint32_t pool = STD ? (1u << STD_POOL_BITS) : P.pool, pool_shift = 32u - (STD ? STD_POOL_BITS : P.pool_bits);
-    const uint32_t words_cap = STD ? STD_EPT * STD_WPE : P.words_cap;
+    const uint32_t pool = STD ? (1u << C_POOL_BITS) : P.pool, pool_shift = 32u - (STD ? C_POOL_BITS : P.pool_bits);
+    const uint32_t words_cap = STD ? C_EPT * STD_WPE : P.words_cap;
     const TileLayout T = tile_layout(ept, pmax, words_cap, pool);
     // (these five point at the current tile's copy; see the top of the tile loop)
     uint32_t *s_gwoff = vs_lds + T.woff;   // global word offsets (mask reads, slow path)
@@ -2036,6 +2046,9 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     // longer strides and reads (k = 127 with 2 x 250 bases): the straight-line kernel with more windows
     const bool fast_long = !fast && (!reads->d_mask || reads->d_inv4) && idx.s <= 128u && maxlen <= VS_SEED_VERIFIED(idx.w) + 256u &&
                            ctx->max_node_len < (1u << 23) && !tn.no_fast;
+    if (fast_long && ept == STD2_EPT && P.pool_bits == STD2_POOL_BITS && idx.K == STD2_K && idx.w == STD2_W && idx.s == STD2_S &&
+        wpe == 16u && pmax == 3u && P.accumulate && !P.debug_stop && !P.count_postings && !P.dbg_counts && !tn.no_std)
+        std_shape = 4;
     // VS_INLINE=1 (experiment mode): 32-byte postings with the text around the seed, where most postings fit their flanks
     // (graphs of short nodes).  Exact, but slower than the 16-byte records: a wavefront nearly always holds
     // SOME posting that needs the node text after all, so it runs both comparisons.
@@ -2048,6 +2061,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
                            : std_shape == 2 ? (const void *)k_pe_tiles<1, 8u, 4u>
                            : std_shape == 3 ? (const void *)k_pe_tiles<1, 7u, 3u>
                            : fast           ? (const void *)k_pe_tiles<1, 0u, 0u>
+                           : std_shape == 4 ? (const void *)k_pe_tiles<2, 16u, 3u>
                            : fast_long      ? (const void *)k_pe_tiles<2, 0u, 0u>
                                             : (const void *)k_pe_tiles<0, 0u, 0u>;
     if (!use_walk && lds > 64u * 1024u)
@@ -2149,6 +2163,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
                        : std_shape == 2 ? "k_pe_tiles<1, 8u, 4u>"
                        : std_shape == 3 ? "k_pe_tiles<1, 7u, 3u>"
                        : fast           ? "k_pe_tiles<1, 0u, 0u>"
+                       : std_shape == 4 ? "k_pe_tiles<2, 16u, 3u>"
                        : fast_long      ? "k_pe_tiles<2, 0u, 0u>"
                                         : "k_pe_tiles<0, 0u, 0u>";
     if (inl && std_shape == 1)
@@ -2167,6 +2182,8 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         hipLaunchKernelGGL((k_pe_tiles<1, 7u, 3u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
     else if (fast)
         hipLaunchKernelGGL((k_pe_tiles<1, 0u, 0u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
+    else if (std_shape == 4)
+        hipLaunchKernelGGL((k_pe_tiles<2, 16u, 3u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
     else if (fast_long)
         hipLaunchKernelGGL((k_pe_tiles<2, 0u, 0u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
     else
