@@ -436,6 +436,16 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
 // INL (MODE 1 only): multi-posting seeds are read as 32-byte records that hold the node text around the seed
 // (VsIndexDev::postings32): a posting whose match cannot leave those VS_FLANK bases is compared without touching the node
 // text -- one dependent load less, no alignment of the text side -- and only the others (long nodes) take the text.
+// tile and pair indices inside k_pe_tiles: a block holds fewer than 2^32 ends, so 32 bits do (-DVS_TILE32=0: 64, as before --
+// six more scalar registers spilled and two more vector registers in the k = 55 shape)
+#ifndef VS_TILE32
+#define VS_TILE32 1
+#endif
+#if VS_TILE32
+typedef uint32_t tidx_t;
+#else
+typedef uint64_t tidx_t;
+#endif
 template <int MODE, uint32_t SW, uint32_t SP, bool INL = false>
 __global__ void __launch_bounds__(TTPB)
 __attribute__((amdgpu_waves_per_eu(MODE == 2 ? TILES_WAVES_LONG : TILES_WAVES, MODE == 2 ? TILES_WAVES_LONG : TILES_WAVES)))
@@ -494,19 +504,21 @@ k_pe_tiles(PeParams P) {
     // node text) is then cached in one L2 instead of eight.
     uint32_t wg = blockIdx.x;
     if ((gridDim.x & 7u) == 0u && !P.no_xcd_map) wg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const uint64_t tile_lo = (uint64_t)wg * P.tiles_per_wg;
-    const uint64_t tile_hi = tile_lo + P.tiles_per_wg < P.n_tiles ? tile_lo + P.tiles_per_wg : P.n_tiles;
+    // (pairs and tiles of a block fit 32 bits: vs_reads holds fewer than 2^32 ends)
+    const tidx_t n_pairs32 = (tidx_t)P.n_pairs, n_tiles32 = (tidx_t)P.n_tiles;
+    const tidx_t tile_lo = (tidx_t)wg * P.tiles_per_wg;
+    const tidx_t tile_hi = tile_lo + P.tiles_per_wg < n_tiles32 ? tile_lo + P.tiles_per_wg : n_tiles32;
     // The headers of a tile (pair order -> end index -> word offset, length) are two dependent
     // global loads; they run ahead in registers, one link per tile (pair order two tiles ahead, word
     // offset and length one tile ahead; one end per thread, ept <= TTPB), so that neither waits for
     // the other and both are covered by the previous tiles' work.
     uint32_t pf_gend = 0, pf_gwoff = 0, pf_meta = 0, pf_inv = 0xFFFFFFFFu, pf_pair = 0xFFFFFFFFu;
     uint32_t cur_inv = 0xFFFFFFFFu;  // this thread's end of the CURRENT tile (goes to LDS at the top of the tile)
-    auto prefetch_pair = [&](uint64_t t) {  // pair (in input order) of this thread's end in tile t
+    auto prefetch_pair = [&](tidx_t t) {  // pair (in input order) of this thread's end in tile t
         pf_pair = 0xFFFFFFFFu;
         if (t < tile_hi && tid < ept) {
-            const uint64_t p = t * ppt + (tid >> 1);
-            if (p < P.n_pairs) pf_pair = P.perm ? P.perm[p] : (uint32_t)p;
+            const tidx_t p = t * ppt + (tid >> 1);
+            if (p < n_pairs32) pf_pair = P.perm ? P.perm[p] : (uint32_t)p;
         }
     };
     auto prefetch_headers = [&]() {  // of the tile whose pair order sits in pf_pair
@@ -545,7 +557,7 @@ k_pe_tiles(PeParams P) {
     prefetch_pair(tile_lo);
     prefetch_headers();
     {
-        const uint64_t np0 = P.n_pairs - tile_lo * ppt;
+        const tidx_t np0 = n_pairs32 - tile_lo * ppt;
         const uint32_t ne0 = 2u * (uint32_t)(np0 < ppt ? np0 : ppt);
         if (tid < ne0) {
             s_gend[tid] = pf_gend;
@@ -564,9 +576,9 @@ k_pe_tiles(PeParams P) {
     prefetch_pair(tile_lo + 1u);
     prefetch_headers();
     prefetch_pair(tile_lo + 2u);
-    for (uint64_t tile = tile_lo; tile < tile_hi; tile++) {
-        const uint64_t p0 = tile * ppt;
-        const uint32_t npair = (uint32_t)((P.n_pairs - p0) < ppt ? (P.n_pairs - p0) : ppt);
+    for (tidx_t tile = tile_lo; tile < tile_hi; tile++) {
+        const tidx_t p0 = tile * ppt;
+        const uint32_t npair = (uint32_t)((n_pairs32 - p0) < ppt ? (n_pairs32 - p0) : ppt);
         const uint32_t ne = 2u * npair;
         const uint32_t cur = (uint32_t)(tile - tile_lo) & 1u, nxt = cur ^ 1u;
         s_gwoff = vs_lds + T.woff + cur * hw;
@@ -577,7 +589,7 @@ k_pe_tiles(PeParams P) {
         uint32_t *n_meta = vs_lds + T.meta + nxt * ept, *n_words = vs_lds + T.words + nxt * wcap;
         uint32_t ne1 = 0;  // ends of the next tile of this run
         if (tile + 1u < tile_hi) {
-            const uint64_t np1 = P.n_pairs - (tile + 1u) * ppt;
+            const tidx_t np1 = n_pairs32 - (tile + 1u) * ppt;
             ne1 = 2u * (uint32_t)(np1 < ppt ? np1 : ppt);
         }
         __syncthreads();  // previous tile fully consumed; this tile's words have landed (see before P4)
@@ -880,10 +892,10 @@ k_pe_tiles(PeParams P) {
         // ---- P5: hand the accepted lists to k_pe_accumulate (one LC-word row per end, tile order;
         // length 0 for ends of dropped pairs and of pairs the slow path takes)
         if (accumulate) {
-            uint32_t *ol = P.out_lists + tile * ept * LC;
+            uint32_t *ol = P.out_lists + (uint64_t)tile * ept * LC;
             for (uint32_t i = tid; i < ne * LC; i += TTPB) ol[i] = s_list[i];
             for (uint32_t i = tid; i < ne; i += TTPB)
-                P.out_counts[tile * ept + i] = (s_state[i] & 3u) == 1u ? s_ns[i] : 0u;
+                P.out_counts[(uint64_t)tile * ept + i] = (s_state[i] & 3u) == 1u ? s_ns[i] : 0u;
         }
         if (want_dbg) {
             for (uint32_t i = tid; i < ne; i += TTPB) {
