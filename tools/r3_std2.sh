@@ -7,4 +7,4 @@ P='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d
 for env in "VS_NO_STD=1" "X=0" "VS_NO_STD=1" "X=0"; do
   echo -n "config 3 [$env]: "; env $env timeout 600 python bench.py --config 3 --steps 10 --warmup 2 --cpu-seconds 3 --ingest-pairs 0 --no-extract 2>/dev/null | python -c "$P"
 done 2>&1 | tee gpurun_out/r3_std2.log
-FUZZ_K=127 python tests/fuzz_pe.py 60 55 2>&1 | tail -1 | cut -c1-200 | tee -a gpurun_out/r3_std2.log
+FUZZ_STD=1 python tests/fuzz_pe.py 60 55 2>&1 | tail -1 | cut -c1-200 | tee -a gpurun_out/r3_std2.log
