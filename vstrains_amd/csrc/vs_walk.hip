@@ -158,3 +158,138 @@ const char *vs_walk_kernel_name(uint32_t nw) {
     static const char *names[6] = {"", "k_pe_walk<1>", "k_pe_walk<2>", "k_pe_walk<3>", "k_pe_walk<4>", "k_pe_walk<5>"};
     return nw >= 1u && nw <= 5u ? names[nw] : "";
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Probe-rate gate for a one-lane-per-WINDOW mapping kernel (VERDICT r3 "next" #2a; timing only, no result is kept).
+// Such a kernel would look up every (k+1)-window of every read end in the (k+1)-mer table above: 2 x 95 x 1e7 = 1.9e9
+// scattered 16-byte slot loads per launch at configs[2].  This kernel does just that and nothing else:
+//   mode 0: one slot load per lane at a slot derived from (end, window) by an integer mix -- the bare rate of scattered
+//           dwordx4 loads out of an L2-resident table;
+//   mode 1: the real addresses -- the packed reads of a tile of 64 ends staged in LDS, the window at read offset j formed
+//           by funnel shifts and hashed as k_pe_walk hashes it, its probe chain followed to the tag match or the empty slot.
+// One lane per window: item i of a tile is (end i / P, window i % P), P = rlen_max - K + 1.
+// ---------------------------------------------------------------------------------------------------------------------
+#define GATE_EPT 64u
+template <uint32_t NW, int MODE>
+__global__ void __launch_bounds__(256) k_probe_gate(VsWalkDev wk, VsReadsDev rd, const uint32_t *__restrict__ perm, uint32_t K, uint32_t P,
+                                                    uint32_t wpe, uint64_t n_ends, uint64_t n_tiles, uint32_t tiles_per_wg,
+                                                    unsigned long long *sink) {
+    __shared__ uint32_t s_words[GATE_EPT * 20u + 8u];
+    __shared__ uint32_t s_gwoff[GATE_EPT], s_len[GATE_EPT];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t ws = wpe | 1u;
+    const uint32_t kmask = (1u << wk.k_bits) - 1u;
+    uint32_t wg = blockIdx.x;
+    if ((gridDim.x & 7u) == 0u) wg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const uint64_t tile_lo = (uint64_t)wg * tiles_per_wg;
+    const uint64_t tile_hi = tile_lo + tiles_per_wg < n_tiles ? tile_lo + tiles_per_wg : n_tiles;
+    uint32_t acc = 0u;
+    const uint32_t magic_p = (uint32_t)(0x100000000ull / P) + 1u;
+    for (uint64_t tile = tile_lo; tile < tile_hi; tile++) {
+        const uint64_t e0 = tile * GATE_EPT;
+        const uint32_t ne = (uint32_t)((n_ends - e0) < GATE_EPT ? (n_ends - e0) : GATE_EPT);
+        __syncthreads();
+        if (tid < GATE_EPT) {
+            uint32_t gw = 0u, len = 0u;
+            if (tid < ne) {
+                const uint64_t e = e0 + tid;
+                const uint32_t pair = perm ? perm[e >> 1] : (uint32_t)(e >> 1);
+                const uint32_t gend = 2u * pair + (uint32_t)(e & 1u);
+                gw = rd.woff[gend];
+                len = rd.meta[gend] & VS_LEN_MASK;
+            }
+            s_gwoff[tid] = gw;
+            s_len[tid] = len;
+        }
+        if (tid < 8u) s_words[GATE_EPT * ws + tid] = 0u;
+        __syncthreads();
+        if (MODE == 1) {
+            for (uint32_t i = tid; i < GATE_EPT * ws; i += 256u) {
+                const uint32_t e = i / ws, k2 = i - e * ws;
+                s_words[i] = k2 < ((s_len[e] + 15u) >> 4) ? rd.words[s_gwoff[e] + k2] : 0u;
+            }
+            __syncthreads();
+        }
+        const uint32_t items = ne * P;
+        for (uint32_t it = tid; it < items; it += 256u) {
+            const uint32_t e = __umulhi(it, magic_p), j = it - e * P;
+            if (MODE == 0) {
+                const uint64_t h = vs_mix64(((e0 + e) << 8) | j);
+                const VsKSlot sl = wk.ktab[(uint32_t)h & kmask];
+                acc ^= sl.pos + sl.ns + sl.tag + sl.woff;
+            } else {
+                if (j + K > s_len[e]) continue;
+                uint64_t h = vs_kmer_hash_init(K);
+#pragma unroll
+                for (uint32_t i = 0; i < NW; i++) {
+                    uint64_t w = vsw_win(s_words, e * ws * 16u + j + 32u * i);
+                    if (i == NW - 1u) w &= vsw_lowmask(2u * K - 64u * (NW - 1u));
+                    h = vs_kmer_hash_step(h, w);
+                }
+                h = vs_kmer_hash_done(h);
+                const uint32_t tag = (uint32_t)(h >> 32);
+                uint32_t s = (uint32_t)h & kmask;
+                for (uint32_t tries = 0; tries < 16u; tries++) {
+                    const VsKSlot sl = wk.ktab[s];
+                    if (sl.ns == VS_WALK_EMPTY) break;
+                    if (sl.tag == tag) { acc ^= sl.pos + sl.ns + sl.woff; break; }
+                    s = (s + 1u) & kmask;
+                }
+            }
+        }
+    }
+    if (acc == 0x9E3779B9u) atomicAdd(sink, 1ull);  // (keeps the loads alive)
+}
+
+extern "C" int vs_exp_probe_gate(vs_ctx *ctx, const vs_reads *reads, int mode, int use_perm, int reps, double *ms_out,
+                                 uint64_t *probes_out) {
+    if (!ctx || !reads || !ms_out) return vs_fail(ctx, VS_E_ARG, "vs_exp_probe_gate: bad argument");
+    if (!ctx->has_index || !ctx->walk_ok) return vs_fail(ctx, VS_E_STATE, "vs_exp_probe_gate: no walk index (VS_EXPERIMENT=1 VS_WALK=1 and a certified graph)");
+    VS_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t K = ctx->idx.K;
+    if (reads->max_len < K) return vs_fail(ctx, VS_E_ARG, "vs_exp_probe_gate: reads shorter than k + 1");
+    const uint32_t P = (uint32_t)reads->max_len - K + 1u;
+    const uint32_t wpe = (uint32_t)((reads->max_len + 15u) / 16u) + 1u;
+    if ((wpe | 1u) > 20u) return vs_fail(ctx, VS_E_RANGE, "vs_exp_probe_gate: reads longer than the gate's LDS rows");
+    const uint64_t n_ends = reads->n_ends, n_tiles = (n_ends + GATE_EPT - 1u) / GATE_EPT;
+    uint32_t grid = (uint32_t)ctx->n_cu * 32u;
+    if (grid > n_tiles) grid = (uint32_t)(n_tiles ? n_tiles : 1u);
+    grid &= ~7u;
+    if (!grid) grid = 8u;
+    const uint32_t tpw = (uint32_t)((n_tiles + grid - 1u) / grid);
+    unsigned long long *sink = nullptr;
+    VS_HIP(ctx, hipMalloc((void **)&sink, 8));
+    VS_HIP(ctx, hipMemsetAsync(sink, 0, 8, ctx->stream));
+    const uint32_t *perm = use_perm && ctx->d_perm && ctx->locus_cap >= n_ends / 2u ? (const uint32_t *)ctx->d_perm : nullptr;
+    hipEvent_t a, b;
+    VS_HIP(ctx, hipEventCreate(&a));
+    VS_HIP(ctx, hipEventCreate(&b));
+    const VsReadsDev rd = reads->dev();
+    auto launch = [&]() {
+#define GATE_CASE(NWV)                                                                                                        \
+    if (mode == 0) hipLaunchKernelGGL((k_probe_gate<NWV, 0>), dim3(grid), dim3(256), 0, ctx->stream, ctx->walk, rd, perm, K, P, wpe, n_ends, n_tiles, tpw, sink); \
+    else hipLaunchKernelGGL((k_probe_gate<NWV, 1>), dim3(grid), dim3(256), 0, ctx->stream, ctx->walk, rd, perm, K, P, wpe, n_ends, n_tiles, tpw, sink);
+        switch (ctx->walk.nw) {
+            case 1: GATE_CASE(1) break;
+            case 2: GATE_CASE(2) break;
+            case 3: GATE_CASE(3) break;
+            case 4: GATE_CASE(4) break;
+            default: GATE_CASE(5) break;
+        }
+#undef GATE_CASE
+    };
+    launch();  // warm-up
+    VS_HIP(ctx, hipEventRecord(a, ctx->stream));
+    for (int r = 0; r < (reps > 0 ? reps : 1); r++) launch();
+    VS_HIP(ctx, hipEventRecord(b, ctx->stream));
+    VS_HIP(ctx, hipEventSynchronize(b));
+    VS_HIP(ctx, hipGetLastError());
+    float ms = 0.f;
+    VS_HIP(ctx, hipEventElapsedTime(&ms, a, b));
+    *ms_out = (double)ms / (reps > 0 ? reps : 1);
+    if (probes_out) *probes_out = n_ends * (uint64_t)P;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    (void)hipFree(sink);
+    return VS_OK;
+}
