@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VS_ABI_VERSION 5
+#define VS_ABI_VERSION 6
 
 enum {
     VS_OK = 0,
@@ -31,8 +31,12 @@ enum {
                             dies with KeyError in reverse_seq (PE_Inference.py:12-13,122) */
     VS_E_STATE = -5,     /* call order (e.g. counting before an index exists) */
     VS_E_RANGE = -6,     /* a size exceeds what this build supports */
-    VS_E_UTF8 = -7       /* a FASTQ sequence line holds bytes that are not valid UTF-8: the reference's
+    VS_E_UTF8 = -7,      /* a FASTQ sequence line holds bytes that are not valid UTF-8: the reference's
                             text-mode readlines() raises UnicodeDecodeError (PE_Inference.py:147-152) */
+    VS_E_KEY = -8,       /* a graph stage looked up an id / index that is not there: the reference raises
+                            KeyError / IndexError / ValueError at that point (vs_stage_error names which) */
+    VS_E_FPE = -9        /* an edge flow would divide by a zero neighbour sum: FloatingPointError under the
+                            reference's numpy.seterr(all="raise") (vstrains:25, Utilities.py:20-30) */
 };
 
 typedef struct vs_ctx vs_ctx;     /* one per device */
@@ -284,6 +288,65 @@ int vs_stage_rebuild(vs_ctx *ctx, uint32_t n_vertices, uint32_t n_edges, const u
                      uint32_t *nbr, uint32_t *eidx, double *flow, uint8_t *nontrivial,
                      uint8_t *fork_kind, int32_t *chain_next, int32_t *chain_top,
                      int32_t *chain_rank, uint32_t *zero_sum_edge);
+
+/* ---- graph stages: native stage handle ----------------------------------------------------------
+ * The state the reference keeps in a graph_tool.Graph plus Python dicts and re-derives from a GFA file after every
+ * pass -- graph, simp_node_dict, simp_edge_dict, contig_dict, the rewritten pe_info, full_link, usages -- as ONE
+ * object in this library, with every stage of VStrains_SPAdes.py:140-248 as one call on it.  Flows, vertex scan and
+ * chain ranking of each re-initialised graph and all PE-link sums run on the device (K5-K7 above); the decisions run
+ * on the host inside the call; stage GFA files are written by worker threads of the handle and are complete when the
+ * call that names them returns.  One entry per reference function:
+ *   vs_stage_edge_cleaning          edge_cleaning, Decomposition.py:822-905
+ *   vs_stage_reinit                 store_reinit_graph, IO.py:630-642
+ *   vs_stage_disentangle            iter_graph_disentanglement, Decomposition.py:908-1042 (balance_split :91-530,
+ *                                   trivial_split :533-688, simp_path_compactification Utilities.py:383-574,
+ *                                   contig_dict_remapping :281-380, contig_dup_removed_s :589-616, trim_contig_dict :147-159)
+ *   vs_stage_best_matching          best_matching, Extension.py:10-111
+ *   vs_stage_increment_nt_coverage  increment_nt_branch_coverage, Utilities.py:183-208
+ *   vs_stage_write_gfa              graph_to_gfa, IO.py:337-372
+ *   vs_stage_path_extension         path_extension, Extension.py:484-899 (global_trivial_split Decomposition.py:691-819,
+ *                                   contig_extension / final_extension Extension.py:115-418, reduce_graph :429-455)
+ *   vs_stage_write_contigs          contig_dict_to_path IO.py:558-595 / contig_dict_to_fasta :518-536 of contig_dict
+ * State crosses the boundary as byte blobs (vs_stage_import / vs_stage_export): a sequence of sections, each a
+ * uint32 tag (VS_STAGE_*) and a payload of little-endian arrays and newline-joined string lists; the layout is stated
+ * where it is written, vstrains_amd/graph/native_stage.py.  `links` must outlive the handle.  Errors: the return
+ * code, and vs_stage_error for the message and the name of the exception the reference raises in that situation. */
+typedef struct vs_stage vs_stage;
+enum {
+    VS_STAGE_GRAPH = 1,    /* vertices, adjacency rows, edge slots, free list, the two ordered maps */
+    VS_STAGE_CONTIGS = 2,  /* contig_dict */
+    VS_STAGE_LINKS = 4,    /* full_link (best_matching's result, consumed by path_extension) */
+    VS_STAGE_STRAINS = 8,  /* strain_dict (export only) */
+    VS_STAGE_USAGES = 16,  /* usages (export only) */
+    VS_STAGE_LOG = 32,     /* the log lines of the calls since the last export of this section (export only) */
+    VS_STAGE_SCAN = 64     /* non-trivial branches, fork kinds, chain ranks of the last re-initialisation */
+};
+int vs_stage_create(vs_ctx *ctx, const vs_links *links, vs_stage **out);
+void vs_stage_destroy(vs_stage *st);
+const char *vs_stage_error(const vs_stage *st, const char **kind);
+int vs_stage_set_debug(vs_stage *st, int on); /* also collect the DEBUG lines */
+/* names of the rows of `links`, '\n'-joined (the nodes of s_graph_L1 in the numbering the table was built in) */
+int vs_stage_set_link_names(vs_stage *st, uint32_t n, const uint8_t *joined, uint64_t len);
+int vs_stage_import(vs_stage *st, const uint8_t *blob, uint64_t len);
+/* the buffer belongs to the handle and is valid until the next call on it */
+int vs_stage_export(vs_stage *st, uint32_t what, const uint8_t **blob, uint64_t *len);
+int vs_stage_edge_cleaning(vs_stage *st);
+int vs_stage_reinit(vs_stage *st, const char *gfa_path);
+/* scan of an imported graph without gray objects (the reference asks get_non_trivial_branches, Utilities.py:175-180,
+ * of whatever graph it is handed); flows are left as they are */
+int vs_stage_refresh_scan(vs_stage *st);
+int vs_stage_disentangle(vs_stage *st, double threshold, const char *temp_dir);
+int vs_stage_best_matching(vs_stage *st);
+int vs_stage_increment_nt_coverage(vs_stage *st);
+int vs_stage_write_gfa(vs_stage *st, const char *path);
+int vs_stage_write_contigs(vs_stage *st, const char *paths_file, const char *fasta_file); /* either may be NULL */
+int vs_stage_path_extension(vs_stage *st, double threshold, const char *temp_dir);
+/* numpy.median of the vertex depths (the thresholds of VStrains_SPAdes.py:187,237 are 0.05 x this) */
+int vs_stage_median_depth(vs_stage *st, double *out);
+/* info[0] re-initialisations, [1] of which reused an untouched state, [2] flow/scan launches, [3] link-sum launches,
+ * [4] files written, [5] bytes written, [6] vertices, [7] live edges; secs[0] in re-initialisations, [1] of which in
+ * the flow/scan operation, [2] in link sums, [3] busy time of the file writers */
+int vs_stage_counters(vs_stage *st, uint64_t info[8], double secs[4]);
 
 /* ---- device memory helpers for C callers without another allocator ----------------------- */
 int vs_dev_alloc(vs_ctx *ctx, size_t bytes, void **out); /* zero-filled */

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvstrains_hip.so")
 
 VS_OK = 0
-VS_E_ARG, VS_E_HIP, VS_E_OOM, VS_E_NODE_BASE, VS_E_STATE, VS_E_RANGE, VS_E_UTF8 = -1, -2, -3, -4, -5, -6, -7
+VS_E_ARG, VS_E_HIP, VS_E_OOM, VS_E_NODE_BASE, VS_E_STATE, VS_E_RANGE, VS_E_UTF8, VS_E_KEY, VS_E_FPE = -1, -2, -3, -4, -5, -6, -7, -8, -9
 
 # name -> (restype, argtypes); every symbol include/vstrains_hip.h declares
 SYMBOLS = {
@@ -69,6 +69,7 @@ SYMBOLS = {
     "vs_links_group_matrix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "vs_graph_refresh": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 13 + [C.POINTER(C.c_uint32)]),
     "vs_stage_rebuild": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 13 + [C.POINTER(C.c_uint32)]),
+    "vs_stage_create": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "vs_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vs_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vs_dev_zero": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -102,6 +103,9 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
+        from .graph import native_stage
+
+        native_stage.bind(L)  # the vs_stage_* entry points (their prototypes live next to the blob layout)
         _lib = L
     return _lib
 

@@ -608,3 +608,45 @@ int vs_graph_refresh(vs_ctx *ctx, uint32_t n_vertices, uint32_t n_edge_slots, co
 }
 
 }  // extern "C"
+
+// =============================================================================================
+// Native stage handle (vs_stage.h / vs_stage.cpp): its three device operations on this context.
+// =============================================================================================
+#include "vs_stage.h"
+
+namespace {
+struct HipStageOps : VsStageOps {
+    vs_ctx *ctx;
+    const vs_links *links;
+    std::vector<uint8_t> ones_v, ones_e;
+    HipStageOps(vs_ctx *c, const vs_links *l) : ctx(c), links(l) {}
+    int refresh(uint32_t nv, uint32_t ne, const uint64_t *row_ptr, const uint32_t *n_out, const uint32_t *nbr, const uint32_t *eidx,
+                const double *dp, double *flow, uint8_t *nontrivial, uint8_t *fork_kind, int32_t *chain_next, int32_t *chain_top,
+                int32_t *chain_rank, uint32_t *zero_sum_edge, std::string &err) override {
+        if (ones_v.size() < nv) ones_v.assign((size_t)nv + nv / 2 + 16, 1);
+        if (ones_e.size() < ne) ones_e.assign((size_t)ne + ne / 2 + 16, 1);
+        int rc = vs_graph_refresh(ctx, nv, ne, row_ptr, n_out, nbr, eidx, dp, ones_v.data(), ones_e.data(), flow, nontrivial, fork_kind,
+                                  chain_next, chain_top, chain_rank, zero_sum_edge);
+        if (rc) err = ctx->err;
+        return rc;
+    }
+    uint32_t link_rows() const override { return links ? links->n : 0u; }
+    int block_sums(const uint64_t *list_off, const uint32_t *list_idx, uint32_t n_lists, const uint32_t *qa, const uint32_t *qb,
+                   uint64_t n_queries, int64_t *out, std::string &err) override {
+        int rc = vs_links_block_sums(ctx, links, list_off, list_idx, n_lists, qa, qb, n_queries, out);
+        if (rc) err = ctx->err;
+        return rc;
+    }
+    int group_matrix(const uint64_t *list_off, const uint32_t *list_idx, uint32_t n_groups, int64_t *out, std::string &err) override {
+        int rc = vs_links_group_matrix(ctx, links, list_off, list_idx, n_groups, out);
+        if (rc) err = ctx->err;
+        return rc;
+    }
+};
+}  // namespace
+
+extern "C" int vs_stage_create(vs_ctx *ctx, const vs_links *links, vs_stage **out) {
+    if (!ctx || !links || !out) return vs_fail(ctx, VS_E_ARG, "vs_stage_create: bad argument");
+    *out = vs_stage_make(new HipStageOps(ctx, links));
+    return VS_OK;
+}

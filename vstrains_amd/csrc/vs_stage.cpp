@@ -1,0 +1,2692 @@
+// Native stage graph: the disentanglement and path-extraction stages of the hot path on one C++ object
+// (vs_stage.h states what it is; include/vstrains_hip.h, "graph stages: native stage handle", is its C ABI).
+//
+// Restates, decision for decision (the outputs are compared byte for byte with the reference's):
+//   store_reinit_graph            utils/VStrains_IO.py:630-642 (+ graph_to_gfa :337-372, flipped_gfa_to_graph :298-334)
+//   edge_cleaning                 utils/VStrains_Decomposition.py:822-905
+//   balance_split                 :91-530 (link_split :7-28, cov_split :31-88)
+//   trivial_split                 :533-688        global_trivial_split :691-819
+//   iter_graph_disentanglement    :908-1042
+//   simp_path_compactification    utils/VStrains_Utilities.py:383-574
+//   contig_dict_remapping         :281-380        trim_contig_dict :147-159        contig_dup_removed_s :589-616
+//   increment_nt_branch_coverage  :183-208        path_len :839-850        path_to_seq :909-921
+//   best_matching                 utils/VStrains_Extension.py:10-111
+//   contig_extension / final_extension :115-418   reduce_graph :429-455    reduce_Anode :469-481
+//   path_extension                :484-899
+// Graph-container semantics (adjacency order, edge-index reuse) are the ones vstrains_amd/graph/asm_graph.py states.
+// Device work goes through VsStageOps: flows + scan + chain ranking once per re-initialisation, PE-link sums batched per
+// pass, the final link table as one grouped contraction.  Stage GFA files are formatted from cached per-vertex / per-edge
+// lines and written by worker threads while the stages go on.
+#include "vs_stage.h"
+
+#include <fcntl.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+#include "../../include/vstrains_hip.h"
+#include "vs_stage_core.h"
+
+using namespace vsg;
+
+namespace {
+
+[[noreturn]] void key_error(const std::string &what) { throw StageError{VS_E_KEY, "KeyError", what}; }
+[[noreturn]] void state_error(const std::string &what) { throw StageError{VS_E_STATE, "RuntimeError", what}; }
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---- text of the stage files: lines live in chunks that never move --------------------------------------------------
+struct LineRef {
+    const char *p = nullptr;
+    uint32_t n = 0;
+};
+struct LineArena {
+    std::vector<std::unique_ptr<char[]>> chunks;
+    size_t used = 0, cap = 0;
+    char *alloc(size_t n) {
+        if (used + n > cap) {
+            cap = std::max<size_t>(n, (size_t)1 << 22);
+            chunks.emplace_back(new char[cap]);
+            used = 0;
+        }
+        char *p = chunks.back().get() + used;
+        used += n;
+        return p;
+    }
+};
+
+struct WriteJob {
+    std::string path;
+    std::shared_ptr<std::vector<LineRef>> lines;
+};
+
+// Worker threads that turn line lists into files (open O_TRUNC, buffered write) while the stages go on.
+struct FileWriter {
+    std::vector<std::thread> threads;
+    std::deque<WriteJob> queue;
+    std::mutex mu;
+    std::condition_variable cv, cv_done;
+    size_t in_flight = 0;
+    bool stop = false;
+    std::string first_error;
+    double busy_s = 0;
+    uint64_t bytes = 0, files = 0;
+
+    void start(unsigned n) {
+        for (unsigned i = 0; i < n; i++) threads.emplace_back([this] { run(); });
+    }
+    ~FileWriter() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto &t : threads) t.join();
+    }
+    static std::string write_file(const WriteJob &job, uint64_t *n_bytes) {
+        int fd = ::open(job.path.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+        if (fd < 0) return "cannot open " + job.path + ": " + strerror(errno);
+        std::vector<char> buf((size_t)1 << 20);
+        size_t fill = 0;
+        std::string err;
+        auto flush = [&]() {
+            size_t off = 0;
+            while (off < fill) {
+                ssize_t w = ::write(fd, buf.data() + off, fill - off);
+                if (w < 0) {
+                    if (errno == EINTR) continue;
+                    err = "write to " + job.path + " failed: " + strerror(errno);
+                    return false;
+                }
+                off += (size_t)w;
+            }
+            *n_bytes += fill;
+            fill = 0;
+            return true;
+        };
+        for (const LineRef &l : *job.lines) {
+            if (fill + l.n > buf.size() && !flush()) break;
+            if (l.n > buf.size()) buf.resize(l.n);
+            memcpy(buf.data() + fill, l.p, l.n);
+            fill += l.n;
+        }
+        if (err.empty()) flush();
+        ::close(fd);
+        return err;
+    }
+    void run() {
+        for (;;) {
+            WriteJob job;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [this] { return stop || !queue.empty(); });
+                if (queue.empty()) return;
+                job = std::move(queue.front());
+                queue.pop_front();
+            }
+            const double t0 = now_s();
+            uint64_t nb = 0;
+            std::string err = write_file(job, &nb);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!err.empty() && first_error.empty()) first_error = err;
+                busy_s += now_s() - t0;
+                bytes += nb;
+                files++;
+                in_flight--;
+            }
+            cv_done.notify_all();
+        }
+    }
+    void submit(WriteJob job) {
+        if (threads.empty()) {  // synchronous mode
+            uint64_t nb = 0;
+            const double t0 = now_s();
+            std::string err = write_file(job, &nb);
+            if (!err.empty() && first_error.empty()) first_error = err;
+            busy_s += now_s() - t0;
+            bytes += nb;
+            files++;
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            queue.push_back(std::move(job));
+            in_flight++;
+        }
+        cv.notify_one();
+    }
+    // all files handed over so far are on disk (or the first failure is reported)
+    void drain() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [this] { return in_flight == 0; });
+        if (!first_error.empty()) {
+            std::string e = first_error;
+            first_error.clear();
+            throw StageError{VS_E_ARG, "OSError", e};
+        }
+    }
+};
+
+// ---- the graph container (asm_graph.AsmGraph, index for index) -------------------------------------------------------
+struct Graph {
+    std::vector<Nid> vid;
+    std::vector<uint32_t> vseq;  // index into Engine::seqs
+    std::vector<double> vdp;
+    std::vector<uint8_t> vblack;
+    std::vector<LineRef> vline;  // cached "S ..." line (p == nullptr: not built / depth changed since)
+    // adjacency: row v = a_nbr / a_e [off[v], off[v] + len[v]), out-entries [0, nout[v]) first
+    std::vector<uint32_t> off, len, cap, nout;
+    std::vector<uint32_t> a_nbr, a_e;
+    std::vector<uint32_t> esrc, etgt;
+    std::vector<int64_t> eovl;
+    std::vector<double> eflow;
+    std::vector<uint8_t> eblack;
+    std::vector<LineRef> eline;  // cached "L ..." line
+    std::deque<uint32_t> free_;
+    uint32_t n_edges = 0;
+
+    uint32_t num_vertices() const { return (uint32_t)vid.size(); }
+    uint32_t out_degree(uint32_t v) const { return nout[v]; }
+    uint32_t in_degree(uint32_t v) const { return len[v] - nout[v]; }
+
+    uint32_t add_vertex(Nid name, double dp, uint32_t seq, bool black) {
+        vid.push_back(name);
+        vdp.push_back(dp);
+        vseq.push_back(seq);
+        vblack.push_back(black ? 1 : 0);
+        vline.push_back(LineRef());
+        off.push_back((uint32_t)a_nbr.size());
+        len.push_back(0);
+        cap.push_back(0);
+        nout.push_back(0);
+        return (uint32_t)vid.size() - 1;
+    }
+    void row_reserve_one(uint32_t v) {
+        if (len[v] < cap[v]) return;
+        if (off[v] + cap[v] == a_nbr.size()) {  // the row ends the arena: grow in place
+            uint32_t add = cap[v] ? cap[v] : 4;
+            a_nbr.resize(a_nbr.size() + add);
+            a_e.resize(a_e.size() + add);
+            cap[v] += add;
+            return;
+        }
+        const uint32_t ncap = cap[v] ? 2 * cap[v] : 4;
+        const uint32_t noff = (uint32_t)a_nbr.size();
+        a_nbr.resize(a_nbr.size() + ncap);
+        a_e.resize(a_e.size() + ncap);
+        for (uint32_t i = 0; i < len[v]; i++) {
+            a_nbr[noff + i] = a_nbr[off[v] + i];
+            a_e[noff + i] = a_e[off[v] + i];
+        }
+        off[v] = noff;
+        cap[v] = ncap;
+    }
+    // add_edge(s, t): the new out-entry goes to slot n_out of s, an in-entry living there moves to the back; the
+    // in-entry of t is appended.  A reused index keeps the property values stored at it unless given.
+    uint32_t add_edge(uint32_t s, uint32_t t) {
+        uint32_t e;
+        if (!free_.empty()) {
+            e = free_.front();
+            free_.pop_front();
+            esrc[e] = s;
+            etgt[e] = t;
+            eline[e] = LineRef();
+        } else {
+            e = (uint32_t)esrc.size();
+            esrc.push_back(s);
+            etgt.push_back(t);
+            eovl.push_back(0);
+            eflow.push_back(0.0);
+            eblack.push_back(0);
+            eline.push_back(LineRef());
+        }
+        row_reserve_one(s);
+        {
+            const uint32_t b = off[s], slot = nout[s], l = len[s];
+            if (slot < l) {
+                a_nbr[b + l] = a_nbr[b + slot];
+                a_e[b + l] = a_e[b + slot];
+            }
+            a_nbr[b + slot] = t;
+            a_e[b + slot] = e;
+            nout[s] = slot + 1;
+            len[s] = l + 1;
+        }
+        row_reserve_one(t);
+        {
+            const uint32_t b = off[t], l = len[t];
+            a_nbr[b + l] = s;
+            a_e[b + l] = e;
+            len[t] = l + 1;
+        }
+        n_edges++;
+        return e;
+    }
+    void row_erase(uint32_t v, uint32_t at) {
+        const uint32_t b = off[v];
+        for (uint32_t i = at; i + 1 < len[v]; i++) {
+            a_nbr[b + i] = a_nbr[b + i + 1];
+            a_e[b + i] = a_e[b + i + 1];
+        }
+        len[v]--;
+    }
+    void remove_edge(uint32_t e) {
+        const uint32_t s = esrc[e], t = etgt[e];
+        {
+            uint32_t at = 0xFFFFFFFFu;
+            for (uint32_t i = 0; i < nout[s]; i++)
+                if (a_nbr[off[s] + i] == t && a_e[off[s] + i] == e) { at = i; break; }
+            if (at == 0xFFFFFFFFu) state_error("remove_edge: out-entry not found");
+            row_erase(s, at);
+            nout[s]--;
+        }
+        {
+            uint32_t at = 0xFFFFFFFFu;
+            for (uint32_t i = nout[t]; i < len[t]; i++)
+                if (a_nbr[off[t] + i] == s && a_e[off[t] + i] == e) { at = i; break; }
+            if (at == 0xFFFFFFFFu) state_error("remove_edge: in-entry not found");
+            row_erase(t, at);
+        }
+        free_.push_back(e);
+        n_edges--;
+    }
+    // first out-entry of s that leads to t (any colour), or -1
+    int64_t edge(uint32_t s, uint32_t t) const {
+        for (uint32_t i = 0; i < nout[s]; i++)
+            if (a_nbr[off[s] + i] == t) return a_e[off[s] + i];
+        return -1;
+    }
+    template <class F>
+    void each_out(uint32_t v, F f) const {  // f(neighbour, edge)
+        for (uint32_t i = 0; i < nout[v]; i++) f(a_nbr[off[v] + i], a_e[off[v] + i]);
+    }
+    template <class F>
+    void each_in(uint32_t v, F f) const {
+        for (uint32_t i = nout[v]; i < len[v]; i++) f(a_nbr[off[v] + i], a_e[off[v] + i]);
+    }
+    std::vector<uint32_t> out_neighbors(uint32_t v) const {
+        return std::vector<uint32_t>(a_nbr.begin() + off[v], a_nbr.begin() + off[v] + nout[v]);
+    }
+    std::vector<uint32_t> in_neighbors(uint32_t v) const {
+        return std::vector<uint32_t>(a_nbr.begin() + off[v] + nout[v], a_nbr.begin() + off[v] + len[v]);
+    }
+    std::vector<uint32_t> black_in_edges(uint32_t v) const {
+        std::vector<uint32_t> r;
+        each_in(v, [&](uint32_t, uint32_t e) { if (eblack[e]) r.push_back(e); });
+        return r;
+    }
+    std::vector<uint32_t> black_out_edges(uint32_t v) const {
+        std::vector<uint32_t> r;
+        each_out(v, [&](uint32_t, uint32_t e) { if (eblack[e]) r.push_back(e); });
+        return r;
+    }
+};
+
+struct Contig {
+    std::vector<Nid> ids;
+    int64_t len = 0;
+    double cov = 0;
+    bool cov_np = false;  // the coverage came out of numpy.median (a numpy.float64 in the reference: round() differs)
+};
+
+struct Scan {
+    std::vector<uint8_t> nontrivial, fork_kind;
+    std::vector<int32_t> chain_next, chain_top, chain_rank;
+    bool valid = false;
+};
+
+struct LogLine {
+    int level;  // 10 DEBUG, 20 INFO, 30 WARNING
+    std::string text;
+};
+
+typedef NameMap<PairMap<int64_t>> LinkTable;
+
+}  // namespace
+
+struct vs_stage {
+    std::unique_ptr<VsStageOps> ops;
+    Names names;
+    std::vector<std::string> seqs;
+    Graph g;
+    NameMap<uint32_t> nodes;   // simp_node_dict: id -> vertex
+    PairMap<uint32_t> edges;   // simp_edge_dict: (id, id) -> edge
+    NameMap<Contig> contigs;   // contig_dict
+    LinkTable full_link;       // best_matching's table, consumed by path_extension
+    NameMap<Contig> strains;   // path_extension's result
+    NameMap<int64_t> usages;
+    Scan scan;
+    bool dirty = true;  // written to since the last re-initialisation
+    std::shared_ptr<std::vector<LineRef>> last_text;  // lines of the stage file of the last re-initialisation
+    LineArena arena;
+    std::unique_ptr<FileWriter> writer;
+    std::vector<LogLine> log;
+    bool debug_log = false;
+    // PE links (ops.LiveLinks): support rows of every live id, fresh / derived marks, cached sums
+    std::vector<int32_t> link_row;  // by name: row of P0, -1 = not an original node
+    std::unordered_map<Nid, std::vector<uint32_t>> supp;
+    std::vector<uint8_t> fresh, derived;  // by name
+    std::vector<Nid> fresh_list;
+    FlatIdx link_cache_idx;
+    std::vector<int64_t> link_cache_val;
+    // counters
+    uint64_t n_reinit = 0, n_reinit_reused = 0, n_refresh = 0, n_link_calls = 0;
+    double t_refresh = 0, t_links = 0, t_reinit = 0;
+    // error of the last call, export buffer
+    std::string err_kind, err_msg;
+    std::string blob;
+
+    // ---- small helpers
+    void info(const std::string &s) { log.push_back(LogLine{20, s}); }
+    void debug(const std::string &s) { if (debug_log) log.push_back(LogLine{10, s}); }
+    void warning(const std::string &s) { log.push_back(LogLine{30, s}); }
+    const std::string &name_of(uint32_t v) const { return names[g.vid[v]]; }
+    uint32_t node(Nid name) const {
+        const uint32_t *v = nodes.get(name);
+        if (!v) key_error(names[name]);
+        return *v;
+    }
+    uint32_t edge_of(Nid a, Nid b) const {
+        const uint32_t *e = edges.get(pair_key(a, b));
+        if (!e) key_error("(" + names[a] + ", " + names[b] + ")");
+        return *e;
+    }
+    uint32_t new_seq(std::string s) {
+        seqs.push_back(std::move(s));
+        return (uint32_t)seqs.size() - 1;
+    }
+    void set_dp(uint32_t v, double dp) {
+        g.vdp[v] = dp;
+        g.vline[v] = LineRef();
+        dirty = true;
+    }
+    // Utilities.py:934-1000
+    uint32_t add_vertex(Nid name, double dp, uint32_t seq) {
+        uint32_t v = g.add_vertex(name, dp, seq, true);
+        nodes.set(name, v);
+        dirty = true;
+        return v;
+    }
+    uint32_t retire_vertex(Nid name) {
+        uint32_t v;
+        if (!nodes.pop(name, &v)) key_error(names[name]);
+        g.vblack[v] = 0;
+        dirty = true;
+        return v;
+    }
+    uint32_t add_edge(uint32_t s, uint32_t t, int64_t overlap, double flow) {
+        uint32_t e = g.add_edge(s, t);
+        g.eovl[e] = overlap;
+        g.eflow[e] = flow;
+        g.eblack[e] = 1;
+        edges.set(pair_key(g.vid[s], g.vid[t]), e);
+        dirty = true;
+        return e;
+    }
+    uint32_t retire_edge(Nid a, Nid b) {
+        uint32_t e;
+        if (!edges.pop(pair_key(a, b), &e)) key_error("(" + names[a] + ", " + names[b] + ")");
+        g.eblack[e] = 0;
+        dirty = true;
+        return e;
+    }
+    void mark_size(std::vector<uint8_t> &m) {
+        if (m.size() < names.size()) m.resize(names.size() + names.size() / 2 + 16, 0);
+    }
+
+    // ---- formats
+    int64_t path_length(const std::vector<uint32_t> &path) const {
+        int64_t total = 0;
+        for (uint32_t u : path) total += (int64_t)seqs[g.vseq[u]].size();
+        for (size_t i = 0; i + 1 < path.size(); i++) {
+            int64_t e = g.edge(path[i], path[i + 1]);
+            if (e >= 0) total -= g.eovl[e];
+        }
+        return total;
+    }
+    int64_t path_length_ids(const std::vector<Nid> &ids) const {
+        std::vector<uint32_t> p;
+        p.reserve(ids.size());
+        for (Nid n : ids) p.push_back(node(n));
+        return path_length(p);
+    }
+    // path_to_seq (Utilities.py:909-921): consecutive vertices must be joined by an edge
+    std::string path_sequence(const std::vector<uint32_t> &path) const {
+        std::string out;
+        for (size_t i = 0; i < path.size(); i++) {
+            const std::string &s = seqs[g.vseq[path[i]]];
+            size_t take = s.size();
+            if (i + 1 != path.size()) {
+                int64_t e = g.edge(path[i], path[i + 1]);
+                if (e < 0) state_error("path_sequence: no edge " + name_of(path[i]) + " -> " + name_of(path[i + 1]));
+                int64_t ovl = g.eovl[e];
+                if (ovl != 0) take = py_slice_end(s.size(), ovl);
+            }
+            out.append(s, 0, take);
+        }
+        return out;
+    }
+    // path_ids_to_seq (Utilities.py:893-906): a missing edge counts as overlap 0
+    std::string path_ids_sequence(const std::vector<Nid> &ids) const {
+        std::string out;
+        for (size_t i = 0; i < ids.size(); i++) {
+            uint32_t u = node(ids[i]);
+            const std::string &s = seqs[g.vseq[u]];
+            size_t take = s.size();
+            if (i + 1 != ids.size()) {
+                int64_t e = g.edge(u, node(ids[i + 1]));
+                int64_t ovl = e >= 0 ? g.eovl[e] : 0;
+                if (ovl != 0) take = py_slice_end(s.size(), ovl);
+            }
+            out.append(s, 0, take);
+        }
+        return out;
+    }
+    // len(seq[:-ovl]) for ovl != 0 (a negative overlap would slice from the front, as Python does)
+    static size_t py_slice_end(size_t n, int64_t ovl) {
+        if (ovl > 0) return (size_t)ovl >= n ? 0 : n - (size_t)ovl;
+        int64_t stop = -ovl;  // seq[:k] with k = -ovl > 0
+        return (size_t)std::min<int64_t>(stop, (int64_t)n);
+    }
+
+    // ---- the stages (bodies below)
+    void reinit(const std::string &filename);
+    void write_gfa(const std::string &filename);
+    std::shared_ptr<std::vector<LineRef>> stage_text();
+    LineRef seg_line(uint32_t v);
+    LineRef link_line(uint32_t e, Nid u, Nid w);
+    void refresh();
+    void edge_cleaning();
+    bool is_non_trivial(uint32_t v) const;
+    std::vector<std::pair<Nid, uint32_t>> nontrivial_ids() const;
+    int64_t balance_split(double threshold, bool is_prim);
+    int64_t trivial_split(NameMap<std::vector<Nid>> &id_mapping);
+    int64_t global_trivial_split(NameMap<std::vector<Nid>> &id_mapping);
+    std::vector<std::vector<uint32_t>> simple_chains();
+    void contract_simple_paths(bool with_contigs, bool with_links);
+    void disentangle(double threshold, const std::string &temp_dir);
+    void trim_contigs(NameMap<Contig> &cd);
+    void drop_duplicate_contigs(NameMap<Contig> &cd);
+    struct Closure;
+    void remap_contigs(const NameMap<std::vector<Nid>> &id_mapping, Closure &closure);
+    void best_matching();
+    void increment_nt_branch_coverage();
+    void walk(std::vector<uint32_t> &path, std::vector<uint8_t> &visited, uint32_t start, bool forward, const LinkTable &table,
+              bool use_coverage, double ccov, double threshold);
+    std::vector<uint32_t> extend(const std::vector<Nid> &contig, const LinkTable &table, bool use_coverage, double ccov, double threshold);
+    void consume(const std::vector<uint32_t> &path, double pcov, double threshold);
+    std::vector<Nid> expand_path_names(Nid name, const NameMap<std::vector<Nid>> &members);
+    std::vector<Nid> origin_ids(const std::vector<Nid> &ids);
+    void path_extension(double threshold, const std::string &temp_dir);
+    void write_contig_files(const std::string &paths_file, const std::string &fasta_file);
+    // PE links
+    const std::vector<uint32_t> &rows(Nid name);
+    void links_prefetch(const std::vector<std::pair<Nid, Nid>> &pairs);
+    int64_t links_get(Nid a, Nid b);
+    void links_born(Nid name, std::vector<uint32_t> support, bool is_fresh);
+    void links_end_pass();
+};
+
+// =====================================================================================================================
+// PE links (vstrains_amd/graph/ops.py:LiveLinks): pe(X, Y) = sum over supp(X) x supp(Y) of P0, never rewritten
+// =====================================================================================================================
+const std::vector<uint32_t> &vs_stage::rows(Nid name) {
+    auto it = supp.find(name);
+    if (it != supp.end()) return it->second;
+    if (name >= link_row.size() || link_row[name] < 0) key_error(names[name]);
+    return supp.emplace(name, std::vector<uint32_t>{(uint32_t)link_row[name]}).first->second;
+}
+
+void vs_stage::links_prefetch(const std::vector<std::pair<Nid, Nid>> &pairs) {
+    std::vector<uint64_t> want;
+    FlatIdx seen;
+    for (auto &p : pairs) {
+        Nid a = std::min(p.first, p.second), b = std::max(p.first, p.second);
+        uint64_t k = pair_key(a, b);
+        if (link_cache_idx.find(k) >= 0 || seen.find(k) >= 0) continue;
+        seen.put(k, 0);
+        want.push_back(k);
+    }
+    if (want.empty()) return;
+    // one list per distinct id of the batch (its support rows); list 0 is the empty list
+    std::vector<uint64_t> list_off{0, 0};
+    std::vector<uint32_t> list_idx;
+    std::unordered_map<Nid, uint32_t> list_of;
+    auto list_for = [&](Nid n) {
+        auto it = list_of.find(n);
+        if (it != list_of.end()) return it->second;
+        const std::vector<uint32_t> &r = rows(n);
+        list_idx.insert(list_idx.end(), r.begin(), r.end());
+        list_off.push_back(list_idx.size());
+        uint32_t id = (uint32_t)list_off.size() - 2;
+        list_of.emplace(n, id);
+        return id;
+    };
+    mark_size(derived);
+    std::vector<uint32_t> qa(want.size()), qb(want.size());
+    for (size_t i = 0; i < want.size(); i++) {
+        Nid a = key_first(want[i]), b = key_second(want[i]);
+        if (a == b) {
+            // an original node keeps its diagonal count; every derived id has 0 with itself
+            qa[i] = qb[i] = derived[a] ? 0u : list_for(a);
+            if (derived[a]) rows(a);  // (the reference's lookup of the id itself: unknown ids raise)
+        } else {
+            qa[i] = list_for(a);
+            qb[i] = list_for(b);
+        }
+    }
+    std::vector<int64_t> out(want.size(), 0);
+    std::string err;
+    const double t0 = now_s();
+    int rc = ops->block_sums(list_off.data(), list_idx.data(), (uint32_t)list_off.size() - 1, qa.data(), qb.data(), want.size(), out.data(), err);
+    t_links += now_s() - t0;
+    n_link_calls++;
+    if (rc) throw StageError{rc, "RuntimeError", err};
+    for (size_t i = 0; i < want.size(); i++) {
+        link_cache_idx.put(want[i], (uint32_t)link_cache_val.size());
+        link_cache_val.push_back(out[i]);
+    }
+}
+
+int64_t vs_stage::links_get(Nid a, Nid b) {
+    uint64_t k = pair_key(std::min(a, b), std::max(a, b));
+    uint32_t i;
+    if (!link_cache_idx.get(k, &i)) {
+        links_prefetch({{a, b}});
+        if (!link_cache_idx.get(k, &i)) state_error("links_get: prefetch did not fill the key");
+    }
+    return link_cache_val[i];
+}
+
+void vs_stage::links_born(Nid name, std::vector<uint32_t> support, bool is_fresh) {
+    supp[name] = std::move(support);
+    mark_size(derived);
+    mark_size(fresh);
+    derived[name] = 1;
+    if (is_fresh && !fresh[name]) {
+        fresh[name] = 1;
+        fresh_list.push_back(name);
+    }
+}
+
+void vs_stage::links_end_pass() {
+    for (Nid n : fresh_list) fresh[n] = 0;
+    fresh_list.clear();
+}
+
+// =====================================================================================================================
+// store_reinit_graph (IO.py:630-642)
+// =====================================================================================================================
+LineRef vs_stage::seg_line(uint32_t v) {
+    if (g.vline[v].p) return g.vline[v];
+    const std::string &id = names[g.vid[v]], &seq = seqs[g.vseq[v]];
+    const std::string dp = py_repr(g.vdp[v]);
+    const size_t n = 2 + id.size() + 1 + seq.size() + 6 + dp.size() + 1;
+    char *p = arena.alloc(n), *q = p;
+    *q++ = 'S'; *q++ = '\t';
+    memcpy(q, id.data(), id.size()); q += id.size();
+    *q++ = '\t';
+    memcpy(q, seq.data(), seq.size()); q += seq.size();
+    memcpy(q, "\tDP:f:", 6); q += 6;
+    memcpy(q, dp.data(), dp.size()); q += dp.size();
+    *q++ = '\n';
+    g.vline[v] = LineRef{p, (uint32_t)n};
+    return g.vline[v];
+}
+
+LineRef vs_stage::link_line(uint32_t e, Nid u, Nid w) {
+    if (g.eline[e].p) return g.eline[e];
+    char num[32];
+    int nn = snprintf(num, sizeof(num), "%lld", (long long)g.eovl[e]);
+    const std::string &a = names[u], &b = names[w];
+    const size_t n = 2 + a.size() + 3 + b.size() + 3 + (size_t)nn + 2;
+    char *p = arena.alloc(n), *q = p;
+    *q++ = 'L'; *q++ = '\t';
+    memcpy(q, a.data(), a.size()); q += a.size();
+    memcpy(q, "\t+\t", 3); q += 3;
+    memcpy(q, b.data(), b.size()); q += b.size();
+    memcpy(q, "\t+\t", 3); q += 3;
+    memcpy(q, num, (size_t)nn); q += nn;
+    *q++ = 'M'; *q++ = '\n';
+    g.eline[e] = LineRef{p, (uint32_t)n};
+    return g.eline[e];
+}
+
+// graph_to_gfa (IO.py:337-372): black vertices in map order, then black edges between black, mapped vertices in map order
+std::shared_ptr<std::vector<LineRef>> vs_stage::stage_text() {
+    auto lines = std::make_shared<std::vector<LineRef>>();
+    lines->reserve(nodes.size() + edges.size());
+    for (auto &ent : nodes.ents)
+        if (ent.live && g.vblack[ent.v]) lines->push_back(seg_line(ent.v));
+    for (auto &ent : edges.ents) {
+        if (!ent.live) continue;
+        const uint32_t *vu = nodes.get(key_first(ent.k)), *vw = nodes.get(key_second(ent.k));
+        if (!vu || !vw) continue;
+        if (!(g.vblack[*vu] && g.vblack[*vw] && g.eblack[ent.v])) continue;
+        lines->push_back(link_line(ent.v, key_first(ent.k), key_second(ent.k)));
+    }
+    return lines;
+}
+
+void vs_stage::write_gfa(const std::string &filename) {
+    writer->submit(WriteJob{filename, stage_text()});
+    info(filename + " is stored..");
+}
+
+void vs_stage::refresh() {
+    const uint32_t nv = g.num_vertices(), ne = (uint32_t)g.esrc.size();
+    std::vector<uint64_t> row_ptr(nv + 1);
+    for (uint32_t v = 0; v < nv; v++) row_ptr[v] = g.off[v];
+    row_ptr[nv] = g.a_nbr.size();
+    scan.nontrivial.assign(nv, 0);
+    scan.fork_kind.assign(nv, 0);
+    scan.chain_next.assign(nv, -1);
+    scan.chain_top.assign(nv, 0);
+    scan.chain_rank.assign(nv, 0);
+    g.eflow.assign(ne, 0.0);
+    uint32_t bad = 0xFFFFFFFFu;
+    std::string err;
+    const double t0 = now_s();
+    int rc = ops->refresh(nv, ne, row_ptr.data(), g.nout.data(), g.a_nbr.data(), g.a_e.data(), g.vdp.data(), g.eflow.data(),
+                          scan.nontrivial.data(), scan.fork_kind.data(), scan.chain_next.data(), scan.chain_top.data(),
+                          scan.chain_rank.data(), &bad, err);
+    t_refresh += now_s() - t0;
+    n_refresh++;
+    if (rc) throw StageError{rc, "RuntimeError", err};
+    if (bad != 0xFFFFFFFFu)  // numpy.seterr(all="raise") in the reference's main process (vstrains:25)
+        throw StageError{VS_E_FPE, "FloatingPointError",
+                         "divide by zero encountered in edge flow of edge " + name_of(g.esrc[bad]) + " -> " + name_of(g.etgt[bad])};
+    scan.valid = true;
+}
+
+// Write the stage GFA, rebuild the graph as re-parsing that file would (drops gray objects, vertex order = map order,
+// edges numbered in map order, every edge flow recomputed).  A stage that was not written to since it was made gives
+// the same file and the same graph: the text is written under the new name and the state kept.
+void vs_stage::reinit(const std::string &filename) {
+    const double t0 = now_s();
+    n_reinit++;
+    if (!dirty && last_text && scan.valid) {
+        writer->submit(WriteJob{filename, last_text});
+        info(filename + " is stored..");
+        n_reinit_reused++;
+        t_reinit += now_s() - t0;
+        return;
+    }
+    Graph ng;
+    const size_t nv_est = nodes.size();
+    ng.vid.reserve(nv_est); ng.vseq.reserve(nv_est); ng.vdp.reserve(nv_est); ng.vline.reserve(nv_est);
+    auto lines = std::make_shared<std::vector<LineRef>>();
+    lines->reserve(nodes.size() + edges.size());
+    // surviving vertices, map order
+    NameMap<uint32_t> nn;
+    nn.slot.assign(names.size(), -1);
+    nn.ents.reserve(nv_est);
+    for (auto &ent : nodes.ents) {
+        if (!ent.live || !g.vblack[ent.v]) continue;
+        const uint32_t v = ent.v;
+        lines->push_back(seg_line(v));
+        const uint32_t nvx = (uint32_t)ng.vid.size();
+        ng.vid.push_back(g.vid[v]);
+        ng.vseq.push_back(g.vseq[v]);
+        ng.vdp.push_back(g.vdp[v]);
+        ng.vline.push_back(g.vline[v]);
+        nn.set(g.vid[v], nvx);
+    }
+    const uint32_t nv = (uint32_t)ng.vid.size();
+    ng.vblack.assign(nv, 1);
+    // surviving edges, map order (both ends looked up BY NAME among the surviving vertices, as graph_to_gfa does)
+    PairMap<uint32_t> ne_map;
+    ne_map.reserve(edges.size());
+    std::vector<uint32_t> deg(nv, 0);
+    for (auto &ent : edges.ents) {
+        if (!ent.live) continue;
+        const uint32_t *s = nn.get(key_first(ent.k)), *t = nn.get(key_second(ent.k));
+        if (!s || !t || !g.eblack[ent.v]) continue;
+        lines->push_back(link_line(ent.v, key_first(ent.k), key_second(ent.k)));
+        const uint32_t ei = (uint32_t)ng.esrc.size();
+        ng.esrc.push_back(*s);
+        ng.etgt.push_back(*t);
+        ng.eovl.push_back(g.eovl[ent.v]);
+        ng.eline.push_back(g.eline[ent.v]);
+        ne_map.set(ent.k, ei);
+        deg[*s]++;
+        deg[*t]++;
+    }
+    const uint32_t n_e = (uint32_t)ng.esrc.size();
+    writer->submit(WriteJob{filename, lines});
+    info(filename + " is stored..");
+    // adjacency rows by the container's placement rule, edges re-inserted in file order
+    ng.off.resize(nv); ng.len.assign(nv, 0); ng.cap.resize(nv); ng.nout.assign(nv, 0);
+    uint32_t acc = 0;
+    for (uint32_t v = 0; v < nv; v++) {
+        ng.off[v] = acc;
+        ng.cap[v] = deg[v];
+        acc += deg[v];
+    }
+    ng.a_nbr.resize(acc);
+    ng.a_e.resize(acc);
+    for (uint32_t e = 0; e < n_e; e++) {
+        const uint32_t s = ng.esrc[e], t = ng.etgt[e];
+        {
+            const uint32_t b = ng.off[s], slot = ng.nout[s], l = ng.len[s];
+            if (slot < l) { ng.a_nbr[b + l] = ng.a_nbr[b + slot]; ng.a_e[b + l] = ng.a_e[b + slot]; }
+            ng.a_nbr[b + slot] = t; ng.a_e[b + slot] = e;
+            ng.nout[s] = slot + 1;
+            ng.len[s] = l + 1;
+        }
+        {
+            const uint32_t b = ng.off[t], l = ng.len[t];
+            ng.a_nbr[b + l] = s; ng.a_e[b + l] = e;
+            ng.len[t] = l + 1;
+        }
+    }
+    ng.eflow.assign(n_e, 0.0);
+    ng.eblack.assign(n_e, 1);
+    ng.n_edges = n_e;
+    g = std::move(ng);
+    nodes = std::move(nn);
+    edges = std::move(ne_map);
+    refresh();
+    last_text = lines;
+    dirty = false;
+    t_reinit += now_s() - t0;
+}
+
+// =====================================================================================================================
+// edge_cleaning (Decomposition.py:822-905)
+// =====================================================================================================================
+void vs_stage::edge_cleaning() {
+    // assigned: (source id, target id) -> bool, in g.edges() order (vertex-major, out-entry order)
+    PairMap<uint8_t> assigned;
+    for (uint32_t v = 0; v < g.num_vertices(); v++)
+        g.each_out(v, [&](uint32_t t, uint32_t) { assigned.set(pair_key(g.vid[v], g.vid[t]), 0); });
+    FlatIdx steps;  // contig_steps: (id, next id) some contig takes
+    for (auto &c : contigs.ents)
+        if (c.live)
+            for (size_t i = 0; i + 1 < c.v.ids.size(); i++) steps.put(pair_key(c.v.ids[i], c.v.ids[i + 1]), 1);
+    int64_t open_edges = g.n_edges;
+    debug("Total edges: " + std::to_string(open_edges));
+    int64_t before = 0;
+    for (;;) {
+        for (uint32_t v = 0; v < g.num_vertices(); v++) {
+            std::vector<uint64_t> pend_in, pend_out;
+            g.each_in(v, [&](uint32_t s, uint32_t) { uint64_t k = pair_key(g.vid[s], g.vid[v]); if (!*assigned.get(k)) pend_in.push_back(k); });
+            g.each_out(v, [&](uint32_t t, uint32_t) { uint64_t k = pair_key(g.vid[v], g.vid[t]); if (!*assigned.get(k)) pend_out.push_back(k); });
+            if (pend_in.size() == 1) { *assigned.get(pend_in[0]) = 1; open_edges--; }
+            // (evaluated on the lists taken before the in-edge above was marked, as the reference does)
+            if (pend_out.size() == 1) { *assigned.get(pend_out[0]) = 1; open_edges--; }
+        }
+        if (before == open_edges) break;
+        before = open_edges;
+    }
+    debug("un-assigned edges after node-weight coverage iteration : " + std::to_string(open_edges));
+    for (auto &a : assigned.ents)
+        if (!a.v && steps.find(a.k) >= 0) a.v = 1;
+    std::vector<uint8_t> taken_src(names.size(), 0), taken_tgt(names.size(), 0);
+    for (auto &a : assigned.ents)
+        if (a.v) { taken_src[key_first(a.k)] = 1; taken_tgt[key_second(a.k)] = 1; }
+    for (auto &a : assigned.ents) {
+        if (a.v || !(taken_src[key_first(a.k)] || taken_tgt[key_second(a.k)])) continue;
+        uint32_t e;
+        if (!edges.pop(a.k, &e)) key_error("(" + names[key_first(a.k)] + ", " + names[key_second(a.k)] + ")");
+        g.remove_edge(e);
+        dirty = true;
+        debug("intersect unsupported edge: " + names[key_first(a.k)] + " -> " + names[key_second(a.k)] + ", removed");
+    }
+}
+
+// =====================================================================================================================
+// branch tests
+// =====================================================================================================================
+bool vs_stage::is_non_trivial(uint32_t v) const {  // Utilities.py:162-172 on the live graph
+    std::vector<Nid> us, ws;
+    g.each_in(v, [&](uint32_t s, uint32_t e) { if (g.eblack[e]) us.push_back(g.vid[s]); });
+    g.each_out(v, [&](uint32_t t, uint32_t e) { if (g.eblack[e]) ws.push_back(g.vid[t]); });
+    size_t both = 0;
+    std::vector<Nid> seen;
+    for (Nid u : us) {
+        if (std::find(seen.begin(), seen.end(), u) != seen.end()) continue;
+        seen.push_back(u);
+        if (std::find(ws.begin(), ws.end(), u) != ws.end()) both++;
+    }
+    const size_t m = std::max<size_t>(both, 1);
+    return us.size() > m && ws.size() > m;
+}
+
+std::vector<std::pair<Nid, uint32_t>> vs_stage::nontrivial_ids() const {  // get_non_trivial_branches, node-map order
+    if (!scan.valid) state_error("the stage has no scan (no re-initialisation yet)");
+    std::vector<std::pair<Nid, uint32_t>> out;
+    for (auto &ent : nodes.ents) {
+        if (!ent.live) continue;
+        if (ent.v >= scan.nontrivial.size()) state_error("vertex younger than the scan: " + names[ent.k]);
+        if (scan.nontrivial[ent.v]) out.push_back({ent.k, ent.v});
+    }
+    return out;
+}
+
+namespace {
+// a handful of (id -> number) pairs in first-insertion order (dict.fromkeys(us, 0), {u: flow ...})
+template <class V>
+struct SmallMap {
+    std::vector<std::pair<Nid, V>> e;
+    V *get(Nid k) {
+        for (auto &p : e)
+            if (p.first == k) return &p.second;
+        return nullptr;
+    }
+    V &at(Nid k, const Names &names) {
+        V *p = get(k);
+        if (!p) key_error(names[k]);
+        return *p;
+    }
+    void set(Nid k, V v) {
+        V *p = get(k);
+        if (p) *p = v; else e.push_back({k, v});
+    }
+};
+struct Triple {
+    Nid u, w;
+    int64_t pe;
+};
+struct Kept {
+    double flow;
+    int64_t pe;
+};
+}  // namespace
+
+// node id -> contig names that visit it (first-seen order, each once)
+static std::unordered_map<Nid, std::vector<Nid>> contigs_by_node(const NameMap<Contig> &cd) {
+    std::unordered_map<Nid, std::vector<Nid>> by;
+    for (auto &c : cd.ents) {
+        if (!c.live) continue;
+        for (Nid n : c.v.ids) {
+            auto &lst = by[n];
+            if (lst.empty() || lst.back() != c.k) {
+                // (a contig that visits the node twice: both visits come from the same pass over its ids, so "already
+                // there" can only be the last entry)
+                lst.push_back(c.k);
+            }
+        }
+    }
+    return by;
+}
+
+static size_t index_of(const std::vector<Nid> &ids, Nid x, const Names &names) {
+    for (size_t i = 0; i < ids.size(); i++)
+        if (ids[i] == x) return i;
+    throw StageError{VS_E_KEY, "ValueError", names[x] + " is not in list"};
+}
+
+// =====================================================================================================================
+// balance_split (Decomposition.py:91-530)
+// =====================================================================================================================
+int64_t vs_stage::balance_split(double threshold, bool is_prim) {
+    info(std::string("balance split using contigs&paired end links&coverage information.. isPrim: ") + (is_prim ? "True" : "False"));
+    auto branches = nontrivial_ids();
+    auto black_us = [&](uint32_t v) {
+        std::vector<Nid> r;
+        g.each_in(v, [&](uint32_t s, uint32_t e) { if (g.eblack[e]) r.push_back(g.vid[s]); });
+        return r;
+    };
+    auto black_ws = [&](uint32_t v) {
+        std::vector<Nid> r;
+        g.each_out(v, [&](uint32_t t, uint32_t e) { if (g.eblack[e]) r.push_back(g.vid[t]); });
+        return r;
+    };
+    {   // one batched device lookup for every (in-neighbour, out-neighbour) combination of the pass
+        std::vector<std::pair<Nid, Nid>> wanted;
+        for (auto &br : branches) {
+            auto us = black_us(br.second), ws = black_ws(br.second);
+            for (Nid u : us)
+                for (Nid w : ws) wanted.push_back({u, w});
+        }
+        links_prefetch(wanted);
+    }
+    auto by_node = contigs_by_node(contigs);
+    std::vector<Nid> done;
+    mark_size(fresh);
+    for (auto &br : branches) {
+        const Nid no = br.first;
+        const uint32_t v = br.second;
+        auto us = black_us(v), ws = black_ws(v);
+        debug("current non trivial branch: " + names[no] + ", in-degree: " + std::to_string(us.size()) + ", out-degree: " + std::to_string(ws.size()));
+        mark_size(fresh);
+        bool any_fresh = false;
+        for (Nid x : us) any_fresh = any_fresh || fresh[x];
+        for (Nid x : ws) any_fresh = any_fresh || fresh[x];
+        if (any_fresh) continue;
+        if (!is_non_trivial(v)) continue;
+        if (us.size() != ws.size()) continue;
+
+        bool via_links = true;
+        auto all_pieces_starred = [&](const std::string &leaf) {
+            size_t p = 0;
+            for (;;) {
+                size_t q = leaf.find('&', p);
+                std::string piece = leaf.substr(p, q == std::string::npos ? std::string::npos : q - p);
+                if (piece.find('*') == std::string::npos) return false;
+                if (q == std::string::npos) return true;
+                p = q + 1;
+            }
+        };
+        for (Nid leaf : us)
+            if (via_links && all_pieces_starred(names[leaf])) via_links = false;
+        for (Nid leaf : ws)
+            if (via_links && all_pieces_starred(names[leaf])) via_links = false;
+        {
+            bool all_zero = true;
+            for (Nid u : us)
+                for (Nid w : ws)
+                    if (links_get(u, w) != 0) all_zero = false;
+            if (all_zero) via_links = false;
+        }
+        std::vector<Nid> support;
+        {
+            auto it = by_node.find(no);
+            if (it != by_node.end()) support = it->second;
+        }
+        FlatIdx through;
+        for (Nid cno : support) {
+            const std::vector<Nid> &ids = contigs.get(cno)->ids;
+            size_t at = index_of(ids, no, names);
+            if (at > 0 && at + 1 < ids.size()) through.put(pair_key(ids[at - 1], ids[at + 1]), 1);
+        }
+        PairMap<Kept> kept;
+        std::vector<Triple> sec;
+        SmallMap<int> in_use, out_use;
+        SmallMap<double> in_cap, out_cap;
+        for (Nid u : us) { in_use.set(u, 0); in_cap.set(u, g.eflow[edge_of(u, no)]); }
+        for (Nid w : ws) { out_use.set(w, 0); out_cap.set(w, g.eflow[edge_of(no, w)]); }
+        for (Nid u : us)
+            for (Nid w : ws) {
+                int64_t pe = links_get(u, w);
+                if (through.find(pair_key(u, w)) >= 0 || u == w) {
+                    in_use.at(u, names) += 1;
+                    out_use.at(w, names) += 1;
+                    kept.set(pair_key(u, w), Kept{(in_cap.at(u, names) + out_cap.at(w, names)) / 2, pe});
+                } else {
+                    sec.push_back(Triple{u, w, pe});
+                }
+            }
+        std::stable_sort(sec.begin(), sec.end(), [](const Triple &a, const Triple &b) { return a.pe > b.pe; });
+        if (is_prim) {
+            if (via_links) {  // link_split
+                for (auto &t : sec) {
+                    if (t.pe <= 0) break;
+                    in_use.at(t.u, names) += 1;
+                    out_use.at(t.w, names) += 1;
+                    kept.set(pair_key(t.u, t.w), Kept{(in_cap.at(t.u, names) + out_cap.at(t.w, names)) / 2, t.pe});
+                }
+            }
+        } else {  // cov_split
+            for (auto &t : sec) {
+                if (t.pe <= 0) break;
+                if (in_use.at(t.u, names) > 0 || out_use.at(t.w, names) > 0) continue;
+                in_use.at(t.u, names) += 1;
+                out_use.at(t.w, names) += 1;
+                kept.set(pair_key(t.u, t.w), Kept{(in_cap.at(t.u, names) + out_cap.at(t.w, names)) / 2, t.pe});
+            }
+            for (Nid u : us) {
+                if (in_use.at(u, names) > 0) continue;
+                std::vector<Nid> w_rank(ws), u_rank(us);
+                const double cu = in_cap.at(u, names);
+                std::stable_sort(w_rank.begin(), w_rank.end(), [&](Nid a, Nid b) {
+                    return std::fabs(cu - out_cap.at(a, names)) < std::fabs(cu - out_cap.at(b, names)); });
+                const Nid w = w_rank[0];
+                const double cw = out_cap.at(w, names);
+                std::stable_sort(u_rank.begin(), u_rank.end(), [&](Nid a, Nid b) {
+                    return std::fabs(in_cap.at(a, names) - cw) < std::fabs(in_cap.at(b, names) - cw); });
+                if (u_rank[0] == u && out_use.at(w, names) == 0 && !kept.has(pair_key(u, w))) {
+                    const double guard = 2 * std::fabs(cu - cw);
+                    if (u_rank.size() < 2 || w_rank.size() < 2) throw StageError{VS_E_KEY, "IndexError", "list index out of range"};
+                    if (std::fabs(in_cap.at(u_rank[1], names) - cw) <= guard || std::fabs(cu - out_cap.at(w_rank[1], names)) <= guard) continue;
+                    in_use.at(u, names) += 1;
+                    out_use.at(w, names) += 1;
+                    kept.set(pair_key(u, w), Kept{(cu + cw) / 2, links_get(u, w)});
+                }
+            }
+        }
+        bool one_each = true;
+        for (auto &p : in_use.e) one_each = one_each && p.second == 1;
+        for (auto &p : out_use.e) one_each = one_each && p.second == 1;
+        if (!one_each) {
+            debug("->Not satisfy N-N split, skip: " + names[no]);
+            continue;
+        }
+        double worst = -1;
+        bool first = true;
+        for (auto &k : kept.ents) {
+            if (!k.live) continue;
+            double d = std::fabs(in_cap.at(key_first(k.k), names) - out_cap.at(key_second(k.k), names));
+            if (first || d > worst) worst = d;
+            first = false;
+        }
+        if (first) throw StageError{VS_E_KEY, "ValueError", "max() arg is an empty sequence"};
+        if (worst > 4 * threshold) continue;
+        debug("->perform split: " + names[no]);
+
+        done.push_back(no);
+        PairMap<Nid> sub_of;
+        {
+            int serial = 0;
+            for (auto &k : kept.ents) {
+                if (!k.live) continue;
+                const Nid u = key_first(k.k), w = key_second(k.k);
+                const Nid sub = names.intern(names[no] + "*" + std::to_string(serial++));
+                const uint32_t sv = add_vertex(sub, k.v.flow, g.vseq[v]);
+                add_edge(node(u), sv, g.eovl[edge_of(u, no)], k.v.flow);
+                add_edge(sv, node(w), g.eovl[edge_of(no, w)], k.v.flow);
+                sub_of.set(k.k, sub);
+            }
+        }
+        auto suffix = [&](Nid sub) {  // str(sub.split("*")[-1])
+            const std::string &s = names[sub];
+            size_t p = s.rfind('*');
+            return p == std::string::npos ? s : s.substr(p + 1);
+        };
+        for (Nid cno : support) {
+            Contig c;
+            if (!contigs.pop(cno, &c)) key_error(names[cno]);
+            size_t at = index_of(c.ids, no, names);
+            const bool has_u = at > 0, has_w = at + 1 < c.ids.size();
+            const Nid u = has_u ? c.ids[at - 1] : NO_NID, w = has_w ? c.ids[at + 1] : NO_NID;
+            if (has_u && has_w) {
+                const Nid *sub = sub_of.get(pair_key(u, w));
+                if (!sub) key_error("(" + names[u] + ", " + names[w] + ")");
+                c.ids[at] = *sub;
+                contigs.set(cno, std::move(c));
+            } else if (!has_u && !has_w) {
+                for (auto &so : sub_of.ents) {
+                    const uint32_t sv = node(so.v);
+                    Contig nc;
+                    nc.ids = {so.v};
+                    nc.len = (int64_t)seqs[g.vseq[sv]].size();
+                    nc.cov = g.vdp[sv];
+                    contigs.set(names.intern(names[cno] + "$" + suffix(so.v)), std::move(nc));
+                }
+            } else if (has_u) {
+                for (auto &so : sub_of.ents)
+                    if (key_first(so.k) == u) {
+                        c.ids[at] = so.v;
+                        Contig nc = c;
+                        contigs.set(names.intern(names[cno] + "$" + suffix(so.v)), std::move(nc));
+                    }
+            } else {
+                for (auto &so : sub_of.ents)
+                    if (key_second(so.k) == w) {
+                        c.ids[at] = so.v;
+                        Contig nc = c;
+                        contigs.set(names.intern(names[cno] + "$" + suffix(so.v)), std::move(nc));
+                    }
+            }
+        }
+        for (Nid u : us) retire_edge(u, no);
+        for (Nid w : ws) retire_edge(no, w);
+        retire_vertex(no);
+        by_node = contigs_by_node(contigs);
+        for (auto &so : sub_of.ents) links_born(so.v, {}, true);  // note_split: rows of the copies start empty
+    }
+    links_end_pass();
+    std::sort(done.begin(), done.end());
+    const int64_t n_done = (int64_t)(std::unique(done.begin(), done.end()) - done.begin());
+    debug("No of branch be removed: " + std::to_string(n_done));
+    info("done");
+    return n_done;
+}
+
+// =====================================================================================================================
+// trivial splits (Decomposition.py:533-688, :691-819)
+// =====================================================================================================================
+static std::string fork_letter(size_t i) {  // chr(ord("A") + i), UTF-8
+    uint32_t cp = 65u + (uint32_t)i;
+    std::string s;
+    if (cp < 0x80) s.push_back((char)cp);
+    else if (cp < 0x800) { s.push_back((char)(0xC0 | (cp >> 6))); s.push_back((char)(0x80 | (cp & 0x3F))); }
+    else if (cp < 0x10000) { s.push_back((char)(0xE0 | (cp >> 12))); s.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); s.push_back((char)(0x80 | (cp & 0x3F))); }
+    else { s.push_back((char)(0xF0 | (cp >> 18))); s.push_back((char)(0x80 | ((cp >> 12) & 0x3F))); s.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); s.push_back((char)(0x80 | (cp & 0x3F))); }
+    return s;
+}
+
+int64_t vs_stage::trivial_split(NameMap<std::vector<Nid>> &id_mapping) {
+    info("graph trivial split on NT related vertices..");
+    auto branches = nontrivial_ids();
+    int64_t forks = 0;
+    auto kids_of = [&](Nid n) -> std::vector<Nid> & {
+        if (!id_mapping.has(n)) id_mapping.set(n, {});
+        return *id_mapping.get(n);
+    };
+    for (auto &br : branches) {
+        const uint32_t ntv = br.second;
+        if (!g.vblack[ntv]) continue;
+        {
+            PyIntSet ins;
+            for (uint32_t x : g.in_neighbors(ntv)) ins.add(x);
+            for (uint32_t iv : ins.order()) {
+                if (!g.vblack[iv]) continue;
+                const Nid ino = g.vid[iv];
+                auto ines = g.black_in_edges(iv), outes = g.black_out_edges(iv);
+                if (ines.size() > 1 && outes.size() == 1) {
+                    g.vblack[iv] = 0;
+                    const int64_t to_nt = g.edge(iv, ntv);
+                    if (to_nt < 0) state_error("trivial_split: no edge to the branch");
+                    g.eblack[to_nt] = 0;
+                    dirty = true;
+                    for (size_t i = 0; i < ines.size(); i++) {
+                        const uint32_t ine = ines[i], src = g.esrc[ine];
+                        const Nid sub = names.intern(names[ino] + "*" + fork_letter(i));
+                        const uint32_t sv = add_vertex(sub, g.eflow[ine], g.vseq[iv]);
+                        g.eblack[ine] = 0;
+                        add_edge(src, sv, g.eovl[ine], g.eflow[ine]);
+                        add_edge(sv, ntv, g.eovl[g.edge(iv, ntv)], g.eflow[ine]);
+                        auto &kids = kids_of(ino);
+                        if (std::find(kids.begin(), kids.end(), sub) == kids.end()) kids.push_back(sub);
+                        links_born(sub, {}, true);
+                    }
+                    forks++;
+                }
+            }
+        }
+        {
+            PyIntSet outs;
+            for (uint32_t x : g.out_neighbors(ntv)) outs.add(x);
+            for (uint32_t ov : outs.order()) {
+                if (!g.vblack[ov]) continue;
+                const Nid ono = g.vid[ov];
+                auto ines = g.black_in_edges(ov), outes = g.black_out_edges(ov);
+                if (ines.size() == 1 && outes.size() > 1) {
+                    g.vblack[ov] = 0;
+                    const int64_t from_nt = g.edge(ntv, ov);
+                    if (from_nt < 0) state_error("trivial_split: no edge from the branch");
+                    g.eblack[from_nt] = 0;
+                    dirty = true;
+                    for (size_t i = 0; i < outes.size(); i++) {
+                        const uint32_t oute = outes[i], tgt = g.etgt[oute];
+                        const Nid sub = names.intern(names[ono] + "*" + fork_letter(i));
+                        const uint32_t sv = add_vertex(sub, g.eflow[oute], g.vseq[ov]);
+                        g.eblack[oute] = 0;
+                        add_edge(sv, tgt, g.eovl[oute], g.eflow[oute]);
+                        add_edge(ntv, sv, g.eovl[g.edge(ntv, ov)], g.eflow[oute]);
+                        auto &kids = kids_of(ono);
+                        if (std::find(kids.begin(), kids.end(), sub) == kids.end()) kids.push_back(sub);
+                        links_born(sub, {}, true);
+                    }
+                    forks++;
+                }
+            }
+        }
+    }
+    links_end_pass();
+    debug("Total split-ted trivial branch count: " + std::to_string(forks));
+    return forks;
+}
+
+// Fixpoint of single-sided forks over ALL vertices.  Returns the fork count, or -1 where the reference gives up (None).
+int64_t vs_stage::global_trivial_split(NameMap<std::vector<Nid>> &id_mapping) {
+    info("graph trivial split..");
+    const uint64_t bound = (uint64_t)nodes.size() * (uint64_t)nodes.size();
+    uint64_t forks = 0;
+    // A stage that is still the graph its scan looked at and in which no vertex has one black edge on one side and
+    // several on the other has nothing to fork.
+    if (!dirty && scan.valid && scan.fork_kind.size() == g.num_vertices()) {
+        bool any = false;
+        for (uint8_t k : scan.fork_kind) any = any || k;
+        if (!any) {
+            debug("No of trivial branch be removed: 0");
+            info("done");
+            return 0;
+        }
+    }
+    bool progressed = true;
+    while (progressed && forks < bound) {
+        progressed = false;
+        std::vector<Nid> sweep = nodes.keys();
+        for (Nid name : sweep) {
+            const uint32_t v = node(name);
+            if (!g.vblack[v]) continue;
+            const uint32_t n_o = g.nout[v], n_i = g.len[v] - n_o;
+            if (n_o == 0 || n_i == 0 || n_o + n_i < 3) continue;
+            auto ines = g.black_in_edges(v), outes = g.black_out_edges(v);
+            if (ines.size() == 1 && outes.size() > 1) {
+                if (!id_mapping.has(name)) id_mapping.set(name, {});
+                g.vblack[v] = 0;
+                const uint32_t ine = ines[0], src = g.esrc[ine];
+                g.eblack[ine] = 0;
+                dirty = true;
+                for (size_t i = 0; i < outes.size(); i++) {
+                    const uint32_t oute = outes[i], tgt = g.etgt[oute];
+                    const Nid sub = names.intern(names[name] + "*" + fork_letter(i));
+                    const uint32_t sv = add_vertex(sub, g.eflow[oute], g.vseq[v]);
+                    g.eblack[oute] = 0;
+                    add_edge(sv, tgt, g.eovl[oute], g.eflow[oute]);
+                    add_edge(src, sv, g.eovl[ine], g.eflow[oute]);
+                    auto &kids = *id_mapping.get(name);
+                    if (std::find(kids.begin(), kids.end(), sub) == kids.end()) kids.push_back(sub);
+                }
+                progressed = true;
+                forks++;
+            } else if (ines.size() > 1 && outes.size() == 1) {
+                if (!id_mapping.has(name)) id_mapping.set(name, {});
+                g.vblack[v] = 0;
+                const uint32_t oute = outes[0], tgt = g.etgt[oute];
+                g.eblack[oute] = 0;
+                dirty = true;
+                for (size_t i = 0; i < ines.size(); i++) {
+                    const uint32_t ine = ines[i], src = g.esrc[ine];
+                    const Nid sub = names.intern(names[name] + "*" + fork_letter(i));
+                    const uint32_t sv = add_vertex(sub, g.eflow[ine], g.vseq[v]);
+                    g.eblack[ine] = 0;
+                    add_edge(src, sv, g.eovl[ine], g.eflow[ine]);
+                    add_edge(sv, tgt, g.eovl[oute], g.eflow[ine]);
+                    auto &kids = *id_mapping.get(name);
+                    if (std::find(kids.begin(), kids.end(), sub) == kids.end()) kids.push_back(sub);
+                }
+                progressed = true;
+                forks++;
+            }
+        }
+    }
+    if (forks >= bound) {
+        warning("Strange topology detected, exit trivial split immediately");
+        return -1;
+    }
+    debug("No of trivial branch be removed: " + std::to_string(forks));
+    info("done");
+    return (int64_t)forks;
+}
+
+// =====================================================================================================================
+// simple-path contraction (Utilities.py:383-574)
+// =====================================================================================================================
+// Maximal chains of simple edges as vertex lists, in the order the reference discovers them: heads in edge-map order.
+// The scan ranked every vertex inside its chain (pointer jumping on the device), so a chain is a bucket sorted by rank.
+std::vector<std::vector<uint32_t>> vs_stage::simple_chains() {
+    const uint32_t nv = g.num_vertices();
+    if (!scan.valid || scan.chain_rank.size() != nv) state_error("simple_chains: the scan is not of this graph");
+    std::unordered_map<uint32_t, std::vector<std::pair<int32_t, uint32_t>>> members;
+    for (uint32_t v = 0; v < nv; v++)
+        if (scan.chain_rank[v] > 0) members[(uint32_t)scan.chain_top[v]].push_back({scan.chain_rank[v], v});
+    std::vector<std::vector<uint32_t>> chains;
+    for (auto &ent : edges.ents) {
+        if (!ent.live) continue;
+        const uint32_t s = g.esrc[ent.v];
+        if (scan.chain_rank[s] == 0 && scan.chain_next[s] >= 0) {
+            auto it = members.find(s);
+            if (it == members.end()) continue;
+            std::sort(it->second.begin(), it->second.end());
+            std::vector<uint32_t> chain{s};
+            for (auto &m : it->second) chain.push_back(m.second);
+            members.erase(it);
+            chains.push_back(std::move(chain));
+        }
+    }
+    return chains;
+}
+
+void vs_stage::contract_simple_paths(bool with_contigs, bool with_links) {
+    info("non-branching path contraction..");
+    auto chains = simple_chains();
+    struct Built {
+        Nid first, last;
+        uint32_t cv;
+        std::vector<std::pair<Nid, int64_t>> ins, outs;  // (other end's id, overlap)
+    };
+    // merged_into: only the members of a chain map to something else
+    std::unordered_map<Nid, Nid> merged_into;
+    NameMap<uint8_t> at_start;  // the ids that were nodes when the pass began (merged_into's keys)
+    if (with_contigs)
+        for (auto &ent : nodes.ents)
+            if (ent.live) at_start.set(ent.k, 1);
+    std::vector<Built> built;
+    built.reserve(chains.size());
+    for (auto &chain : chains) {
+        std::vector<Nid> ids;
+        std::vector<double> dps;
+        for (uint32_t v : chain) { ids.push_back(g.vid[v]); dps.push_back(g.vdp[v]); }
+        const double cov = np_mean(dps);
+        std::string new_id;
+        for (size_t i = 0; i < ids.size(); i++) {
+            if (i) new_id.push_back('&');
+            new_id += names[ids[i]];
+        }
+        std::string seq = path_sequence(chain);
+        Built b;
+        b.first = ids.front();
+        b.last = ids.back();
+        g.each_in(chain.front(), [&](uint32_t s, uint32_t e) { b.ins.push_back({g.vid[s], g.eovl[e]}); });
+        g.each_out(chain.back(), [&](uint32_t t, uint32_t e) { b.outs.push_back({g.vid[t], g.eovl[e]}); });
+        const Nid nid = names.intern(new_id);
+        for (size_t i = 0; i < ids.size(); i++) {
+            merged_into[ids[i]] = nid;
+            retire_vertex(ids[i]);
+            if (i + 1 != ids.size()) retire_edge(ids[i], ids[i + 1]);
+        }
+        b.cv = add_vertex(nid, cov, new_seq(std::move(seq)));
+        if (with_links) {  // note_merge: a contraction concatenates the supports of its members
+            std::vector<uint32_t> support;
+            for (Nid m : ids) {
+                const std::vector<uint32_t> &r = rows(m);
+                support.insert(support.end(), r.begin(), r.end());
+            }
+            links_born(nid, std::move(support), false);
+        }
+        built.push_back(std::move(b));
+    }
+    // a neighbour that was itself contracted is reached through its chain's new vertex
+    std::unordered_map<Nid, uint32_t> by_last, by_first;
+    for (auto &b : built) {
+        by_last[b.last] = b.cv;
+        by_first[b.first] = b.cv;
+    }
+    for (auto &b : built) {
+        const Nid me = g.vid[b.cv];
+        for (auto &in : b.ins) {
+            const Nid u = in.first;
+            if (nodes.has(u) && !edges.has(pair_key(u, me))) add_edge(node(u), b.cv, in.second, 0.0);
+            auto it = by_last.find(u);
+            if (it != by_last.end() && !edges.has(pair_key(g.vid[it->second], me))) add_edge(it->second, b.cv, in.second, 0.0);
+        }
+        for (auto &out : b.outs) {
+            const Nid w = out.first;
+            if (nodes.has(w) && !edges.has(pair_key(me, w))) add_edge(b.cv, node(w), out.second, 0.0);
+            auto it = by_first.find(w);
+            if (it != by_first.end() && !edges.has(pair_key(me, g.vid[it->second]))) add_edge(b.cv, it->second, out.second, 0.0);
+        }
+    }
+    if (with_contigs) {
+        for (auto &c : contigs.ents) {
+            if (!c.live) continue;
+            std::vector<Nid> folded;
+            for (Nid name : c.v.ids) {
+                if (!at_start.has(name)) key_error(names[name]);
+                auto it = merged_into.find(name);
+                if (it == merged_into.end()) folded.push_back(name);
+                else if (folded.empty() || it->second != folded.back()) folded.push_back(it->second);
+            }
+            c.v.ids = std::move(folded);
+            c.v.len = path_length_ids(c.v.ids);
+        }
+    }
+    info("done");
+}
+
+// =====================================================================================================================
+// contig bookkeeping (Utilities.py:147-159, :281-380, :589-616)
+// =====================================================================================================================
+void vs_stage::trim_contigs(NameMap<Contig> &cd) {
+    info("trim contig..");
+    for (auto &c : cd.ents) {
+        if (!c.live) continue;
+        std::vector<Nid> uniq;
+        for (Nid n : c.v.ids)
+            if (std::find(uniq.begin(), uniq.end(), n) == uniq.end()) uniq.push_back(n);
+        c.v.ids = std::move(uniq);
+        c.v.len = path_length_ids(c.v.ids);
+    }
+    info("done");
+}
+
+// Node-SET comparison: equal sets drop the later one, a proper subset drops the smaller.
+void vs_stage::drop_duplicate_contigs(NameMap<Contig> &cd) {
+    info("drop duplicated contigs..");
+    cd.compact();
+    const size_t n = cd.ents.size();
+    std::vector<std::vector<Nid>> sets(n);
+    std::unordered_map<Nid, std::vector<uint32_t>> by_node;
+    for (size_t i = 0; i < n; i++) {
+        sets[i] = cd.ents[i].v.ids;
+        std::sort(sets[i].begin(), sets[i].end());
+        sets[i].erase(std::unique(sets[i].begin(), sets[i].end()), sets[i].end());
+        for (Nid x : sets[i]) by_node[x].push_back((uint32_t)i);
+    }
+    std::vector<uint8_t> dropped(n, 0);
+    std::vector<uint32_t> cand;
+    for (size_t a = 0; a < n; a++) {
+        // only a contig that shares a node with `a` can have as many common nodes as one of the two lists is long
+        // (every list holds at least one id); an empty list matches everything, as in the reference
+        const size_t la = cd.ents[a].v.ids.size();
+        cand.clear();
+        if (la == 0) {
+            for (size_t b = 0; b < n; b++) cand.push_back((uint32_t)b);
+        } else {
+            for (Nid x : sets[a]) {
+                auto &lst = by_node[x];
+                cand.insert(cand.end(), lst.begin(), lst.end());
+            }
+            std::sort(cand.begin(), cand.end());
+            cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+            bool has_empty = false;
+            for (size_t b = 0; b < n && !has_empty; b++) has_empty = cd.ents[b].v.ids.empty();
+            if (has_empty) {
+                cand.clear();
+                for (size_t b = 0; b < n; b++) cand.push_back((uint32_t)b);
+            }
+        }
+        for (uint32_t b : cand) {
+            if (dropped[a] || dropped[b] || a == b) continue;
+            size_t common = 0;
+            {
+                const auto &sa = sets[a], &sb = sets[b];
+                size_t i = 0, j = 0;
+                while (i < sa.size() && j < sb.size()) {
+                    if (sa[i] == sb[j]) { common++; i++; j++; }
+                    else if (sa[i] < sb[j]) i++;
+                    else j++;
+                }
+            }
+            const size_t lb = cd.ents[b].v.ids.size();
+            if (common == la && common == lb) dropped[b] = 1;
+            else if (common == la) dropped[a] = 1;
+            else if (common == lb) dropped[b] = 1;
+        }
+    }
+    for (size_t i = 0; i < n; i++)
+        if (dropped[i]) cd.pop(cd.ents[i].k);
+    info("done");
+}
+
+// id -> ordered set of the ids it ended up as (transitive closure of id_mapping), worked out on demand
+struct vs_stage::Closure {
+    const NameMap<std::vector<Nid>> *mapping = nullptr;
+    std::vector<uint8_t> known;  // by name: an id of the graph before the pass
+    std::unordered_map<Nid, std::vector<Nid>> memo;
+    const Names *names = nullptr;
+    void leaves(Nid name, std::vector<Nid> &out) const {
+        const std::vector<Nid> *kids = mapping->get(name);
+        if (!kids || kids->empty()) {
+            if (std::find(out.begin(), out.end(), name) == out.end()) out.push_back(name);
+            return;
+        }
+        for (Nid k : *kids) leaves(k, out);
+    }
+    const std::vector<Nid> &operator[](Nid name) {
+        auto it = memo.find(name);
+        if (it != memo.end()) return it->second;
+        if (name >= known.size() || !known[name]) key_error((*names)[name]);
+        std::vector<Nid> out;
+        leaves(name, out);
+        return memo.emplace(name, std::move(out)).first->second;
+    }
+    bool is_known(Nid name) const { return name < known.size() && known[name]; }
+};
+
+void vs_stage::remap_contigs(const NameMap<std::vector<Nid>> &id_mapping, Closure &closure) {
+    info("contig resolution..");
+    (void)id_mapping;
+    for (Nid cno : contigs.keys()) {
+        const Contig &c = *contigs.get(cno);
+        if (c.ids.empty()) throw StageError{VS_E_KEY, "IndexError", "list index out of range"};
+        // images: every way of threading the contig through the forked ids along existing edges
+        std::vector<std::vector<Nid>> paths;
+        for (Nid s : closure[c.ids[0]]) paths.push_back({s});
+        for (size_t i = 1; i < c.ids.size(); i++) {
+            const std::vector<Nid> &cands = closure[c.ids[i]];
+            std::vector<std::vector<Nid>> grown;
+            for (auto &p : paths)
+                for (Nid cand : cands)
+                    if (edges.has(pair_key(p.back(), cand))) {
+                        grown.push_back(p);
+                        grown.back().push_back(cand);
+                    }
+            paths.swap(grown);
+        }
+        if (paths.empty()) {
+            debug("error, contig missed: " + names[cno]);
+        } else if (paths.size() == 1) {
+            if (paths[0] != c.ids) {
+                Contig nc;
+                contigs.pop(cno, &nc);
+                nc.ids = paths[0];
+                nc.len = path_length_ids(nc.ids);
+                contigs.set(cno, std::move(nc));
+            }
+        } else {
+            Contig nc;
+            contigs.pop(cno, &nc);
+            std::vector<Nid> common = paths[0];
+            for (size_t k = 1; k < paths.size(); k++) {
+                std::vector<Nid> next;
+                for (Nid x : common)
+                    if (std::find(paths[k].begin(), paths[k].end(), x) != paths[k].end()) next.push_back(x);
+                common.swap(next);
+            }
+            if (!common.empty()) {
+                nc.ids = common;
+                nc.len = path_length_ids(nc.ids);
+                contigs.set(cno, std::move(nc));
+            }
+        }
+    }
+    info("done");
+}
+
+// =====================================================================================================================
+// iter_graph_disentanglement (Decomposition.py:908-1042)
+// =====================================================================================================================
+void vs_stage::disentangle(double threshold, const std::string &temp_dir) {
+    const uint64_t bound = (uint64_t)nodes.size() * (uint64_t)nodes.size();
+    uint64_t it = 0;
+    int64_t removed_total = 0;
+    int label = 'A';
+    auto file = [&](const char *suffix) {
+        return temp_dir + "/gfa/split_graph_L" + fork_letter((size_t)(label - 'A')) + suffix + ".gfa";
+    };
+    for (int pass = 0; pass < 2; pass++) {
+        const bool is_prim = pass == 0;
+        bool may_fork = true;
+        while (it < bound) {
+            const int64_t n_split = balance_split(threshold, is_prim);
+            reinit(file("d"));
+            contract_simple_paths(true, true);
+            reinit(file("dc"));
+            if (n_split > 0) {
+                may_fork = true;
+            } else if (may_fork) {
+                Closure closure;
+                closure.names = &names;
+                closure.known.assign(names.size(), 0);
+                for (auto &ent : nodes.ents)
+                    if (ent.live) closure.known[ent.k] = 1;
+                NameMap<std::vector<Nid>> id_mapping;
+                trivial_split(id_mapping);
+                reinit(file("dct"));
+                closure.mapping = &id_mapping;
+                remap_contigs(id_mapping, closure);
+                contract_simple_paths(true, true);
+                reinit(file("dctd"));
+            }
+            drop_duplicate_contigs(contigs);
+            trim_contigs(contigs);
+            removed_total += n_split;
+            it++;
+            label++;
+            if (n_split == 0) {
+                if (may_fork) may_fork = false; else break;
+            }
+        }
+    }
+    debug("Total non-trivial branches removed: " + std::to_string(removed_total));
+    reinit(temp_dir + "/gfa/split_graph_final.gfa");
+}
+
+// =====================================================================================================================
+// best_matching (Extension.py:10-111), increment_nt_branch_coverage (Utilities.py:183-208)
+// =====================================================================================================================
+void vs_stage::best_matching() {
+    auto branches = nontrivial_ids();
+    auto by_node = contigs_by_node(contigs);
+    std::vector<std::pair<Nid, Nid>> pairs;
+    std::vector<std::pair<std::vector<Nid>, std::vector<Nid>>> shape(branches.size());
+    for (size_t i = 0; i < branches.size(); i++) {
+        const uint32_t v = branches[i].second;
+        for (uint32_t x : g.in_neighbors(v)) shape[i].first.push_back(g.vid[x]);
+        for (uint32_t x : g.out_neighbors(v)) shape[i].second.push_back(g.vid[x]);
+        for (Nid u : shape[i].first)
+            for (Nid w : shape[i].second) pairs.push_back({u, w});
+    }
+    links_prefetch(pairs);
+    full_link.clear();
+    for (size_t i = 0; i < branches.size(); i++) {
+        const Nid no = branches[i].first;
+        const auto &us = shape[i].first, &ws = shape[i].second;
+        FlatIdx through;
+        auto it = by_node.find(no);
+        if (it != by_node.end())
+            for (Nid cno : it->second) {
+                const std::vector<Nid> &ids = contigs.get(cno)->ids;
+                size_t at = index_of(ids, no, names);
+                if (at > 0 && at + 1 < ids.size()) through.put(pair_key(ids[at - 1], ids[at + 1]), 1);
+            }
+        PairMap<int64_t> kept;
+        std::vector<Triple> later;
+        for (Nid u : us)
+            for (Nid w : ws) {
+                const int64_t pe = links_get(u, w);
+                if (through.find(pair_key(u, w)) >= 0 || u == w) kept.set(pair_key(u, w), pe);
+                else later.push_back(Triple{u, w, pe});
+            }
+        std::stable_sort(later.begin(), later.end(), [](const Triple &a, const Triple &b) { return a.pe > b.pe; });
+        for (auto &t : later)
+            if (t.pe > 0) kept.set(pair_key(t.u, t.w), t.pe);
+        full_link.set(no, std::move(kept));
+    }
+}
+
+void vs_stage::increment_nt_branch_coverage() {
+    for (auto &br : nontrivial_ids()) {
+        const uint32_t v = br.second;
+        const double before = g.vdp[v];
+        auto ins = g.in_neighbors(v), outs = g.out_neighbors(v);
+        uint64_t so = 0, si = 0;
+        for (uint32_t x : ins) so += g.out_degree(x);
+        for (uint32_t y : outs) si += g.in_degree(y);
+        double a = 0.0, b = 0.0;  // Python sum(): left to right from 0
+        if (so == g.in_degree(v) && si == g.out_degree(v)) {
+            for (uint32_t n : ins) a += g.vdp[n];
+            for (uint32_t n : outs) b += g.vdp[n];
+        } else {
+            g.each_in(v, [&](uint32_t, uint32_t e) { a += g.eflow[e]; });
+            g.each_out(v, [&](uint32_t, uint32_t e) { b += g.eflow[e]; });
+        }
+        double best = before;  // max([before, a, b]): the first of equal maxima
+        if (a > best) best = a;
+        if (b > best) best = b;
+        if (best != g.vdp[v] || std::signbit(best) != std::signbit(g.vdp[v])) set_dp(v, best);
+        debug("NT Branch:" + names[br.first] + ", cov: " + py_repr(before) + " -> " + py_repr(g.vdp[v]));
+    }
+}
+
+// =====================================================================================================================
+// the greedy walk (Extension.py:115-418)
+// =====================================================================================================================
+void vs_stage::walk(std::vector<uint32_t> &path, std::vector<uint8_t> &visited, uint32_t start, bool forward, const LinkTable &table,
+                    bool use_coverage, double ccov, double threshold) {
+    const std::vector<double> &dp = g.vdp;
+    int64_t cur = start;
+    while (cur >= 0 && !visited[(uint32_t)cur]) {
+        visited[(uint32_t)cur] = 1;
+        if (forward) path.push_back((uint32_t)cur); else path.insert(path.begin(), (uint32_t)cur);
+        int64_t prev = -1;
+        if (path.size() > 1) prev = forward ? path[path.size() - 2] : path[1];
+        const uint32_t here = (uint32_t)cur;
+        std::vector<uint32_t> choices = forward ? g.out_neighbors(here) : g.in_neighbors(here);
+        if (choices.empty()) { cur = -1; continue; }
+        if (choices.size() == 1) { cur = choices[0]; continue; }
+        bool by_coverage = false;
+        const PairMap<int64_t> *tab = table.get(g.vid[here]);
+        if (tab && prev >= 0) {
+            const Nid prev_id = g.vid[(uint32_t)prev];
+            std::vector<uint32_t> cands;
+            for (auto &l : tab->ents) {
+                if (!l.live) continue;
+                if (forward) { if (key_first(l.k) == prev_id) cands.push_back(node(key_second(l.k))); }
+                else { if (key_second(l.k) == prev_id) cands.push_back(node(key_first(l.k))); }
+            }
+            if (cands.size() == 1) {
+                if (use_coverage && dp[cands[0]] - ccov <= -2 * threshold) cur = -1; else cur = cands[0];
+            } else if (cands.size() > 1) {
+                cur = -1;
+            } else {
+                if (use_coverage) by_coverage = true;  // cur stays on the branch vertex for now
+                else cur = -1;
+            }
+        } else {
+            cur = -1;
+        }
+        if (!use_coverage) continue;
+        if (by_coverage) {
+            std::vector<uint32_t> rivals = forward ? g.in_neighbors(here) : g.out_neighbors(here);
+            if (prev >= 0 && !rivals.empty()) {
+                const double dprev = dp[(uint32_t)prev];
+                std::vector<uint32_t> ahead_rank(choices);
+                std::stable_sort(ahead_rank.begin(), ahead_rank.end(), [&](uint32_t a, uint32_t b) { return std::fabs(dprev - dp[a]) < std::fabs(dprev - dp[b]); });
+                const uint32_t best = ahead_rank[0];
+                const double dbest = dp[best];
+                std::vector<uint32_t> rival_rank(rivals);
+                std::stable_sort(rival_rank.begin(), rival_rank.end(), [&](uint32_t a, uint32_t b) { return std::fabs(dbest - dp[a]) < std::fabs(dbest - dp[b]); });
+                if ((int64_t)rival_rank[0] == prev) {
+                    const double guard = std::max(2 * std::fabs(dprev - dbest), threshold);
+                    const bool clash = (rival_rank.size() > 1 && std::fabs(dp[rival_rank[1]] - dbest) <= guard) ||
+                                       (ahead_rank.size() > 1 && std::fabs(dprev - dp[ahead_rank[1]]) <= guard);
+                    if (clash) continue;  // cur is still the visited branch vertex: the loop ends, no last-bit rule
+                    cur = best;
+                } else {
+                    cur = -1;
+                }
+            } else {
+                cur = -1;
+            }
+        }
+        if (cur < 0) {
+            std::vector<uint32_t> top(choices);
+            std::stable_sort(top.begin(), top.end(), [&](uint32_t a, uint32_t b) { return dp[a] > dp[b]; });
+            if (dp[top[0]] - ccov > -threshold && dp[top[1]] - ccov <= -threshold) cur = top[0];
+        }
+    }
+}
+
+std::vector<uint32_t> vs_stage::extend(const std::vector<Nid> &contig, const LinkTable &table, bool use_coverage, double ccov, double threshold) {
+    // visited: by vertex (ids are unique per vertex of a re-initialised stage); every vertex is in the node map
+    std::vector<uint8_t> visited(g.num_vertices(), 0);
+    std::vector<uint32_t> all;
+    for (Nid n : contig) all.push_back(node(n));
+    for (size_t i = 1; i + 1 < all.size(); i++) visited[all[i]] = 1;
+    std::vector<uint32_t> path;
+    for (size_t i = 1; i + 1 < all.size(); i++) path.push_back(all[i]);
+    walk(path, visited, all.back(), true, table, use_coverage, ccov, threshold);
+    const uint32_t first = all.front();
+    if (contig.size() == 1) {
+        if (path.empty()) throw StageError{VS_E_KEY, "IndexError", "list index out of range"};
+        auto ins = g.in_neighbors(first);
+        if (std::find(ins.begin(), ins.end(), path.back()) == ins.end()) {
+            visited[first] = 0;
+            path.erase(path.begin());
+        }
+    }
+    walk(path, visited, first, false, table, use_coverage, ccov, threshold);
+    return path;
+}
+
+// reduce_graph: subtract the path coverage; vertices at or under the threshold go gray and leave `usages`; links
+// touching a gray vertex are dropped
+void vs_stage::consume(const std::vector<uint32_t> &path, double pcov, double threshold) {
+    bool grayed = false;
+    for (uint32_t v : path) {
+        int64_t *u = usages.get(g.vid[v]);
+        if (!u) key_error(name_of(v));
+        *u += 1;
+        set_dp(v, g.vdp[v] - pcov);
+        if (g.vdp[v] <= threshold) {
+            g.vblack[v] = 0;
+            usages.pop(g.vid[v]);
+            grayed = true;
+        }
+    }
+    if (!grayed) return;  // (every linked vertex was black when the pass filtered the table against the re-initialised graph)
+    for (auto &t : full_link.ents) {
+        if (!t.live) continue;
+        for (uint64_t k : t.v.keys()) {
+            if (!g.vblack[node(key_first(k))] || !g.vblack[node(key_second(k))]) t.v.pop(k);
+        }
+    }
+}
+
+// reduce_Anode: replace extracted-path ids (A<n>, possibly with a split suffix) by their member ids until none is left
+std::vector<Nid> vs_stage::expand_path_names(Nid name, const NameMap<std::vector<Nid>> &members) {
+    std::vector<Nid> ids{name};
+    for (;;) {
+        size_t at = ids.size();
+        for (size_t i = 0; i < ids.size(); i++)
+            if (!names[ids[i]].empty() && names[ids[i]][0] == 'A') { at = i; break; }
+        if (at == ids.size()) break;
+        const std::string &s = names[ids[at]];
+        const std::string key = s.substr(0, s.find('*'));
+        const Nid kid = names.find(key);
+        const std::vector<Nid> *m = kid == NO_NID ? nullptr : members.get(kid);
+        if (!m) key_error(key);
+        std::vector<Nid> repl = *m;
+        ids.erase(ids.begin() + (long)at);
+        ids.insert(ids.begin() + (long)at, repl.begin(), repl.end());
+    }
+    return ids;
+}
+
+// un-zip contracted ids and strip split suffixes: a&b*0 -> a, b (contig_resolve, reduce_id_simple)
+std::vector<Nid> vs_stage::origin_ids(const std::vector<Nid> &ids) {
+    std::vector<Nid> out;
+    for (Nid name : ids) {
+        const std::string s = names[name];
+        size_t p = 0;
+        for (;;) {
+            size_t q = s.find('&', p);
+            std::string piece = s.substr(p, q == std::string::npos ? std::string::npos : q - p);
+            size_t star = piece.find('*');
+            out.push_back(names.intern(star == std::string::npos ? piece : piece.substr(0, star)));
+            if (q == std::string::npos) break;
+            p = q + 1;
+        }
+    }
+    return out;
+}
+
+// =====================================================================================================================
+// path_extension (Extension.py:484-899)
+// =====================================================================================================================
+void vs_stage::path_extension(double threshold, const std::string &temp_dir) {
+    debug("-------------------------PATH Extension, delta: " + py_repr(threshold));
+    usages.clear();
+    for (auto &ent : nodes.ents)
+        if (ent.live) usages.set(ent.k, 0);
+    strains.clear();
+    NameMap<std::vector<Nid>> members;
+    LinkTable &table = full_link;
+    int64_t rid = 1;
+    auto bubble_vertices = [&](const std::vector<Nid> &ids) {
+        std::vector<double> dps;
+        for (Nid n : ids) {
+            const uint32_t v = node(n);
+            if (g.in_degree(v) == 1 && g.out_degree(v) == 1) dps.push_back(g.vdp[v]);
+        }
+        return dps;
+    };
+    while (contigs.size() > 0) {
+        Closure closure;
+        closure.names = &names;
+        closure.known.assign(names.size(), 0);
+        for (auto &ent : nodes.ents)
+            if (ent.live) closure.known[ent.k] = 1;
+        NameMap<std::vector<Nid>> id_mapping;
+        const int64_t n_forks = global_trivial_split(id_mapping);
+        reinit(temp_dir + "/gfa/graph_S" + std::to_string(rid) + ".gfa");
+        closure.mapping = &id_mapping;
+        remap_contigs(id_mapping, closure);
+        table.compact();
+        if (n_forks == 0) {
+            // nothing forked: every id stands for itself; the rewrite only drops what no longer is a link between an
+            // in- and an out-neighbour, the survivors keep their order
+            for (Nid no : table.keys()) {
+                if (!nodes.has(no)) { table.pop(no); continue; }
+                PairMap<int64_t> &kept = *table.get(no);
+                if (kept.size() == 0) continue;
+                const uint32_t v = node(no);
+                auto ins = g.in_neighbors(v), outs = g.out_neighbors(v);
+                for (uint64_t link : kept.keys()) {
+                    const uint32_t a = node(key_first(link)), b = node(key_second(link));
+                    if (!(std::find(ins.begin(), ins.end(), a) != ins.end() && std::find(outs.begin(), outs.end(), b) != outs.end())) kept.pop(link);
+                }
+            }
+            for (auto &u : usages.ents)
+                if (u.live && !closure.is_known(u.k)) key_error(names[u.k]);
+        } else {
+            for (Nid no : table.keys()) {
+                if (!nodes.has(no)) { table.pop(no); continue; }
+                PairMap<int64_t> kept;
+                table.pop(no, &kept);
+                const uint32_t v = node(no);
+                auto ins = g.in_neighbors(v), outs = g.out_neighbors(v);
+                std::vector<std::pair<uint64_t, int64_t>> items;
+                for (auto &l : kept.ents)
+                    if (l.live) items.push_back({l.k, l.v});
+                for (auto &item : items) {
+                    const Nid u = key_first(item.first), w = key_second(item.first);
+                    kept.pop(item.first);
+                    if (closure[u].size() == 1 || closure[w].size() == 1) {
+                        const std::vector<Nid> cu = closure[u], cw = closure[w];
+                        for (Nid uu : cu)
+                            for (Nid ww : cw) {
+                                if (kept.has(pair_key(uu, ww))) continue;
+                                if (std::find(ins.begin(), ins.end(), node(uu)) == ins.end()) continue;
+                                if (std::find(outs.begin(), outs.end(), node(ww)) == outs.end()) continue;
+                                kept.set(pair_key(uu, ww), item.second);
+                            }
+                    }
+                }
+                kept.compact();
+                table.set(no, std::move(kept));
+            }
+            std::vector<std::pair<Nid, int64_t>> old;
+            for (auto &u : usages.ents)
+                if (u.live) old.push_back({u.k, u.v});
+            for (auto &o : old) {
+                usages.pop(o.first);
+                for (Nid new_no : closure[o.first]) usages.set(new_no, o.second);
+            }
+            usages.compact();
+        }
+
+        // the longest contig (the first of equal lengths, in map order)
+        Nid longest = NO_NID;
+        {
+            int64_t best = 0;
+            for (auto &c : contigs.ents) {
+                if (!c.live) continue;
+                if (longest == NO_NID || c.v.len > best) { longest = c.k; best = c.v.len; }
+            }
+        }
+        Contig cc;
+        contigs.pop(longest, &cc);
+        contigs.compact();
+        const std::vector<Nid> &contig = cc.ids;
+        const double ccov = cc.cov;
+        {
+            bool all_used = true;
+            for (Nid n : contig) {
+                const int64_t *u = usages.get(n);
+                if (!u) key_error(names[n]);
+                if (!(*u > 0)) { all_used = false; break; }
+            }
+            if (all_used) continue;
+            bool any_gray = false;
+            for (Nid n : contig)
+                if (!g.vblack[node(n)]) { any_gray = true; break; }
+            if (any_gray) continue;
+        }
+        auto cb = bubble_vertices(contig);
+        const bool cb_np = !cb.empty();
+        const double bbl_cov = cb_np ? np_median(cb) : ccov;
+        std::vector<uint32_t> path = extend(contig, table, true, std::min(ccov, bbl_cov), threshold);
+        const Nid pno = names.intern("A" + std::to_string(rid));
+        const int64_t plen = path_length(path);
+        std::vector<Nid> path_ids;
+        for (uint32_t v : path) path_ids.push_back(g.vid[v]);
+        std::vector<Nid> mem;
+        for (Nid pid : path_ids) {
+            const std::vector<Nid> *m = members.get(pid);
+            if (m) mem.insert(mem.end(), m->begin(), m->end()); else mem.push_back(pid);
+        }
+        members.set(pno, mem);
+        auto pb = bubble_vertices(path_ids);
+        const bool pb_np = !pb.empty();
+        const double bbl_pcov = pb_np ? np_median(pb) : ccov;
+        // pcov = min([ccov, bbl_pcov, bbl_cov]): the first of equal minima
+        double pcov = ccov;
+        bool pcov_np = false;
+        if (bbl_pcov < pcov) { pcov = bbl_pcov; pcov_np = pb_np; }
+        if (bbl_cov < pcov) { pcov = bbl_cov; pcov_np = cb_np; }
+        debug("name: " + names[pno] + ", plen: " + std::to_string(plen) + ", pcov: " + py_repr(pcov) + ", bubble cov: " + py_repr(bbl_pcov));
+        {
+            Contig st;
+            st.ids = mem;
+            st.len = plen;
+            st.cov = pcov;
+            st.cov_np = pcov_np;
+            strains.set(pno, std::move(st));
+        }
+        for (Nid pid : path_ids) strains.pop(pid);
+        const bool has_in = g.in_degree(path.front()) != 0, has_out = g.out_degree(path.back()) != 0;
+        if (!has_in && !has_out) {
+            consume(path, pcov, threshold);
+        } else if (path.size() > 1) {
+            const size_t lo = has_in ? 1 : 0, hi = has_out ? path.size() - 1 : path.size();
+            std::vector<uint32_t> inner;
+            for (size_t i = lo; i < hi; i++) inner.push_back(path[i]);
+            consume(inner, pcov, threshold);
+            if (!inner.empty()) {
+                const uint32_t pv = add_vertex(pno, pcov, new_seq(path_sequence(inner)));
+                if (has_in) {
+                    const int64_t e = g.edge(path[0], path[1]);
+                    if (e < 0) state_error("path_extension: the path's first step is no edge");
+                    add_edge(path[0], pv, g.eovl[e], pcov);
+                }
+                if (has_out) {
+                    const int64_t e = g.edge(path[path.size() - 2], path[path.size() - 1]);
+                    if (e < 0) state_error("path_extension: the path's last step is no edge");
+                    add_edge(pv, path.back(), g.eovl[e], pcov);
+                }
+                usages.set(pno, 0);
+            }
+        }
+        reinit(temp_dir + "/gfa/graph_S" + std::to_string(rid) + "post.gfa");
+        for (Nid cno : contigs.keys()) {
+            bool gone = false;
+            for (Nid n : contigs.get(cno)->ids)
+                if (!nodes.has(n)) { gone = true; break; }
+            if (gone) contigs.pop(cno);
+        }
+        rid++;
+    }
+
+    // vertices that carry the same sequence (fork copies): keep the deepest one
+    {
+        std::unordered_map<std::string, size_t> group_of;
+        std::vector<std::vector<uint32_t>> groups;
+        for (uint32_t v = 0; v < g.num_vertices(); v++) {
+            auto it = group_of.find(seqs[g.vseq[v]]);
+            if (it == group_of.end()) {
+                group_of.emplace(seqs[g.vseq[v]], groups.size());
+                groups.push_back({v});
+            } else {
+                groups[it->second].push_back(v);
+            }
+        }
+        for (auto &group : groups) {
+            if (group.size() < 2) continue;
+            std::vector<uint32_t> order(group);
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return g.vdp[a] > g.vdp[b]; });
+            for (size_t i = 1; i < order.size(); i++) {
+                retire_vertex(g.vid[order[i]]);
+                if (!usages.pop(g.vid[order[i]])) key_error(name_of(order[i]));
+            }
+        }
+    }
+    reinit(temp_dir + "/gfa/graph_S_final.gfa");
+
+    // link strength between the surviving vertices, from the ORIGINAL PE table: one grouped contraction
+    const uint32_t nv = g.num_vertices();
+    std::vector<int64_t> strength((size_t)nv * nv, 0);
+    {
+        std::vector<uint64_t> list_off{0};
+        std::vector<uint32_t> list_idx;
+        for (uint32_t v = 0; v < nv; v++) {
+            for (Nid x : origin_ids(expand_path_names(g.vid[v], members))) {
+                if (x >= link_row.size() || link_row[x] < 0) key_error(names[x]);
+                list_idx.push_back((uint32_t)link_row[x]);
+            }
+            list_off.push_back(list_idx.size());
+        }
+        if (nv) {
+            std::string err;
+            const double t0 = now_s();
+            int rc = ops->group_matrix(list_off.data(), list_idx.data(), nv, strength.data(), err);
+            t_links += now_s() - t0;
+            n_link_calls++;
+            if (rc) throw StageError{rc, "RuntimeError", err};
+        }
+    }
+    LinkTable final_links;
+    for (auto &br : nontrivial_ids()) {
+        const uint32_t v = br.second;
+        auto ins = g.in_neighbors(v), outs = g.out_neighbors(v);
+        SmallMap<int> in_use, out_use;
+        for (uint32_t x : ins) in_use.set(g.vid[x], 0);
+        for (uint32_t x : outs) out_use.set(g.vid[x], 0);
+        std::vector<Triple> combos;
+        for (uint32_t a : ins)
+            for (uint32_t b : outs) combos.push_back(Triple{g.vid[a], g.vid[b], strength[(size_t)a * nv + b]});
+        std::stable_sort(combos.begin(), combos.end(), [](const Triple &x, const Triple &y) { return x.pe > y.pe; });
+        PairMap<int64_t> fl;
+        for (auto &t : combos)
+            if (t.pe > 0 && in_use.at(t.u, names) == 0 && out_use.at(t.w, names) == 0) {
+                fl.set(pair_key(t.u, t.w), t.pe);
+                in_use.at(t.u, names) += 1;
+                out_use.at(t.w, names) += 1;
+            }
+        final_links.set(br.first, std::move(fl));
+    }
+    {
+        std::vector<uint32_t> by_len(nv);
+        for (uint32_t v = 0; v < nv; v++) by_len[v] = v;
+        std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t a, uint32_t b) { return seqs[g.vseq[a]].size() > seqs[g.vseq[b]].size(); });
+        for (uint32_t v : by_len) {
+            if (seqs[g.vseq[v]].size() <= 600) break;
+            const int64_t *used = usages.get(g.vid[v]);
+            if (!used) key_error(name_of(v));
+            if (*used != 0) continue;
+            std::vector<uint32_t> path = extend({g.vid[v]}, final_links, false, 0.0, 0.0);
+            const Nid pno = names.intern("N" + std::to_string(rid));
+            const int64_t plen = path_length(path);
+            std::vector<Nid> path_ids, pids;
+            for (uint32_t x : path) path_ids.push_back(g.vid[x]);
+            for (Nid pid : path_ids) {
+                const std::vector<Nid> *m = members.get(pid);
+                if (m) pids.insert(pids.end(), m->begin(), m->end()); else pids.push_back(pid);
+            }
+            for (Nid pid : path_ids) strains.pop(pid);
+            auto pb = bubble_vertices(path_ids);
+            Contig st;
+            st.ids = pids;
+            st.len = plen;
+            st.cov_np = !pb.empty();
+            st.cov = st.cov_np ? np_median(pb) : g.vdp[v];
+            strains.set(pno, std::move(st));
+            for (uint32_t x : path) {
+                int64_t *u = usages.get(g.vid[x]);
+                if (!u) key_error(name_of(x));
+                *u += 1;
+            }
+            rid++;
+        }
+    }
+    for (Nid sno : strains.keys())
+        if (strains.get(sno)->cov <= 2 * threshold) strains.pop(sno);
+    for (auto &s : strains.ents) {
+        if (!s.live) continue;
+        std::vector<Nid> flat;
+        for (Nid name : s.v.ids) {
+            auto o = origin_ids(expand_path_names(name, members));
+            flat.insert(flat.end(), o.begin(), o.end());
+        }
+        s.v.ids = std::move(flat);
+    }
+    strains.compact();
+}
+
+// =====================================================================================================================
+// contig files (IO.py:518-536, :558-595 with keep_original=False)
+// =====================================================================================================================
+void vs_stage::write_contig_files(const std::string &paths_file, const std::string &fasta_file) {
+    std::vector<const NameMap<Contig>::Ent *> order;
+    for (auto &c : contigs.ents)
+        if (c.live) order.push_back(&c);
+    std::stable_sort(order.begin(), order.end(), [](const NameMap<Contig>::Ent *a, const NameMap<Contig>::Ent *b) { return a->v.len > b->v.len; });
+    auto put = [&](const std::string &path, const std::string &text) {
+        char *p = arena.alloc(text.size() ? text.size() : 1);
+        memcpy(p, text.data(), text.size());
+        auto lines = std::make_shared<std::vector<LineRef>>();
+        lines->push_back(LineRef{p, (uint32_t)text.size()});
+        writer->submit(WriteJob{path, lines});
+    };
+    if (!paths_file.empty()) {
+        std::string text;
+        for (auto *c : order) {
+            text += "NODE_" + names[c->k] + "_" + std::to_string(c->v.len) + "_" + py_repr(c->v.cov) + "\n";
+            std::string body;
+            for (Nid nid : c->v.ids) {
+                const std::string &s = names[nid];
+                size_t p = 0;
+                for (;;) {
+                    size_t q = s.find('&', p);
+                    std::string piece = s.substr(p, q == std::string::npos ? std::string::npos : q - p);
+                    size_t star = piece.find('*');
+                    body += star == std::string::npos ? piece : piece.substr(0, star);
+                    body.push_back(',');
+                    if (q == std::string::npos) break;
+                    p = q + 1;
+                }
+            }
+            if (!body.empty()) body.pop_back();  // "a,b,c," minus its last character
+            text += body + "\n";
+        }
+        put(paths_file, text);
+    }
+    if (!fasta_file.empty()) {
+        std::string text;
+        for (auto *c : order) {
+            text += ">" + names[c->k] + "_" + std::to_string(c->v.len) + "_" + py_repr(py_round2(c->v.cov)) + "\n";
+            text += path_ids_sequence(c->v.ids) + "\n";
+        }
+        put(fasta_file, text);
+    }
+}
+
+// =====================================================================================================================
+// C ABI
+// =====================================================================================================================
+namespace {
+
+struct Reader {
+    const uint8_t *p, *end;
+    template <class T>
+    T get() {
+        if ((size_t)(end - p) < sizeof(T)) throw StageError{VS_E_ARG, "ValueError", "import blob cut short"};
+        T v;
+        memcpy(&v, p, sizeof(T));
+        p += sizeof(T);
+        return v;
+    }
+    template <class T>
+    std::vector<T> arr(size_t n) {
+        if ((size_t)(end - p) < n * sizeof(T)) throw StageError{VS_E_ARG, "ValueError", "import blob cut short"};
+        std::vector<T> v(n);
+        if (n) memcpy(v.data(), p, n * sizeof(T));
+        p += n * sizeof(T);
+        return v;
+    }
+    // n strings joined by '\n' behind a u64 byte count
+    std::vector<std::string> strings(size_t n) {
+        const uint64_t bytes = get<uint64_t>();
+        if ((uint64_t)(end - p) < bytes) throw StageError{VS_E_ARG, "ValueError", "import blob cut short"};
+        std::vector<std::string> out;
+        out.reserve(n);
+        const char *s = (const char *)p, *e = s + bytes;
+        for (size_t i = 0; i < n; i++) {
+            const char *q = (const char *)memchr(s, '\n', (size_t)(e - s));
+            if (!q) q = e;
+            out.emplace_back(s, q);
+            s = q < e ? q + 1 : e;
+        }
+        p += bytes;
+        return out;
+    }
+};
+
+struct Writer {
+    std::string &b;
+    template <class T>
+    void put(T v) { b.append((const char *)&v, sizeof(T)); }
+    template <class T>
+    void arr(const std::vector<T> &v) { if (!v.empty()) b.append((const char *)v.data(), v.size() * sizeof(T)); }
+    void strings(const std::vector<const std::string *> &v) {
+        uint64_t bytes = v.empty() ? 0 : v.size() - 1;
+        for (auto *s : v) bytes += s->size();
+        put<uint64_t>(bytes);
+        for (size_t i = 0; i < v.size(); i++) {
+            if (i) b.push_back('\n');
+            b += *v[i];
+        }
+    }
+};
+
+template <class F>
+int guarded(vs_stage *st, F f) {
+    if (!st) return VS_E_ARG;
+    st->err_kind.clear();
+    st->err_msg.clear();
+    try {
+        f();
+        return VS_OK;
+    } catch (const StageError &e) {
+        st->err_kind = e.kind;
+        st->err_msg = e.msg;
+        try { st->writer->drain(); } catch (...) {}
+        return e.code ? e.code : VS_E_STATE;
+    } catch (const std::bad_alloc &) {
+        st->err_kind = "MemoryError";
+        st->err_msg = "out of host memory";
+        return VS_E_OOM;
+    } catch (const std::exception &e) {
+        st->err_kind = "RuntimeError";
+        st->err_msg = e.what();
+        return VS_E_STATE;
+    }
+}
+
+void read_contigs(vs_stage *st, Reader &r, NameMap<Contig> &cd) {
+    cd.clear();
+    const uint32_t n = r.get<uint32_t>();
+    auto cnames = r.strings(n);
+    auto lens = r.arr<int64_t>(n);
+    auto covs = r.arr<double>(n);
+    auto flags = r.arr<uint8_t>(n);
+    auto counts = r.arr<uint32_t>(n);
+    uint64_t total = 0;
+    for (uint32_t c : counts) total += c;
+    auto ids = r.strings(total);
+    size_t at = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        Contig c;
+        c.len = lens[i];
+        c.cov = covs[i];
+        c.cov_np = flags[i] != 0;
+        for (uint32_t k = 0; k < counts[i]; k++) c.ids.push_back(st->names.intern(ids[at++]));
+        cd.set(st->names.intern(cnames[i]), std::move(c));
+    }
+}
+
+void write_contigs(vs_stage *st, Writer &w, const NameMap<Contig> &cd) {
+    std::vector<const std::string *> cnames, ids;
+    std::vector<int64_t> lens;
+    std::vector<double> covs;
+    std::vector<uint8_t> flags;
+    std::vector<uint32_t> counts;
+    for (auto &c : cd.ents) {
+        if (!c.live) continue;
+        cnames.push_back(&st->names[c.k]);
+        lens.push_back(c.v.len);
+        covs.push_back(c.v.cov);
+        flags.push_back(c.v.cov_np ? 1 : 0);
+        counts.push_back((uint32_t)c.v.ids.size());
+        for (Nid n : c.v.ids) ids.push_back(&st->names[n]);
+    }
+    w.put<uint32_t>((uint32_t)cnames.size());
+    w.strings(cnames);
+    w.arr(lens);
+    w.arr(covs);
+    w.arr(flags);
+    w.arr(counts);
+    w.strings(ids);
+}
+
+void read_link_table(vs_stage *st, Reader &r, LinkTable &t) {
+    t.clear();
+    const uint32_t n = r.get<uint32_t>();
+    auto nos = r.strings(n);
+    auto counts = r.arr<uint32_t>(n);
+    uint64_t total = 0;
+    for (uint32_t c : counts) total += c;
+    auto us = r.strings(total), ws = r.strings(total);
+    auto pes = r.arr<int64_t>(total);
+    size_t at = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        PairMap<int64_t> kept;
+        for (uint32_t k = 0; k < counts[i]; k++, at++) kept.set(pair_key(st->names.intern(us[at]), st->names.intern(ws[at])), pes[at]);
+        t.set(st->names.intern(nos[i]), std::move(kept));
+    }
+}
+
+void write_link_table(vs_stage *st, Writer &w, const LinkTable &t) {
+    std::vector<const std::string *> nos, us, ws;
+    std::vector<uint32_t> counts;
+    std::vector<int64_t> pes;
+    for (auto &e : t.ents) {
+        if (!e.live) continue;
+        nos.push_back(&st->names[e.k]);
+        uint32_t c = 0;
+        for (auto &l : e.v.ents) {
+            if (!l.live) continue;
+            us.push_back(&st->names[key_first(l.k)]);
+            ws.push_back(&st->names[key_second(l.k)]);
+            pes.push_back(l.v);
+            c++;
+        }
+        counts.push_back(c);
+    }
+    w.put<uint32_t>((uint32_t)nos.size());
+    w.strings(nos);
+    w.arr(counts);
+    w.strings(us);
+    w.strings(ws);
+    w.arr(pes);
+}
+
+}  // namespace
+
+vs_stage *vs_stage_make(VsStageOps *ops) {
+    vs_stage *st = new vs_stage();
+    st->ops.reset(ops);
+    st->writer.reset(new FileWriter());
+    unsigned n = 2;
+    if (const char *e = getenv("VS_STAGE_WRITERS")) n = (unsigned)atoi(e);
+    st->writer->start(n > 16 ? 16 : n);
+    return st;
+}
+
+extern "C" {
+
+void vs_stage_destroy(vs_stage *st) {
+    if (!st) return;
+    try { st->writer->drain(); } catch (...) {}
+    st->writer.reset();
+    delete st;
+}
+
+const char *vs_stage_error(const vs_stage *st, const char **kind) {
+    if (!st) return "";
+    if (kind) *kind = st->err_kind.c_str();
+    return st->err_msg.c_str();
+}
+
+int vs_stage_set_debug(vs_stage *st, int on) {
+    if (!st) return VS_E_ARG;
+    st->debug_log = on != 0;
+    return VS_OK;
+}
+
+// names of the rows of the PE-link matrix (the nodes of s_graph_L1, in the order the matrix was built in)
+int vs_stage_set_link_names(vs_stage *st, uint32_t n, const uint8_t *blob, uint64_t len) {
+    return guarded(st, [&] {
+        if (n != st->ops->link_rows()) throw StageError{VS_E_ARG, "ValueError", "link names do not match the rows of the link table"};
+        std::string joined((const char *)blob, (size_t)len);
+        std::vector<std::string> v;
+        size_t p = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            size_t q = joined.find('\n', p);
+            v.push_back(joined.substr(p, q == std::string::npos ? std::string::npos : q - p));
+            p = q == std::string::npos ? joined.size() : q + 1;
+        }
+        std::vector<Nid> ids;
+        for (auto &s : v) ids.push_back(st->names.intern(s));
+        st->link_row.assign(st->names.size(), -1);
+        for (uint32_t i = 0; i < n; i++) st->link_row[ids[i]] = (int32_t)i;
+        st->supp.clear();
+        st->link_cache_idx.clear();
+        st->link_cache_val.clear();
+    });
+}
+
+// Load state: a sequence of sections, each a u32 tag (one of the bits above) followed by its payload (see
+// vstrains_amd/graph/native_stage.py, which writes and reads this layout), closed by tag 0.
+int vs_stage_import(vs_stage *st, const uint8_t *blob, uint64_t len) {
+    return guarded(st, [&] {
+        Reader r{blob, blob + len};
+        for (;;) {
+            const uint32_t tag = r.get<uint32_t>();
+            if (tag == 0) break;
+            if (tag == VS_STAGE_GRAPH) {
+                Graph ng;
+                const uint32_t nv = r.get<uint32_t>();
+                auto ids = r.strings(nv);
+                const uint32_t n_seq = r.get<uint32_t>();
+                auto sq = r.strings(n_seq);
+                auto seq_of = r.arr<uint32_t>(nv);
+                const uint32_t seq_base = (uint32_t)st->seqs.size();
+                for (auto &s : sq) st->seqs.push_back(std::move(s));
+                ng.vdp = r.arr<double>(nv);
+                ng.vblack = r.arr<uint8_t>(nv);
+                ng.len = r.arr<uint32_t>(nv);
+                ng.nout = r.arr<uint32_t>(nv);
+                uint64_t tot = 0;
+                ng.off.resize(nv);
+                for (uint32_t v = 0; v < nv; v++) { ng.off[v] = (uint32_t)tot; tot += ng.len[v]; }
+                ng.cap = ng.len;
+                ng.a_nbr = r.arr<uint32_t>(tot);
+                ng.a_e = r.arr<uint32_t>(tot);
+                const uint32_t n_slots = r.get<uint32_t>();
+                ng.esrc = r.arr<uint32_t>(n_slots);
+                ng.etgt = r.arr<uint32_t>(n_slots);
+                ng.eovl = r.arr<int64_t>(n_slots);
+                ng.eflow = r.arr<double>(n_slots);
+                ng.eblack = r.arr<uint8_t>(n_slots);
+                const uint32_t n_free = r.get<uint32_t>();
+                for (uint32_t e : r.arr<uint32_t>(n_free)) ng.free_.push_back(e);
+                ng.n_edges = r.get<uint32_t>();
+                ng.vid.resize(nv);
+                ng.vseq.resize(nv);
+                for (uint32_t v = 0; v < nv; v++) {
+                    ng.vid[v] = st->names.intern(ids[v]);
+                    if (seq_of[v] >= n_seq) throw StageError{VS_E_ARG, "ValueError", "sequence index out of range"};
+                    ng.vseq[v] = seq_base + seq_of[v];
+                    if (ng.nout[v] > ng.len[v]) throw StageError{VS_E_ARG, "ValueError", "malformed adjacency row"};
+                }
+                for (uint64_t i = 0; i < tot; i++)
+                    if (ng.a_nbr[i] >= nv || ng.a_e[i] >= n_slots) throw StageError{VS_E_ARG, "ValueError", "adjacency entry out of range"};
+                ng.vline.assign(nv, LineRef());
+                ng.eline.assign(n_slots, LineRef());
+                const uint32_t n_nodes = r.get<uint32_t>();
+                auto nnames = r.strings(n_nodes);
+                auto nverts = r.arr<uint32_t>(n_nodes);
+                const uint32_t n_em = r.get<uint32_t>();
+                auto eu = r.strings(n_em), ew = r.strings(n_em);
+                auto eedges = r.arr<uint32_t>(n_em);
+                st->g = std::move(ng);
+                st->nodes.clear();
+                for (uint32_t i = 0; i < n_nodes; i++) {
+                    if (nverts[i] >= nv) throw StageError{VS_E_ARG, "ValueError", "node map entry out of range"};
+                    st->nodes.set(st->names.intern(nnames[i]), nverts[i]);
+                }
+                st->edges.clear();
+                st->edges.reserve(n_em);
+                for (uint32_t i = 0; i < n_em; i++) {
+                    if (eedges[i] >= n_slots) throw StageError{VS_E_ARG, "ValueError", "edge map entry out of range"};
+                    st->edges.set(pair_key(st->names.intern(eu[i]), st->names.intern(ew[i])), eedges[i]);
+                }
+                st->dirty = true;
+                st->scan.valid = false;
+                st->last_text.reset();
+            } else if (tag == VS_STAGE_SCAN) {
+                const uint32_t nv = r.get<uint32_t>();
+                st->scan.nontrivial = r.arr<uint8_t>(nv);
+                st->scan.fork_kind = r.arr<uint8_t>(nv);
+                st->scan.chain_next = r.arr<int32_t>(nv);
+                st->scan.chain_top = r.arr<int32_t>(nv);
+                st->scan.chain_rank = r.arr<int32_t>(nv);
+                st->scan.valid = true;
+            } else if (tag == VS_STAGE_CONTIGS) {
+                read_contigs(st, r, st->contigs);
+            } else if (tag == VS_STAGE_LINKS) {
+                read_link_table(st, r, st->full_link);
+            } else {
+                throw StageError{VS_E_ARG, "ValueError", "unknown section in the import blob"};
+            }
+        }
+        if (st->link_row.size() < st->names.size()) st->link_row.resize(st->names.size(), -1);
+    });
+}
+
+// Export the sections named by the bits of `what`, in ascending bit order, each as in vs_stage_import; the buffer stays
+// valid until the next call on the handle.
+int vs_stage_export(vs_stage *st, uint32_t what, const uint8_t **blob, uint64_t *len) {
+    return guarded(st, [&] {
+        st->blob.clear();
+        Writer w{st->blob};
+        if (what & VS_STAGE_GRAPH) {
+            const Graph &g = st->g;
+            const uint32_t nv = g.num_vertices();
+            w.put<uint32_t>(VS_STAGE_GRAPH);
+            w.put<uint32_t>(nv);
+            std::vector<const std::string *> ids;
+            for (uint32_t v = 0; v < nv; v++) ids.push_back(&st->names[g.vid[v]]);
+            w.strings(ids);
+            // the sequences the vertices use, each once
+            std::unordered_map<uint32_t, uint32_t> local;
+            std::vector<const std::string *> sq;
+            std::vector<uint32_t> seq_of(nv);
+            for (uint32_t v = 0; v < nv; v++) {
+                auto it = local.find(g.vseq[v]);
+                if (it == local.end()) {
+                    it = local.emplace(g.vseq[v], (uint32_t)sq.size()).first;
+                    sq.push_back(&st->seqs[g.vseq[v]]);
+                }
+                seq_of[v] = it->second;
+            }
+            w.put<uint32_t>((uint32_t)sq.size());
+            w.strings(sq);
+            w.arr(seq_of);
+            w.arr(g.vdp);
+            w.arr(g.vblack);
+            w.arr(g.len);
+            w.arr(g.nout);
+            std::vector<uint32_t> nbr, ae;
+            for (uint32_t v = 0; v < nv; v++)
+                for (uint32_t i = 0; i < g.len[v]; i++) { nbr.push_back(g.a_nbr[g.off[v] + i]); ae.push_back(g.a_e[g.off[v] + i]); }
+            w.arr(nbr);
+            w.arr(ae);
+            w.put<uint32_t>((uint32_t)g.esrc.size());
+            w.arr(g.esrc);
+            w.arr(g.etgt);
+            w.arr(g.eovl);
+            w.arr(g.eflow);
+            w.arr(g.eblack);
+            w.put<uint32_t>((uint32_t)g.free_.size());
+            w.arr(std::vector<uint32_t>(g.free_.begin(), g.free_.end()));
+            w.put<uint32_t>(g.n_edges);
+            std::vector<const std::string *> nn;
+            std::vector<uint32_t> nvt;
+            for (auto &e : st->nodes.ents)
+                if (e.live) { nn.push_back(&st->names[e.k]); nvt.push_back(e.v); }
+            w.put<uint32_t>((uint32_t)nn.size());
+            w.strings(nn);
+            w.arr(nvt);
+            std::vector<const std::string *> eu, ew;
+            std::vector<uint32_t> ee;
+            for (auto &e : st->edges.ents)
+                if (e.live) { eu.push_back(&st->names[key_first(e.k)]); ew.push_back(&st->names[key_second(e.k)]); ee.push_back(e.v); }
+            w.put<uint32_t>((uint32_t)eu.size());
+            w.strings(eu);
+            w.strings(ew);
+            w.arr(ee);
+        }
+        if (what & VS_STAGE_CONTIGS) {
+            w.put<uint32_t>(VS_STAGE_CONTIGS);
+            write_contigs(st, w, st->contigs);
+        }
+        if (what & VS_STAGE_LINKS) {
+            w.put<uint32_t>(VS_STAGE_LINKS);
+            write_link_table(st, w, st->full_link);
+        }
+        if (what & VS_STAGE_STRAINS) {
+            w.put<uint32_t>(VS_STAGE_STRAINS);
+            write_contigs(st, w, st->strains);
+        }
+        if (what & VS_STAGE_USAGES) {
+            w.put<uint32_t>(VS_STAGE_USAGES);
+            std::vector<const std::string *> nn;
+            std::vector<int64_t> vals;
+            for (auto &e : st->usages.ents)
+                if (e.live) { nn.push_back(&st->names[e.k]); vals.push_back(e.v); }
+            w.put<uint32_t>((uint32_t)nn.size());
+            w.strings(nn);
+            w.arr(vals);
+        }
+        if (what & VS_STAGE_LOG) {
+            w.put<uint32_t>(VS_STAGE_LOG);
+            std::vector<const std::string *> lines;
+            std::vector<int32_t> levels;
+            for (auto &l : st->log) { lines.push_back(&l.text); levels.push_back(l.level); }
+            w.put<uint32_t>((uint32_t)lines.size());
+            w.arr(levels);
+            // (log lines may hold anything but a newline)
+            w.strings(lines);
+        }
+        if (what & VS_STAGE_SCAN) {
+            w.put<uint32_t>(VS_STAGE_SCAN);
+            const uint32_t nv = st->scan.valid ? (uint32_t)st->scan.nontrivial.size() : 0;
+            w.put<uint32_t>(nv);
+            if (nv) {
+                w.arr(st->scan.nontrivial);
+                w.arr(st->scan.fork_kind);
+                w.arr(st->scan.chain_next);
+                w.arr(st->scan.chain_top);
+                w.arr(st->scan.chain_rank);
+            }
+        }
+        w.put<uint32_t>(0);
+        if (what & VS_STAGE_LOG) st->log.clear();
+        *blob = (const uint8_t *)st->blob.data();
+        *len = st->blob.size();
+    });
+}
+
+int vs_stage_edge_cleaning(vs_stage *st) {
+    return guarded(st, [&] { st->edge_cleaning(); });
+}
+
+int vs_stage_reinit(vs_stage *st, const char *gfa_path) {
+    return guarded(st, [&] {
+        st->reinit(gfa_path);
+        st->writer->drain();
+    });
+}
+
+int vs_stage_refresh_scan(vs_stage *st) {
+    // the scan of the graph as it stands (the reference asks get_non_trivial_branches of whatever graph it is handed);
+    // valid for a graph without gray objects whose rows are packed: a freshly imported or re-initialised one
+    return guarded(st, [&] {
+        const Graph &g = st->g;
+        uint64_t tot = 0;
+        for (uint32_t v = 0; v < g.num_vertices(); v++) {
+            if (g.off[v] != tot) state_error("vs_stage_refresh_scan: adjacency rows are not packed");
+            tot += g.len[v];
+        }
+        std::vector<double> keep = st->g.eflow;
+        st->refresh();
+        st->g.eflow = keep;  // (flows stay as they were: the scan alone is asked for)
+    });
+}
+
+int vs_stage_disentangle(vs_stage *st, double threshold, const char *temp_dir) {
+    return guarded(st, [&] {
+        st->disentangle(threshold, temp_dir);
+        st->writer->drain();
+    });
+}
+
+int vs_stage_best_matching(vs_stage *st) {
+    return guarded(st, [&] { st->best_matching(); });
+}
+
+int vs_stage_increment_nt_coverage(vs_stage *st) {
+    return guarded(st, [&] { st->increment_nt_branch_coverage(); });
+}
+
+int vs_stage_write_gfa(vs_stage *st, const char *path) {
+    return guarded(st, [&] {
+        st->write_gfa(path);
+        st->writer->drain();
+    });
+}
+
+int vs_stage_write_contigs(vs_stage *st, const char *paths_file, const char *fasta_file) {
+    return guarded(st, [&] {
+        st->write_contig_files(paths_file ? paths_file : "", fasta_file ? fasta_file : "");
+        st->writer->drain();
+    });
+}
+
+int vs_stage_path_extension(vs_stage *st, double threshold, const char *temp_dir) {
+    return guarded(st, [&] {
+        st->path_extension(threshold, temp_dir);
+        st->writer->drain();
+    });
+}
+
+// numpy.median of the vertex depths (the thresholds of VStrains_SPAdes.py:187,237 are 0.05 x this)
+int vs_stage_median_depth(vs_stage *st, double *out) {
+    return guarded(st, [&] { *out = np_median(st->g.vdp); });
+}
+
+// info[0] re-initialisations, [1] of which reused the untouched state, [2] flow/scan launches, [3] link-sum launches,
+// [4] stage files written, [5] bytes written, [6] vertices, [7] live edges; secs[0] in re-initialisations, [1] of which
+// in the flow/scan operation, [2] in link sums, [3] file-writer busy time
+int vs_stage_counters(vs_stage *st, uint64_t info[8], double secs[4]) {
+    if (!st || !info || !secs) return VS_E_ARG;
+    info[0] = st->n_reinit; info[1] = st->n_reinit_reused; info[2] = st->n_refresh; info[3] = st->n_link_calls;
+    {
+        std::lock_guard<std::mutex> lk(st->writer->mu);
+        info[4] = st->writer->files; info[5] = st->writer->bytes;
+        secs[3] = st->writer->busy_s;
+    }
+    info[6] = st->g.num_vertices(); info[7] = st->g.n_edges;
+    secs[0] = st->t_reinit; secs[1] = st->t_refresh; secs[2] = st->t_links;
+    return VS_OK;
+}
+
+}  // extern "C"

@@ -402,3 +402,9 @@ class HipBackend:
 
     def live_links(self, table: PeLinks) -> LiveLinks:
         return LiveLinks(table)
+
+    def native_stage(self, table: HipPeLinks):
+        """The stage graph in the library (``vs_stage``): what ``pipeline.extract_strains`` runs on."""
+        from .native_stage import NativeStage
+
+        return NativeStage.on_device(self.ctx, table, table.names)

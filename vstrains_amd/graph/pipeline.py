@@ -98,7 +98,50 @@ def extract_strains(pre: Prepared, table, backend, logger, out: str):
             gc.enable()
 
 
+def _extract_native(pre: Prepared, table, backend, logger, out: str):
+    """The stages of VStrains_SPAdes.py:140-248 on the native stage handle (``native_stage.NativeStage``): the graph, the
+    contigs and the link bookkeeping are loaded into the library once, every stage is one call, the strain records come
+    back at the end.  Same files, same log lines, same order as the calls below state."""
+    import logging
+
+    st = backend.native_stage(table)
+    st.set_debug(logger.isEnabledFor(logging.DEBUG))
+    marks = [("start", time.perf_counter())]
+    st.load_graph(pre.g1, pre.nodes1, pre.edges1)
+    st.load_contigs(pre.contigs)
+    marks.append(("load_s", time.perf_counter()))
+    st.edge_cleaning(logger)
+    st.reinit("{0}/gfa/es_graph_L2.gfa".format(out), logger)
+    st.write_contigs("{0}/tmp/pre_contigs.paths".format(out), "{0}/tmp/pre_contigs.fasta".format(out))
+    marks.append(("edge_cleaning_s", time.perf_counter()))
+
+    delta = 0.05 * st.median_depth()
+    st.disentangle(delta, out, logger)
+    st.write_contigs("{0}/tmp/post_contigs.paths".format(out), "{0}/tmp/post_contigs.fasta".format(out))
+    marks.append(("disentanglement_s", time.perf_counter()))
+
+    logger.info(">>>STAGE: contig path extension")
+    st.best_matching(logger)
+    st.increment_nt_branch_coverage(logger)
+    st.write_gfa("{0}/gfa/split_graph_final.gfa".format(out), logger)
+    marks.append(("best_matching_s", time.perf_counter()))
+    p_delta = 0.05 * st.median_depth()
+    st.path_extension(p_delta, out, logger)
+    marks.append(("path_extension_s", time.perf_counter()))
+    strains = st.strains()
+    st.contigs_into(pre.contigs)  # (consumed in place, as the reference's contig_dict is)
+    marks.append(("export_s", time.perf_counter()))
+    extract_strains.last_stages = {name: t - marks[i][1] for i, (name, t) in enumerate(marks[1:])}
+    extract_strains.last_stages.update(st.counters())
+    extract_strains.last_stages["engine"] = "native stage handle (vs_stage)"
+    st.close()
+    return strains
+
+
 def _extract_strains(pre: Prepared, table, backend, logger, out: str):
+    if hasattr(backend, "native_stage"):
+        strains = _extract_native(pre, table, backend, logger, out)
+        return _final_process(pre, strains, logger, out)
     ops = backend.graph_ops
     contigs = pre.contigs
     links = backend.live_links(table)
@@ -132,6 +175,11 @@ def _extract_strains(pre: Prepared, table, backend, logger, out: str):
         if hasattr(ops, attr):
             extract_strains.last_stages[attr] = getattr(ops, attr)
 
+    return _final_process(pre, strains, logger, out)
+
+
+def _final_process(pre: Prepared, strains, logger, out: str):
+    """VStrains_SPAdes.py:251-272."""
     logger.info(">>>STAGE: final process")
     resolve_contigs(strains)
     gl, nodesl, _ = read_stage_gfa("{0}/gfa/es_graph_L2.gfa".format(out))
