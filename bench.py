@@ -93,13 +93,13 @@ def strain_extract(ctx, counter, pre, names, logger, out_dir):
         pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(30)
         pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(40)
     n_stage_graphs = len([f for f in os.listdir(os.path.join(out_dir, "gfa")) if f.endswith(".gfa")])
-    from vstrains_amd import graph as graph_pkg
 
+    stages = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in getattr(pipeline.extract_strains, "last_stages", {}).items()}
+    # share of the leg spent inside the library (the stage calls: host decisions in C++ + device operations) as opposed
+    # to the Python around it (loading the prepared graph into the handle, the final strain records and files)
+    in_library = sum(stages.get(k, 0.0) for k in ("edge_cleaning_s", "disentanglement_s", "best_matching_s", "path_extension_s"))
     return {"seconds": secs, "strains": len(strains), "stage_graphs_written": n_stage_graphs,
-            "stages": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in getattr(pipeline.extract_strains, "last_stages", {}).items()},
-            "host_modules": graph_pkg.host_modules(),
-            "sections": {k: round(v, 4) for k, v in sorted(__import__("vstrains_amd.graph._timing", fromlist=["SECTIONS"]).SECTIONS.items())},
-            "graph_refresh_launches": backend.graph_ops.calls, "link_table_launches": table.calls,
+            "stages": stages, "library_share": round(in_library / secs, 3) if secs > 0 else None,
             "longest_strain_bp": max([rec[1] for rec in strains.values()] or [0])}
 
 

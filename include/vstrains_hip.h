@@ -277,18 +277,6 @@ int vs_graph_refresh(vs_ctx *ctx, uint32_t n_vertices, uint32_t n_edge_slots,
                      uint8_t *fork_kind, int32_t *chain_next, int32_t *chain_top,
                      int32_t *chain_rank, uint32_t *zero_sum_edge);
 
-/* One re-initialised stage graph in one call (store_reinit_graph, VStrains_IO.py:630-642, from the
- * point where the surviving vertices and edges are known): src/tgt[n_edges] = the edges in the
- * order they are re-inserted (file order of the stage GFA); the adjacency comes back in the order
- * rules of the graph container (row_ptr[n_vertices+1], n_out[n_vertices], nbr/eidx[2*n_edges]:
- * out-entries, then in-entries, see vstrains_amd/graph/asm_graph.py), followed by everything
- * vs_graph_refresh computes on it (all vertices and edges live).  Host pointers. */
-int vs_stage_rebuild(vs_ctx *ctx, uint32_t n_vertices, uint32_t n_edges, const uint32_t *src,
-                     const uint32_t *tgt, const double *dp, uint64_t *row_ptr, uint32_t *n_out,
-                     uint32_t *nbr, uint32_t *eidx, double *flow, uint8_t *nontrivial,
-                     uint8_t *fork_kind, int32_t *chain_next, int32_t *chain_top,
-                     int32_t *chain_rank, uint32_t *zero_sum_edge);
-
 /* ---- graph stages: native stage handle ----------------------------------------------------------
  * The state the reference keeps in a graph_tool.Graph plus Python dicts and re-derives from a GFA file after every
  * pass -- graph, simp_node_dict, simp_edge_dict, contig_dict, the rewritten pe_info, full_link, usages -- as ONE
@@ -319,7 +307,8 @@ enum {
     VS_STAGE_STRAINS = 8,  /* strain_dict (export only) */
     VS_STAGE_USAGES = 16,  /* usages (export only) */
     VS_STAGE_LOG = 32,     /* the log lines of the calls since the last export of this section (export only) */
-    VS_STAGE_SCAN = 64     /* non-trivial branches, fork kinds, chain ranks of the last re-initialisation */
+    VS_STAGE_SCAN = 64,    /* non-trivial branches, fork kinds, chain ranks of the last re-initialisation */
+    VS_STAGE_ASSIGNED = 128 /* edge_cleaning's result: (source id, target id) -> accounted for (export only) */
 };
 int vs_stage_create(vs_ctx *ctx, const vs_links *links, vs_stage **out);
 void vs_stage_destroy(vs_stage *st);
@@ -330,6 +319,8 @@ int vs_stage_set_link_names(vs_stage *st, uint32_t n, const uint8_t *joined, uin
 int vs_stage_import(vs_stage *st, const uint8_t *blob, uint64_t len);
 /* the buffer belongs to the handle and is valid until the next call on it */
 int vs_stage_export(vs_stage *st, uint32_t what, const uint8_t **blob, uint64_t *len);
+/* pe_info[(a, b)] as the dict the reference rewrites through every split / fork / contraction would hold it now */
+int vs_stage_link(vs_stage *st, const char *a, const char *b, int64_t *out);
 int vs_stage_edge_cleaning(vs_stage *st);
 int vs_stage_reinit(vs_stage *st, const char *gfa_path);
 /* scan of an imported graph without gray objects (the reference asks get_non_trivial_branches, Utilities.py:175-180,

@@ -1,0 +1,87 @@
+"""CHECKER (test infrastructure, not product code): the contig bookkeeping only the stages need, for the Python
+restatement of the stages in this package.  Restates ``contig_dict_remapping`` Utilities.py:281-380.
+
+Where the reference iterates a Python ``set`` of strings (whose order changes with PYTHONHASHSEED) this code iterates
+in first-insertion order; the golden cases record whether the reference's outputs are invariant to the hash seed
+(``case.json:hashseed_invariant``).
+"""
+from __future__ import annotations
+
+from functools import reduce
+from typing import Dict, List, Tuple
+
+from vstrains_amd.graph.asm_graph import AsmGraph, EdgeMap, NodeMap
+from vstrains_amd.graph.contigs import contig_steps, contigs_by_node  # noqa: F401  (re-exported for the stage modules)
+from vstrains_amd.graph.formats import ContigDict, path_length
+
+
+class _Closure(dict):
+    """id -> ordered set of the ids it ended up as, for the ids of the graph before the pass
+    (anything else is a KeyError, as with the plain dict); filled on first use."""
+
+    __slots__ = ("_leaves", "known")
+
+    def __init__(self, leaves, known):
+        super().__init__()
+        self._leaves = leaves
+        self.known = known
+
+    def __missing__(self, name):
+        if name not in self.known:
+            raise KeyError(name)
+        out = self[name] = self._leaves(name)
+        return out
+
+
+def remap_contigs(g: AsmGraph, nodes: NodeMap, edges: EdgeMap, contigs: ContigDict,
+                  id_mapping: Dict[str, Dict[str, None]], prev_ids: List[str], logger):
+    """Follow ``id_mapping`` (id -> ids it was forked into) transitively, then re-thread every
+    contig through the forked ids along existing edges.  Returns the transitive mapping as
+    ordered sets (dict keys)."""
+
+    def leaves(name: str) -> Dict[str, None]:
+        kids = id_mapping.get(name, ())
+        if len(kids) == 0:
+            return {name: None}
+        out: Dict[str, None] = {}
+        for kid in kids:
+            out.update(leaves(kid))
+        return out
+
+    logger.info("contig resolution..")
+    known = set(prev_ids)
+    if not known <= id_mapping.keys():
+        for name in prev_ids:
+            id_mapping[name]  # the reference indexes it directly: unknown ids are an error
+    # (the closure of an id is worked out when somebody asks for it: a pass forks a handful of the
+    # thousands of ids, and the callers index by id only)
+    closure = _Closure(leaves, known)
+
+    def images(ids: List[str]) -> List[List[str]]:
+        paths = [[s] for s in closure[ids[0]]]
+        for nxt in ids[1:]:
+            grown = []
+            for p in paths:
+                for cand in closure[nxt]:
+                    if (p[-1], cand) in edges:
+                        grown.append(p + [cand])
+            paths = grown
+        return paths
+
+    for cno, (ids, _, cov) in list(contigs.items()):
+        paths = images(ids)
+        if len(paths) < 1:
+            logger.debug("error, contig missed: " + str(cno) + str(ids))
+        elif len(paths) == 1:
+            if paths[0] != ids:
+                contigs.pop(cno)
+                contigs[cno] = [paths[0], path_length(g, [nodes[n] for n in paths[0]]), cov]
+        else:
+            contigs.pop(cno)
+            common = reduce(lambda a, b: [i for i in a if i in b], paths)
+            if len(common) > 0:
+                contigs[cno] = [common, path_length(g, [nodes[n] for n in common]), cov]
+    logger.info("done")
+    return closure
+
+

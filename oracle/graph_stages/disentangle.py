@@ -1,4 +1,8 @@
-"""Graph disentanglement: edge cleaning, branch splitting, simple-path contraction.
+"""CHECKER (test infrastructure, not product code): graph disentanglement -- edge cleaning, branch splitting,
+simple-path contraction -- restated in Python over ``AsmGraph``.  The product runs these stages in the native stage handle
+(vstrains_amd/csrc/vs_stage.cpp); this statement is pinned to the reference by the golden cases and the reference
+campaigns (tests/golden/fuzz_reference.py) and the native engine is compared with it file by file (tests/fuzz_native_cpu.py,
+tests/test_native_stage_cpu.py, and on the device tests/test_graph_gpu.py).
 
 Restates ``utils/VStrains_Decomposition.py`` (``edge_cleaning`` :822-905, ``balance_split``
 :91-530 with ``link_split`` :7-28 and ``cov_split`` :31-88, ``trivial_split`` :533-688,
@@ -19,15 +23,15 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy
 
-from .asm_graph import BLACK, GRAY, AsmGraph, EdgeMap, NodeMap
-from .contigs import (contig_steps, contigs_by_node, drop_duplicate_contigs, remap_contigs,
-                      trim_contigs)
-from .formats import (ContigDict, path_length, path_sequence, read_stage_gfa, stage_graph_from_state,
+from vstrains_amd.graph.asm_graph import BLACK, GRAY, AsmGraph, EdgeMap, NodeMap
+from vstrains_amd.graph.contigs import drop_duplicate_contigs, trim_contigs
+from .contig_ops import contig_steps, contigs_by_node, remap_contigs
+from vstrains_amd.graph.formats import (ContigDict, path_length, path_sequence, read_stage_gfa, stage_graph_from_state,
                       write_stage_gfa)
-from .ops import GraphOps, GraphScan, LiveLinks, nontrivial_ids
+from vstrains_amd.graph.ops import GraphOps, GraphScan
+from .links import LiveLinks, nontrivial_ids
 
 
-from . import _timing as _tm
 
 _CHECK_UNTOUCHED = os.environ.get("VS_CHECK_UNTOUCHED", "") not in ("", "0")
 
@@ -89,8 +93,6 @@ def reinit(stage: Stage, ops: GraphOps, logger, filename: str, untouched: bool =
     counts and sums (``_Snapshot.quick_matches``; VS_CHECK_UNTOUCHED=1 makes the full comparison anyway and
     insists; the test suites run with it)."""
     snap = stage.snap
-    if _tm.ON:
-        _tc = _tm.now()
     if untouched and snap is not None and _CHECK_UNTOUCHED:
         assert snap.matches(stage.g, stage.nodes, stage.edges), "stage changed behind an 'untouched' hint: " + filename
     # (a stage that was written to behind an 'untouched' hint fails the quick guard and takes the full comparison)
@@ -102,8 +104,6 @@ def reinit(stage: Stage, ops: GraphOps, logger, filename: str, untouched: bool =
             fh.write(snap.text)
         logger.info(filename + " is stored..")
         return Stage(stage.g, stage.nodes, stage.edges, stage.scan, snap)
-    if _tm.ON:
-        _tm.add("reinit.compare_with_snapshot", _tc)
     # one pass: the file write_stage_gfa would write, and the graph read_stage_gfa(filename) would
     # give back (float(repr(dp)) == dp), without the parse
     if hasattr(ops, "reinit"):  # the device backend does rebuild + flows + scan in one library call
@@ -113,11 +113,6 @@ def reinit(stage: Stage, ops: GraphOps, logger, filename: str, untouched: bool =
         g, nodes, edges, text = stage_graph_from_state(stage.g, stage.nodes, stage.edges, gfa_path=filename, want_text=True)
         logger.info(filename + " is stored..")
         scan = ops.refresh(g)
-    if _tm.ON:
-        _t = _tm.now()
-        snap2 = _Snapshot(g, nodes, edges, text)
-        _tm.add("reinit.snapshot", _t)
-        return Stage(g, nodes, edges, scan, snap2)
     return Stage(g, nodes, edges, scan, _Snapshot(g, nodes, edges, text))
 
 

@@ -1,4 +1,5 @@
-"""Iterative strain-path extraction over the disentangled graph.
+"""CHECKER (test infrastructure, not product code): iterative strain-path extraction over the disentangled graph,
+restated in Python over ``AsmGraph`` (see disentangle.py in this package for how it is used).
 
 Restates ``utils/VStrains_Extension.py`` (``best_matching`` :10-111, ``contig_extension``
 :115-342, ``final_extension`` :345-418, ``reduce_graph`` :429-455, ``reduce_Anode`` :469-481,
@@ -16,12 +17,13 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy
 
-from .asm_graph import GRAY, AsmGraph, NodeMap
-from .contigs import contigs_by_node, origin_ids, remap_contigs
+from vstrains_amd.graph.asm_graph import GRAY, AsmGraph, NodeMap
+from vstrains_amd.graph.contigs import origin_ids
+from .contig_ops import contigs_by_node, remap_contigs
 from .disentangle import _CHECK_UNTOUCHED, Stage, _add_edge, _add_vertex, _retire_vertex, global_trivial_split, reinit
-from . import _timing as _tm
-from .formats import ContigDict, path_length, path_sequence
-from .ops import GraphOps, LiveLinks, PeLinks, nontrivial_ids
+from vstrains_amd.graph.formats import ContigDict, path_length, path_sequence
+from vstrains_amd.graph.ops import GraphOps, PeLinks
+from .links import LiveLinks, nontrivial_ids
 
 LinkTable = Dict[str, Dict[Tuple[str, str], int]]
 
@@ -238,21 +240,13 @@ def path_extension(stage: Stage, contigs: ContigDict, table: LinkTable, frozen: 
     members: Dict[str, List[str]] = {}
     rid = 1
     while len(contigs) > 0:
-        if _tm.ON:
-            _t = _tm.now()
         prev_ids = list(stage.nodes.keys())
         n_forks, id_mapping = global_trivial_split(stage, logger)
-        if _tm.ON:
-            _t = _tm.add("px.trivial_split", _t)
         # (from the second path on, nothing lies between the re-initialisation that closed the previous
         # round and this one except the trivial split: no fork, no change)
         stage = reinit(stage, ops, logger, "{0}/gfa/graph_S{1}.gfa".format(temp_dir, rid), untouched=(n_forks == 0 and rid > 1))
         g, nodes, edges = stage.triple()
-        if _tm.ON:
-            _t = _tm.add("px.reinit_S", _t)
         closure = remap_contigs(g, nodes, edges, contigs, id_mapping, prev_ids, logger)
-        if _tm.ON:
-            _t = _tm.add("px.remap_contigs", _t)
         if n_forks == 0:
             # Nothing forked: every id stands for itself and the graph is the one the pass started from, so the
             # rewrite below only drops what no longer is a link between an in- and an out-neighbour; popping
@@ -302,8 +296,6 @@ def path_extension(stage: Stage, contigs: ContigDict, table: LinkTable, frozen: 
                 for new_no in closure[no]:
                     usages[new_no] = used
 
-        if _tm.ON:
-            _t = _tm.add("px.table_and_usages", _t)
         longest, (contig, clen, ccov) = max(contigs.items(), key=lambda kv: kv[1][1])
         contigs.pop(longest)
         if all(usages[n] > 0 for n in contig):
@@ -347,16 +339,10 @@ def path_extension(stage: Stage, contigs: ContigDict, table: LinkTable, frozen: 
                 if has_out:
                     _add_edge(g, edges, pv, path[-1], g.eovl[g.edge(path[-2], path[-1])], pcov)
                 usages[pno] = 0
-        if _tm.ON:
-            _t = _tm.add("px.extend_and_consume", _t)
         stage = reinit(stage, ops, logger, "{0}/gfa/graph_S{1}post.gfa".format(temp_dir, rid))
-        if _tm.ON:
-            _t = _tm.add("px.reinit_post", _t)
         for cno in list(contigs.keys()):
             if any(n not in stage.nodes for n in contigs[cno][0]):
                 contigs.pop(cno)
-        if _tm.ON:
-            _t = _tm.add("px.contig_filter", _t)
         rid += 1
 
     # vertices that carry the same sequence (fork copies): keep the deepest one

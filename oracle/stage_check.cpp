@@ -156,3 +156,29 @@ extern "C" int vs_stage_check_create(const int64_t *p0, uint32_t n, vs_stage **o
     *out = vs_stage_make(ops);
     return VS_OK;
 }
+
+// ---- probes of the engine's Python-semantics helpers (vs_stage_core.h), for tests/test_native_stage_cpu.py ---------------
+#include <string.h>
+
+#include "../vstrains_amd/csrc/vs_stage_core.h"
+
+extern "C" {
+// repr(float) as the engine prints depths into the stage files; returns the length
+int vs_check_py_repr(double x, char *buf, int cap) {
+    const std::string s = vsg::py_repr(x);
+    if ((int)s.size() >= cap) return -1;
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+double vs_check_py_round2(double x) { return vsg::py_round2(x); }
+double vs_check_np_mean(const double *a, uint64_t n) { return vsg::np_mean(std::vector<double>(a, a + n)); }
+double vs_check_np_median(const double *a, uint64_t n) { return vsg::np_median(std::vector<double>(a, a + n)); }
+// iteration order of set(values) for small non-negative ints; returns how many distinct values came out
+uint32_t vs_check_int_set_order(const uint32_t *values, uint32_t n, uint32_t *out) {
+    vsg::PyIntSet s;
+    for (uint32_t i = 0; i < n; i++) s.add(values[i]);
+    std::vector<uint32_t> o = s.order();
+    for (size_t i = 0; i < o.size(); i++) out[i] = o[i];
+    return (uint32_t)o.size();
+}
+}

@@ -24,16 +24,15 @@ sys.path.insert(0, ROOT)
 
 from oracle import graph_ops as chk  # noqa: E402
 from vstrains_amd.graph import pipeline  # noqa: E402
-from vstrains_amd.graph.ops import LiveLinks  # noqa: E402
+from oracle.graph_stages.run import PythonStages  # noqa: E402
 from vstrains_amd.workloads import CONFIGS, workload  # noqa: E402
 
 
-class Backend:
+class Backend(PythonStages):
+    """The Python restatement of the stages (oracle/graph_stages) over the numpy checker of the device operations."""
+
     def __init__(self):
         self.graph_ops = chk.NumpyGraphOps()
-
-    def live_links(self, table):
-        return LiveLinks(table)
 
 
 class NumpyPeLinks(chk.DictPeLinks):
@@ -57,6 +56,14 @@ class NumpyPeLinks(chk.DictPeLinks):
         return np.stack([rows[:, list(g)].sum(axis=1) for g in groups], axis=1) if len(groups) else rows
 
 
+class NativeBackend:
+    def native_stage(self, table):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import native_check
+
+        return native_check.stage_over_checker(table.names, native_check.dense_links(table))
+
+
 def digests(out_dir):
     res = {}
     for base, _, files in os.walk(out_dir):
@@ -76,6 +83,7 @@ def main():
     ap.add_argument("--dir", default=os.path.join(ROOT, "gpurun_out"))
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--native", action="store_true", help="the native stage engine over the C++ checker instead of the Python stages")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     work_dir = tempfile.mkdtemp(prefix="vstrains_prof_")
@@ -104,8 +112,10 @@ def main():
             prof = cProfile.Profile()
             prof.enable()
         t0 = time.perf_counter()
-        strains = pipeline.extract_strains(pre_i, table, Backend(), logger, out_dir)
+        strains = pipeline.extract_strains(pre_i, table, NativeBackend() if args.native else Backend(), logger, out_dir)
         times.append(time.perf_counter() - t0)
+        if args.native:
+            print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in pipeline.extract_strains.last_stages.items()})
         if prof is not None:
             import pstats
 
@@ -113,10 +123,9 @@ def main():
             pstats.Stats(prof).sort_stats("tottime").print_stats(45)
     got = digests(out_dir)
     bad = sorted(f for f in set(got) | set(want["files"]) if got.get(f) != want["files"].get(f))
-    from vstrains_amd import graph as graph_pkg
-
-    print("host modules: %s; seconds %s (device run: %s, %s)" % (
-        graph_pkg.host_modules(), ["%.3f" % t for t in times], ["%.3f" % t for t in want["seconds"]], want["host_modules"]))
+    print("%s; seconds %s (device run that left the digests: %s)" % (
+        "native engine over the C++ checker" if args.native else "Python stages over the numpy checker", ["%.3f" % t for t in times],
+        ["%.3f" % t for t in want["seconds"]]))
     print("strains %d (device run %d); %d files, %d differ %s" % (len(strains), want["strains"], len(got), len(bad), bad[:8]))
     return 1 if bad else 0
 

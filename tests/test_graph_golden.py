@@ -1,24 +1,26 @@
-"""Host logic of the graph stages against the reference's outputs (CPU; device ops replaced by
-the checker in oracle/graph_ops.py).  Every intermediate GFA, contig file and the final
-strain.paths / strain.fasta must match the golden run byte for byte (sequences via digest)."""
+"""The graph stages against the reference's outputs on the CPU: the NATIVE stage engine (vstrains_amd/csrc/vs_stage.cpp,
+the code the product runs, here over the CPU checker of its three device operations, oracle/stage_check.cpp) and the
+Python restatement of the stages it is compared with (oracle/graph_stages, over oracle/graph_ops.py: closed-form links
+and the literal pe_info dict).  Every intermediate GFA, contig file and the final strain.paths / strain.fasta must match
+the golden run byte for byte (sequences via digest)."""
 import os
 
 import pytest
 
 from graph_case import Case, case_names, compare, file_logger, quiet_logger
+import native_check
 from oracle import graph_ops as chk
 from oracle import pe_oracle
+from oracle.graph_stages.links import LiveLinks
+from oracle.graph_stages.run import PythonStages
 from vstrains_amd.graph import pipeline
-from vstrains_amd.graph.ops import LiveLinks
 
 
-class CheckerBackend:
-    """PE files come from the fixture; graph ops are the numpy/dict checker."""
+class FixtureLinks:
+    """PE files come from the fixture (the reference's own hand-off: two N^2-line text files)."""
 
-    def __init__(self, case, literal_dict):
+    def __init__(self, case):
         self.case = case
-        self.literal = literal_dict
-        self.graph_ops = chk.NumpyGraphOps()
 
     def pe_links(self, gfa, aln_dir, fwd, rve, ksize, names):
         assert ksize == self.case.meta["k"]
@@ -29,13 +31,34 @@ class CheckerBackend:
         self.case.write_info_files(names, aln_dir)
         return chk.DictPeLinks.from_files(names, os.path.join(aln_dir, "pe_info"), os.path.join(aln_dir, "st_info"))
 
+
+
+class CheckerBackend(FixtureLinks, PythonStages):
+    """The Python restatement of the stages over the numpy / dict checker."""
+
+    def __init__(self, case, literal_dict):
+        FixtureLinks.__init__(self, case)
+        self.literal = literal_dict
+        self.graph_ops = chk.NumpyGraphOps()
+
     def live_links(self, table):
         return chk.DictLiveLinks(table) if self.literal else LiveLinks(table)
 
 
-@pytest.mark.parametrize("literal", [False, True], ids=["closed_form_links", "literal_dict_links"])
+class NativeBackend(FixtureLinks):
+    """The native stage engine over the C++ checker of its device operations."""
+
+    def native_stage(self, table):
+        return native_check.stage_over_checker(table.names, native_check.dense_links(table))
+
+
+def make_backend(case, engine):
+    return NativeBackend(case) if engine == "native_engine" else CheckerBackend(case, engine == "literal_dict_links")
+
+
+@pytest.mark.parametrize("engine", ["native_engine", "closed_form_links", "literal_dict_links"])
 @pytest.mark.parametrize("name", case_names())
-def test_pipeline_matches_reference_outputs(name, literal, tmp_path):
+def test_pipeline_matches_reference_outputs(name, engine, tmp_path):
     case = Case(name)
     inp = case.inputs(str(tmp_path))
     out = str(tmp_path / "out")
@@ -45,9 +68,9 @@ def test_pipeline_matches_reference_outputs(name, literal, tmp_path):
         # the reference exits non-zero (its PE subprocess raises KeyError); so must this build, after
         # writing the same files up to that point
         with pytest.raises(KeyError):
-            pipeline.run(args, logger, CheckerBackend(case, literal))
+            pipeline.run(args, logger, make_backend(case, engine))
     else:
-        pipeline.run(args, logger, CheckerBackend(case, literal))
+        pipeline.run(args, logger, make_backend(case, engine))
     for h in list(logger.handlers):
         h.flush()
     # files the reference itself does not produce deterministically (they change with PYTHONHASHSEED, see case.json)

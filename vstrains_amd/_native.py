@@ -68,7 +68,6 @@ SYMBOLS = {
                                       C.c_void_p, C.c_uint64, C.c_void_p]),
     "vs_links_group_matrix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "vs_graph_refresh": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 13 + [C.POINTER(C.c_uint32)]),
-    "vs_stage_rebuild": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 13 + [C.POINTER(C.c_uint32)]),
     "vs_stage_create": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "vs_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vs_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -495,44 +495,6 @@ int vs_links_group_matrix(vs_ctx *ctx, const vs_links *links, const uint64_t *li
     return VS_OK;
 }
 
-// One re-initialised stage graph in one call: adjacency rows from the edge list by the container's
-// placement rule (vstrains_amd/graph/asm_graph.py: an out-entry goes to slot n_out of its source and
-// an in-entry living there moves to the back; the in-entry of the target is appended), then the
-// flows and the scan of that graph.
-int vs_stage_rebuild(vs_ctx *ctx, uint32_t n_vertices, uint32_t n_edges, const uint32_t *src, const uint32_t *tgt,
-                     const double *dp, uint64_t *row_ptr, uint32_t *n_out, uint32_t *nbr, uint32_t *eidx, double *flow,
-                     uint8_t *nontrivial, uint8_t *fork_kind, int32_t *chain_next, int32_t *chain_top, int32_t *chain_rank,
-                     uint32_t *zero_sum_edge) {
-    if (!ctx || !row_ptr || (n_vertices && (!n_out || !dp)) || (n_edges && (!src || !tgt || !nbr || !eidx)))
-        return vs_fail(ctx, VS_E_ARG, "vs_stage_rebuild: bad argument");
-    for (uint32_t e = 0; e < n_edges; e++)
-        if (src[e] >= n_vertices || tgt[e] >= n_vertices) return vs_fail(ctx, VS_E_RANGE, "vs_stage_rebuild: edge %u out of range", e);
-    std::vector<uint32_t> filled(n_vertices, 0u);
-    for (uint32_t v = 0; v <= n_vertices; v++) row_ptr[v] = 0;
-    for (uint32_t e = 0; e < n_edges; e++) { row_ptr[src[e] + 1]++; row_ptr[tgt[e] + 1]++; }
-    for (uint32_t v = 0; v < n_vertices; v++) { row_ptr[v + 1] += row_ptr[v]; n_out[v] = 0; }
-    for (uint32_t e = 0; e < n_edges; e++) {
-        const uint32_t s = src[e], t = tgt[e];
-        {
-            const uint64_t b = row_ptr[s];
-            const uint32_t slot = n_out[s], len = filled[s];
-            if (slot < len) { nbr[b + len] = nbr[b + slot]; eidx[b + len] = eidx[b + slot]; }
-            nbr[b + slot] = t; eidx[b + slot] = e;
-            n_out[s] = slot + 1;
-            filled[s] = len + 1;
-        }
-        {
-            const uint64_t b = row_ptr[t];
-            const uint32_t len = filled[t];
-            nbr[b + len] = s; eidx[b + len] = e;
-            filled[t] = len + 1;
-        }
-    }
-    std::vector<uint8_t> vb(n_vertices ? n_vertices : 1, 1), eb(n_edges ? n_edges : 1, 1);
-    return vs_graph_refresh(ctx, n_vertices, n_edges, row_ptr, n_out, nbr, eidx, dp, vb.data(), eb.data(), flow, nontrivial,
-                            fork_kind, chain_next, chain_top, chain_rank, zero_sum_edge);
-}
-
 int vs_graph_refresh(vs_ctx *ctx, uint32_t n_vertices, uint32_t n_edge_slots, const uint64_t *row_ptr, const uint32_t *n_out,
                      const uint32_t *nbr, const uint32_t *eidx, const double *dp, const uint8_t *vertex_black,
                      const uint8_t *edge_black, double *flow, uint8_t *nontrivial, uint8_t *fork_kind,

@@ -364,6 +364,7 @@ struct vs_stage {
     LinkTable full_link;       // best_matching's table, consumed by path_extension
     NameMap<Contig> strains;   // path_extension's result
     NameMap<int64_t> usages;
+    PairMap<uint8_t> assigned;  // edge_cleaning's result: (source id, target id) -> the edge is accounted for
     Scan scan;
     bool dirty = true;  // written to since the last re-initialisation
     std::shared_ptr<std::vector<LineRef>> last_text;  // lines of the stage file of the last re-initialisation
@@ -806,7 +807,7 @@ void vs_stage::reinit(const std::string &filename) {
 // =====================================================================================================================
 void vs_stage::edge_cleaning() {
     // assigned: (source id, target id) -> bool, in g.edges() order (vertex-major, out-entry order)
-    PairMap<uint8_t> assigned;
+    assigned.clear();
     for (uint32_t v = 0; v < g.num_vertices(); v++)
         g.each_out(v, [&](uint32_t t, uint32_t) { assigned.set(pair_key(g.vid[v], g.vid[t]), 0); });
     FlatIdx steps;  // contig_steps: (id, next id) some contig takes
@@ -1931,6 +1932,7 @@ void vs_stage::path_extension(double threshold, const std::string &temp_dir) {
                 if (longest == NO_NID || c.v.len > best) { longest = c.k; best = c.v.len; }
             }
         }
+        if (longest == NO_NID) throw StageError{VS_E_KEY, "ValueError", "max() arg is an empty sequence"};  // (the re-threading dropped the last contig)
         Contig cc;
         contigs.pop(longest, &cc);
         contigs.compact();
@@ -2586,6 +2588,17 @@ int vs_stage_export(vs_stage *st, uint32_t what, const uint8_t **blob, uint64_t 
             // (log lines may hold anything but a newline)
             w.strings(lines);
         }
+        if (what & VS_STAGE_ASSIGNED) {
+            w.put<uint32_t>(VS_STAGE_ASSIGNED);
+            std::vector<const std::string *> eu, ew;
+            std::vector<uint8_t> flags;
+            for (auto &e : st->assigned.ents)
+                if (e.live) { eu.push_back(&st->names[key_first(e.k)]); ew.push_back(&st->names[key_second(e.k)]); flags.push_back(e.v); }
+            w.put<uint32_t>((uint32_t)eu.size());
+            w.strings(eu);
+            w.strings(ew);
+            w.arr(flags);
+        }
         if (what & VS_STAGE_SCAN) {
             w.put<uint32_t>(VS_STAGE_SCAN);
             const uint32_t nv = st->scan.valid ? (uint32_t)st->scan.nontrivial.size() : 0;
@@ -2602,6 +2615,16 @@ int vs_stage_export(vs_stage *st, uint32_t what, const uint8_t **blob, uint64_t 
         if (what & VS_STAGE_LOG) st->log.clear();
         *blob = (const uint8_t *)st->blob.data();
         *len = st->blob.size();
+    });
+}
+
+// pe_info[(min(a, b), max(a, b))] as the dict the reference rewrites through every split / fork / contraction would hold it
+int vs_stage_link(vs_stage *st, const char *a, const char *b, int64_t *out) {
+    return guarded(st, [&] {
+        const Nid na = st->names.find(a), nb = st->names.find(b);
+        if (na == NO_NID) key_error(a);
+        if (nb == NO_NID) key_error(b);
+        *out = st->links_get(na, nb);
     });
 }
 
@@ -2625,7 +2648,10 @@ int vs_stage_refresh_scan(vs_stage *st) {
         for (uint32_t v = 0; v < g.num_vertices(); v++) {
             if (g.off[v] != tot) state_error("vs_stage_refresh_scan: adjacency rows are not packed");
             tot += g.len[v];
+            if (!g.vblack[v]) state_error("vs_stage_refresh_scan: the graph holds gray vertices (re-initialise it first)");
         }
+        for (uint64_t i = 0; i < tot; i++)
+            if (!g.eblack[g.a_e[i]]) state_error("vs_stage_refresh_scan: the graph holds gray edges (re-initialise it first)");
         std::vector<double> keep = st->g.eflow;
         st->refresh();
         st->g.eflow = keep;  // (flows stay as they were: the scan alone is asked for)

@@ -9,11 +9,9 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from . import _timing as _tm
-
 from .. import _native as nat
 from .asm_graph import AsmGraph
-from .ops import GraphOps, GraphScan, LiveLinks, PeLinks
+from .ops import GraphOps, GraphScan, PeLinks
 
 
 def _ptr(a: np.ndarray):
@@ -21,22 +19,13 @@ def _ptr(a: np.ndarray):
 
 
 class HipGraphOps(GraphOps):
-    """K6 + K7: one ``vs_graph_refresh`` call computes the flows and the scan of a graph snapshot
-    (the reference recomputes flows after every re-initialisation and asks for the branch /
-    simple-edge facts of the same snapshot right after: ``refresh``)."""
+    """K6 + K7 called directly: one ``vs_graph_refresh`` call computes the flows and the scan of a graph snapshot.
+    (The stages reach the same kernels from inside the library, through the native stage handle; this wrapper is for
+    callers that hold an ``AsmGraph`` -- the kernel tests.)"""
 
     def __init__(self, ctx):
         self.ctx = ctx
         self.calls = 0
-        self.reinit_s = 0.0     # seconds spent in reinit() since the object was made, of which in the library call:
-        self.native_s = 0.0
-        self.reinit_calls = 0
-        self._seg_lines: Dict[str, tuple] = {}   # id -> (depth, "S ..." line)
-        self._link_lines: Dict[tuple, tuple] = {}  # (id, id) -> (overlap, "L ..." line)
-        from . import fast_module
-
-        self._fast = fast_module("_stage_fast")   # typed Cython front half of reinit, or None
-        self._dp_repr: Dict[float, bytes] = {}     # depth -> repr(depth) as it goes into a segment line
 
     def _refresh(self, g: AsmGraph):
         nv = g.num_vertices()
@@ -78,147 +67,6 @@ class HipGraphOps(GraphOps):
         nv = g.num_vertices()
         return GraphScan(nt[:nv].astype(bool).tolist(), fk[:nv].tolist(), nxt[:nv].tolist(), top[:nv].tolist(),
                          rank[:nv].tolist())
-
-    def reinit(self, g: AsmGraph, nodes, edges, gfa_path: str):
-        import time
-
-        t0 = time.perf_counter()
-        try:
-            return self._reinit(g, nodes, edges, gfa_path)
-        finally:
-            self.reinit_s += time.perf_counter() - t0
-            self.reinit_calls += 1
-
-    def _reinit(self, g: AsmGraph, nodes, edges, gfa_path: str):
-        """``formats.stage_graph_from_state`` + ``refresh`` with the per-edge work in the library
-        (``vs_stage_rebuild``): this side filters the surviving vertices and edges (map order, by
-        name, as the reference's ``graph_to_gfa`` does, IO.py:345-369), writes the stage GFA, and
-        gets back the adjacency in the container's order together with the flows and the scan.
-        -> (graph, node map, edge map, GFA text, scan)"""
-        from .asm_graph import BLACK
-
-        fast = self._fast
-        if _tm.ON:
-            _t0 = _tm.now()
-        if fast is not None:
-            try:
-                (n_vid, n_vdp, n_vseq, nn, kept_keys, src, tgt, ovl, a_src, a_tgt, a_dp, text) = fast.prepare(
-                    g.vblack, g.vid, g.vdp, g.vseq, g.eblack, g.eovl, g.esrc, g.etgt, nodes, edges, self._dp_repr)
-            except TypeError:  # (ids that are not str, overlaps that are not int: the Python statement handles them)
-                fast = None
-        if fast is not None:
-            if len(self._dp_repr) > 1 << 20:
-                self._dp_repr.clear()
-            nv, n_e = len(n_vid), len(src)
-            if _tm.ON:
-                _t = _tm.add("reinit.prepare", _t0)
-            with open(gfa_path, "wb") as fh:
-                fh.write(text)
-            if _tm.ON:
-                _tm.add("reinit.write_file", _t)
-            return self._rebuild(n_vid, n_vdp, n_vseq, nn, kept_keys, src, tgt, ovl, a_src, a_tgt, a_dp, text)
-        vblack, vid, vdp, vseq = g.vblack, g.vid, g.vdp, g.vseq
-        keep = [v for v in nodes.values() if vblack[v]]
-        n_vid = [vid[v] for v in keep]
-        n_vdp = [vdp[v] for v in keep]
-        n_vseq = [vseq[v] for v in keep]
-        nv = len(keep)
-        nn = dict(zip(n_vid, range(nv)))
-        # GFA lines: most vertices and edges of a stage were there, unchanged, in the stage before --
-        # their lines are kept (a segment line by id, checked against depth and sequence object)
-        sl = self._seg_lines
-        chunks = []
-        add = chunks.append
-        for t in zip(n_vid, n_vseq, n_vdp):
-            hit = sl.get(t[0])
-            if hit is None or hit[0] != t[2] or hit[2] is not t[1]:  # (same depth, the very same sequence object)
-                hit = (t[2], "S\t%s\t%s\tDP:f:%r\n" % t, t[1])
-                sl[t[0]] = hit
-            add(hit[1])
-        eblack, eovl_src = g.eblack, g.eovl
-        get = nn.get
-        src: List[int] = []
-        tgt: List[int] = []
-        ovl: List[int] = []
-        kept_keys = []
-        for key, e in edges.items():
-            s_ = get(key[0])
-            t_ = get(key[1])
-            if s_ is None or t_ is None or not eblack[e]:
-                continue
-            src.append(s_)
-            tgt.append(t_)
-            ovl.append(eovl_src[e])
-            kept_keys.append(key)
-        n_e = len(src)
-        ll = self._link_lines
-        for k, o in zip(kept_keys, ovl):
-            hit = ll.get(k)
-            if hit is None or hit[0] != o:
-                hit = (o, "L\t%s\t+\t%s\t+\t%dM\n" % (k[0], k[1], o))
-                ll[k] = hit
-            add(hit[1])
-        if len(sl) > 8 * nv + 4096:  # (ids of retired nodes pile up over a run: start over now and then)
-            sl.clear()
-        if len(ll) > 8 * n_e + 4096:
-            ll.clear()
-        text = "".join(chunks)
-        with open(gfa_path, "w") as fh:
-            fh.write(text)
-        a_src = np.asarray(src, dtype=np.uint32)
-        a_tgt = np.asarray(tgt, dtype=np.uint32)
-        a_dp = np.asarray(n_vdp, dtype=np.float64)
-        return self._rebuild(n_vid, n_vdp, n_vseq, nn, kept_keys, src, tgt, ovl, a_src, a_tgt, a_dp, text)
-
-    def _rebuild(self, n_vid, n_vdp, n_vseq, nn, kept_keys, src, tgt, ovl, a_src, a_tgt, a_dp, text):
-        """Back half of ``reinit``: adjacency, flows and scan of the filtered stage (``vs_stage_rebuild``),
-        unpacked into a fresh ``AsmGraph``."""
-        from .asm_graph import BLACK
-
-        nv, n_e = len(n_vid), len(src)
-        if _tm.ON:
-            _tr = _tm.now()
-        row_ptr = np.zeros(nv + 1, dtype=np.uint64)
-        n_out = np.zeros(max(nv, 1), dtype=np.uint32)
-        nbr = np.zeros(max(2 * n_e, 1), dtype=np.uint32)
-        eidx = np.zeros(max(2 * n_e, 1), dtype=np.uint32)
-        flow = np.zeros(max(n_e, 1), dtype=np.float64)
-        nt = np.zeros(max(nv, 1), dtype=np.uint8)
-        fk = np.zeros(max(nv, 1), dtype=np.uint8)
-        nxt = np.full(max(nv, 1), -1, dtype=np.int32)
-        top = np.zeros(max(nv, 1), dtype=np.int32)
-        rank = np.zeros(max(nv, 1), dtype=np.int32)
-        bad = C.c_uint32(0xFFFFFFFF)
-        import time
-
-        t0 = time.perf_counter()
-        nat.check(self.ctx._h, nat.lib().vs_stage_rebuild(
-            self.ctx._h, nv, n_e, _ptr(a_src), _ptr(a_tgt), _ptr(a_dp), row_ptr.ctypes.data, n_out.ctypes.data,
-            nbr.ctypes.data, eidx.ctypes.data, flow.ctypes.data, nt.ctypes.data, fk.ctypes.data, nxt.ctypes.data,
-            top.ctypes.data, rank.ctypes.data, C.byref(bad)))
-        self.native_s += time.perf_counter() - t0
-        self.calls += 1
-        if _tm.ON:
-            _t = _tm.add("reinit.arrays_and_native", _tr)
-        ng = AsmGraph()
-        ng.vid, ng.vdp, ng.vseq = n_vid, n_vdp, n_vseq
-        ng.vblack = [BLACK] * nv
-        pairs = list(zip(nbr[: 2 * n_e].tolist(), eidx[: 2 * n_e].tolist()))
-        ptr = row_ptr.tolist()
-        ng.adj = [pairs[a:b] for a, b in zip(ptr[:-1], ptr[1:])]
-        ng.nout = n_out[:nv].tolist()
-        ng.esrc, ng.etgt, ng.eovl = src, tgt, ovl
-        ng.eflow = flow[:n_e].tolist()
-        ng.eblack = [BLACK] * n_e
-        ng._n_edges = n_e
-        if bad.value != 0xFFFFFFFF:
-            raise FloatingPointError("divide by zero encountered in edge flow of edge %s -> %s"
-                                     % (n_vid[src[bad.value]], n_vid[tgt[bad.value]]))
-        ne = dict(zip(kept_keys, range(n_e)))
-        scan = self._as_scan(ng, nt, fk, nxt, top, rank)
-        if _tm.ON:
-            _tm.add("reinit.unpack", _t)
-        return ng, nn, ne, text, scan
 
     def edge_flows(self, g: AsmGraph) -> None:
         flow, _, _, _, _, _, bad = self._refresh(g)
@@ -399,9 +247,6 @@ class HipBackend:
     def links_from_files(self, names: Sequence[str], pe_file: str, st_file: str) -> HipPeLinks:
         """``process_pe_info`` (IO.py:598-627) from the two text files, table resident on the device."""
         return HipPeLinks.from_files(self.ctx, list(names), pe_file, st_file)
-
-    def live_links(self, table: PeLinks) -> LiveLinks:
-        return LiveLinks(table)
 
     def native_stage(self, table: HipPeLinks):
         """The stage graph in the library (``vs_stage``): what ``pipeline.extract_strains`` runs on."""

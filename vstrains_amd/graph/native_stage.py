@@ -17,6 +17,7 @@ Blob layout (little endian; what ``vs_stage_import`` reads and ``vs_stage_export
   ``u32 count[n]``, ids[sum count].
 * LINKS (4): ``u32 n``, branch ids[n], ``u32 count[n]``, in ids[sum], out ids[sum], ``i64 pe[sum]``.
 * USAGES (16): ``u32 n``, ids[n], ``i64[n]``.   LOG (32): ``u32 n``, ``i32 level[n]``, lines[n].
+* ASSIGNED (128): ``u32 n``, source ids[n], target ids[n], ``u8 flag[n]``.
 * SCAN (64): ``u32 nv``, ``u8 nontrivial[nv]``, ``u8 fork_kind[nv]``, ``i32 chain_next / chain_top / chain_rank [nv]``.
 """
 from __future__ import annotations
@@ -29,7 +30,7 @@ import numpy as np
 
 from .asm_graph import AsmGraph
 
-GRAPH, CONTIGS, LINKS, STRAINS, USAGES, LOG, SCAN = 1, 2, 4, 8, 16, 32, 64
+GRAPH, CONTIGS, LINKS, STRAINS, USAGES, LOG, SCAN, ASSIGNED = 1, 2, 4, 8, 16, 32, 64, 128
 
 STAGE_SYMBOLS = {
     "vs_stage_destroy": (None, [C.c_void_p]),
@@ -38,6 +39,7 @@ STAGE_SYMBOLS = {
     "vs_stage_set_link_names": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint64]),
     "vs_stage_import": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64]),
     "vs_stage_export": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "vs_stage_link": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int64)]),
     "vs_stage_edge_cleaning": (C.c_int, [C.c_void_p]),
     "vs_stage_reinit": (C.c_int, [C.c_void_p, C.c_char_p]),
     "vs_stage_refresh_scan": (C.c_int, [C.c_void_p]),
@@ -243,22 +245,27 @@ class NativeStage:
         except Exception:
             pass
 
-    def _check(self, rc: int) -> None:
-        if rc == 0:
-            return
+    def _error(self, rc: int):
+        """The exception the reference raises in the situation the library reports (the library names it)."""
         kind = C.c_char_p()
         msg = self._lib.vs_stage_error(self._h, C.byref(kind))
         text = msg.decode("utf-8", "replace") if msg else "?"
         exc = _EXCEPTIONS.get(kind.value.decode() if kind.value else "", None)
         if exc is None:
-            raise RuntimeError("vs_stage: %s (code %d)" % (text, rc))
-        raise exc(text)
+            return RuntimeError("vs_stage: %s (code %d)" % (text, rc))
+        return exc(text)
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise self._error(rc)
 
     def _call(self, fn, logger, *args) -> None:
         rc = fn(self._h, *args)
+        err = self._error(rc) if rc != 0 else None  # (read before the next call on the handle clears it)
         if logger is not None:
             self.drain_log(logger)
-        self._check(rc)
+        if err is not None:
+            raise err
 
     # ---- state in
     def set_link_names(self, names) -> None:
@@ -338,6 +345,20 @@ class NativeStage:
         nv = r.u32()
         return GraphScan(r.arr(nv, "u1").astype(bool).tolist(), r.arr(nv, "u1").tolist(), r.arr(nv, "<i4").tolist(),
                          r.arr(nv, "<i4").tolist(), r.arr(nv, "<i4").tolist())
+
+    def assigned(self) -> Dict[Tuple[str, str], bool]:
+        """``edge_cleaning``'s result (Decomposition.py:822-905)."""
+        r = self._export(ASSIGNED)
+        assert r.u32() == ASSIGNED
+        n = r.u32()
+        eu, ew = r.strings(n), r.strings(n)
+        return dict(zip(zip(eu, ew), [bool(x) for x in r.arr(n, "u1").tolist()]))
+
+    def link(self, a: str, b: str) -> int:
+        """``pe_info[(min(a, b), max(a, b))]`` as the reference's rewritten dict would hold it now."""
+        out = C.c_int64()
+        self._check(self._lib.vs_stage_link(self._h, a.encode(), b.encode(), C.byref(out)))
+        return int(out.value)
 
     def median_depth(self) -> np.float64:
         out = C.c_double()

@@ -2,8 +2,9 @@
 intermediate files under ``OUT/{gfa,tmp,aln}``, same final ``strain.fasta`` / ``strain.paths``.
 
 ``backend`` supplies the device side: PE-link inference (boundary 1 of SURVEY.md 8b, here an
-in-process call instead of a ``python VStrains_PE_Inference.py`` subprocess) and the graph
-kernels.  The default backend is the HIP one and fails loudly without a GPU; tests inject the
+in-process call instead of a ``python VStrains_PE_Inference.py`` subprocess) and the native stage
+handle the graph stages run on (``native_stage.NativeStage``: the library's C++ engine over the HIP
+kernels).  The default backend is the HIP one and fails loudly without a GPU; tests inject the
 checker from ``oracle/``.
 """
 from __future__ import annotations
@@ -15,8 +16,6 @@ from typing import Dict
 
 import numpy
 
-from . import disentangle as dis
-from . import extend as ext
 from . import prep
 from .contigs import drop_duplicate_contigs, resolve_contigs, restore_repeats, trim_contigs
 from .formats import read_stage_gfa, write_contig_fasta, write_contig_paths, write_stage_gfa
@@ -84,11 +83,8 @@ def extract_strains(pre: Prepared, table, backend, logger, out: str):
     ``table``: the PE-link table (``ops.PeLinks``) over the nodes of ``s_graph_L1``.  This is the
     "end-to-end strain-extract" leg of BASELINE.json's metric.
 
-    The stages allocate containers by the hundred thousand per stage graph (lists of tuples,
-    per-id dicts) and free them again; none of them form reference cycles, but every 700 net
-    allocations make the interpreter's cycle collector walk the young objects, and its full passes
-    walk the whole graph state.  The collector is paused for the duration (measured at
-    configs[2]: 0.58 s -> 0.35 s) and put back as it was afterwards."""
+    The interpreter's cycle collector is paused for the duration (the prepared graph and the records that cross the
+    boundary are cycle-free containers by the ten thousand) and put back as it was afterwards."""
     was_enabled = gc.isenabled()
     gc.disable()
     try:
@@ -139,42 +135,12 @@ def _extract_native(pre: Prepared, table, backend, logger, out: str):
 
 
 def _extract_strains(pre: Prepared, table, backend, logger, out: str):
-    if hasattr(backend, "native_stage"):
+    # (a test backend may bring its own statement of the stages -- oracle/graph_stages, the checker the native engine is
+    # compared with -- through ``extract_stages``; the product backend offers only the native stage handle)
+    if hasattr(backend, "extract_stages"):
+        strains = backend.extract_stages(pre, table, logger, out)
+    else:
         strains = _extract_native(pre, table, backend, logger, out)
-        return _final_process(pre, strains, logger, out)
-    ops = backend.graph_ops
-    contigs = pre.contigs
-    links = backend.live_links(table)
-    # where the leg's time goes (seconds per part; `reinit_s` / `native_s` of the graph ops, where they keep them, say how
-    # much of it is re-initialisation and how much of that the library call): extract_strains.last_stages
-    marks = [("start", time.perf_counter())]
-    stage1 = dis.Stage(pre.g1, pre.nodes1, pre.edges1)
-    dis.edge_cleaning(pre.g1, pre.edges1, contigs, links, logger)
-    stage2 = dis.reinit(stage1, ops, logger, "{0}/gfa/es_graph_L2.gfa".format(out))
-    write_contig_paths(contigs, "{0}/tmp/pre_contigs.paths".format(out))
-    write_contig_fasta(stage2.g, stage2.nodes, contigs, "{0}/tmp/pre_contigs.fasta".format(out))
-    marks.append(("edge_cleaning_s", time.perf_counter()))
-
-    delta = 0.05 * numpy.median([stage2.g.vdp[v] for v in range(stage2.g.num_vertices())])
-    stagef = dis.iter_graph_disentanglement(stage2, contigs, links, ops, logger, delta, out)
-    write_contig_paths(contigs, "{0}/tmp/post_contigs.paths".format(out))
-    write_contig_fasta(stagef.g, stagef.nodes, contigs, "{0}/tmp/post_contigs.fasta".format(out))
-    marks.append(("disentanglement_s", time.perf_counter()))
-
-    logger.info(">>>STAGE: contig path extension")
-    full_link = ext.best_matching(stagef, contigs, links, logger)
-    ext.increment_nt_branch_coverage(stagef, logger)
-    write_stage_gfa(stagef.g, stagef.nodes, stagef.edges, "{0}/gfa/split_graph_final.gfa".format(out))
-    _stored(logger, "{0}/gfa/split_graph_final.gfa".format(out))
-    marks.append(("best_matching_s", time.perf_counter()))
-    p_delta = 0.05 * numpy.median([stagef.g.vdp[v] for v in range(stagef.g.num_vertices())])
-    strains, usages = ext.path_extension(stagef, contigs, full_link, table, ops, logger, p_delta, out)
-    marks.append(("path_extension_s", time.perf_counter()))
-    extract_strains.last_stages = {name: t - marks[i][1] for i, (name, t) in enumerate(marks[1:])}
-    for attr in ("reinit_s", "native_s", "reinit_calls", "reinit_reused"):
-        if hasattr(ops, attr):
-            extract_strains.last_stages[attr] = getattr(ops, attr)
-
     return _final_process(pre, strains, logger, out)
 
 
