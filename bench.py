@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[i]")
     ap.add_argument("--pairs", type=int, default=0, help="read pairs per GPU (default: the config's total / its GPU count)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: every rank counts the config's per-GPU block (the driver's contract); strong: the ranks split ONE block "
+                         "(the N = 1 workload of the config) between them -- the question north_star asks at configs[2]")
     ap.add_argument("--dirty", type=float, default=0.0,
                     help="fraction of read BASES replaced by lower-case / IUPAC bytes (real FASTQ holds such bytes; 0 = none)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time (0 = skip)")
@@ -155,7 +158,14 @@ def main():
     from vstrains_amd import pe as host
 
     L, k = cfg["read_len"], cfg["k"]
-    R = args.pairs if args.pairs > 0 else cfg["total_pairs"] // cfg["gpus"]
+    block = args.pairs if args.pairs > 0 else cfg["total_pairs"] // cfg["gpus"]  # what one GPU counts per step at N = 1
+    from vstrains_amd import dist as vdist
+
+    if args.scaling == "strong":
+        lo, hi = vdist.strong_share(block, rank, world)  # contiguous slices of the one block
+        R, first_pair = hi - lo, lo
+    else:
+        R, first_pair = block, rank * block
     seed = 20250000 + args.config
     sub_thresh = int(0.005 * 2 ** 32)
     n_thresh = int(0.001 * 2 ** 32)
@@ -179,44 +189,54 @@ def main():
     ctx.build_index(g.seqs, k)
     ctx.sync()
     index_s = time.time() - t0
-    reads = ctx.synth_pairs(st.genomes, cum, seed, rank * R, R, L, sub_thresh, n_thresh)
+    reads = ctx.synth_pairs(st.genomes, cum, seed, first_pair, R, L, sub_thresh, n_thresh)
     if args.dirty > 0.0:
         reads = dirty_block(ctx, reads, args.dirty, seed)
-    # One step = zero the counters, count the block, all-reduce the counters over the ranks.  With
-    # more than one rank there are two counter buffers: the all-reduce of step i (RCCL's own stream)
-    # runs while step i+1 counts into the other buffer; a buffer is reused only after its
-    # all-reduce has been waited for, and everything outstanding is drained inside the timed region.
-    # A graph whose dense [2,N,N] buffer is above the sparse-exchange threshold (configs[4]: 23.7 GB, ~0.7 s per
-    # dense ring all-reduce against 0.1 s of counting) sums its counters by exchanging the non-zero cells
-    # (PeCounter.all_reduce -> dist.sum_counts_sparse), blocking, one buffer; config.parallelism says which.
-    from vstrains_amd import dist as vdist
-
+    # One step = zero the counters, count the block, sum the counters over the ranks.  With more than one rank there are
+    # two counter buffers and a side stream: the sum of step i (PeCounter.all_reduce: the ranks' occupied 64-cell
+    # stretches through the RCCL ring, or the whole buffer when it is dense -- dist.sum_counts_compact) is issued on the
+    # side stream right after the count of step i+1 was enqueued on the main stream, so the exchange -- and the host
+    # waits it needs to learn sizes -- run while the next block is counted.  A buffer is counted into again only after its
+    # sum has finished, and everything outstanding is drained inside the timed region.
     n_nodes = len(g.seqs)
     dense_bytes = 2 * n_nodes * n_nodes * 4
-    sparse_min = int(os.environ.get("VS_SPARSE_ALLREDUCE_BYTES", vdist.SPARSE_MIN_BYTES))
-    blocking_exchange = use_dist and sparse_min > 0 and dense_bytes >= sparse_min
-    counters = [host.PeCounter(ctx) for _ in range(2 if (use_dist and not blocking_exchange) else 1)]
-    pending = [[] for _ in counters]
+    counters = [host.PeCounter(ctx) for _ in range(2 if use_dist else 1)]
+    main_stream = torch.cuda.current_stream()
+    side_stream = torch.cuda.Stream() if use_dist else None
+    counted = [None for _ in counters]
+    summed = [None for _ in counters]
+    waiting = [None]  # the buffer whose block is counted and not yet summed
     step_no = [0]
+    exchanges = []
+
+    def exchange(b):
+        with torch.cuda.stream(side_stream):
+            side_stream.wait_event(counted[b])
+            counters[b].all_reduce()
+            exchanges.append(counters[b].last_all_reduce)
+            summed[b] = side_stream.record_event()
 
     def step():
         b = step_no[0] % len(counters)
         step_no[0] += 1
         c = counters[b]
-        for wk in pending[b]:
-            wk.wait()
+        if summed[b] is not None:
+            main_stream.wait_event(summed[b])
         c.reset()
         c.add(reads)
-        if blocking_exchange:
-            c.all_reduce()
-        else:
-            pending[b] = c.all_reduce_async() if use_dist else []
+        if use_dist:
+            counted[b] = main_stream.record_event()
+            if waiting[0] is not None:
+                exchange(waiting[0])
+            waiting[0] = b
 
     def drain():
-        for b in range(len(counters)):
-            for wk in pending[b]:
-                wk.wait()
-            pending[b] = []
+        if use_dist and waiting[0] is not None:
+            exchange(waiting[0])
+            waiting[0] = None
+        for ev in summed:
+            if ev is not None:
+                main_stream.wait_event(ev)
 
     def barrier():
         if use_dist:
@@ -268,7 +288,8 @@ def main():
     if rank == 0:
         b_alg = 2 * ((L + 3) // 4) + 2 * (L - k) * 8 + 16
         ms_step = elapsed / args.steps * 1e3
-        value = world * R * args.steps / elapsed
+        job_pairs = block if args.scaling == "strong" else world * R  # pairs all ranks together count per step
+        value = job_pairs * args.steps / elapsed
         avg_kernel_ms = float(np.mean(kernel_ms))
         achieved = R * b_alg / (avg_kernel_ms * 1e-3) / 1e9
         kernel_name = ctx.last_kernel
@@ -281,7 +302,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
@@ -292,9 +313,11 @@ def main():
                 "baseline_config": args.config,
                 "pairs_per_gpu": R, "read_len": L, "k": k, "nodes": len(g.seqs),
                 "node_bases": int(sum(len(s) for s in g.seqs)),
-                "parallelism": ("read-block sharding x%d + per-step exchange of the non-zero counter cells (%s; dense [2,N,N] = %.1f GB)"
-                                % (world, getattr(counter, "last_all_reduce", "n/a"), dense_bytes / 1e9)) if blocking_exchange else
-                               "read-block sharding x%d + all-reduce of [2,N,N] counters (RCCL, overlapped with the next block)" % world,
+                "parallelism": ("read-block sharding x%d (%s: %d pairs per rank per step) + per-step sum of the [2,N,N] counters over the ranks, "
+                                "overlapped with the next block: occupied 64-cell stretches of the union through the ring or the whole %.2f GB "
+                                "buffer when it is dense (steps of this run: %s)"
+                                % (world, args.scaling, R, dense_bytes / 1e9, ", ".join("%s x%d" % (m, exchanges.count(m)) for m in sorted(set(exchanges))) or "none"))
+                               if use_dist else "one GPU, no exchange",
                 "rccl_ranks": rccl_ranks, "collective_backend": coll_backend,
                 "index": ctx.index_info, "index_build_s": index_s, "workload_build_s": workload_s,
                 "node_numbering": "along the graph's paths (vs_node_order_host), results mapped back" if ctx.node_order is not None else "as given",

@@ -332,12 +332,19 @@ int vs_stage_increment_nt_coverage(vs_stage *st);
 int vs_stage_write_gfa(vs_stage *st, const char *path);
 int vs_stage_write_contigs(vs_stage *st, const char *paths_file, const char *fasta_file); /* either may be NULL */
 int vs_stage_path_extension(vs_stage *st, double threshold, const char *temp_dir);
+/* VStrains_SPAdes.py:251-262 on the strain records path_extension left: contig_resolve (Utilities.py:211-224),
+ * trim_contig_dict (:147-159) measured on the graph kept by vs_stage_keep_graph -- call it right after the
+ * es_graph_L2 re-initialisation --, contig_dup_removed_s (:589-616), tmp/tmp_strain.paths (IO.py:558-595) */
+int vs_stage_keep_graph(vs_stage *st);
+int vs_stage_finish_strains(vs_stage *st, const char *tmp_paths_file);
 /* numpy.median of the vertex depths (the thresholds of VStrains_SPAdes.py:187,237 are 0.05 x this) */
 int vs_stage_median_depth(vs_stage *st, double *out);
 /* info[0] re-initialisations, [1] of which reused an untouched state, [2] flow/scan launches, [3] link-sum launches,
  * [4] files written, [5] bytes written, [6] vertices, [7] live edges; secs[0] in re-initialisations, [1] of which in
  * the flow/scan operation, [2] in link sums, [3] busy time of the file writers */
 int vs_stage_counters(vs_stage *st, uint64_t info[8], double secs[4]);
+/* "name=seconds;" per section of the stage calls so far (where a leg's time goes), into buf */
+int vs_stage_sections(vs_stage *st, char *buf, uint64_t cap);
 
 /* ---- device memory helpers for C callers without another allocator ----------------------- */
 int vs_dev_alloc(vs_ctx *ctx, size_t bytes, void **out); /* zero-filled */

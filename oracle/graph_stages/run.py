@@ -6,14 +6,15 @@ from __future__ import annotations
 
 import numpy
 
-from vstrains_amd.graph.formats import write_contig_fasta, write_contig_paths, write_stage_gfa
+from vstrains_amd.graph.contigs import drop_duplicate_contigs, resolve_contigs, trim_contigs
+from vstrains_amd.graph.formats import read_stage_gfa, write_contig_fasta, write_contig_paths, write_stage_gfa
 
 from . import disentangle as dis
 from . import extend as ext
 
 
 def extract_stages(pre, table, ops, links, logger, out: str):
-    """-> strain_dict (before the final process).  ``links``: a ``LiveLinks`` / ``DictLiveLinks`` over ``table``."""
+    """-> strain_dict as of VStrains_SPAdes.py:262 (resolved, trimmed on es_graph_L2, duplicates dropped).  ``links``: a ``LiveLinks`` / ``DictLiveLinks`` over ``table``."""
     contigs = pre.contigs
     stage1 = dis.Stage(pre.g1, pre.nodes1, pre.edges1)
     dis.edge_cleaning(pre.g1, pre.edges1, contigs, links, logger)
@@ -33,6 +34,13 @@ def extract_stages(pre, table, ops, links, logger, out: str):
     logger.info("{0}/gfa/split_graph_final.gfa is stored..".format(out))
     p_delta = 0.05 * numpy.median([stagef.g.vdp[v] for v in range(stagef.g.num_vertices())])
     strains, _ = ext.path_extension(stagef, contigs, full_link, table, ops, logger, p_delta, out)
+
+    logger.info(">>>STAGE: final process")  # VStrains_SPAdes.py:251-262
+    resolve_contigs(strains)
+    gl, nodesl, _ = read_stage_gfa("{0}/gfa/es_graph_L2.gfa".format(out))
+    trim_contigs(gl, nodesl, strains, logger)
+    drop_duplicate_contigs(strains, logger)
+    write_contig_paths(strains, "{0}/tmp/tmp_strain.paths".format(out), None, False)
     return strains
 
 

@@ -376,6 +376,53 @@ def test_native_reinit_equals_the_python_rebuild(backend, tmp_path):
     st.close()
 
 
+def test_chain_ranking_of_a_large_graph_on_the_device(backend, tmp_path):
+    """More than 8 192 vertices take the multi-workgroup pointer jumping (rounds that find nothing left return at once):
+    long simple paths, short ones, a ring of simple edges and a branching remainder, scan and flows against the checker."""
+    from vstrains_amd.graph.hip_ops import HipPeLinks
+    from vstrains_amd.graph.native_stage import NativeStage
+
+    import random
+
+    rng = random.Random(3)
+    g = AsmGraph()
+    def path(n, ring=False):
+        vs = [g.add_vertex(str(g.num_vertices()), rng.uniform(1.0, 500.0), "ACGT", True) for _ in range(n)]
+        for a, b in zip(vs, vs[1:]):
+            g.add_edge(a, b, 21, 0.0, True)
+        if ring:
+            g.add_edge(vs[-1], vs[0], 21, 0.0, True)
+        return vs
+    ends = [path(n) for n in (1, 2, 3, 100, 5000, 2500, 700)]
+    path(50, ring=True)
+    hubs = [g.add_vertex(str(g.num_vertices()), rng.uniform(1.0, 500.0), "ACGT", True) for _ in range(600)]
+    for h in hubs:  # branching part: chains end in hubs, hubs feed chains
+        g.add_edge(rng.choice(ends)[-1], h, 21, 0.0, True) if rng.random() < 0.5 else None
+        t = rng.choice(hubs)
+        if t != h and g.edge(h, t) is None:
+            g.add_edge(h, t, 21, 0.0, True)
+    assert g.num_vertices() > 8192
+    nodes = {g.vid[v]: v for v in range(g.num_vertices())}
+    edges = {(g.vid[g.esrc[e]], g.vid[g.etgt[e]]): e for e in g.edges()}
+    from vstrains_amd.graph.formats import stage_graph_from_state
+
+    a = stage_graph_from_state(g, nodes, edges)
+    want = chk.NumpyGraphOps().refresh(a[0])
+    table = HipPeLinks.from_matrices(backend.ctx, ["x"], np.zeros((1, 1), dtype=np.int64), np.zeros((1, 1), dtype=np.int64))
+    st = NativeStage.on_device(backend.ctx, table, table.names)
+    st.load_graph(g, nodes, edges)
+    st.reinit(str(tmp_path / "big.gfa"))
+    got = st.scan()
+    gb, _, _ = st.graph()
+    assert gb.eflow == a[0].eflow
+    assert (want.nontrivial, want.fork_kind, want.chain_next, want.chain_rank) == (got.nontrivial, got.fork_kind, got.chain_next, got.chain_rank)
+    assert max(want.chain_rank) == 4999 and min(want.chain_rank) == -1
+    for v in range(a[0].num_vertices()):
+        if want.chain_rank[v] >= 0:
+            assert want.chain_top[v] == got.chain_top[v]
+    st.close()
+
+
 @pytest.mark.parametrize("config", [0, 1, 2])
 def test_extraction_on_the_device_equals_the_checker_at_bench_size(backend, config, tmp_path):
     """The strain-extract leg of bench configs[0] / configs[1] / configs[2] (216 / 853 / 5 039 nodes, the reference cannot run

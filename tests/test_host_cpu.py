@@ -216,14 +216,14 @@ def _rank_range(rank, world, port, q):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     out = []
     # (a) the uint32 buffers can hold the sum: summed as they are (int32 storage, unsigned meaning)
-    a = _cpu_counter(4, 2 ** 29)
+    a = _cpu_counter(16, 2 ** 29)
     _set_cell(a, 1, 2, 2, 2 ** 31 + 5 if rank == 0 else 2 ** 31 - 10)
     _set_cell(a, 0, 0, 3, 7 + rank)
     a.all_reduce()
     out.append(("u32", a.wide is None, a.pairs_in_buffer, a.result()))
     how = [getattr(a, "last_all_reduce", None)]
     # (b) they cannot: every rank folds, the int64 totals are summed
-    b = _cpu_counter(4, 2 ** 31 - 1)
+    b = _cpu_counter(16, 2 ** 31 - 1)
     _set_cell(b, 1, 2, 2, 2 ** 32 - 1)
     _set_cell(b, 0, 0, 3, 2 ** 31 + rank)
     b.all_reduce()
@@ -244,35 +244,41 @@ def _rank_range(rank, world, port, q):
         out.append(("async", False, 0, None))
     except OverflowError:
         out.append(("async", True, 0, None))
-    # the two exchanges on random mostly-zero counters, cell for cell (values beyond 2^31 included)
+    # the two exchanges on random mostly-zero counters, cell for cell (values beyond 2^31 included): a banded one (few
+    # occupied stretches: compact), a dense one (falls back to the whole buffer), sizes that leave a tail of < 64 cells
     import torch
 
     from vstrains_amd import dist as vdist
 
     gen = torch.Generator().manual_seed(100 + rank)
+    modes = []
     for dtype, top in ((torch.int32, 2 ** 31 - 1), (torch.int64, 2 ** 40)):
-        m = torch.randint(0, top, (2, 60, 60), generator=gen, dtype=torch.int64)
-        m = (m * (torch.rand((2, 60, 60), generator=gen) < 0.05)).to(dtype)
-        if dtype == torch.int32:
-            m[0, 3, 4] = -7  # (uint32 2^32 - 7 in int32 storage)
-        dense, sparse = m.clone(), m.clone()
-        dist.all_reduce(dense, op=dist.ReduceOp.SUM)
-        vdist.sum_counts_sparse(sparse)
-        assert torch.equal(dense, sparse)
-        assert vdist.count_nonzero_cells(m) == int((m != 0).sum())
+        for n, fill in ((61, 0.002), (61, 0.9), (64, 0.002), (5, 0.5)):
+            m = torch.randint(0, top, (2, n, n), generator=gen, dtype=torch.int64)
+            m = (m * (torch.rand((2, n, n), generator=gen) < fill)).to(dtype)
+            if dtype == torch.int32:
+                m[0, 3, 4] = -7  # (uint32 2^32 - 7 in int32 storage)
+            dense, compact = m.clone(), m.clone()
+            dist.all_reduce(dense, op=dist.ReduceOp.SUM)
+            modes.append(vdist.sum_counts_compact(compact))
+            assert torch.equal(dense, compact)
+            off = m.clone()
+            assert vdist.sum_counts_compact(off, allow_compact=False) == "dense" and torch.equal(off, dense)
+    assert modes[:4] == ["compact", "dense", "compact", "dense"], modes
+    assert vdist.strong_share(10, 0, 2) == (0, 5) and vdist.strong_share(11, 1, 2) == (5, 11)
     if rank == 0:
         q.put((out, how))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["dense", "sparse"])
+@pytest.mark.parametrize("exchange", ["dense", "compact"])
 def test_counter_range_across_two_ranks_gloo(exchange, monkeypatch):
-    """... and the same sums when the ranks exchange their non-zero cells instead of the dense buffers
-    (what PeCounter.all_reduce does for counters of several GB that are mostly zero; forced here)."""
+    """... and the same sums when the ranks sum the occupied 64-cell stretches of their counters instead of the whole
+    buffers (dist.sum_counts_compact: what PeCounter.all_reduce does by default; "dense": turned off)."""
     import torch.multiprocessing as mp
 
-    monkeypatch.setenv("VS_SPARSE_ALLREDUCE_BYTES", "1" if exchange == "sparse" else "0")
+    monkeypatch.setenv("VS_COMPACT_ALLREDUCE", "1" if exchange == "compact" else "0")
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
     port = 29500 + ((os.getpid() + (41 if exchange == "dense" else 97)) % 500)

@@ -731,7 +731,7 @@ def test_fastq_block_refuses_invalid_utf8_and_takes_dirty_reads(host, ctx, tmp_p
     assert stats == tuple(int(x) for x in ref[2])
 
 
-@pytest.mark.parametrize("exchange", ["dense", "sparse"])
+@pytest.mark.parametrize("exchange", ["dense", "compact"])
 def test_sharded_drop_in_two_ranks_on_one_gpu(tmp_path, exchange):
     """The PE drop-in under torchrun with two ranks: each rank counts its contiguous block of the
     pairs with the real kernels, the counters are summed, rank 0 alone touches the output
@@ -744,9 +744,9 @@ def test_sharded_drop_in_two_ranks_on_one_gpu(tmp_path, exchange):
     out = tmp_path / "aln"
     out.mkdir()
     (out / "stale_file").write_text("x")  # rank 0 wipes the directory (PE_Inference.py:93-96); nobody else may
-    # ("sparse": the ranks exchange their non-zero cells instead of the dense counters, as they would for a
-    # 50 k-node graph -- forced here by a one-byte threshold)
-    env = dict(os.environ, VS_DIST_BACKEND="gloo", VS_DIST_DEVICE="0", VS_SPARSE_ALLREDUCE_BYTES="1" if exchange == "sparse" else "0")
+    # ("compact": the ranks sum the occupied 64-cell stretches of their counters instead of the whole buffers,
+    # dist.sum_counts_compact -- the default; "dense": turned off for every rank)
+    env = dict(os.environ, VS_DIST_BACKEND="gloo", VS_DIST_DEVICE="0", VS_COMPACT_ALLREDUCE="1" if exchange == "compact" else "0")
     for attempt in range(3):  # (a port that was free when asked for may be taken a moment later: ask again)
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
@@ -790,6 +790,59 @@ def test_bench_step_with_two_ranks_on_one_gpu(tmp_path):
     assert abs(out["value"] - 2 * 200000 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
     st = out["pe_stats"]
     assert st["n_reads"] + st["short_reads"] + st["used_reads"] == 2 * 200000  # both ranks' pairs, summed
+    weak_sums = (st["node_mat_sum"], st["short_mat_sum"])
+    # strong scaling: the two ranks split ONE block of 400 000 pairs -- the same pairs as the weak run's two blocks, so the
+    # same counters; the line counts the block once
+    proc = subprocess.run(
+        [sys.executable, "bench.py", "--gpus", "2", "--config", "1", "--pairs", "400000", "--steps", "2", "--warmup", "1",
+         "--cpu-seconds", "0", "--no-extract", "--scaling", "strong"],
+        cwd=ROOT, capture_output=True, text=True, env=env, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    out = json.loads([l for l in proc.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["pairs_per_gpu"] == 200000
+    assert abs(out["value"] - 400000 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    st = out["pe_stats"]
+    assert st["n_reads"] + st["short_reads"] + st["used_reads"] == 400000
+    assert (st["node_mat_sum"], st["short_mat_sum"]) == weak_sums
+    assert "compact" in out["config"]["parallelism"] or "dense" in out["config"]["parallelism"]
+
+
+def test_two_gpu_rccl_step_and_sharded_drop_in(tmp_path):
+    """On a box with two or more GPUs: `bench.py --gpus 2` and the sharded PE drop-in with one rank per GPU and RCCL as the
+    collective (backend "nccl" IS RCCL on ROCm) -- the path the 1-GPU boxes of this pool can only run over gloo.  Skips
+    where there is one GPU."""
+    import json
+    import socket
+
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU here: RCCL with two ranks needs two devices")
+    env = dict(os.environ)
+    for key in ("VS_DIST_BACKEND", "VS_DIST_DEVICE", "WORLD_SIZE"):
+        env.pop(key, None)
+    proc = subprocess.run(
+        [sys.executable, "bench.py", "--gpus", "2", "--config", "1", "--pairs", "200000", "--steps", "3", "--warmup", "1",
+         "--cpu-seconds", "0", "--no-extract"],
+        cwd=ROOT, capture_output=True, text=True, env=env, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    out = json.loads([l for l in proc.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["config"]["collective_backend"] == "nccl" and out["config"]["rccl_ranks"] == 2
+    st = out["pe_stats"]
+    assert st["n_reads"] + st["short_reads"] + st["used_reads"] == 2 * 200000
+    name, d, meta = [c for c in pe_cases() if c[0] == "errors_k21"][0]
+    outdir = tmp_path / "aln"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    proc = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), "-m", "vstrains_amd.pe_inference", "-g", os.path.join(d, "graph.gfa"), "-o", str(outdir),
+         "-f", os.path.join(d, "fwd.fq"), "-r", os.path.join(d, "rve.fq"), "-k", str(meta["k"])],
+        cwd=ROOT, capture_output=True, text=True, env=env, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    assert _read(outdir / "pe_info") == _read(os.path.join(d, "pe_info"))
+    assert _read(outdir / "st_info") == _read(os.path.join(d, "st_info"))
 
 
 @pytest.mark.parametrize("mode", ["boundaries", "tile_shapes", "walk"])

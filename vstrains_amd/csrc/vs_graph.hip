@@ -7,6 +7,11 @@
 // -ffp-contract=off and the sums follow numpy's pairwise_sum order.
 #include "vs_internal.h"
 
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
 #include <vector>
 
 struct vs_links {
@@ -201,29 +206,41 @@ __global__ void __launch_bounds__(256) k_vertex_scan(uint32_t nv, const uint64_t
                                                     const uint8_t *__restrict__ vblack, const uint8_t *__restrict__ eblack,
                                                     double *__restrict__ out_sum, double *__restrict__ in_sum,
                                                     uint8_t *__restrict__ nontrivial, uint8_t *__restrict__ fork_kind,
-                                                    int32_t *__restrict__ chain_next, int32_t *__restrict__ chain_pred) {
+                                                    int32_t *__restrict__ chain_next, int32_t *__restrict__ chain_pred,
+                                                    uint32_t *__restrict__ big_list, uint32_t *__restrict__ big_count) {
     uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nv) return;
     uint64_t lo = row_ptr[v], hi = row_ptr[v + 1];
     uint32_t no = n_out[v];
     uint32_t ni = (uint32_t)(hi - lo) - no;
-    out_sum[v] = vs_np_pairwise(dp, nbr, lo, no);
-    in_sum[v] = vs_np_pairwise(dp, nbr, lo + no, ni);
-    uint32_t bin = 0, bout = 0, both = 0;
-    for (uint64_t i = lo + no; i < hi; i++) {
-        if (!eblack[eidx[i]]) continue;
-        bin++;
-        // count this source once if it is also a black out-target and was not seen earlier
-        uint32_t s = nbr[i];
-        bool first = true;
-        for (uint64_t k = lo + no; k < i; k++)
-            if (eblack[eidx[k]] && nbr[k] == s) { first = false; break; }
-        if (!first) continue;
-        for (uint64_t k = lo; k < lo + no; k++)
-            if (eblack[eidx[k]] && nbr[k] == s) { both++; break; }
+    // sums of more than 128 addends split recursively (numpy's pairwise_sum): rare, and the explicit stack that takes
+    // costs every thread scratch memory -- such vertices are listed for k_vertex_sums_big instead
+    if (no > 128u || ni > 128u) {
+        big_list[atomicAdd(big_count, 1u)] = v;
+    } else {
+        out_sum[v] = vs_np_pairwise_le128(dp, nbr, lo, no);
+        in_sum[v] = vs_np_pairwise_le128(dp, nbr, lo + no, ni);
     }
+    uint32_t bin = 0, bout = 0, both = 0;
+    for (uint64_t i = lo + no; i < hi; i++)
+        if (eblack[eidx[i]]) bin++;
     for (uint64_t k = lo; k < lo + no; k++)
         if (eblack[eidx[k]]) bout++;
+    if (bin > 1 && bout > 1) {  // (with one black edge on a side the vertex is no branch whatever the overlap is)
+        for (uint64_t i = lo + no; i < hi; i++) {
+            if (!eblack[eidx[i]]) continue;
+            // count this source once if it is also a black out-target and was not seen earlier
+            uint32_t s = nbr[i];
+            bool is_target = false;
+            for (uint64_t k = lo; k < lo + no; k++)
+                if (nbr[k] == s && eblack[eidx[k]]) { is_target = true; break; }
+            if (!is_target) continue;
+            bool first = true;
+            for (uint64_t k = lo + no; k < i; k++)
+                if (nbr[k] == s && eblack[eidx[k]]) { first = false; break; }
+            if (first) both++;
+        }
+    }
     uint32_t m = both > 1 ? both : 1;
     nontrivial[v] = (bin > m && bout > m) ? 1 : 0;
     uint8_t fk = 0;
@@ -246,40 +263,117 @@ __global__ void __launch_bounds__(256) k_vertex_scan(uint32_t nv, const uint64_t
     chain_pred[v] = pd;
 }
 
-// K6b  list ranking of the simple chains by pointer jumping (double buffered): after
-// ceil(log2(V)) rounds anc[v] = -1 and rank[v] = distance of v from the head of its chain,
-// top[v] = that head.  Vertices on a ring of simple edges never reach -1 and are reported with
-// rank = -1 (the reference finds no head there either and leaves rings alone).
-__global__ void __launch_bounds__(256) k_chain_init(uint32_t nv, const int32_t *__restrict__ pred, int32_t *__restrict__ anc,
-                                                   int32_t *__restrict__ rank, int32_t *__restrict__ top) {
-    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= nv) return;
-    int32_t p = pred[v];
-    anc[v] = p;
-    rank[v] = p >= 0 ? 1 : 0;
-    top[v] = p >= 0 ? p : (int32_t)v;
+// neighbour sums of the vertices k_vertex_scan listed (more than 128 neighbours on a side)
+__global__ void __launch_bounds__(64) k_vertex_sums_big(const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ big_count,
+                                                       const uint64_t *__restrict__ row_ptr, const uint32_t *__restrict__ n_out,
+                                                       const uint32_t *__restrict__ nbr, const double *__restrict__ dp,
+                                                       double *__restrict__ out_sum, double *__restrict__ in_sum) {
+    const uint32_t n = *big_count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t v = big_list[i];
+        const uint64_t lo = row_ptr[v], hi = row_ptr[v + 1];
+        const uint32_t no = n_out[v], ni = (uint32_t)(hi - lo) - no;
+        out_sum[v] = vs_np_pairwise(dp, nbr, lo, no);
+        in_sum[v] = vs_np_pairwise(dp, nbr, lo + no, ni);
+    }
 }
 
-__global__ void __launch_bounds__(256) k_chain_jump(uint32_t nv, const int32_t *__restrict__ anc_in, const int32_t *__restrict__ rank_in,
-                                                   const int32_t *__restrict__ top_in, int32_t *__restrict__ anc_out,
-                                                   int32_t *__restrict__ rank_out, int32_t *__restrict__ top_out) {
-    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+// K6b  list ranking of the simple chains by pointer jumping: after ceil(log2(longest chain)) rounds anc[v] = -1 and
+// rank[v] = distance of v from the head of its chain, top[v] = that head.  ONE workgroup runs all the rounds (a stage
+// graph has at most tens of thousands of vertices and is re-ranked several hundred times per run: a launch per round
+// cost more than the rounds themselves), double buffered in global memory, and stops after the first round in which no
+// vertex still had an ancestor to jump over -- chains are short, so that is a handful of rounds instead of log2(V).
+// Vertices on a ring of simple edges never reach -1 and are reported with rank = -1 (the reference finds no head there
+// either and leaves rings alone).  buf: 6 * stride int32 of scratch (anc / rank / top, two copies each).
+#define CHAIN_TPB 1024
+__global__ void __launch_bounds__(CHAIN_TPB) k_chain_rank(uint32_t nv, const int32_t *__restrict__ pred, int32_t *__restrict__ buf,
+                                                          uint32_t stride, int32_t *__restrict__ top_out, int32_t *__restrict__ rank_out) {
+    __shared__ int s_live;
+    int32_t *anc[2] = {buf, buf + stride}, *rank[2] = {buf + 2 * stride, buf + 3 * stride}, *top[2] = {buf + 4 * stride, buf + 5 * stride};
+    for (uint32_t v = threadIdx.x; v < nv; v += CHAIN_TPB) {
+        const int32_t p = pred[v];
+        anc[0][v] = p;
+        rank[0][v] = p >= 0 ? 1 : 0;
+        top[0][v] = p >= 0 ? p : (int32_t)v;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (uint64_t span = 1; span < nv; span <<= 1) {
+        if (threadIdx.x == 0) s_live = 0;
+        __syncthreads();
+        int live = 0;
+        for (uint32_t v = threadIdx.x; v < nv; v += CHAIN_TPB) {
+            const int32_t a = anc[cur][v];
+            if (a >= 0) {
+                rank[cur ^ 1][v] = rank[cur][v] + rank[cur][a];
+                top[cur ^ 1][v] = top[cur][a];
+                const int32_t aa = anc[cur][a];
+                anc[cur ^ 1][v] = aa;
+                live |= aa >= 0;
+            } else {
+                rank[cur ^ 1][v] = rank[cur][v];
+                top[cur ^ 1][v] = top[cur][v];
+                anc[cur ^ 1][v] = -1;
+            }
+        }
+        if (live) s_live = 1;
+        __syncthreads();
+        cur ^= 1;
+        if (!s_live) break;
+        __syncthreads();
+    }
+    // (a vertex whose ancestor is still set after the last round lies on a ring)
+    for (uint32_t v = threadIdx.x; v < nv; v += CHAIN_TPB) {
+        top_out[v] = top[cur][v];
+        rank_out[v] = anc[cur][v] >= 0 ? -1 : rank[cur][v];
+    }
+}
+
+// The same ranking for graphs too large for one workgroup to be quick about (tens of thousands of vertices): one launch
+// per round over all vertices, ceil(log2(V)) launches enqueued back to back -- but a round first looks at what the round
+// before it reported (ctl[1 + r]: some vertex still had an ancestor to jump over) and returns at once when there was
+// nothing left, so the launches behind the last productive round cost a few microseconds each and no host round trip
+// decides anything.  ctl[0] = rounds that did work (its parity names the buffer that holds the result).
+__global__ void __launch_bounds__(256) k_chain_init_wide(uint32_t nv, const int32_t *__restrict__ pred, int32_t *__restrict__ buf, uint32_t stride,
+                                                        int32_t *__restrict__ ctl) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < 40u) ctl[v] = v == 1u ? 1 : 0;  // ctl[1] = 1: round 0 always runs
     if (v >= nv) return;
-    int32_t a = anc_in[v];
+    const int32_t p = pred[v];
+    buf[v] = p;
+    buf[2 * stride + v] = p >= 0 ? 1 : 0;
+    buf[4 * stride + v] = p >= 0 ? p : (int32_t)v;
+}
+__global__ void __launch_bounds__(256) k_chain_jump_wide(uint32_t nv, uint32_t round, int32_t *__restrict__ buf, uint32_t stride,
+                                                        int32_t *__restrict__ ctl) {
+    if (!__hip_atomic_load(&ctl[1 + round], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t cur = round & 1u, nxt = cur ^ 1u;
+    const int32_t *anc_in = buf + cur * stride, *rank_in = buf + (2 + cur) * stride, *top_in = buf + (4 + cur) * stride;
+    int32_t *anc_out = buf + nxt * stride, *rank_out = buf + (2 + nxt) * stride, *top_out = buf + (4 + nxt) * stride;
+    if (v == 0) ctl[0] = (int32_t)round + 1;
+    if (v >= nv) return;
+    const int32_t a = anc_in[v];
     if (a >= 0) {
         rank_out[v] = rank_in[v] + rank_in[a];
         top_out[v] = top_in[a];
-        anc_out[v] = anc_in[a];
+        const int32_t aa = anc_in[a];
+        anc_out[v] = aa;
+        if (aa >= 0) __hip_atomic_store(&ctl[2 + round], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         rank_out[v] = rank_in[v];
         top_out[v] = top_in[v];
         anc_out[v] = -1;
     }
 }
-
-__global__ void __launch_bounds__(256) k_chain_finish(uint32_t nv, const int32_t *__restrict__ anc, int32_t *__restrict__ rank) {
-    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v < nv && anc[v] >= 0) rank[v] = -1;
+__global__ void __launch_bounds__(256) k_chain_finish_wide(uint32_t nv, const int32_t *__restrict__ buf, uint32_t stride,
+                                                          const int32_t *__restrict__ ctl, int32_t *__restrict__ top_out,
+                                                          int32_t *__restrict__ rank_out) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    const uint32_t cur = (uint32_t)ctl[0] & 1u;
+    top_out[v] = buf[(4 + cur) * stride + v];
+    rank_out[v] = buf[cur * stride + v] >= 0 ? -1 : buf[(2 + cur) * stride + v];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -303,6 +397,7 @@ __global__ void __launch_bounds__(256) k_edge_flow(uint32_t nv, const uint64_t *
         double dv = dp[v], is = in_sum[v];
         if (os == 0.0 || is == 0.0) {
             atomicMin(bad, eidx[lo + k]);
+            flow[eidx[lo + k]] = 0.0;
             continue;
         }
         double a = (dv / os) * du;
@@ -514,7 +609,7 @@ int vs_graph_refresh(vs_ctx *ctx, uint32_t n_vertices, uint32_t n_edge_slots, co
     VS_HIP(ctx, hipSetDevice(ctx->device));
     SlotCounter sc;
     DevBuf d_row, d_no, d_nbr, d_eidx, d_dp, d_vb, d_eb, d_os, d_is, d_nt, d_fk, d_nx, d_pd, d_flow, d_bad;
-    DevBuf d_anc[2], d_rank[2], d_top[2];
+    DevBuf d_chain, d_top, d_rank, d_big;
     VS_TRY(dev_upload(ctx, sc, d_row, row_ptr, (size_t)(n_vertices + 1) * sizeof(uint64_t)));
     VS_TRY(dev_upload(ctx, sc, d_no, n_out, (size_t)n_vertices * sizeof(uint32_t)));
     VS_TRY(dev_upload(ctx, sc, d_nbr, nbr, (size_t)n_adj * sizeof(uint32_t)));
@@ -530,39 +625,34 @@ int vs_graph_refresh(vs_ctx *ctx, uint32_t n_vertices, uint32_t n_edge_slots, co
     VS_TRY(dev_alloc(ctx, sc, d_pd, (size_t)n_vertices * sizeof(int32_t)));
     VS_TRY(dev_alloc(ctx, sc, d_flow, (size_t)(n_edge_slots ? n_edge_slots : 1) * sizeof(double)));
     VS_TRY(dev_alloc(ctx, sc, d_bad, sizeof(uint32_t)));
-    for (int i = 0; i < 2; i++) {
-        VS_TRY(dev_alloc(ctx, sc, d_anc[i], (size_t)n_vertices * sizeof(int32_t)));
-        VS_TRY(dev_alloc(ctx, sc, d_rank[i], (size_t)n_vertices * sizeof(int32_t)));
-        VS_TRY(dev_alloc(ctx, sc, d_top[i], (size_t)n_vertices * sizeof(int32_t)));
-    }
+    VS_TRY(dev_alloc(ctx, sc, d_big, (size_t)(n_vertices + 1) * sizeof(uint32_t)));
+    VS_HIP(ctx, hipMemsetAsync(d_big.p, 0, sizeof(uint32_t), ctx->stream));
+    const uint32_t chain_stride = (n_vertices + 3u) & ~3u;
+    VS_TRY(dev_alloc(ctx, sc, d_chain, (size_t)6 * chain_stride * sizeof(int32_t)));
+    VS_TRY(dev_alloc(ctx, sc, d_top, (size_t)n_vertices * sizeof(int32_t)));
+    VS_TRY(dev_alloc(ctx, sc, d_rank, (size_t)n_vertices * sizeof(int32_t)));
     VS_HIP(ctx, hipMemsetAsync(d_bad.p, 0xFF, sizeof(uint32_t), ctx->stream));
     VS_HIP(ctx, hipMemsetAsync(d_flow.p, 0, (size_t)(n_edge_slots ? n_edge_slots : 1) * sizeof(double), ctx->stream));
     dim3 grid((n_vertices + 255) / 256), block(256);
     hipLaunchKernelGGL(k_vertex_scan, grid, block, 0, ctx->stream, n_vertices, d_row.as<uint64_t>(), d_no.as<uint32_t>(),
                        d_nbr.as<uint32_t>(), d_eidx.as<uint32_t>(), d_dp.as<double>(), d_vb.as<uint8_t>(), d_eb.as<uint8_t>(),
                        d_os.as<double>(), d_is.as<double>(), d_nt.as<uint8_t>(), d_fk.as<uint8_t>(), d_nx.as<int32_t>(),
-                       d_pd.as<int32_t>());
+                       d_pd.as<int32_t>(), d_big.as<uint32_t>() + 1, d_big.as<uint32_t>());
+    hipLaunchKernelGGL(k_vertex_sums_big, dim3(64), dim3(64), 0, ctx->stream, d_big.as<uint32_t>() + 1, d_big.as<uint32_t>(), d_row.as<uint64_t>(),
+                       d_no.as<uint32_t>(), d_nbr.as<uint32_t>(), d_dp.as<double>(), d_os.as<double>(), d_is.as<double>());
     hipLaunchKernelGGL(k_edge_flow, grid, block, 0, ctx->stream, n_vertices, d_row.as<uint64_t>(), d_no.as<uint32_t>(),
                        d_nbr.as<uint32_t>(), d_eidx.as<uint32_t>(), d_dp.as<double>(), d_os.as<double>(), d_is.as<double>(),
                        d_flow.as<double>(), d_bad.as<uint32_t>());
-    hipLaunchKernelGGL(k_chain_init, grid, block, 0, ctx->stream, n_vertices, d_pd.as<int32_t>(), d_anc[0].as<int32_t>(),
-                       d_rank[0].as<int32_t>(), d_top[0].as<int32_t>());
-    int cur = 0;
-    for (uint64_t span = 1; span < n_vertices; span <<= 1) {
-        hipLaunchKernelGGL(k_chain_jump, grid, block, 0, ctx->stream, n_vertices, d_anc[cur].as<int32_t>(),
-                           d_rank[cur].as<int32_t>(), d_top[cur].as<int32_t>(), d_anc[cur ^ 1].as<int32_t>(),
-                           d_rank[cur ^ 1].as<int32_t>(), d_top[cur ^ 1].as<int32_t>());
-        cur ^= 1;
-    }
-    hipLaunchKernelGGL(k_chain_finish, grid, block, 0, ctx->stream, n_vertices, d_anc[cur].as<int32_t>(), d_rank[cur].as<int32_t>());
+    hipLaunchKernelGGL(k_chain_rank, dim3(1), dim3(CHAIN_TPB), 0, ctx->stream, n_vertices, d_pd.as<int32_t>(), d_chain.as<int32_t>(),
+                       chain_stride, d_top.as<int32_t>(), d_rank.as<int32_t>());
     VS_HIP(ctx, hipGetLastError());
     uint32_t bad = 0xFFFFFFFFu;
     if (flow && n_edge_slots) VS_HIP(ctx, hipMemcpyAsync(flow, d_flow.p, (size_t)n_edge_slots * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (nontrivial) VS_HIP(ctx, hipMemcpyAsync(nontrivial, d_nt.p, n_vertices, hipMemcpyDeviceToHost, ctx->stream));
     if (fork_kind) VS_HIP(ctx, hipMemcpyAsync(fork_kind, d_fk.p, n_vertices, hipMemcpyDeviceToHost, ctx->stream));
     if (chain_next) VS_HIP(ctx, hipMemcpyAsync(chain_next, d_nx.p, (size_t)n_vertices * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (chain_top) VS_HIP(ctx, hipMemcpyAsync(chain_top, d_top[cur].p, (size_t)n_vertices * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (chain_rank) VS_HIP(ctx, hipMemcpyAsync(chain_rank, d_rank[cur].p, (size_t)n_vertices * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (chain_top) VS_HIP(ctx, hipMemcpyAsync(chain_top, d_top.p, (size_t)n_vertices * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (chain_rank) VS_HIP(ctx, hipMemcpyAsync(chain_rank, d_rank.p, (size_t)n_vertices * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     VS_HIP(ctx, hipMemcpyAsync(&bad, d_bad.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (zero_sum_edge) *zero_sum_edge = bad;
@@ -577,18 +667,134 @@ int vs_graph_refresh(vs_ctx *ctx, uint32_t n_vertices, uint32_t n_edge_slots, co
 #include "vs_stage.h"
 
 namespace {
+// One re-initialised stage graph per call, several hundred calls per run: everything the kernels need travels in ONE
+// pinned upload and everything they produce in ONE pinned download; device and staging buffers are kept and grow only.
 struct HipStageOps : VsStageOps {
     vs_ctx *ctx;
     const vs_links *links;
-    std::vector<uint8_t> ones_v, ones_e;
+    void *h_up = nullptr, *h_down = nullptr, *d_up = nullptr, *d_down = nullptr, *d_tmp = nullptr, *d_ones = nullptr;
+    size_t cap_up = 0, cap_down = 0, cap_tmp = 0, cap_ones = 0;
+    double t_pack = 0, t_enqueue = 0, t_wait = 0, t_unpack = 0;  // where a call's host time goes (VS_STAGE_OP_TIMING=1 prints the sums)
+    uint64_t n_calls = 0;
+    static double now() {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+    }
     HipStageOps(vs_ctx *c, const vs_links *l) : ctx(c), links(l) {}
+    ~HipStageOps() override {
+        if (getenv("VS_STAGE_OP_TIMING"))
+            fprintf(stderr, "[vs] stage flow/scan operation: %llu calls, pack %.4f s, enqueue %.4f s, wait %.4f s, unpack %.4f s\n",
+                    (unsigned long long)n_calls, t_pack, t_enqueue, t_wait, t_unpack);
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (h_up) (void)hipHostFree(h_up);
+        if (h_down) (void)hipHostFree(h_down);
+        if (d_up) (void)hipFree(d_up);
+        if (d_down) (void)hipFree(d_down);
+        if (d_tmp) (void)hipFree(d_tmp);
+        if (d_ones) (void)hipFree(d_ones);
+    }
+    static size_t up8(size_t x) { return (x + 7u) & ~(size_t)7u; }
+    int grow(void **host, void **dev, size_t *cap, size_t need) {
+        if (*cap >= need) return VS_OK;
+        VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (host && *host) { VS_HIP(ctx, hipHostFree(*host)); *host = nullptr; }
+        if (*dev) { VS_HIP(ctx, hipFree(*dev)); *dev = nullptr; }
+        *cap = 0;
+        const size_t c = need + need / 2 + 4096;
+        if (host) VS_HIP(ctx, hipHostMalloc(host, c, hipHostMallocDefault));
+        VS_HIP(ctx, hipMalloc(dev, c));
+        *cap = c;
+        return VS_OK;
+    }
+    int run(uint32_t nv, uint32_t ne, const uint64_t *row_ptr, const uint32_t *n_out, const uint32_t *nbr, const uint32_t *eidx,
+            const double *dp, double *flow, uint8_t *nontrivial, uint8_t *fork_kind, int32_t *chain_next, int32_t *chain_top,
+            int32_t *chain_rank, uint32_t *zero_sum_edge) {
+        *zero_sum_edge = 0xFFFFFFFFu;
+        if (nv == 0) return VS_OK;
+        VS_HIP(ctx, hipSetDevice(ctx->device));
+        const uint64_t n_adj = row_ptr[nv];
+        // upload: row_ptr | dp | n_out | nbr | eidx
+        const size_t o_row = 0, o_dp = o_row + up8((size_t)(nv + 1) * 8), o_no = o_dp + (size_t)nv * 8, o_nbr = o_no + up8((size_t)nv * 4),
+                     o_eidx = o_nbr + up8((size_t)n_adj * 4), up_bytes = o_eidx + up8((size_t)n_adj * 4);
+        // download: flow | chain_next | chain_top | chain_rank | bad | nontrivial | fork_kind  (top / rank are copied in on the device)
+        const size_t q_flow = 0, q_next = q_flow + (size_t)ne * 8, q_top = q_next + up8((size_t)nv * 4), q_rank = q_top + up8((size_t)nv * 4),
+                     q_bad = q_rank + up8((size_t)nv * 4), q_nt = q_bad + 8, q_fk = q_nt + up8(nv), down_bytes = q_fk + up8(nv);
+        // device scratch: out_sum | in_sum | pred | chain ranking (anc / rank / top, two copies each)
+        const uint32_t chain_stride = (nv + 3u) & ~3u;
+        const size_t t_os = 0, t_is = t_os + (size_t)nv * 8, t_pd = t_is + (size_t)nv * 8, t_pj = t_pd + up8((size_t)nv * 4),
+                     t_ctl = t_pj + (size_t)6 * chain_stride * 4, t_big = t_ctl + 64 * 4, tmp_bytes = t_big + ((size_t)nv + 2) * 4;
+        VS_TRY(grow(&h_up, &d_up, &cap_up, up_bytes));
+        VS_TRY(grow(&h_down, &d_down, &cap_down, down_bytes));
+        VS_TRY(grow(nullptr, &d_tmp, &cap_tmp, tmp_bytes));
+        const size_t need_ones = (size_t)(nv > ne ? nv : ne) + 1;
+        if (cap_ones < need_ones) {
+            VS_TRY(grow(nullptr, &d_ones, &cap_ones, need_ones));
+            VS_HIP(ctx, hipMemsetAsync(d_ones, 1, cap_ones, ctx->stream));
+        }
+        char *hu = (char *)h_up, *du = (char *)d_up, *dd = (char *)d_down, *dt = (char *)d_tmp;
+        const double t0 = now();
+        n_calls++;
+        memcpy(hu + o_row, row_ptr, (size_t)(nv + 1) * 8);
+        memcpy(hu + o_dp, dp, (size_t)nv * 8);
+        memcpy(hu + o_no, n_out, (size_t)nv * 4);
+        if (n_adj) {
+            memcpy(hu + o_nbr, nbr, (size_t)n_adj * 4);
+            memcpy(hu + o_eidx, eidx, (size_t)n_adj * 4);
+        }
+        const double t1 = now();
+        VS_HIP(ctx, hipMemcpyAsync(d_up, h_up, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+        VS_HIP(ctx, hipMemsetAsync(dd + q_bad, 0xFF, 8, ctx->stream));
+        VS_HIP(ctx, hipMemsetAsync(dt + t_big, 0, 4, ctx->stream));
+        const uint64_t *d_row = (const uint64_t *)(du + o_row);
+        const double *d_dp = (const double *)(du + o_dp);
+        const uint32_t *d_no = (const uint32_t *)(du + o_no), *d_nbr = (const uint32_t *)(du + o_nbr), *d_eidx = (const uint32_t *)(du + o_eidx);
+        double *d_os = (double *)(dt + t_os), *d_is = (double *)(dt + t_is);
+        int32_t *d_pd = (int32_t *)(dt + t_pd);
+        dim3 grid((nv + 255) / 256), block(256);
+        hipLaunchKernelGGL(k_vertex_scan, grid, block, 0, ctx->stream, nv, d_row, d_no, d_nbr, d_eidx, d_dp, (const uint8_t *)d_ones,
+                           (const uint8_t *)d_ones, d_os, d_is, (uint8_t *)(dd + q_nt), (uint8_t *)(dd + q_fk), (int32_t *)(dd + q_next), d_pd,
+                           (uint32_t *)(dt + t_big) + 1, (uint32_t *)(dt + t_big));
+        hipLaunchKernelGGL(k_vertex_sums_big, dim3(64), dim3(64), 0, ctx->stream, (const uint32_t *)(dt + t_big) + 1, (const uint32_t *)(dt + t_big),
+                           d_row, d_no, d_nbr, d_dp, d_os, d_is);
+        hipLaunchKernelGGL(k_edge_flow, grid, block, 0, ctx->stream, nv, d_row, d_no, d_nbr, d_eidx, d_dp, d_os, d_is, (double *)(dd + q_flow),
+                           (uint32_t *)(dd + q_bad));
+        if (nv <= 8192u) {
+            hipLaunchKernelGGL(k_chain_rank, dim3(1), dim3(CHAIN_TPB), 0, ctx->stream, nv, d_pd, (int32_t *)(dt + t_pj), chain_stride,
+                               (int32_t *)(dd + q_top), (int32_t *)(dd + q_rank));
+        } else {
+            int32_t *buf = (int32_t *)(dt + t_pj), *ctl = (int32_t *)(dt + t_ctl);
+            hipLaunchKernelGGL(k_chain_init_wide, grid, block, 0, ctx->stream, nv, d_pd, buf, chain_stride, ctl);
+            uint32_t round = 0;
+            for (uint64_t span = 1; span < nv && round < 36u; span <<= 1, round++)
+                hipLaunchKernelGGL(k_chain_jump_wide, grid, block, 0, ctx->stream, nv, round, buf, chain_stride, ctl);
+            hipLaunchKernelGGL(k_chain_finish_wide, grid, block, 0, ctx->stream, nv, buf, chain_stride, ctl, (int32_t *)(dd + q_top),
+                               (int32_t *)(dd + q_rank));
+        }
+        VS_HIP(ctx, hipGetLastError());
+        VS_HIP(ctx, hipMemcpyAsync(h_down, d_down, down_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        const double t2 = now();
+        VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const double t3 = now();
+        const char *hd = (const char *)h_down;
+        if (ne) memcpy(flow, hd + q_flow, (size_t)ne * 8);
+        memcpy(chain_next, hd + q_next, (size_t)nv * 4);
+        memcpy(chain_top, hd + q_top, (size_t)nv * 4);
+        memcpy(chain_rank, hd + q_rank, (size_t)nv * 4);
+        memcpy(zero_sum_edge, hd + q_bad, 4);
+        memcpy(nontrivial, hd + q_nt, nv);
+        memcpy(fork_kind, hd + q_fk, nv);
+        t_pack += t1 - t0;
+        t_enqueue += t2 - t1;
+        t_wait += t3 - t2;
+        t_unpack += now() - t3;
+        return VS_OK;
+    }
     int refresh(uint32_t nv, uint32_t ne, const uint64_t *row_ptr, const uint32_t *n_out, const uint32_t *nbr, const uint32_t *eidx,
                 const double *dp, double *flow, uint8_t *nontrivial, uint8_t *fork_kind, int32_t *chain_next, int32_t *chain_top,
                 int32_t *chain_rank, uint32_t *zero_sum_edge, std::string &err) override {
-        if (ones_v.size() < nv) ones_v.assign((size_t)nv + nv / 2 + 16, 1);
-        if (ones_e.size() < ne) ones_e.assign((size_t)ne + ne / 2 + 16, 1);
-        int rc = vs_graph_refresh(ctx, nv, ne, row_ptr, n_out, nbr, eidx, dp, ones_v.data(), ones_e.data(), flow, nontrivial, fork_kind,
-                                  chain_next, chain_top, chain_rank, zero_sum_edge);
+        int rc = run(nv, ne, row_ptr, n_out, nbr, eidx, dp, flow, nontrivial, fork_kind, chain_next, chain_top, chain_rank, zero_sum_edge);
         if (rc) err = ctx->err;
         return rc;
     }

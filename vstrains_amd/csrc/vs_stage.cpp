@@ -194,6 +194,14 @@ struct Graph {
     std::deque<uint32_t> free_;
     uint32_t n_edges = 0;
 
+    // empty graph, allocations kept (a re-initialisation builds into the graph it replaced the time before)
+    void reset() {
+        vid.clear(); vseq.clear(); vdp.clear(); vblack.clear(); vline.clear();
+        off.clear(); len.clear(); cap.clear(); nout.clear(); a_nbr.clear(); a_e.clear();
+        esrc.clear(); etgt.clear(); eovl.clear(); eflow.clear(); eblack.clear(); eline.clear();
+        free_.clear();
+        n_edges = 0;
+    }
     uint32_t num_vertices() const { return (uint32_t)vid.size(); }
     uint32_t out_degree(uint32_t v) const { return nout[v]; }
     uint32_t in_degree(uint32_t v) const { return len[v] - nout[v]; }
@@ -344,6 +352,24 @@ struct Scan {
     bool valid = false;
 };
 
+// seconds per named section of the stages (vs_stage_sections): where a leg's time goes
+struct Sections {
+    std::deque<std::pair<std::string, double>> acc;  // (a deque: running timers hold references into it)
+    double &slot(const char *name) {
+        for (auto &p : acc)
+            if (p.first == name) return p.second;
+        acc.push_back({name, 0.0});
+        return acc.back().second;
+    }
+};
+struct SectionTimer {
+    double &dst;
+    double t0;
+    SectionTimer(Sections &s, const char *name) : dst(s.slot(name)), t0(now_s()) {}
+    ~SectionTimer() { dst += now_s() - t0; }
+};
+#define VS_SECTION(name) SectionTimer section_timer_##__LINE__(sections, name)
+
 struct LogLine {
     int level;  // 10 DEBUG, 20 INFO, 30 WARNING
     std::string text;
@@ -366,8 +392,32 @@ struct vs_stage {
     NameMap<int64_t> usages;
     PairMap<uint8_t> assigned;  // edge_cleaning's result: (source id, target id) -> the edge is accounted for
     Scan scan;
+    Graph ref_g;                 // the graph as it stood when vs_stage_keep_graph was called (es_graph_L2: the final strain
+    NameMap<uint32_t> ref_nodes; // records are measured on it, VStrains_SPAdes.py:253-258)
+    bool have_ref = false;
+    Graph spare_g;               // the graph, node map and edge map of the stage before: the next re-initialisation builds into them
+    NameMap<uint32_t> spare_nodes;
+    PairMap<uint32_t> spare_edges;
+    std::vector<uint32_t> spare_deg;
     bool dirty = true;  // written to since the last re-initialisation
     std::shared_ptr<std::vector<LineRef>> last_text;  // lines of the stage file of the last re-initialisation
+    std::vector<std::shared_ptr<std::vector<LineRef>>> line_pool;  // line lists the writers are done with, to be filled again
+    std::shared_ptr<std::vector<LineRef>> fresh_lines(size_t n) {
+        for (auto &p : line_pool)
+            if (p.use_count() == 1) {  // (only the pool holds it: no writer, not the last stage's text)
+                p->clear();
+                p->reserve(n);
+                return p;
+            }
+        if (line_pool.size() < 16) {
+            line_pool.push_back(std::make_shared<std::vector<LineRef>>());
+            line_pool.back()->reserve(n);
+            return line_pool.back();
+        }
+        auto p = std::make_shared<std::vector<LineRef>>();
+        p->reserve(n);
+        return p;
+    }
     LineArena arena;
     std::unique_ptr<FileWriter> writer;
     std::vector<LogLine> log;
@@ -382,6 +432,7 @@ struct vs_stage {
     // counters
     uint64_t n_reinit = 0, n_reinit_reused = 0, n_refresh = 0, n_link_calls = 0;
     double t_refresh = 0, t_links = 0, t_reinit = 0;
+    Sections sections;
     // error of the last call, export buffer
     std::string err_kind, err_msg;
     std::string blob;
@@ -516,6 +567,8 @@ struct vs_stage {
     void contract_simple_paths(bool with_contigs, bool with_links);
     void disentangle(double threshold, const std::string &temp_dir);
     void trim_contigs(NameMap<Contig> &cd);
+    void finish_strains(const std::string &tmp_paths_file);
+    void write_paths_file(const NameMap<Contig> &cd, const std::string &paths_file);
     void drop_duplicate_contigs(NameMap<Contig> &cd);
     struct Closure;
     void remap_contigs(const NameMap<std::vector<Nid>> &id_mapping, Closure &closure);
@@ -629,6 +682,7 @@ void vs_stage::links_end_pass() {
 // =====================================================================================================================
 LineRef vs_stage::seg_line(uint32_t v) {
     if (g.vline[v].p) return g.vline[v];
+
     const std::string &id = names[g.vid[v]], &seq = seqs[g.vseq[v]];
     const std::string dp = py_repr(g.vdp[v]);
     const size_t n = 2 + id.size() + 1 + seq.size() + 6 + dp.size() + 1;
@@ -646,6 +700,7 @@ LineRef vs_stage::seg_line(uint32_t v) {
 
 LineRef vs_stage::link_line(uint32_t e, Nid u, Nid w) {
     if (g.eline[e].p) return g.eline[e];
+
     char num[32];
     int nn = snprintf(num, sizeof(num), "%lld", (long long)g.eovl[e]);
     const std::string &a = names[u], &b = names[w];
@@ -684,6 +739,7 @@ void vs_stage::write_gfa(const std::string &filename) {
 }
 
 void vs_stage::refresh() {
+    VS_SECTION("reinit.flow_scan_op");
     const uint32_t nv = g.num_vertices(), ne = (uint32_t)g.esrc.size();
     std::vector<uint64_t> row_ptr(nv + 1);
     for (uint32_t v = 0; v < nv; v++) row_ptr[v] = g.off[v];
@@ -722,14 +778,16 @@ void vs_stage::reinit(const std::string &filename) {
         t_reinit += now_s() - t0;
         return;
     }
-    Graph ng;
+    SectionTimer rebuild_timer(sections, "reinit.rebuild");
+    Graph &ng = spare_g;
+    ng.reset();
     const size_t nv_est = nodes.size();
     ng.vid.reserve(nv_est); ng.vseq.reserve(nv_est); ng.vdp.reserve(nv_est); ng.vline.reserve(nv_est);
-    auto lines = std::make_shared<std::vector<LineRef>>();
-    lines->reserve(nodes.size() + edges.size());
+    auto lines = fresh_lines(nodes.size() + edges.size());
     // surviving vertices, map order
-    NameMap<uint32_t> nn;
-    nn.slot.assign(names.size(), -1);
+    NameMap<uint32_t> &nn = spare_nodes;
+    nn.clear();
+    if (nn.slot.size() < names.size()) nn.slot.resize(names.size() + names.size() / 4, -1);
     nn.ents.reserve(nv_est);
     for (auto &ent : nodes.ents) {
         if (!ent.live || !g.vblack[ent.v]) continue;
@@ -745,26 +803,34 @@ void vs_stage::reinit(const std::string &filename) {
     const uint32_t nv = (uint32_t)ng.vid.size();
     ng.vblack.assign(nv, 1);
     // surviving edges, map order (both ends looked up BY NAME among the surviving vertices, as graph_to_gfa does)
-    PairMap<uint32_t> ne_map;
+    PairMap<uint32_t> &ne_map = spare_edges;
+    ne_map.clear();
     ne_map.reserve(edges.size());
-    std::vector<uint32_t> deg(nv, 0);
+    std::vector<uint32_t> &deg = spare_deg;
+    deg.assign(nv, 0);
+    // (nn was filled front to back without a pop: its slot of a name IS the new vertex index)
+    const int32_t *new_of_name = nn.slot.data();
+    const size_t n_names = nn.slot.size();
+    ng.esrc.reserve(edges.size()); ng.etgt.reserve(edges.size()); ng.eovl.reserve(edges.size()); ng.eline.reserve(edges.size());
     for (auto &ent : edges.ents) {
-        if (!ent.live) continue;
-        const uint32_t *s = nn.get(key_first(ent.k)), *t = nn.get(key_second(ent.k));
-        if (!s || !t || !g.eblack[ent.v]) continue;
-        lines->push_back(link_line(ent.v, key_first(ent.k), key_second(ent.k)));
+        if (!ent.live || !g.eblack[ent.v]) continue;
+        const Nid nu = key_first(ent.k), nw = key_second(ent.k);
+        const int32_t s = nu < n_names ? new_of_name[nu] : -1, t = nw < n_names ? new_of_name[nw] : -1;
+        if (s < 0 || t < 0) continue;
+        lines->push_back(link_line(ent.v, nu, nw));
         const uint32_t ei = (uint32_t)ng.esrc.size();
-        ng.esrc.push_back(*s);
-        ng.etgt.push_back(*t);
+        ng.esrc.push_back((uint32_t)s);
+        ng.etgt.push_back((uint32_t)t);
         ng.eovl.push_back(g.eovl[ent.v]);
         ng.eline.push_back(g.eline[ent.v]);
         ne_map.set(ent.k, ei);
-        deg[*s]++;
-        deg[*t]++;
+        deg[s]++;
+        deg[t]++;
     }
     const uint32_t n_e = (uint32_t)ng.esrc.size();
     writer->submit(WriteJob{filename, lines});
     info(filename + " is stored..");
+
     // adjacency rows by the container's placement rule, edges re-inserted in file order
     ng.off.resize(nv); ng.len.assign(nv, 0); ng.cap.resize(nv); ng.nout.assign(nv, 0);
     uint32_t acc = 0;
@@ -793,10 +859,12 @@ void vs_stage::reinit(const std::string &filename) {
     ng.eflow.assign(n_e, 0.0);
     ng.eblack.assign(n_e, 1);
     ng.n_edges = n_e;
-    g = std::move(ng);
-    nodes = std::move(nn);
-    edges = std::move(ne_map);
+    std::swap(g, spare_g);
+    std::swap(nodes, spare_nodes);
+    std::swap(edges, spare_edges);
+    rebuild_timer.dst += now_s() - rebuild_timer.t0;
     refresh();
+    rebuild_timer.t0 = now_s();
     last_text = lines;
     dirty = false;
     t_reinit += now_s() - t0;
@@ -806,6 +874,7 @@ void vs_stage::reinit(const std::string &filename) {
 // edge_cleaning (Decomposition.py:822-905)
 // =====================================================================================================================
 void vs_stage::edge_cleaning() {
+    VS_SECTION("edge_cleaning");
     // assigned: (source id, target id) -> bool, in g.edges() order (vertex-major, out-entry order)
     assigned.clear();
     for (uint32_t v = 0; v < g.num_vertices(); v++)
@@ -931,6 +1000,7 @@ static size_t index_of(const std::vector<Nid> &ids, Nid x, const Names &names) {
 // balance_split (Decomposition.py:91-530)
 // =====================================================================================================================
 int64_t vs_stage::balance_split(double threshold, bool is_prim) {
+    VS_SECTION("balance_split");
     info(std::string("balance split using contigs&paired end links&coverage information.. isPrim: ") + (is_prim ? "True" : "False"));
     auto branches = nontrivial_ids();
     auto black_us = [&](uint32_t v) {
@@ -952,7 +1022,25 @@ int64_t vs_stage::balance_split(double threshold, bool is_prim) {
         }
         links_prefetch(wanted);
     }
-    auto by_node = contigs_by_node(contigs);
+    // node id -> contigs that visit it, kept up to date through the splits of the pass; the reference rebuilds
+    // contig_map_node after every split and reads it in contig-dict order, which is the order of the contigs' slots
+    std::unordered_map<Nid, std::vector<Nid>> visits;
+    auto visits_add = [&](Nid cno, const std::vector<Nid> &ids) {
+        for (Nid n : ids) {
+            auto &l = visits[n];
+            if (std::find(l.begin(), l.end(), cno) == l.end()) l.push_back(cno);
+        }
+    };
+    auto visits_remove = [&](Nid cno, const std::vector<Nid> &ids) {
+        for (Nid n : ids) {
+            auto it = visits.find(n);
+            if (it == visits.end()) continue;
+            auto &l = it->second;
+            l.erase(std::remove(l.begin(), l.end(), cno), l.end());
+        }
+    };
+    for (auto &c : contigs.ents)
+        if (c.live) visits_add(c.k, c.v.ids);
     std::vector<Nid> done;
     mark_size(fresh);
     for (auto &br : branches) {
@@ -992,8 +1080,9 @@ int64_t vs_stage::balance_split(double threshold, bool is_prim) {
         }
         std::vector<Nid> support;
         {
-            auto it = by_node.find(no);
-            if (it != by_node.end()) support = it->second;
+            auto it = visits.find(no);
+            if (it != visits.end()) support = it->second;
+            std::sort(support.begin(), support.end(), [&](Nid a, Nid b) { return contigs.slot[a] < contigs.slot[b]; });
         }
         FlatIdx through;
         for (Nid cno : support) {
@@ -1097,6 +1186,13 @@ int64_t vs_stage::balance_split(double threshold, bool is_prim) {
         for (Nid cno : support) {
             Contig c;
             if (!contigs.pop(cno, &c)) key_error(names[cno]);
+            visits_remove(cno, c.ids);
+            auto put = [&](Nid name, Contig rec) {
+                const Contig *old = contigs.get(name);
+                if (old) visits_remove(name, old->ids);
+                visits_add(name, rec.ids);
+                contigs.set(name, std::move(rec));
+            };
             size_t at = index_of(c.ids, no, names);
             const bool has_u = at > 0, has_w = at + 1 < c.ids.size();
             const Nid u = has_u ? c.ids[at - 1] : NO_NID, w = has_w ? c.ids[at + 1] : NO_NID;
@@ -1104,7 +1200,7 @@ int64_t vs_stage::balance_split(double threshold, bool is_prim) {
                 const Nid *sub = sub_of.get(pair_key(u, w));
                 if (!sub) key_error("(" + names[u] + ", " + names[w] + ")");
                 c.ids[at] = *sub;
-                contigs.set(cno, std::move(c));
+                put(cno, std::move(c));
             } else if (!has_u && !has_w) {
                 for (auto &so : sub_of.ents) {
                     const uint32_t sv = node(so.v);
@@ -1112,28 +1208,27 @@ int64_t vs_stage::balance_split(double threshold, bool is_prim) {
                     nc.ids = {so.v};
                     nc.len = (int64_t)seqs[g.vseq[sv]].size();
                     nc.cov = g.vdp[sv];
-                    contigs.set(names.intern(names[cno] + "$" + suffix(so.v)), std::move(nc));
+                    put(names.intern(names[cno] + "$" + suffix(so.v)), std::move(nc));
                 }
             } else if (has_u) {
                 for (auto &so : sub_of.ents)
                     if (key_first(so.k) == u) {
                         c.ids[at] = so.v;
                         Contig nc = c;
-                        contigs.set(names.intern(names[cno] + "$" + suffix(so.v)), std::move(nc));
+                        put(names.intern(names[cno] + "$" + suffix(so.v)), std::move(nc));
                     }
             } else {
                 for (auto &so : sub_of.ents)
                     if (key_second(so.k) == w) {
                         c.ids[at] = so.v;
                         Contig nc = c;
-                        contigs.set(names.intern(names[cno] + "$" + suffix(so.v)), std::move(nc));
+                        put(names.intern(names[cno] + "$" + suffix(so.v)), std::move(nc));
                     }
             }
         }
         for (Nid u : us) retire_edge(u, no);
         for (Nid w : ws) retire_edge(no, w);
         retire_vertex(no);
-        by_node = contigs_by_node(contigs);
         for (auto &so : sub_of.ents) links_born(so.v, {}, true);  // note_split: rows of the copies start empty
     }
     links_end_pass();
@@ -1158,6 +1253,7 @@ static std::string fork_letter(size_t i) {  // chr(ord("A") + i), UTF-8
 }
 
 int64_t vs_stage::trivial_split(NameMap<std::vector<Nid>> &id_mapping) {
+    VS_SECTION("trivial_split");
     info("graph trivial split on NT related vertices..");
     auto branches = nontrivial_ids();
     int64_t forks = 0;
@@ -1232,6 +1328,7 @@ int64_t vs_stage::trivial_split(NameMap<std::vector<Nid>> &id_mapping) {
 
 // Fixpoint of single-sided forks over ALL vertices.  Returns the fork count, or -1 where the reference gives up (None).
 int64_t vs_stage::global_trivial_split(NameMap<std::vector<Nid>> &id_mapping) {
+    VS_SECTION("global_trivial_split");
     info("graph trivial split..");
     const uint64_t bound = (uint64_t)nodes.size() * (uint64_t)nodes.size();
     uint64_t forks = 0;
@@ -1333,6 +1430,7 @@ std::vector<std::vector<uint32_t>> vs_stage::simple_chains() {
 }
 
 void vs_stage::contract_simple_paths(bool with_contigs, bool with_links) {
+    VS_SECTION("contract_simple_paths");
     info("non-branching path contraction..");
     auto chains = simple_chains();
     struct Built {
@@ -1423,6 +1521,7 @@ void vs_stage::contract_simple_paths(bool with_contigs, bool with_links) {
 // contig bookkeeping (Utilities.py:147-159, :281-380, :589-616)
 // =====================================================================================================================
 void vs_stage::trim_contigs(NameMap<Contig> &cd) {
+    VS_SECTION("trim_contigs");
     info("trim contig..");
     for (auto &c : cd.ents) {
         if (!c.live) continue;
@@ -1435,8 +1534,41 @@ void vs_stage::trim_contigs(NameMap<Contig> &cd) {
     info("done");
 }
 
+// VStrains_SPAdes.py:251-262: contig_resolve on the strain records, trim_contig_dict on es_graph_L2 (the graph kept by
+// vs_stage_keep_graph), contig_dup_removed_s, tmp/tmp_strain.paths.
+void vs_stage::finish_strains(const std::string &tmp_paths_file) {
+    if (!have_ref) state_error("finish_strains: no graph was kept (vs_stage_keep_graph after the es_graph_L2 re-initialisation)");
+    for (auto &s : strains.ents)
+        if (s.live) s.v.ids = origin_ids(s.v.ids);
+    info("trim contig..");
+    for (auto &c : strains.ents) {
+        if (!c.live) continue;
+        std::vector<Nid> uniq;
+        for (Nid n : c.v.ids)
+            if (std::find(uniq.begin(), uniq.end(), n) == uniq.end()) uniq.push_back(n);
+        c.v.ids = std::move(uniq);
+        int64_t total = 0;
+        std::vector<uint32_t> path;
+        for (Nid n : c.v.ids) {
+            const uint32_t *v = ref_nodes.get(n);
+            if (!v) key_error(names[n]);
+            path.push_back(*v);
+            total += (int64_t)seqs[ref_g.vseq[*v]].size();
+        }
+        for (size_t i = 0; i + 1 < path.size(); i++) {
+            const int64_t e = ref_g.edge(path[i], path[i + 1]);
+            if (e >= 0) total -= ref_g.eovl[e];
+        }
+        c.v.len = total;
+    }
+    info("done");
+    drop_duplicate_contigs(strains);
+    write_paths_file(strains, tmp_paths_file);
+}
+
 // Node-SET comparison: equal sets drop the later one, a proper subset drops the smaller.
 void vs_stage::drop_duplicate_contigs(NameMap<Contig> &cd) {
+    VS_SECTION("drop_duplicate_contigs");
     info("drop duplicated contigs..");
     cd.compact();
     const size_t n = cd.ents.size();
@@ -1508,10 +1640,16 @@ struct vs_stage::Closure {
         }
         for (Nid k : *kids) leaves(k, out);
     }
-    const std::vector<Nid> &operator[](Nid name) {
+    // the closure of `name`; an id that was not forked stands for itself and costs no table entry (`scratch` holds it)
+    const std::vector<Nid> &get(Nid name, std::vector<Nid> &scratch) {
+        if (name >= known.size() || !known[name]) key_error((*names)[name]);
+        const std::vector<Nid> *kids = mapping->get(name);
+        if (!kids || kids->empty()) {
+            scratch.assign(1, name);
+            return scratch;
+        }
         auto it = memo.find(name);
         if (it != memo.end()) return it->second;
-        if (name >= known.size() || !known[name]) key_error((*names)[name]);
         std::vector<Nid> out;
         leaves(name, out);
         return memo.emplace(name, std::move(out)).first->second;
@@ -1520,16 +1658,35 @@ struct vs_stage::Closure {
 };
 
 void vs_stage::remap_contigs(const NameMap<std::vector<Nid>> &id_mapping, Closure &closure) {
+    VS_SECTION("remap_contigs");
     info("contig resolution..");
-    (void)id_mapping;
+    bool any_kids = false;
+    for (auto &m : id_mapping.ents) any_kids = any_kids || (m.live && !m.v.empty());
+    if (!any_kids) {
+        // the closure of every id is the id itself: a contig has one image (itself) or none (a step that is no edge:
+        // "contig missed", kept as it is) -- only the lookup of an id the graph did not hold before the pass raises
+        for (auto &c : contigs.ents) {
+            if (!c.live) continue;
+            if (c.v.ids.empty()) throw StageError{VS_E_KEY, "IndexError", "list index out of range"};
+            bool alive = true;  // (the reference looks an id up only while some image is still being threaded)
+            for (size_t i = 0; i < c.v.ids.size() && alive; i++) {
+                if (!closure.is_known(c.v.ids[i])) key_error(names[c.v.ids[i]]);
+                if (i > 0 && !edges.has(pair_key(c.v.ids[i - 1], c.v.ids[i]))) alive = false;
+            }
+            if (!alive) debug("error, contig missed: " + names[c.k]);
+        }
+        info("done");
+        return;
+    }
     for (Nid cno : contigs.keys()) {
         const Contig &c = *contigs.get(cno);
         if (c.ids.empty()) throw StageError{VS_E_KEY, "IndexError", "list index out of range"};
         // images: every way of threading the contig through the forked ids along existing edges
         std::vector<std::vector<Nid>> paths;
-        for (Nid s : closure[c.ids[0]]) paths.push_back({s});
+        std::vector<Nid> scratch;
+        for (Nid s : closure.get(c.ids[0], scratch)) paths.push_back({s});
         for (size_t i = 1; i < c.ids.size(); i++) {
-            const std::vector<Nid> &cands = closure[c.ids[i]];
+            const std::vector<Nid> &cands = closure.get(c.ids[i], scratch);
             std::vector<std::vector<Nid>> grown;
             for (auto &p : paths)
                 for (Nid cand : cands)
@@ -1622,6 +1779,7 @@ void vs_stage::disentangle(double threshold, const std::string &temp_dir) {
 // best_matching (Extension.py:10-111), increment_nt_branch_coverage (Utilities.py:183-208)
 // =====================================================================================================================
 void vs_stage::best_matching() {
+    VS_SECTION("best_matching");
     auto branches = nontrivial_ids();
     auto by_node = contigs_by_node(contigs);
     std::vector<std::pair<Nid, Nid>> pairs;
@@ -1755,6 +1913,7 @@ void vs_stage::walk(std::vector<uint32_t> &path, std::vector<uint8_t> &visited, 
 }
 
 std::vector<uint32_t> vs_stage::extend(const std::vector<Nid> &contig, const LinkTable &table, bool use_coverage, double ccov, double threshold) {
+    VS_SECTION("px.extend");
     // visited: by vertex (ids are unique per vertex of a re-initialised stage); every vertex is in the node map
     std::vector<uint8_t> visited(g.num_vertices(), 0);
     std::vector<uint32_t> all;
@@ -1779,6 +1938,7 @@ std::vector<uint32_t> vs_stage::extend(const std::vector<Nid> &contig, const Lin
 // reduce_graph: subtract the path coverage; vertices at or under the threshold go gray and leave `usages`; links
 // touching a gray vertex are dropped
 void vs_stage::consume(const std::vector<uint32_t> &path, double pcov, double threshold) {
+    VS_SECTION("px.consume");
     bool grayed = false;
     for (uint32_t v : path) {
         int64_t *u = usages.get(g.vid[v]);
@@ -1870,23 +2030,34 @@ void vs_stage::path_extension(double threshold, const std::string &temp_dir) {
         closure.mapping = &id_mapping;
         remap_contigs(id_mapping, closure);
         table.compact();
+        const double t_filter = now_s();
         if (n_forks == 0) {
             // nothing forked: every id stands for itself; the rewrite only drops what no longer is a link between an
             // in- and an out-neighbour, the survivors keep their order
-            for (Nid no : table.keys()) {
+            for (size_t ti = 0; ti < table.ents.size(); ti++) {
+                if (!table.ents[ti].live) continue;
+                const Nid no = table.ents[ti].k;
                 if (!nodes.has(no)) { table.pop(no); continue; }
-                PairMap<int64_t> &kept = *table.get(no);
+                PairMap<int64_t> &kept = table.ents[ti].v;
                 if (kept.size() == 0) continue;
                 const uint32_t v = node(no);
-                auto ins = g.in_neighbors(v), outs = g.out_neighbors(v);
-                for (uint64_t link : kept.keys()) {
-                    const uint32_t a = node(key_first(link)), b = node(key_second(link));
-                    if (!(std::find(ins.begin(), ins.end(), a) != ins.end() && std::find(outs.begin(), outs.end(), b) != outs.end())) kept.pop(link);
+                const uint32_t *row = g.a_nbr.data() + g.off[v];
+                const uint32_t n_o = g.nout[v], n_all = g.len[v];
+                for (size_t li = 0; li < kept.ents.size(); li++) {
+                    if (!kept.ents[li].live) continue;
+                    const uint64_t link = kept.ents[li].k;
+                    const uint32_t a = node(key_first(link)), b = node(key_second(link));  // (both looked up: a link to an id that is no node raises)
+                    bool in_ok = false, out_ok = false;
+                    for (uint32_t i = n_o; i < n_all && !in_ok; i++) in_ok = row[i] == a;
+                    for (uint32_t i = 0; i < n_o && !out_ok; i++) out_ok = row[i] == b;
+                    if (!(in_ok && out_ok)) kept.pop(link);
                 }
             }
+            sections.slot("px.table_filter") += now_s() - t_filter;
             for (auto &u : usages.ents)
                 if (u.live && !closure.is_known(u.k)) key_error(names[u.k]);
         } else {
+            std::vector<Nid> scratch_u, scratch_w;
             for (Nid no : table.keys()) {
                 if (!nodes.has(no)) { table.pop(no); continue; }
                 PairMap<int64_t> kept;
@@ -1899,8 +2070,8 @@ void vs_stage::path_extension(double threshold, const std::string &temp_dir) {
                 for (auto &item : items) {
                     const Nid u = key_first(item.first), w = key_second(item.first);
                     kept.pop(item.first);
-                    if (closure[u].size() == 1 || closure[w].size() == 1) {
-                        const std::vector<Nid> cu = closure[u], cw = closure[w];
+                    if (closure.get(u, scratch_u).size() == 1 || closure.get(w, scratch_w).size() == 1) {
+                        const std::vector<Nid> &cu = closure.get(u, scratch_u), &cw = closure.get(w, scratch_w);
                         for (Nid uu : cu)
                             for (Nid ww : cw) {
                                 if (kept.has(pair_key(uu, ww))) continue;
@@ -1918,11 +2089,13 @@ void vs_stage::path_extension(double threshold, const std::string &temp_dir) {
                 if (u.live) old.push_back({u.k, u.v});
             for (auto &o : old) {
                 usages.pop(o.first);
-                for (Nid new_no : closure[o.first]) usages.set(new_no, o.second);
+                for (Nid new_no : closure.get(o.first, scratch_u)) usages.set(new_no, o.second);
             }
             usages.compact();
         }
 
+        sections.slot("px.table_and_usages") += now_s() - t_filter;
+        SectionTimer rest_timer(sections, "px.rest_of_iteration");
         // the longest contig (the first of equal lengths, in map order)
         Nid longest = NO_NID;
         {
@@ -2016,6 +2189,7 @@ void vs_stage::path_extension(double threshold, const std::string &temp_dir) {
         rid++;
     }
 
+    VS_SECTION("px.final");
     // vertices that carry the same sequence (fork copies): keep the deepest one
     {
         std::unordered_map<std::string, size_t> group_of;
@@ -2041,30 +2215,61 @@ void vs_stage::path_extension(double threshold, const std::string &temp_dir) {
     }
     reinit(temp_dir + "/gfa/graph_S_final.gfa");
 
-    // link strength between the surviving vertices, from the ORIGINAL PE table: one grouped contraction
+    // link strength between the surviving vertices, from the ORIGINAL PE table (final_link_info, Extension.py:766-799).
+    // The reference fills the table for every pair of vertices and then reads it for the (in, out) neighbour pairs of
+    // the remaining branches only: those sums are asked of the device in one batch, each over the original nodes the
+    // two vertices stand for.
     const uint32_t nv = g.num_vertices();
-    std::vector<int64_t> strength((size_t)nv * nv, 0);
+    auto final_branches = nontrivial_ids();
+    FlatIdx strength_idx;
+    std::vector<int64_t> strength_val;
     {
         std::vector<uint64_t> list_off{0};
         std::vector<uint32_t> list_idx;
-        for (uint32_t v = 0; v < nv; v++) {
+        std::vector<int32_t> list_of(nv, -1);
+        auto list_for = [&](uint32_t v) {
+            if (list_of[v] >= 0) return (uint32_t)list_of[v];
             for (Nid x : origin_ids(expand_path_names(g.vid[v], members))) {
                 if (x >= link_row.size() || link_row[x] < 0) key_error(names[x]);
                 list_idx.push_back((uint32_t)link_row[x]);
             }
             list_off.push_back(list_idx.size());
+            list_of[v] = (int32_t)list_off.size() - 2;
+            return (uint32_t)list_of[v];
+        };
+        // (the reference expands the id of EVERY vertex, so an id it cannot resolve raises even off the branches)
+        for (uint32_t v = 0; v < nv; v++) list_for(v);
+        std::vector<uint32_t> qa, qb;
+        for (auto &br : final_branches) {
+            const uint32_t v = br.second;
+            g.each_in(v, [&](uint32_t a, uint32_t) {
+                g.each_out(v, [&](uint32_t b, uint32_t) {
+                    const uint64_t k = pair_key(a, b);
+                    if (strength_idx.find(k) >= 0) return;
+                    strength_idx.put(k, (uint32_t)qa.size());
+                    qa.push_back(list_for(a));
+                    qb.push_back(list_for(b));
+                });
+            });
         }
-        if (nv) {
+        strength_val.assign(qa.size(), 0);
+        if (!qa.empty()) {
             std::string err;
             const double t0 = now_s();
-            int rc = ops->group_matrix(list_off.data(), list_idx.data(), nv, strength.data(), err);
+            int rc = ops->block_sums(list_off.data(), list_idx.data(), (uint32_t)list_off.size() - 1, qa.data(), qb.data(), qa.size(),
+                                     strength_val.data(), err);
             t_links += now_s() - t0;
             n_link_calls++;
             if (rc) throw StageError{rc, "RuntimeError", err};
         }
     }
+    auto strength = [&](uint32_t a, uint32_t b) {
+        uint32_t i = 0;
+        if (!strength_idx.get(pair_key(a, b), &i)) state_error("final link strength asked for a pair that was not prepared");
+        return strength_val[i];
+    };
     LinkTable final_links;
-    for (auto &br : nontrivial_ids()) {
+    for (auto &br : final_branches) {
         const uint32_t v = br.second;
         auto ins = g.in_neighbors(v), outs = g.out_neighbors(v);
         SmallMap<int> in_use, out_use;
@@ -2072,7 +2277,7 @@ void vs_stage::path_extension(double threshold, const std::string &temp_dir) {
         for (uint32_t x : outs) out_use.set(g.vid[x], 0);
         std::vector<Triple> combos;
         for (uint32_t a : ins)
-            for (uint32_t b : outs) combos.push_back(Triple{g.vid[a], g.vid[b], strength[(size_t)a * nv + b]});
+            for (uint32_t b : outs) combos.push_back(Triple{g.vid[a], g.vid[b], strength(a, b)});
         std::stable_sort(combos.begin(), combos.end(), [](const Triple &x, const Triple &y) { return x.pe > y.pe; });
         PairMap<int64_t> fl;
         for (auto &t : combos)
@@ -2134,6 +2339,39 @@ void vs_stage::path_extension(double threshold, const std::string &temp_dir) {
 // =====================================================================================================================
 // contig files (IO.py:518-536, :558-595 with keep_original=False)
 // =====================================================================================================================
+// contig_dict_to_path with keep_original=False (IO.py:558-595): records by length, descending; ids un-zipped
+void vs_stage::write_paths_file(const NameMap<Contig> &cd, const std::string &paths_file) {
+    std::vector<const NameMap<Contig>::Ent *> order;
+    for (auto &c : cd.ents)
+        if (c.live) order.push_back(&c);
+    std::stable_sort(order.begin(), order.end(), [](const NameMap<Contig>::Ent *a, const NameMap<Contig>::Ent *b) { return a->v.len > b->v.len; });
+    std::string text;
+    for (auto *c : order) {
+        text += "NODE_" + names[c->k] + "_" + std::to_string(c->v.len) + "_" + py_repr(c->v.cov) + "\n";
+        std::string body;
+        for (Nid nid : c->v.ids) {
+            const std::string &s = names[nid];
+            size_t p = 0;
+            for (;;) {
+                size_t q = s.find('&', p);
+                std::string piece = s.substr(p, q == std::string::npos ? std::string::npos : q - p);
+                size_t star = piece.find('*');
+                body += star == std::string::npos ? piece : piece.substr(0, star);
+                body.push_back(',');
+                if (q == std::string::npos) break;
+                p = q + 1;
+            }
+        }
+        if (!body.empty()) body.pop_back();  // "a,b,c," minus its last character
+        text += body + "\n";
+    }
+    char *p = arena.alloc(text.size() ? text.size() : 1);
+    memcpy(p, text.data(), text.size());
+    auto lines = std::make_shared<std::vector<LineRef>>();
+    lines->push_back(LineRef{p, (uint32_t)text.size()});
+    writer->submit(WriteJob{paths_file, lines});
+}
+
 void vs_stage::write_contig_files(const std::string &paths_file, const std::string &fasta_file) {
     std::vector<const NameMap<Contig>::Ent *> order;
     for (auto &c : contigs.ents)
@@ -2146,29 +2384,7 @@ void vs_stage::write_contig_files(const std::string &paths_file, const std::stri
         lines->push_back(LineRef{p, (uint32_t)text.size()});
         writer->submit(WriteJob{path, lines});
     };
-    if (!paths_file.empty()) {
-        std::string text;
-        for (auto *c : order) {
-            text += "NODE_" + names[c->k] + "_" + std::to_string(c->v.len) + "_" + py_repr(c->v.cov) + "\n";
-            std::string body;
-            for (Nid nid : c->v.ids) {
-                const std::string &s = names[nid];
-                size_t p = 0;
-                for (;;) {
-                    size_t q = s.find('&', p);
-                    std::string piece = s.substr(p, q == std::string::npos ? std::string::npos : q - p);
-                    size_t star = piece.find('*');
-                    body += star == std::string::npos ? piece : piece.substr(0, star);
-                    body.push_back(',');
-                    if (q == std::string::npos) break;
-                    p = q + 1;
-                }
-            }
-            if (!body.empty()) body.pop_back();  // "a,b,c," minus its last character
-            text += body + "\n";
-        }
-        put(paths_file, text);
-    }
+    if (!paths_file.empty()) write_paths_file(contigs, paths_file);
     if (!fasta_file.empty()) {
         std::string text;
         for (auto *c : order) {
@@ -2695,6 +2911,22 @@ int vs_stage_path_extension(vs_stage *st, double threshold, const char *temp_dir
 }
 
 // numpy.median of the vertex depths (the thresholds of VStrains_SPAdes.py:187,237 are 0.05 x this)
+// keep a copy of the graph as it stands (es_graph_L2) for vs_stage_finish_strains
+int vs_stage_keep_graph(vs_stage *st) {
+    return guarded(st, [&] {
+        st->ref_g = st->g;
+        st->ref_nodes = st->nodes;
+        st->have_ref = true;
+    });
+}
+
+int vs_stage_finish_strains(vs_stage *st, const char *tmp_paths_file) {
+    return guarded(st, [&] {
+        st->finish_strains(tmp_paths_file);
+        st->writer->drain();
+    });
+}
+
 int vs_stage_median_depth(vs_stage *st, double *out) {
     return guarded(st, [&] { *out = np_median(st->g.vdp); });
 }
@@ -2702,6 +2934,20 @@ int vs_stage_median_depth(vs_stage *st, double *out) {
 // info[0] re-initialisations, [1] of which reused the untouched state, [2] flow/scan launches, [3] link-sum launches,
 // [4] stage files written, [5] bytes written, [6] vertices, [7] live edges; secs[0] in re-initialisations, [1] of which
 // in the flow/scan operation, [2] in link sums, [3] file-writer busy time
+// "name=seconds" per section of the stage calls so far, ';'-joined, into buf (cut to cap - 1 bytes)
+int vs_stage_sections(vs_stage *st, char *buf, uint64_t cap) {
+    if (!st || !buf || !cap) return VS_E_ARG;
+    std::string out;
+    for (auto &p : st->sections.acc) {
+        char num[64];
+        snprintf(num, sizeof(num), "=%.6f;", p.second);
+        out += p.first + num;
+    }
+    if (out.size() >= cap) out.resize(cap - 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return VS_OK;
+}
+
 int vs_stage_counters(vs_stage *st, uint64_t info[8], double secs[4]) {
     if (!st || !info || !secs) return VS_E_ARG;
     info[0] = st->n_reinit; info[1] = st->n_reinit_reused; info[2] = st->n_refresh; info[3] = st->n_link_calls;

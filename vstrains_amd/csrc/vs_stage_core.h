@@ -188,6 +188,8 @@ inline Nid key_first(uint64_t k) { return (Nid)(k >> 32); }
 inline Nid key_second(uint64_t k) { return (Nid)k; }
 
 // ---- dict keyed by a pair of names --------------------------------------------------------------------------------------
+// Entries in insertion order plus an open-address table of 32-bit entry numbers (0 = empty, ~0 = deleted): a lookup
+// costs one probe into a table a quarter the size of a key table, and the keys are read where the entries are.
 template <class V>
 struct PairMap {
     struct Ent {
@@ -196,46 +198,89 @@ struct PairMap {
         bool live;
     };
     std::vector<Ent> ents;
-    FlatIdx idx;
-    size_t n_live = 0;
+    std::vector<uint32_t> tab;
+    size_t n_live = 0, n_filled = 0;  // live keys; occupied slots (live + deleted)
+    static const uint32_t DELETED = 0xFFFFFFFFu;
 
     size_t size() const { return n_live; }
-    bool has(uint64_t k) const { return idx.find(k) >= 0; }
+    void rebuild_table(size_t cap) {
+        tab.assign(cap, 0u);
+        n_filled = 0;
+        const size_t mask = cap - 1;
+        for (size_t e = 0; e < ents.size(); e++) {
+            if (!ents[e].live) continue;
+            size_t i = (size_t)FlatIdx::mix(ents[e].k) & mask;
+            while (tab[i]) i = (i + 1) & mask;
+            tab[i] = (uint32_t)e + 1u;
+            n_filled++;
+        }
+    }
+    // slot of key k, or -1
+    int64_t find_slot(uint64_t k) const {
+        if (tab.empty()) return -1;
+        const size_t mask = tab.size() - 1;
+        for (size_t i = (size_t)FlatIdx::mix(k) & mask;; i = (i + 1) & mask) {
+            const uint32_t t = tab[i];
+            if (t == 0u) return -1;
+            if (t != DELETED && ents[t - 1u].k == k) return (int64_t)i;
+        }
+    }
+    bool has(uint64_t k) const { return find_slot(k) >= 0; }
     V *get(uint64_t k) {
-        uint32_t i;
-        return idx.get(k, &i) ? &ents[i].v : nullptr;
+        const int64_t i = find_slot(k);
+        return i >= 0 ? &ents[tab[i] - 1u].v : nullptr;
     }
     const V *get(uint64_t k) const {
-        uint32_t i;
-        return idx.get(k, &i) ? &ents[i].v : nullptr;
+        const int64_t i = find_slot(k);
+        return i >= 0 ? &ents[tab[i] - 1u].v : nullptr;
     }
     void set(uint64_t k, V v) {
-        uint32_t i;
-        if (idx.get(k, &i)) {
-            ents[i].v = std::move(v);
-            return;
+        if (tab.empty() || 2 * (n_filled + 1) > tab.size()) {
+            size_t cap = tab.empty() ? 16 : tab.size();
+            while (cap < 4 * (n_live + 1)) cap <<= 1;
+            rebuild_table(cap);
         }
-        idx.put(k, (uint32_t)ents.size());
+        const size_t mask = tab.size() - 1;
+        size_t at = (size_t)-1;
+        for (size_t i = (size_t)FlatIdx::mix(k) & mask;; i = (i + 1) & mask) {
+            const uint32_t t = tab[i];
+            if (t == 0u) {
+                if (at == (size_t)-1) { at = i; n_filled++; }
+                break;
+            }
+            if (t == DELETED) {
+                if (at == (size_t)-1) at = i;
+                continue;
+            }
+            if (ents[t - 1u].k == k) {
+                ents[t - 1u].v = std::move(v);
+                return;
+            }
+        }
+        tab[at] = (uint32_t)ents.size() + 1u;
         ents.push_back(Ent{k, std::move(v), true});
         n_live++;
     }
     bool pop(uint64_t k, V *out = nullptr) {
-        uint32_t i;
-        if (!idx.get(k, &i)) return false;
-        if (out) *out = std::move(ents[i].v);
-        ents[i].live = false;
-        idx.erase(k);
+        const int64_t i = find_slot(k);
+        if (i < 0) return false;
+        Ent &e = ents[tab[i] - 1u];
+        if (out) *out = std::move(e.v);
+        e.live = false;
+        tab[i] = DELETED;
         n_live--;
         return true;
     }
     void clear() {
         ents.clear();
-        idx.clear();
-        n_live = 0;
+        std::fill(tab.begin(), tab.end(), 0u);
+        n_live = n_filled = 0;
     }
     void reserve(size_t n) {
         ents.reserve(n);
-        idx.reserve_for(n);
+        size_t cap = 16;
+        while (cap < 4 * (n + 1)) cap <<= 1;
+        if (cap > tab.size()) rebuild_table(cap);
     }
     void compact() {
         if (ents.size() == n_live) return;
@@ -246,9 +291,7 @@ struct PairMap {
             w++;
         }
         ents.resize(w);
-        idx.clear();
-        idx.reserve_for(w);
-        for (size_t i = 0; i < w; i++) idx.put(ents[i].k, (uint32_t)i);
+        rebuild_table(tab.empty() ? 16 : tab.size());
     }
     std::vector<uint64_t> keys() const {
         std::vector<uint64_t> out;

@@ -55,59 +55,59 @@ def all_reduce_counts_async(mats, stats):
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, async_op=True)]
 
 
-# Above this size a counter tensor is summed by exchanging its non-zero cells when that is less data
-# (VS_SPARSE_ALLREDUCE_BYTES overrides; 0 = never).
-SPARSE_MIN_BYTES = 2 << 30
+# ---- exchange of the occupied stretches only -----------------------------------------------------------------------
+# The counters are mostly zero (a pair of 2x150 bp touches a dozen nodes that lie next to each other in the index's path
+# numbering, so the non-zero cells of [2,N,N] sit in short runs along a band) and every rank's non-zero cells lie in
+# about the SAME places (reads are sharded at random over the same genomes).  So the ranks first OR their occupancy maps
+# of 64-cell stretches (256 bytes of uint32 counters: one small all-reduce), gather the occupied stretches of the UNION
+# into a dense [U, 64] tensor, all-reduce THAT with the ordinary ring, and scatter the sums back.  What moves is
+# U * 256 bytes through the ring instead of the whole buffer; the decision compact / dense follows from U, which every
+# rank knows after the first all-reduce, so no rank can take another branch than its peers.
+STRETCH = 64          # counter cells per stretch
+COMPACT_MAX_FILL = 0.5  # above this share of occupied stretches the dense ring is no worse
 
 
-def count_nonzero_cells(mats) -> int:
-    """Non-zero cells of a counter tensor (chunks of 2^30 cells: the index kernels take 32-bit sizes)."""
+def strong_share(total_pairs: int, rank: int, world: int) -> Tuple[int, int]:
+    """Strong scaling: the job's pairs are fixed and rank r takes pairs [lo, hi) of them (``shard_range``)."""
+    return shard_range(total_pairs, rank, world)
+
+
+def _occupancy(head):
+    """uint8 [M]: 1 where a 64-cell stretch of ``head`` ([M, 64]) holds a non-zero cell (slabs bound the temporaries)."""
     import torch
 
-    flat = mats.view(-1)
-    step = 1 << 30
-    return int(sum(int(torch.count_nonzero(flat[lo:lo + step]).item()) for lo in range(0, flat.numel(), step)))
+    m = head.shape[0]
+    occ = torch.empty(m, dtype=torch.uint8, device=head.device)
+    slab = 1 << 22  # stretches per slab: 1 GiB of int32 cells
+    for lo in range(0, m, slab):
+        occ[lo:lo + slab] = (head[lo:lo + slab] != 0).any(dim=1)
+    return occ
 
 
-def sum_counts_sparse(mats) -> None:
-    """In-place sum over the ranks of a mostly-zero counter tensor by exchanging (cell, count) lists: every rank
-    gathers the others' non-zero cells and adds them into its own copy.  The [2,N,N] counters of a 54 k-node
-    graph are 23.7 GB dense and hold ~1e8 non-zero cells after a rank's 25 M pairs; a dense ring
-    all-reduce moves 1.75 x 23.7 GB per rank, this 7 x ~1.5 GB.  Same integers as the dense sum: additions into
-    int32 storage wrap like the uint32 cells they stand for, int64 totals add as they are."""
+def sum_counts_compact(mats, allow_compact: bool = True) -> str:
+    """In-place sum over the ranks of a counter tensor (int32 storage of uint32 cells, or int64 totals) by way of its
+    occupied 64-cell stretches.  Returns "compact" or "dense" (what was done; the same on every rank).  Same integers as
+    ``all_reduce(SUM)`` on the whole tensor: the stretches that are left out are zero on every rank."""
     import torch
     import torch.distributed as dist
 
-    world, rank = dist.get_world_size(), dist.get_rank()
     flat = mats.view(-1)
-    # (gloo gathers host tensors only: the functional two-ranks-on-one-GPU runs stage the lists through the
-    # host; RCCL gathers device tensors)
-    via_host = flat.is_cuda and dist.get_backend() == "gloo"
-    step = 1 << 30
-    parts = []
-    for lo in range(0, flat.numel(), step):
-        nz = torch.nonzero(flat[lo:lo + step]).view(-1)
-        if nz.numel():
-            parts.append(nz + lo)
-    idx = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device=flat.device)
-    val = flat[idx]
-    where = torch.device("cpu") if via_host else flat.device
-    idx, val = idx.to(where), val.to(where)
-    mine = torch.tensor([idx.numel()], dtype=torch.int64, device=where)
-    sizes = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(sizes, mine)
-    sizes = [int(x.item()) for x in sizes]
-    longest = max(sizes)
-    if longest == 0:
-        return
-    pad_idx = torch.zeros(longest, dtype=torch.int64, device=where)
-    pad_val = torch.zeros(longest, dtype=flat.dtype, device=where)
-    pad_idx[: idx.numel()] = idx
-    pad_val[: idx.numel()] = val
-    all_idx = [torch.empty_like(pad_idx) for _ in range(world)]
-    all_val = [torch.empty_like(pad_val) for _ in range(world)]
-    dist.all_gather(all_idx, pad_idx)
-    dist.all_gather(all_val, pad_val)
-    for r in range(world):
-        if r != rank and sizes[r]:
-            flat.index_add_(0, all_idx[r][: sizes[r]].to(flat.device), all_val[r][: sizes[r]].to(flat.device))
+    m = flat.numel() // STRETCH
+    if not allow_compact or m == 0:
+        dist.all_reduce(mats, op=dist.ReduceOp.SUM)
+        return "dense"
+    head = flat[: m * STRETCH].view(m, STRETCH)
+    occ = _occupancy(head)
+    dist.all_reduce(occ, op=dist.ReduceOp.MAX)  # union of the ranks' occupancy maps
+    idx = torch.nonzero(occ).view(-1)
+    if idx.numel() > COMPACT_MAX_FILL * m:
+        dist.all_reduce(mats, op=dist.ReduceOp.SUM)
+        return "dense"
+    if idx.numel():
+        compact = head.index_select(0, idx)
+        dist.all_reduce(compact, op=dist.ReduceOp.SUM)
+        head.index_copy_(0, idx, compact)
+    tail = flat[m * STRETCH:]
+    if tail.numel():
+        dist.all_reduce(tail, op=dist.ReduceOp.SUM)
+    return "compact"

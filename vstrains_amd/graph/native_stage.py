@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import ctypes as C
 import struct
+from operator import itemgetter
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -49,8 +50,11 @@ STAGE_SYMBOLS = {
     "vs_stage_write_gfa": (C.c_int, [C.c_void_p, C.c_char_p]),
     "vs_stage_write_contigs": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "vs_stage_path_extension": (C.c_int, [C.c_void_p, C.c_double, C.c_char_p]),
+    "vs_stage_keep_graph": (C.c_int, [C.c_void_p]),
+    "vs_stage_finish_strains": (C.c_int, [C.c_void_p, C.c_char_p]),
     "vs_stage_median_depth": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "vs_stage_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    "vs_stage_sections": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64]),
 }
 
 _EXCEPTIONS = {"KeyError": KeyError, "IndexError": IndexError, "ValueError": ValueError, "FloatingPointError": FloatingPointError,
@@ -103,19 +107,22 @@ class _Reader:
 
 
 def pack_graph(g: AsmGraph, nodes: Dict[str, int], edges: Dict[Tuple[str, str], int]) -> bytes:
+    from itertools import chain
+
     nv = len(g.vid)
     seq_index: Dict[str, int] = {}
     seq_of = [seq_index.setdefault(s, len(seq_index)) for s in g.vseq]
-    lens = [len(row) for row in g.adj]
-    flat = [p for row in g.adj for p in row]
+    lens = np.fromiter(map(len, g.adj), dtype="<u4", count=nv)
+    # (neighbour, edge) pairs of all rows, flattened in C: one pass over the tuples
+    flat = np.fromiter(chain.from_iterable(chain.from_iterable(g.adj)), dtype="<u4", count=2 * int(lens.sum()))
     n_slots = len(g.esrc)
     parts = [struct.pack("<II", GRAPH, nv), _strings(g.vid), struct.pack("<I", len(seq_index)), _strings(seq_index.keys()),
-             _arr(seq_of, "<u4"), _arr(g.vdp, "<f8"), _arr(g.vblack, "u1"), _arr(lens, "<u4"), _arr(g.nout, "<u4"),
-             _arr([p[0] for p in flat], "<u4"), _arr([p[1] for p in flat], "<u4"),
+             _arr(seq_of, "<u4"), _arr(g.vdp, "<f8"), _arr(g.vblack, "u1"), lens.tobytes(), _arr(g.nout, "<u4"),
+             np.ascontiguousarray(flat[0::2]).tobytes(), np.ascontiguousarray(flat[1::2]).tobytes(),
              struct.pack("<I", n_slots), _arr(g.esrc, "<u4"), _arr(g.etgt, "<u4"), _arr(g.eovl, "<i8"), _arr(g.eflow, "<f8"),
              _arr(g.eblack, "u1"), struct.pack("<I", len(g._free)), _arr(list(g._free), "<u4"), struct.pack("<I", g._n_edges),
              struct.pack("<I", len(nodes)), _strings(nodes.keys()), _arr(list(nodes.values()), "<u4"),
-             struct.pack("<I", len(edges)), _strings([k[0] for k in edges]), _strings([k[1] for k in edges]),
+             struct.pack("<I", len(edges)), _strings(map(itemgetter(0), edges)), _strings(map(itemgetter(1), edges)),
              _arr(list(edges.values()), "<u4")]
     return b"".join(parts)
 
@@ -374,6 +381,11 @@ class NativeStage:
                 "vertices": int(info[6]), "edges": int(info[7]), "reinit_s": secs[0], "refresh_op_s": secs[1],
                 "link_op_s": secs[2], "file_writer_busy_s": secs[3]}
 
+    def sections(self) -> Dict[str, float]:
+        buf = C.create_string_buffer(4096)
+        self._check(self._lib.vs_stage_sections(self._h, buf, 4096))
+        return {k: float(v) for k, v in (item.split("=") for item in buf.value.decode().split(";") if item)}
+
     # ---- the stages
     def edge_cleaning(self, logger=None) -> None:
         self._call(self._lib.vs_stage_edge_cleaning, logger)
@@ -399,6 +411,14 @@ class NativeStage:
     def write_contigs(self, paths_file: Optional[str], fasta_file: Optional[str]) -> None:
         self._check(self._lib.vs_stage_write_contigs(self._h, paths_file.encode() if paths_file else None,
                                                      fasta_file.encode() if fasta_file else None))
+
+    def keep_graph(self) -> None:
+        """Remember the graph as it stands (es_graph_L2): ``finish_strains`` measures the strain records on it."""
+        self._check(self._lib.vs_stage_keep_graph(self._h))
+
+    def finish_strains(self, tmp_paths_file: str, logger=None) -> None:
+        """VStrains_SPAdes.py:251-262: resolve, trim on es_graph_L2, drop duplicates, ``tmp/tmp_strain.paths``."""
+        self._call(self._lib.vs_stage_finish_strains, logger, tmp_paths_file.encode())
 
     def path_extension(self, threshold, temp_dir: str, logger=None) -> None:
         self._call(self._lib.vs_stage_path_extension, logger, float(threshold), temp_dir.encode())

@@ -17,8 +17,8 @@ from typing import Dict
 import numpy
 
 from . import prep
-from .contigs import drop_duplicate_contigs, resolve_contigs, restore_repeats, trim_contigs
-from .formats import read_stage_gfa, write_contig_fasta, write_contig_paths, write_stage_gfa
+from .contigs import restore_repeats
+from .formats import read_stage_gfa, write_contig_fasta, write_contig_paths, write_stage_gfa  # noqa: F401
 
 
 def _stored(logger, filename: str) -> None:
@@ -108,6 +108,7 @@ def _extract_native(pre: Prepared, table, backend, logger, out: str):
     marks.append(("load_s", time.perf_counter()))
     st.edge_cleaning(logger)
     st.reinit("{0}/gfa/es_graph_L2.gfa".format(out), logger)
+    st.keep_graph()  # (the final strain records are measured on es_graph_L2, VStrains_SPAdes.py:253-258)
     st.write_contigs("{0}/tmp/pre_contigs.paths".format(out), "{0}/tmp/pre_contigs.fasta".format(out))
     marks.append(("edge_cleaning_s", time.perf_counter()))
 
@@ -124,39 +125,36 @@ def _extract_native(pre: Prepared, table, backend, logger, out: str):
     p_delta = 0.05 * st.median_depth()
     st.path_extension(p_delta, out, logger)
     marks.append(("path_extension_s", time.perf_counter()))
+    logger.info(">>>STAGE: final process")
+    st.finish_strains("{0}/tmp/tmp_strain.paths".format(out), logger)
+    marks.append(("finish_strains_s", time.perf_counter()))
     strains = st.strains()
     st.contigs_into(pre.contigs)  # (consumed in place, as the reference's contig_dict is)
     marks.append(("export_s", time.perf_counter()))
     extract_strains.last_stages = {name: t - marks[i][1] for i, (name, t) in enumerate(marks[1:])}
     extract_strains.last_stages.update(st.counters())
     extract_strains.last_stages["engine"] = "native stage handle (vs_stage)"
+    extract_strains.last_stages["sections"] = {k: round(v, 4) for k, v in st.sections().items()}
     st.close()
     return strains
 
 
 def _extract_strains(pre: Prepared, table, backend, logger, out: str):
-    # (a test backend may bring its own statement of the stages -- oracle/graph_stages, the checker the native engine is
-    # compared with -- through ``extract_stages``; the product backend offers only the native stage handle)
+    # Both ways end with the strain records of VStrains_SPAdes.py:262 (resolved, trimmed on es_graph_L2, duplicates
+    # dropped, tmp/tmp_strain.paths written).  A test backend may bring its own statement of the stages
+    # (oracle/graph_stages, the checker the native engine is compared with) through ``extract_stages``; the product
+    # backend offers only the native stage handle.
     if hasattr(backend, "extract_stages"):
         strains = backend.extract_stages(pre, table, logger, out)
     else:
         strains = _extract_native(pre, table, backend, logger, out)
-    return _final_process(pre, strains, logger, out)
-
-
-def _final_process(pre: Prepared, strains, logger, out: str):
-    """VStrains_SPAdes.py:251-272."""
-    logger.info(">>>STAGE: final process")
-    resolve_contigs(strains)
-    gl, nodesl, _ = read_stage_gfa("{0}/gfa/es_graph_L2.gfa".format(out))
-    trim_contigs(gl, nodesl, strains, logger)
-    drop_duplicate_contigs(strains, logger)
-    write_contig_paths(strains, "{0}/tmp/tmp_strain.paths".format(out), None, False)
+    t0 = time.perf_counter()
     restore_repeats(pre.g0, pre.nodes0, strains, pre.contig_info, pre.original_contigs, logger)
-
     logger.info(">>>STAGE: generate result")
     write_contig_fasta(pre.g0, pre.nodes0, strains, "{0}/strain.fasta".format(out))
     write_contig_paths(strains, "{0}/strain.paths".format(out), pre.idx_mapping, True)
+    if isinstance(getattr(extract_strains, "last_stages", None), dict):
+        extract_strains.last_stages["final_files_s"] = time.perf_counter() - t0
     return strains
 
 

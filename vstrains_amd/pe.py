@@ -441,7 +441,7 @@ class PeCounter:
         self.wide = None          # int64 totals, allocated by the first fold
         self.pairs_in_buffer = 0  # pairs counted into ``mats`` since it was last empty (all ranks, after a sum)
         self.pairs_seen = 0
-        self.last_all_reduce = None  # "dense" / "sparse" after all_reduce()
+        self.last_all_reduce = None  # "dense" / "compact" after all_reduce()
         # (the numbering of the index this counter counts under: kept here, so that a later build_index on the same context
         # cannot change how these matrices are read)
         self.node_order = getattr(ctx, "node_order", None)
@@ -490,34 +490,23 @@ class PeCounter:
         from . import dist as vdist
 
         torch = self.torch
-        # (large and mostly zero -- the counters of a 50 k-node graph: the ranks also agree on exchanging the
-        # non-zero cells instead of the dense buffer when everybody's cells together are less data than one buffer)
-        min_bytes = int(os.environ.get("VS_SPARSE_ALLREDUCE_BYTES", vdist.SPARSE_MIN_BYTES))
-        dense_bytes = self.mats.numel() * self.mats.element_size()
-        may_sparse = min_bytes > 0 and dense_bytes >= min_bytes
-        nnz = (vdist.count_nonzero_cells(self.mats) + (vdist.count_nonzero_cells(self.wide) if self.wide is not None else 0)) if may_sparse else 0
-        # one agreement round: sums of (pairs in the buffers, "holds int64 totals", "would exchange sparsely") and the
-        # LARGEST non-zero count -- sum_counts_sparse gathers lists padded to the longest rank, so world * longest is
-        # what moves; a rank whose environment disables the sparse path vetoes it for everybody (no mismatched collectives)
-        flags = torch.tensor([self.pairs_in_buffer, 1 if self.wide is not None else 0, 1 if may_sparse else 0], dtype=torch.int64, device=self.device)
+        # one agreement round: sums of (pairs in the buffers, "holds int64 totals", "may exchange occupied stretches only");
+        # a rank whose environment turns the compact exchange off vetoes it for everybody (no mismatched collectives)
+        may_compact = os.environ.get("VS_COMPACT_ALLREDUCE", "1") not in ("0", "")
+        flags = torch.tensor([self.pairs_in_buffer, 1 if self.wide is not None else 0, 1 if may_compact else 0], dtype=torch.int64, device=self.device)
         all_reduce_counts(None, flags)
-        longest = torch.tensor([nnz], dtype=torch.int64, device=self.device)
-        vdist.all_reduce_max(longest)
-        total_in_buffers, any_wide, sparse_votes, max_nnz = int(flags[0].item()), int(flags[1].item()), int(flags[2].item()), int(longest.item())
+        total_in_buffers, any_wide, compact_votes = int(flags[0].item()), int(flags[1].item()), int(flags[2].item())
         world = group_size()
         fold = bool(any_wide or 2 * total_in_buffers >= U32_LIMIT)
         if fold:
             self.fold()
         target = self.wide if fold else self.mats
-        sparse = sparse_votes == world and world * max_nnz * (8 + target.element_size()) < target.numel() * target.element_size()
-        if sparse:
-            vdist.sum_counts_sparse(target)
-            all_reduce_counts(None, self.stats)
-        else:
-            all_reduce_counts(target, self.stats)
+        # (occupied 64-cell stretches of the union of the ranks' counters through the ring, or the whole buffer when the
+        # counters are dense: dist.sum_counts_compact decides from the union, which every rank sees alike)
+        self.last_all_reduce = vdist.sum_counts_compact(target, allow_compact=compact_votes == world)
+        all_reduce_counts(None, self.stats)
         if not fold:
             self.pairs_in_buffer = total_in_buffers
-        self.last_all_reduce = "sparse" if sparse else "dense"
 
     def all_reduce_async(self):
         """Overlapped form for fixed-size steps (bench.py): the caller keeps counting into a second
@@ -542,11 +531,20 @@ class PeCounter:
         if rank is None:
             return t
         r = torch.from_numpy(rank).to(t.device)
-        node = t[0].index_select(0, r).index_select(1, r)
-        s = t[1]
-        s = s + s.t() - torch.diag(torch.diagonal(s))
-        short = torch.triu(s.index_select(0, r).index_select(1, r))
-        return torch.stack([node, short])
+        # (one matrix at a time, every intermediate freed before the next is made: a 54 k-node graph is 11.8 GB per
+        # int32 matrix, and this runs when a run that counted fine wants its result)
+        out = torch.empty_like(t)
+        rows = t[0].index_select(0, r)
+        torch.index_select(rows, 1, r, out=out[0])
+        del rows
+        s = t[1] + t[1].t()
+        s.diagonal().sub_(t[1].diagonal())  # (the diagonal was doubled by the mirror)
+        rows = s.index_select(0, r)
+        del s
+        torch.index_select(rows, 1, r, out=out[1])
+        del rows
+        out[1].triu_()
+        return out
 
     def result(self):
         """-> (node_mat int64 [N,N], short_mat int64 [N,N], (n_reads, short_reads, used_reads)), in the numbering of
