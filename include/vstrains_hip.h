@@ -75,25 +75,6 @@ int vs_index_info(const vs_ctx *ctx, uint64_t info[6]);
 int vs_node_order_host(const uint8_t *node_ascii, const uint64_t *node_off, uint32_t n_nodes, uint32_t ksize,
                        uint32_t *order_out);
 
-/* Walk index (built by vs_index_build next to the seed index): node sets that certify as proper overlap graphs of
- * (k+1)-mers -- every (k+1)-mer of PE_Inference.py:116-135's table has ONE entry, nodes continue into each other only
- * at their ends (compacted de Bruijn graphs) -- are mapped by following the read through the graph instead of
- * probing seeds (csrc/vs_walk.h states the conditions).  info[0] = 1 if certified, [1] = (k+1)-mers entered (both
- * strands), [2] = presence mers, [3] = successor links, [4] / [5] = slots of the two tables, [6] = device bytes,
- * [7] = presence-mer length; why (may be NULL) receives the reason a node set was not certified. */
-int vs_walk_info(const vs_ctx *ctx, uint64_t info[8], char *why, size_t why_cap);
-/* The same certification on the host alone (no device, no context): what vs_index_build would decide. */
-int vs_walk_certify_host(const uint8_t *node_ascii, const uint64_t *node_off, uint32_t n_nodes, uint32_t ksize,
-                         uint64_t info[8], char *why, size_t why_cap);
-
-/* Host twin of the graph-following kernel's per-end work (tests, no device): the read ends are mapped by the very
- * function k_pe_walk runs per lane.  lists[n_ends * cap], counts[n_ends]: accepted node indices per end (the result of
- * single_end_read_mapping, PE_Inference.py:16-48, in no particular order); counts[e] = 0xFFFFFFFF where the kernel would
- * send the pair to the overflow kernel.  Returns 0; 1 when the node set does not certify (nothing mapped). */
-int vs_walk_map_ends_host(const uint8_t *node_ascii, const uint64_t *node_off, uint32_t n_nodes, uint32_t ksize,
-                          const uint8_t *read_ascii, const uint64_t *read_off, uint64_t n_ends, uint32_t cap,
-                          uint32_t *lists, uint32_t *counts);
-
 /* ---- read blocks ----------------------------------------------------------------------------
  * Replaces the FASTQ record slicing of PE_Inference.py:146-159 from the point where the two
  * sequence strings of a pair are known.  Ends are interleaved: end 2r = forward read of pair
@@ -221,6 +202,14 @@ int vs_pe_last_timing(vs_ctx *ctx, double ms[5]);
 /* Name of the mapping-kernel instantiation the most recent vs_pe_count launched, as a profiler
  * prints it (e.g. "k_pe_tiles<true, 10u, 5u>"); "" before the first call. */
 const char *vs_pe_last_kernel(const vs_ctx *ctx);
+/* Which of the optional kernels the most recent vs_pe_count launched (a run's choice by graph size and read shape): */
+enum {
+    VS_RAN_LOCUS_LDS_SORT = 1,    /* locus order by per-workgroup LDS histograms (k_locus_count / k_locus_scatter) */
+    VS_RAN_LOCUS_GLOBAL_SORT = 2, /* ... by global atomics (k_pe_locus / k_pe_permute): graphs beyond 147 k nodes */
+    VS_RAN_LOCUS_REFINE = 4,      /* second sort key, the reverse read's locus (k_locus_refine): graphs beyond 46 340 nodes */
+    VS_RAN_PE_MID = 8             /* overflow pairs through the wavefront-per-pair kernel first (k_pe_mid) */
+};
+uint32_t vs_pe_last_launched(const vs_ctx *ctx);
 
 /* ---- graph stages: K5 PE-link table ---------------------------------------------------------
  * Replaces process_pe_info (utils/VStrains_IO.py:598-627) and every later read or rewrite of the

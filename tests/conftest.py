@@ -5,9 +5,9 @@ import pytest
 
 # (the 'untouched' hints of the graph stages are verified against the snapshot in every test run)
 os.environ.setdefault("VS_CHECK_UNTOUCHED", "1")
-# the parity-safe tuning switches of vs_pe_count (VS_NO_SORT, VS_EPT, ...) exist only in a process started with
-# VS_EXPERIMENT=1; the variant tests flip them on a live context
-os.environ.setdefault("VS_EXPERIMENT", "1")
+# (No VS_EXPERIMENT here: the suite runs the library as a user gets it.  The parity-safe tuning switches of vs_pe_count
+# -- VS_NO_SORT, VS_EPT, ... -- exist only in a context created with VS_EXPERIMENT=1; the variant tests ask for one
+# through ``experiment_context`` and flip the switches on it.)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
@@ -35,6 +35,19 @@ def pe_cases(ok_only=True):
             continue
         out.append((name, d, meta))
     return out
+
+
+def experiment_context(host, device=0):
+    """A context made in experiment mode (VsTuning level 1): the switches are read from the environment on every call."""
+    old = os.environ.get("VS_EXPERIMENT")
+    os.environ["VS_EXPERIMENT"] = "1"
+    try:
+        return host.Context(device)
+    finally:
+        if old is None:
+            os.environ.pop("VS_EXPERIMENT", None)
+        else:
+            os.environ["VS_EXPERIMENT"] = old
 
 
 @pytest.fixture(scope="session")

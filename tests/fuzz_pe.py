@@ -97,14 +97,10 @@ def main():
         want = pe_oracle_c.Oracle(g.seqs, p["k"]).count_pairs(fwd, rve)
         env = {}
         if rng.random() < 0.3:
-            env = dict([[("VS_NO_STD", "1")], [("VS_NO_FAST", "1")], [("VS_EPT", "6")], [("VS_ACC_WIDE", "2")], [("VS_ACC_WIDE", "4")], [("VS_ACC_WIDE", "1")], [("VS_ACC_MERGE", "1")], [("VS_ACC_FILL", "100")],
+            env = dict([[("VS_NO_STD", "1")], [("VS_NO_FAST", "1")], [("VS_EPT", "6")], [("VS_ACC_WIDE", "2")], [("VS_REFINE", "1")], [("VS_ACC_WIDE", "1")], [("VS_ACC_MERGE", "1")], [("VS_ACC_FILL", "100")],
                         [("VS_NO_SORT", "1")], [("VS_LOCUS_GLOBAL", "1")]][int(rng.integers(0, 10))])
         if rng.random() < 0.15:
             env["VS_NO_MID"] = "1"  # overflow pairs straight to the general kernel
-        if rng.random() < 0.25:
-            env["VS_INLINE"] = "1"  # 32-byte postings with inline flanks (k <= 85, graphs of short nodes)
-        if os.environ.get("FUZZ_WALK") or rng.random() < 0.25:
-            env["VS_WALK"] = "1"  # the graph-following kernel wherever the node set certifies (csrc/vs_walk.h)
         os.environ.update(env)
         try:
             ctx.build_index(g.seqs, p["k"])

@@ -22,6 +22,16 @@ def host():
 
 
 @pytest.fixture(scope="module")
+def xctx(host):
+    """A context in experiment mode: the tuning switches of vs_pe_count are live on it (conftest.experiment_context)."""
+    from conftest import experiment_context
+
+    c = experiment_context(host)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
 def ctx(host):
     c = host.Context(0)
     yield c
@@ -185,7 +195,7 @@ def test_hip_path_reproduces_the_files_of_the_real_reference_script(host, ctx, t
         assert sha(path) == want[name + "_sha256"], name
 
 
-def test_second_sort_key_with_loci_longer_than_its_workgroup_buffer(host, ctx, tmp_path, monkeypatch):
+def test_second_sort_key_with_loci_longer_than_its_workgroup_buffer(host, xctx, tmp_path, monkeypatch):
     """VS_REFINE=1 (the default for graphs beyond 46 k nodes: inside a forward-read locus the pairs are ordered by the
     reverse read's locus, one workgroup per locus with a bitonic sort in LDS) on configs[0]'s 216-node graph with 1.2 M
     pairs: most loci hold more pairs than the 4 096 the workgroup buffer takes and stay in first-key order, the others are
@@ -193,11 +203,15 @@ def test_second_sort_key_with_loci_longer_than_its_workgroup_buffer(host, ctx, t
     from vstrains_amd.workloads import CONFIGS, workload_for
 
     cfg = CONFIGS[0]
+    ctx = xctx
     st, pre, names, seqs, cum, logger, n_in = workload_for(0, str(tmp_path))
     ctx.build_index(seqs, cfg["k"])
     L, seed, R = cfg["read_len"], 5151, 1_200_000
     sub, nth = int(0.005 * 2 ** 32), int(0.001 * 2 ** 32)
+    plain = _count(host, ctx, st, cum, seed, L, [(0, 1000)], sub, nth)
+    assert not ctx.last_launched & ctx.RAN_LOCUS_REFINE  # (a 216-node graph does not take the second key by itself)
     monkeypatch.setenv("VS_REFINE", "1")
     refined = _count(host, ctx, st, cum, seed, L, [(0, R)], sub, nth)
+    assert ctx.last_launched & ctx.RAN_LOCUS_REFINE, "VS_REFINE=1 did not launch k_locus_refine"
     orc = pe_oracle_c.Oracle(seqs, cfg["k"])
     _assert_equals_oracle(refined, orc, st, cum, seed, L, R, sub, nth)

@@ -33,6 +33,16 @@ def ctx(host):
     c.close()
 
 
+@pytest.fixture(scope="module")
+def xctx(host):
+    """A context in experiment mode: the tuning switches of vs_pe_count are live on it (conftest.experiment_context)."""
+    from conftest import experiment_context
+
+    c = experiment_context(host)
+    yield c
+    c.close()
+
+
 def _gpu_matrices(host, ctx, seqs, fwd, rve, k):
     ctx.build_index(seqs, k)
     counter = host.PeCounter(ctx)
@@ -42,13 +52,8 @@ def _gpu_matrices(host, ctx, seqs, fwd, rve, k):
     return res, block
 
 
-@pytest.mark.parametrize("mapper", ["seeds", "walk"])
 @pytest.mark.parametrize("name,d,meta", pe_cases(), ids=[c[0] for c in pe_cases()])
-def test_golden_files_bit_exact(host, ctx, name, d, meta, mapper, monkeypatch):
-    """mapper "walk": VS_WALK=1 -- node sets that certify (csrc/vs_walk.h) go through k_pe_walk, the others (repeats,
-    palindromes) through the seed kernels either way."""
-    if mapper == "walk":
-        monkeypatch.setenv("VS_WALK", "1")
+def test_golden_files_bit_exact(host, ctx, name, d, meta):
     ids, seqs = host.read_gfa_segments(os.path.join(d, "graph.gfa"))
     fq = host.FastqPair(os.path.join(d, "fwd.fq"), os.path.join(d, "rve.fq"), ctx)  # native ingest
     ctx.build_index(seqs, meta["k"])
@@ -61,17 +66,10 @@ def test_golden_files_bit_exact(host, ctx, name, d, meta, mapper, monkeypatch):
     f = pe_oracle.fastq_sequences(os.path.join(d, "fwd.fq"))
     r = pe_oracle.fastq_sequences(os.path.join(d, "rve.fq"))
     assert stats == pe_oracle.pe_matrices(seqs, f, r, meta["k"])[2]
-    if mapper == "walk" and len(f) and len(r):
-        certified = name not in ("palindrome_k5", "odd_split_k6", "repeats_k9", "tiny_k1", "tiny_k2")
-        assert ctx.walk_info["certified"] == certified, ctx.walk_info
-        assert ctx.last_kernel.startswith("k_pe_walk" if certified else "k_pe_tiles"), ctx.last_kernel
 
 
-@pytest.mark.parametrize("mapper", ["seeds", "walk"])
 @pytest.mark.parametrize("name,d,meta", pe_cases(), ids=[c[0] for c in pe_cases()])
-def test_per_end_lists_match_oracle(host, ctx, name, d, meta, mapper, monkeypatch):
-    if mapper == "walk":
-        monkeypatch.setenv("VS_WALK", "1")
+def test_per_end_lists_match_oracle(host, ctx, name, d, meta):
     K = meta["k"] + 1
     ids, seqs = host.read_gfa_segments(os.path.join(d, "graph.gfa"))
     f = pe_oracle.fastq_sequences(os.path.join(d, "fwd.fq"))
@@ -161,7 +159,8 @@ def _dense_case(k, n_pairs, read_len, seed, snp, n_strains=6, glen=1500, sub=0.0
 
 
 @pytest.mark.parametrize("no_mid", ["0", "1"])
-def test_overflow_pairs_take_slow_path_and_stay_exact(host, ctx, no_mid, monkeypatch):
+def test_overflow_pairs_take_slow_path_and_stay_exact(host, xctx, no_mid, monkeypatch):
+    ctx = xctx  # (the switches below exist only on a context made in experiment mode)
     # dense variation at k=11: a 100-base read is accepted by more than 16 short nodes in ~30 % of
     # the ends, which overflows the per-end list kept in LDS: those pairs go to k_pe_mid (one wavefront per
     # pair, state in LDS), or with VS_NO_MID=1 straight to the general kernel k_pe_slow
@@ -228,10 +227,11 @@ def test_random_graphs_against_c_oracle(host, ctx, k, read_len, n_pairs, snp):
 
 
 @pytest.mark.parametrize("read_len", [100, 101, 125, 126, 150, 151, 159, 160])
-def test_read_lengths_around_the_compile_time_shapes(host, ctx, read_len, monkeypatch):
+def test_read_lengths_around_the_compile_time_shapes(host, xctx, read_len, monkeypatch):
     """k = 55 with the read lengths the shape-specialised instantiations of k_pe_tiles are picked
     for (2x100/101, 2x125/126, 2x150/151; 159 = the longest that takes one, 160 = generic layout),
     no N in the block so that the straight-line kernels apply; each also with VS_NO_STD=1."""
+    ctx = xctx  # (the switches below exist only on a context made in experiment mode)
     g, f, r = _dense_case(55, 9000, read_len, seed=900 + read_len, snp=0.03, glen=5000, nrate=0.0)
     orc = pe_oracle_c.Oracle(g.seqs, 55)
     ref_node, ref_short, ref_stats = orc.count_pairs(f, r)
@@ -284,12 +284,13 @@ def test_ragged_block_through_sort_and_double_buffered_tiles(host, ctx, dirty):
 
 
 @pytest.mark.parametrize("k,max_len", [(127, 256), (99, 250), (95, 256), (94, 287), (86, 200), (127, 300), (140, 330)])
-def test_long_stride_kernel_with_ragged_dirty_reads(host, ctx, k, max_len, monkeypatch):
+def test_long_stride_kernel_with_ragged_dirty_reads(host, xctx, k, max_len, monkeypatch):
     """k > 85 (probe stride > 32) / reads beyond 191 bases take the long-window straight-line kernel
     (k_pe_tiles<2>): reads of every length up to its limit, some with N or other bytes outside
     ACGT; the generic kernel (VS_NO_FAST=1) must agree with it and with the oracle.  k >= 95 (k + 1 >= 96):
     63-base seeds with mixed keys -- the comparison then starts at the seed's first base, so the limit is 256
     bases instead of 31 + 256 (k = 94 / 95: either side of that switch)."""
+    ctx = xctx  # (the switches below exist only on a context made in experiment mode)
     g, f, r = _dense_case(k, 9000, max_len, seed=1200 + k, snp=0.02, glen=6000, nrate=0.0)
     rng = np.random.default_rng(k)
     f = [s[: int(rng.integers(0, max_len + 1))] for s in f]
@@ -464,14 +465,14 @@ def test_device_read_generator_equals_cpu_twin(host, ctx):
     {"VS_ACC_QUEUE": "0"}, {"VS_ACC_GRID_PER_CU": "1", "VS_ACC_QUEUE": "0"}, {"VS_NO_XCD_MAP": "1"}, {"VS_GRID_PER_CU": "8"}, {"VS_NO_STD": "1"}, {"VS_SHORTCUT": "1"}, {"VS_SHORTCUT": "0"},
     {"VS_ACC_MERGE": "1"}, {"VS_ACC_MERGE": "1", "VS_NO_AGG": "1"}, {"VS_ACC_MERGE": "1", "VS_ACC_WIDE": "1", "VS_ACC_FILL": "1"},
     {"VS_ACC_WIDE": "2"}, {"VS_ACC_WIDE": "2", "VS_ACC_FILL": "1"}, {"VS_ACC_WIDE": "2", "VS_ACC_FILL": "100", "VS_ACC_MERGE": "1"},
-    {"VS_ACC_WIDE": "4"}, {"VS_ACC_WIDE": "4", "VS_ACC_FILL": "1"}, {"VS_ACC_WIDE": "4", "VS_ACC_MERGE": "1", "VS_ACC_FILL": "100"}, {"VS_ACC_ROUND": "128"},
+    {"VS_ACC_ROUND": "128"},
     {"VS_REFINE": "1"}, {"VS_REFINE": "1", "VS_EPT": "32", "VS_ACC_WIDE": "2"}, {"VS_NO_MID": "1"},
-    {"VS_INLINE": "1"}, {"VS_INLINE": "1", "VS_NO_STD": "1"}, {"VS_WALK": "1"}, {"VS_WALK": "1", "VS_NO_SORT": "1"}, {"VS_WALK": "1", "VS_NO_XCD_MAP": "1", "VS_GRID_PER_CU": "1"}, {"VS_WALK": "1", "VS_ACC_WIDE": "2"},
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
-def test_every_kernel_variant_gives_the_same_counters(host, ctx, env, monkeypatch):
+def test_every_kernel_variant_gives_the_same_counters(host, xctx, env, monkeypatch):
     """The tuning switches select other code paths (input order instead of locus order, global
     atomics instead of the LDS cell table, the global-atomic sort, other tile sizes, table
     flushed constantly / never): all of them must produce the oracle's counters."""
+    ctx = xctx  # (the switches below exist only on a context made in experiment mode)
     from vstrains_amd import synth
 
     # 2 x 150 bases at k = 55: the shape the compile-time-layout instantiation (k_pe_tiles<true, true>)
@@ -487,35 +488,7 @@ def test_every_kernel_variant_gives_the_same_counters(host, ctx, env, monkeypatc
     assert np.array_equal(node_mat, want[0])
     assert np.array_equal(short_mat, want[1])
     assert stats == tuple(int(x) for x in want[2])
-    assert ctx.last_kernel.startswith("k_pe_walk") == ("VS_WALK" in env), ctx.last_kernel
-
-
-def test_inline_flank_postings_on_a_graph_of_short_nodes(host, ctx, monkeypatch):
-    """VS_INLINE=1: 32-byte postings that hold 40 bases of node text on either side of the seed
-    (k_pe_tiles<1, .., true>), taken where at least half of the postings fit those flanks -- a dense graph of
-    many strains; postings of longer nodes in the same graph still go to the text.  Same counters as the oracle,
-    with ragged and dirty reads, in the compile-time tile shape and in the run-time one."""
-    from vstrains_amd import synth
-
-    st = synth.make_strains(30, 3000, 0.085, seed=77)  # (2 587 nodes, median 64 bases: 31 % of the postings have a long flank)
-    g = synth.compact_dbg(st, 55)
-    fwd, rve = synth.sample_pairs(st, 9000, 150, seed=78, sub_rate=0.01, n_rate=0.01)
-    rng = np.random.default_rng(79)
-    for lst in (fwd, rve):
-        for i in rng.choice(len(lst), size=300, replace=False):
-            s_ = lst[int(i)]
-            p_ = int(rng.integers(0, len(s_)))
-            lst[int(i)] = s_[:p_] + str(rng.choice(list("nRYacgt*"))) + s_[p_ + 1:]
-    want = pe_oracle_c.Oracle(g.seqs, 55).count_pairs(fwd, rve)
-    monkeypatch.setenv("VS_INLINE", "1")
-    for no_std, ragged in (("0", False), ("1", True)):
-        monkeypatch.setenv("VS_NO_STD", no_std)
-        f2 = [s_[: int(rng.integers(60, 151))] for s_ in fwd] if ragged else fwd
-        w2 = pe_oracle_c.Oracle(g.seqs, 55).count_pairs(f2, rve) if ragged else want
-        (node_mat, short_mat, stats), _ = _gpu_matrices(host, ctx, g.seqs, f2, rve, 55)
-        assert ctx.last_kernel.endswith("true>"), ctx.last_kernel
-        assert np.array_equal(node_mat, w2[0]) and np.array_equal(short_mat, w2[1])
-        assert stats == tuple(int(x) for x in w2[2])
+    assert ctx.last_kernel.startswith("k_pe_tiles"), ctx.last_kernel
 
 
 def test_switches_do_not_exist_outside_experiment_mode(tmp_path):
@@ -845,7 +818,7 @@ def test_two_gpu_rccl_step_and_sharded_drop_in(tmp_path):
     assert _read(outdir / "st_info") == _read(os.path.join(d, "st_info"))
 
 
-@pytest.mark.parametrize("mode", ["boundaries", "tile_shapes", "walk"])
+@pytest.mark.parametrize("mode", ["boundaries", "tile_shapes"])
 def test_randomized_campaign_short(mode):
     """tests/fuzz_pe.py for ten seconds per mode: random graph / read shapes around the points where
     vs_pe_count switches kernels, every draw against the C oracle (the full campaigns of the round:
@@ -853,8 +826,6 @@ def test_randomized_campaign_short(mode):
     env = dict(os.environ)
     if mode == "tile_shapes":
         env["FUZZ_STD"] = "1"
-    if mode == "walk":
-        env["FUZZ_WALK"] = "1"  # every draw with VS_WALK=1: k_pe_walk wherever the node set certifies
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_pe.py"), "10", "7"], cwd=ROOT, env=env,
                           capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]

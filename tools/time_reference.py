@@ -4,7 +4,7 @@ the C restatement on the same inputs on the same box, so that the two boxes can 
 (SURVEY.md 8d "CPU baseline").  Measurement tooling like bench.py's cpu_baseline leg: it may call
 oracle/; nothing of the product imports it.
 
-    python tools/time_reference.py [--configs 0,1,2] [--prefix 200000] [--out profiles/r3/cpu_reference.json]
+    python tools/time_reference.py [--configs 0,1,2] [--prefix 200000] [--out profiles/r4/cpu_reference.json]
                                    [--digests tests/golden/reference_digests.json]
 
 Also writes the SHA-256 of the pe_info / st_info files the REAL script produced (and of the s_graph_L1.gfa it
@@ -50,7 +50,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="0,1,2")
     ap.add_argument("--prefix", type=int, default=200_000, help="pairs given to the reference for configs > 0")
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r3", "cpu_reference.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r4", "cpu_reference.json"))
     ap.add_argument("--digests", default=os.path.join(ROOT, "tests", "golden", "reference_digests.json"))
     args = ap.parse_args()
     import hashlib
@@ -121,25 +121,50 @@ def main():
         entry["port"] = {"table_build_s": build_s, "pair_loop_s": port_s, "pairs_per_s": n_pairs / port_s,
                          "identical_pe_info_st_info": bool(same)}
         entry["port_over_reference"] = entry["port"]["pairs_per_s"] / entry["reference"]["pairs_per_s"]
-        # ---- configs[0]: the reference graph stages behind the stand-in
+        # ---- configs[0]: the reference's WHOLE command behind the stand-in: timing, and the digests of what it wrote under
+        # both in-edge models of the stand-in and hash seeds 0-3 (the reference iterates sets of contig names) -- the files
+        # that come out the same every time are a fixture the `-m gpu` suite holds the CLI drop-in against
         if ci == 0:
-            env = dict(os.environ)
-            env["PYTHONPATH"] = os.path.join(ROOT, "tests", "golden", "gt_standin") + os.pathsep + env.get("PYTHONPATH", "")
-            env["PYTHONHASHSEED"] = "0"
-            env["MPLBACKEND"] = "Agg"
-            out_v = os.path.join(work, "vstrains_out")
-            t0 = time.perf_counter()
-            pv = subprocess.run([sys.executable, os.path.join(REF, "vstrains"), "-a", "spades", "-g", os.path.join(work, "input.gfa"),
-                                 "-p", os.path.join(work, "input.paths"), "-o", out_v, "-fwd", fq1, "-rve", fq2],
-                                capture_output=True, text=True, env=env, cwd=work)
-            wall_v = time.perf_counter() - t0
-            if pv.returncode == 0:
-                strains = open(os.path.join(out_v, "strain.paths")).read().count("\n") // 2
-                entry["reference_whole_command"] = {
-                    "wall_s": wall_v, "pe_subprocess_s": glob_s, "graph_stages_and_rest_s": wall_v - glob_s, "strains": strains,
-                    "label": "graph stages behind tests/golden/gt_standin (pure-Python model of graph-tool/gfapy; slower than the C++ library)"}
-            else:
-                entry["reference_whole_command"] = {"error": pv.stderr[-800:]}
+            sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+            import make_graph_golden as gold
+
+            runs = {}
+            for model in ("rotate", "plain"):
+                for hashseed in (0, 1, 2, 3):
+                    env = dict(os.environ)
+                    env["PYTHONPATH"] = os.path.join(ROOT, "tests", "golden", "gt_standin") + os.pathsep + env.get("PYTHONPATH", "")
+                    env["PYTHONHASHSEED"] = str(hashseed)
+                    env["GT_STANDIN_INEDGE"] = model
+                    env["MPLBACKEND"] = "Agg"
+                    out_v = os.path.join(work, "vstrains_out_%s_%d" % (model, hashseed))
+                    t0 = time.perf_counter()
+                    pv = subprocess.run([sys.executable, os.path.join(REF, "vstrains"), "-a", "spades", "-g", os.path.join(work, "input.gfa"),
+                                         "-p", os.path.join(work, "input.paths"), "-o", out_v, "-fwd", fq1, "-rve", fq2],
+                                        capture_output=True, text=True, env=env, cwd=work)
+                    wall_v = time.perf_counter() - t0
+                    if pv.returncode != 0:
+                        entry["reference_whole_command"] = {"error": pv.stderr[-800:]}
+                        break
+                    files = {rel: hashlib.sha256(text.encode()).hexdigest() for rel, text in gold.collect(out_v).items()
+                             if rel not in ("aln/pe_info", "aln/st_info", "vstrains.log.info")}
+                    runs[(model, hashseed)] = files
+                    if model == "rotate" and hashseed == 0:
+                        strains = open(os.path.join(out_v, "strain.paths")).read().count("\n") // 2
+                        entry["reference_whole_command"] = {
+                            "wall_s": wall_v, "pe_subprocess_s": glob_s, "graph_stages_and_rest_s": wall_v - glob_s, "strains": strains,
+                            "label": "graph stages behind tests/golden/gt_standin (pure-Python model of graph-tool/gfapy; slower than the C++ library)"}
+            if len(runs) == 8:
+                base = runs[("rotate", 0)]
+                names_all = sorted(set().union(*[set(r) for r in runs.values()]))
+                stable = [f for f in names_all if all(r.get(f) == base.get(f) for r in runs.values())]
+                digests["configs[0]_whole_command"] = {
+                    "workload": cfg["tag"], "pairs": int(n_pairs), "stream_seed": seed,
+                    "files_sha256": {f: base[f] for f in stable},
+                    "digest_form": "tests/golden/make_graph_golden.collect (GFA / FASTA sequences as digests), then SHA-256 of that text",
+                    "differs_between_in_edge_models": sorted(f for f in names_all if any(runs[("plain", h)].get(f) != runs[("rotate", h)].get(f) for h in (0, 1, 2, 3))),
+                    "differs_between_hash_seeds": sorted(f for f in names_all if any(runs[(m, h)].get(f) != runs[(m, 0)].get(f) for m in ("rotate", "plain") for h in (1, 2, 3))),
+                    "produced_by": "the real reference command (/root/reference/vstrains) behind tests/golden/gt_standin, in-edge models rotate and plain, "
+                                   "PYTHONHASHSEED 0-3, run by tools/time_reference.py in the build container; files_sha256 holds the files all eight runs agree on"}
         result["configs"]["configs[%d]" % ci] = entry
         print(json.dumps({("configs[%d]" % ci): entry}, indent=1), flush=True)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)

@@ -26,10 +26,6 @@ SYMBOLS = {
                                  C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]),
     "vs_index_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "vs_node_order_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
-    "vs_walk_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]),
-    "vs_walk_map_ends_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
-                                        C.c_void_p, C.c_void_p]),
-    "vs_walk_certify_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]),
     "vs_reads_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "vs_reads_free": (None, [C.c_void_p, C.c_void_p]),
     "vs_reads_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
@@ -57,6 +53,7 @@ SYMBOLS = {
     "vs_pe_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]),
     "vs_pe_map_ends": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "vs_pe_last_kernel": (C.c_char_p, [C.c_void_p]),
+    "vs_pe_last_launched": (C.c_uint32, [C.c_void_p]),
     "vs_pe_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "vs_links_from_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "vs_links_from_wide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),

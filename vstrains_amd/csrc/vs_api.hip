@@ -41,8 +41,6 @@ void vs_tuning_load(VsTuning &t, int level) {
     t.no_fast = env_on("VS_NO_FAST");
     t.no_std = env_on("VS_NO_STD");
     t.no_agg = env_on("VS_NO_AGG");
-    t.walk = env_on("VS_WALK");
-    t.use_inline = env_on("VS_INLINE");
     t.no_mid = env_on("VS_NO_MID");
     if (const char *v = getenv("VS_ACC_QUEUE")) t.acc_queue = atoi(v) != 0;
     t.acc_merge = env_on("VS_ACC_MERGE");
@@ -127,8 +125,7 @@ int vs_ctx_create(int device, vs_ctx **out) {
 }
 
 static void free_index(vs_ctx *ctx) {
-    void **ps[] = {&ctx->d_meta, &ctx->d_fwd, &ctx->d_rc, &ctx->d_table, &ctx->d_post, &ctx->d_post32, &ctx->d_wrec, &ctx->d_wktab, &ctx->d_wpset};
-    ctx->walk_ok = false;
+    void **ps[] = {&ctx->d_meta, &ctx->d_fwd, &ctx->d_rc, &ctx->d_table, &ctx->d_post};
     for (void **p : ps) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;

@@ -75,7 +75,7 @@ k_seed_insert(VsIndexDev idx, const uint64_t *__restrict__ seed_off, uint64_t n_
 __global__ void __launch_bounds__(TPB)
 k_seed_fill(VsIndexDev idx, const uint64_t *__restrict__ seed_off, uint64_t n_pos,
             const uint32_t *__restrict__ pos_slot, const uint32_t *__restrict__ offs,
-            uint32_t *__restrict__ cursor, uint4 *__restrict__ postings, uint4 *__restrict__ postings32, uint32_t *__restrict__ n_long) {
+            uint32_t *__restrict__ cursor, uint4 *__restrict__ postings) {
     uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
     if (g >= n_pos) return;
     uint32_t node = vs_upper_idx(seed_off, idx.n_nodes + 1, g);
@@ -88,30 +88,6 @@ k_seed_fill(VsIndexDev idx, const uint64_t *__restrict__ seed_off, uint64_t n_po
     VsPosting rec;  // (carries the node header: the mapping kernel needs no second load for it)
     rec.node = node; rec.pos = p; rec.strand = strand; rec.len = m.len; rec.woff = m.woff;
     postings[at] = vs_posting_pack(rec);
-    if (postings32) {
-        // the same posting with VS_FLANK bases of node text on either side of the seed, nearest first (VsIndexDev::postings32)
-        const uint32_t *tw = idx.fwd_words;
-        const uint64_t tb = (uint64_t)m.woff * 16u;
-        const uint32_t nl = p < VS_FLANK ? p : VS_FLANK, rfree = m.len - p - idx.w, nr = rfree < VS_FLANK ? rfree : VS_FLANK;
-        uint32_t a[3] = {0u, 0u, 0u}, b[3] = {0u, 0u, 0u};
-        for (uint32_t i = 0; i < nl; i++) {
-            const uint64_t at2 = tb + p - 1u - i;
-            a[i >> 4] |= ((tw[at2 >> 4] >> (2u * (uint32_t)(at2 & 15u))) & 3u) << (2u * (i & 15u));
-        }
-        for (uint32_t i = 0; i < nr; i++) {
-            const uint64_t at2 = tb + p + idx.w + i;
-            b[i >> 4] |= ((tw[at2 >> 4] >> (2u * (uint32_t)(at2 & 15u))) & 3u) << (2u * (i & 15u));
-        }
-        uint4 h0, h1;
-        h0.x = node | (strand << 31); h0.y = p; h0.z = m.len; h0.w = a[0];
-        h1.x = a[1];
-        h1.y = (a[2] & 0xFFFFu) | (b[0] << 16);
-        h1.z = (b[0] >> 16) | (b[1] << 16);
-        h1.w = (b[1] >> 16) | (b[2] << 16);
-        postings32[2ull * at] = h0;
-        postings32[2ull * at + 1u] = h1;
-        if ((p > VS_FLANK || rfree > VS_FLANK) && n_long) atomicAdd(n_long, 1u);
-    }
 }
 
 __global__ void __launch_bounds__(TPB)
@@ -193,12 +169,8 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
     VS_HIP(ctx, hipMalloc(&ctx->d_fwd, 2 * b_words));  // forward text, then the reverse complements
     ctx->d_rc = nullptr;
     VS_HIP(ctx, hipMalloc(&ctx->d_post, b_post));
-    // 32-byte postings with the text around the seed (VsIndexDev::postings32) for the seed geometry of k <= 85 (stride
-    // <= 32: the straight-line kernel k_pe_tiles<1>, the only one that reads them)
     if (ctx->experiment_level) vs_tuning_load(ctx->tune, ctx->experiment_level);
-    const bool want32 = ctx->tune.use_inline && s <= 32u && w <= 31u;  // (VS_INLINE=1 only: DESIGN 11)
-    if (want32) VS_HIP(ctx, hipMalloc(&ctx->d_post32, 2 * b_post));
-    ctx->index_bytes = b_meta + 2 * b_words + b_post + (want32 ? 2 * b_post : 0);  // (+ the table, sized below)
+    ctx->index_bytes = b_meta + 2 * b_words + b_post;  // (+ the table, sized below)
     // temporaries
     uint8_t *d_ascii = nullptr;
     uint64_t *d_aoff = nullptr, *d_seed_off = nullptr, *d_tmp = nullptr;
@@ -240,7 +212,6 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
         d.rc_words = d.fwd_words + d.rc_delta;
         d.table = (const VsSlot *)ctx->d_table;
         d.postings = (const uint4 *)ctx->d_post;
-        d.postings32 = (const uint4 *)ctx->d_post32;
 
         if (words)
             hipLaunchKernelGGL(k_pack_nodes, dim3((unsigned)((words + TPB - 1) / TPB)), dim3(TPB), 0, st, d_ascii, d_aoff,
@@ -307,7 +278,7 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
             rc = vs_scan_u32(ctx, d_cnts, d_offs, n_slots_final, d_tmp, nullptr);
             if (rc) goto done;
             hipLaunchKernelGGL(k_seed_fill, dim3(nb), dim3(TPB), 0, st, d, d_seed_off, npos, d_pos_slot, d_offs, d_cursor,
-                               (uint4 *)ctx->d_post, (uint4 *)ctx->d_post32, d_flags + 2);
+                               (uint4 *)ctx->d_post);
         }
         hipLaunchKernelGGL(k_table_finalize, dim3((unsigned)((n_slots_final + TPB - 1) / TPB)), dim3(TPB), 0, st, d_keys, d_cnts,
                            d_offs, (const uint4 *)ctx->d_post, (uint32_t)n_slots_final, (VsSlot *)ctx->d_table, d_flags + 1);
@@ -320,19 +291,7 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
         for (uint32_t i = 0; i < n_nodes; i++) ctx->max_node_len = meta[i].len > ctx->max_node_len ? meta[i].len : ctx->max_node_len;
         ctx->n_slots = n_slots_final;
         ctx->n_distinct = h_flags[1];
-        ctx->n_long_flank = h_flags[2];
         ctx->has_index = true;
-        // walk index (vs_walk.h): certified on the host, tables uploaded; a node set that fails keeps the seed kernels
-        if (ctx->experiment_level) vs_tuning_load(ctx->tune, ctx->experiment_level);
-        if (ctx->tune.walk) {  // (VS_WALK=1: the certification and the tables cost 0.1 s at 5 k nodes, only paid when asked for)
-            VsWalkHost wh;
-            vs_walk_build_host(node_ascii, node_off, n_nodes, K, woff.data(), d.rc_delta, wh);
-            ctx->walk_why = wh.why;
-            if (wh.certified) {
-                rc = vs_walk_upload(ctx, wh);
-                if (rc) goto done;
-            }
-        }
     }
 done:
     (void)hipStreamSynchronize(st);
@@ -355,61 +314,5 @@ extern "C" int vs_index_info(const vs_ctx *ctx, uint64_t info[6]) {
     info[3] = ctx->n_slots;
     info[4] = ctx->n_distinct;
     info[5] = ctx->index_bytes;
-    return VS_OK;
-}
-
-// ---- walk index: device copies -----------------------------------------------------------------------------------
-int vs_walk_upload(vs_ctx *ctx, const VsWalkHost &h) {
-    const size_t b_rec = sizeof(VsWalkRec) * h.rec.size(), b_k = sizeof(VsKSlot) * h.ktab.size(), b_p = sizeof(uint64_t) * h.pset.size();
-    VS_HIP(ctx, hipMalloc(&ctx->d_wrec, b_rec ? b_rec : 16));
-    VS_HIP(ctx, hipMalloc(&ctx->d_wktab, b_k ? b_k : 16));
-    VS_HIP(ctx, hipMalloc(&ctx->d_wpset, b_p ? b_p : 16));
-    VS_HIP(ctx, hipMemcpyAsync(ctx->d_wrec, h.rec.data(), b_rec, hipMemcpyHostToDevice, ctx->stream));
-    VS_HIP(ctx, hipMemcpyAsync(ctx->d_wktab, h.ktab.data(), b_k, hipMemcpyHostToDevice, ctx->stream));
-    VS_HIP(ctx, hipMemcpyAsync(ctx->d_wpset, h.pset.data(), b_p, hipMemcpyHostToDevice, ctx->stream));
-    VS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (the host vectors go away with the caller)
-    ctx->walk.rec = (const VsWalkRec *)ctx->d_wrec;
-    ctx->walk.ktab = (const VsKSlot *)ctx->d_wktab;
-    ctx->walk.pset = (const uint64_t *)ctx->d_wpset;
-    ctx->walk.k_bits = h.k_bits;
-    ctx->walk.p_bits = h.p_bits;
-    ctx->walk.wp = h.wp;
-    ctx->walk.nw = h.nw;
-    ctx->walk_info[0] = h.n_kmers; ctx->walk_info[1] = h.n_pmers; ctx->walk_info[2] = h.n_succ;
-    ctx->walk_info[3] = h.ktab.size(); ctx->walk_info[4] = h.pset.size(); ctx->walk_info[5] = b_rec + b_k + b_p;
-    ctx->index_bytes += b_rec + b_k + b_p;
-    ctx->walk_ok = true;
-    return VS_OK;
-}
-
-extern "C" int vs_walk_info(const vs_ctx *ctx, uint64_t info[8], char *why, size_t why_cap) {
-    if (!ctx || !info) return VS_E_ARG;
-    if (!ctx->has_index) return VS_E_STATE;
-    info[0] = ctx->walk_ok ? 1u : 0u;
-    for (int i = 0; i < 6; i++) info[1 + i] = ctx->walk_ok ? ctx->walk_info[i] : 0u;
-    info[7] = ctx->walk_ok ? ctx->walk.wp : 0u;
-    if (why && why_cap) snprintf(why, why_cap, "%s", ctx->walk_why.c_str());
-    return VS_OK;
-}
-
-// Host only (no device, no context): would this node set be certified?  The same code vs_index_build runs.
-extern "C" int vs_walk_certify_host(const uint8_t *node_ascii, const uint64_t *node_off, uint32_t n_nodes, uint32_t ksize,
-                                    uint64_t info[8], char *why, size_t why_cap) {
-    if (!node_off || !info || (!node_ascii && n_nodes && node_off[n_nodes]) || ksize < 1) return VS_E_ARG;
-    std::vector<uint32_t> woff(n_nodes + 1);
-    uint64_t words = 0;
-    for (uint32_t i = 0; i < n_nodes; i++) {
-        woff[i] = (uint32_t)words;
-        words += (node_off[i + 1] - node_off[i] + 15) / 16;
-        if (words > 0x0FFFFFF0ull) return VS_E_RANGE;
-    }
-    woff[n_nodes] = (uint32_t)words;
-    VsWalkHost wh;
-    vs_walk_build_host(node_ascii, node_off, n_nodes, ksize + 1, woff.data(), (uint32_t)(words + VS_PAD_WORDS), wh);
-    info[0] = wh.certified ? 1u : 0u;
-    info[1] = wh.n_kmers; info[2] = wh.n_pmers; info[3] = wh.n_succ; info[4] = wh.ktab.size(); info[5] = wh.pset.size();
-    info[6] = sizeof(VsWalkRec) * wh.rec.size() + sizeof(VsKSlot) * wh.ktab.size() + sizeof(uint64_t) * wh.pset.size();
-    info[7] = wh.wp;
-    if (why && why_cap) snprintf(why, why_cap, "%s", wh.why.c_str());
     return VS_OK;
 }

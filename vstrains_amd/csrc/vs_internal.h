@@ -8,8 +8,6 @@
 #include <vector>
 
 #include "../../include/vstrains_hip.h"
-#define VS_WALK_HOST_DECL
-#include "vs_walk.h"
 
 #define VS_WAVE 64
 #define VS_PAD_WORDS 16  // zero words behind every packed text buffer (window reads may overshoot)
@@ -74,17 +72,7 @@ struct VsIndexDev {
     uint32_t rc_delta;          // so that a kernel can address either strand off one uniform base)
     const VsSlot *table;        // [1 << table_bits]
     const uint4 *postings;      // VsPosting records, the postings of one seed contiguous
-    // The same postings with the node text around the seed inside the record (32 B = two uint4; same index as
-    // `postings`), so that the mapping kernel compares most postings without a third dependent load:
-    //   w0 node | strand << 31   w1 pos   w2 node length
-    //   A = the 40 bases LEFT of the seed, nearest first (A[i] = base pos - 1 - i), B = the 40 bases RIGHT of it, nearest
-    //   first; w3 = A[0..15], w4 = A[16..31], w5 = A[32..39] | B[0..7] << 16, w6 = B[8..23], w7 = B[24..39]
-    // Stored nearest-first on both sides, the flanks of the OTHER strand are the complements with the sides swapped (no
-    // reversal): left' = ~B, right' = ~A.  Bases beyond the node's ends are zero and never looked at (clipped by the
-    // node length).  NULL when the index was built without them.
-    const uint4 *postings32;
 };
-#define VS_FLANK 40u  // bases of node text a 32-byte posting holds on either side of its seed
 
 struct VsReadsDev {
     uint64_t n_ends;
@@ -127,10 +115,6 @@ struct VsTuning {
     bool no_sort = false, locus_global = false, no_xcd_map = false, no_fast = false, no_std = false, no_agg = false;
     bool acc_queue = true, acc_merge = false;
     bool no_mid = false;            // VS_NO_MID: overflow pairs straight to k_pe_slow
-    bool use_inline = false;        // VS_INLINE=1: 32-byte postings that hold the node text around the seed (k_pe_tiles<.., true>) --
-                                    // exact, but 7.2 ms against 5.8 ms at configs[2]: not the default
-    bool walk = false;              // VS_WALK=1: certified graphs (vs_walk.h) through k_pe_walk instead of the seed kernels --
-                                    // exact and tested, but slower on every bench config, hence not the default
     bool debug_postings = false, debug_occ = false, debug_acc = false;
     // timing only (VS_EXPERIMENT=timing): wrong counters by design
     uint32_t debug_stop = 0;        // VS_DEBUG_STOP=1..5
@@ -149,16 +133,9 @@ struct vs_ctx {
     bool has_index = false;
     VsIndexDev idx{};
     // owned device allocations of the index
-    void *d_meta = nullptr, *d_fwd = nullptr, *d_rc = nullptr, *d_table = nullptr, *d_post = nullptr, *d_post32 = nullptr;
-    uint64_t n_long_flank = 0;  // postings with more than VS_FLANK bases of node text on some side of the seed
+    void *d_meta = nullptr, *d_fwd = nullptr, *d_rc = nullptr, *d_table = nullptr, *d_post = nullptr;
     uint64_t n_seed_pos = 0, n_slots = 0, n_distinct = 0, index_bytes = 0;
     uint32_t max_node_len = 0;
-    // walk index (vs_walk.h): present when the node set passed the certification
-    bool walk_ok = false;
-    std::string walk_why;          // why not
-    VsWalkDev walk{};
-    void *d_wrec = nullptr, *d_wktab = nullptr, *d_wpset = nullptr;
-    uint64_t walk_info[6] = {0, 0, 0, 0, 0, 0};  // (k+1)-mers, presence mers, successor links, table slots, set slots, device bytes
     // scratch for vs_pe_count
     void *d_slow_list = nullptr;   // pair indices sent to the slow path
     uint64_t slow_cap = 0;
@@ -185,6 +162,7 @@ struct vs_ctx {
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double last_ms[3] = {0, 0, 0};
     const char *last_kernel = "";  // mapping-kernel instantiation of the last vs_pe_count
+    uint32_t last_launched = 0;    // VS_RAN_* bits: which optional kernels that call launched
     int n_cu = 256;
 };
 
@@ -203,24 +181,6 @@ struct vs_reads {
         return r;
     }
 };
-
-// launch parameters of k_pe_walk (vs_walk.hip): the certified-graph mapping kernel
-struct VsWalkParams {
-    VsIndexDev idx;
-    VsWalkDev wk;
-    VsReadsDev rd;
-    const uint32_t *perm;  // pair order of the tiles (locus-sorted) or NULL = input order
-    uint64_t n_pairs, n_tiles;
-    uint32_t wpe, tiles_per_wg, magic_ws, no_xcd_map, accumulate, dbg_cap;
-    uint32_t *out_lists, *out_counts;
-    unsigned long long *stats;
-    uint32_t *slow_list, *slow_count, *dbg_lists, *dbg_counts;
-};
-#define VS_WALK_EPT 256u  // read ends per tile of k_pe_walk (= its workgroup size)
-size_t vs_walk_lds_bytes(uint32_t wpe);
-int vs_walk_launch(vs_ctx *ctx, const VsWalkParams &P, uint32_t grid, hipStream_t st);
-const char *vs_walk_kernel_name(uint32_t nw);
-int vs_walk_upload(vs_ctx *ctx, const VsWalkHost &h);  // host tables -> device (vs_index.hip)
 
 int vs_fail(vs_ctx *ctx, int code, const char *fmt, ...);
 // grow-only cache of device buffers (see vs_ctx::cache); NULL on allocation failure

@@ -433,9 +433,6 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
 #define STD2_S 66u
 // MODE 0: generic loops (masked reads through the validity mask, any stride / read length);
 //      1: straight-line comparison, stride <= 32, reads <= w + 160; 2: the same for stride <= 128, reads <= w + 256.
-// INL (MODE 1 only): multi-posting seeds are read as 32-byte records that hold the node text around the seed
-// (VsIndexDev::postings32): a posting whose match cannot leave those VS_FLANK bases is compared without touching the node
-// text -- one dependent load less, no alignment of the text side -- and only the others (long nodes) take the text.
 // tile and pair indices inside k_pe_tiles: a block holds fewer than 2^32 ends, so 32 bits do (-DVS_TILE32=0: 64, as before --
 // six more scalar registers spilled and two more vector registers in the k = 55 shape)
 #ifndef VS_TILE32
@@ -446,12 +443,11 @@ typedef uint32_t tidx_t;
 #else
 typedef uint64_t tidx_t;
 #endif
-template <int MODE, uint32_t SW, uint32_t SP, bool INL = false>
+template <int MODE, uint32_t SW, uint32_t SP>
 __global__ void __launch_bounds__(TTPB)
 __attribute__((amdgpu_waves_per_eu(MODE == 2 ? TILES_WAVES_LONG : TILES_WAVES, MODE == 2 ? TILES_WAVES_LONG : TILES_WAVES)))
 k_pe_tiles(PeParams P) {
     constexpr bool FAST = MODE != 0;
-    static_assert(!INL || MODE == 1, "inline flanks: straight-line kernel of k <= 85 only");
     constexpr uint32_t AB = MODE == 2 ? 9u : 8u;  // bits of the read offset packed under the node length (credit / P4)
     constexpr bool STD = SW != 0u;
     constexpr uint32_t STD_WPE = SW, STD_PMAX = SP;
@@ -746,9 +742,6 @@ k_pe_tiles(PeParams P) {
             bool live[PPT];
             uint32_t p_e[PPT], p_j[PPT], p_node[PPT], p_pos[PPT], p_opp[PPT];
             VsNodeMeta p_nm[PPT];
-            // INL: the flanks of the posting (A leftwards, B rightwards, nearest first), woff = ~0 marks "record with flanks"
-            uint64_t p_fa[INL ? PPT : 1u], p_fb[INL ? PPT : 1u];
-            uint32_t p_fa1[INL ? PPT : 1u], p_fb1[INL ? PPT : 1u];
 #pragma unroll
             for (uint32_t k2 = 0; k2 < PPT; k2++) {
                 const uint32_t t = c0 + tid * PPT + k2;
@@ -762,16 +755,7 @@ k_pe_tiles(PeParams P) {
                 p_j[k2] = pi * s;
                 uint32_t node = pa, pos = pb & 0x7FFFFFFFu, opp = pb >> 31;
                 p_nm[k2].woff = 0; p_nm[k2].len = 0;
-                if (INL) { p_fa[k2] = 0ull; p_fb[k2] = 0ull; p_fa1[k2] = 0u; p_fb1[k2] = 0u; }
-                if (INL && live[k2] && cnt != 1u) {
-                    const uint4 h0 = P.idx.postings32[2u * (pa + (t - excl))], h1 = P.idx.postings32[2u * (pa + (t - excl)) + 1u];
-                    node = h0.x & 0x01FFFFFFu; pos = h0.y; opp = (h0.x >> 31) ^ (pb >> 31);
-                    p_nm[k2].woff = 0xFFFFFFFFu; p_nm[k2].len = h0.z;
-                    p_fa[k2] = (uint64_t)h0.w | ((uint64_t)h1.x << 32);
-                    p_fa1[k2] = h1.y & 0xFFFFu;
-                    p_fb[k2] = (uint64_t)(h1.y >> 16) | ((uint64_t)h1.z << 16) | ((uint64_t)(h1.w & 0xFFFFu) << 48);
-                    p_fb1[k2] = h1.w >> 16;
-                } else if (live[k2] && cnt != 1u) {  // (the record carries the node header: no second round trip)
+                if (live[k2] && cnt != 1u) {  // (the record carries the node header: no second round trip)
                     const VsPosting po = vs_posting_unpack(P.idx.postings[pa + (t - excl)]);
                     node = po.node; pos = po.pos; opp = po.strand ^ (pb >> 31);
                     p_nm[k2].woff = po.woff; p_nm[k2].len = po.len;
@@ -812,36 +796,8 @@ k_pe_tiles(PeParams P) {
                     const uint32_t dr = nm.len - q - wv;
                     rem = rem < dr ? rem : dr;
                     uint32_t left = 0u, ext = 0u;
-                    bool done = false;
-                    if (INL && nm.woff == 0xFFFFFFFFu) {
-                        if (rem <= VS_FLANK) {
-                            // the match cannot leave the text the record holds (cl <= s <= 32 on the left): on the read's
-                            // strand the flanks are A / B as stored, on the other one their complements with the sides swapped
-                            const uint64_t lf = opp ? ~p_fb[k2] : p_fa[k2], rf = opp ? ~p_fa[k2] : p_fb[k2];
-                            const uint32_t rf1 = (opp ? ~p_fa1[k2] : p_fb1[k2]) & 0xFFFFu;
-                            const uint32_t rbase = e * wpe * 16u;
-                            left = cl;
-                            if (cl) {  // the cl read bases before the seed, nearest first
-                                uint64_t x = __builtin_bitreverse64(vs_win(s_words, rbase + j - cl));
-                                x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
-                                x = ((x >> (64u - 2u * cl)) ^ lf) & vs_lowmask(2u * cl);
-                                if (x) left = (uint32_t)(__ffsll((long long)x) - 1) >> 1;
-                            }
-                            const uint64_t x0 = vs_win(s_words, rbase + j + w) ^ rf;
-                            ext = x0 ? (uint32_t)(__ffsll((long long)x0) - 1) >> 1 : 32u;
-                            if (ext == 32u && rem > 32u) {
-                                const uint32_t x1 = ((uint32_t)vs_win(s_words, rbase + j + w + 32u) ^ rf1) & 0xFFFFu;
-                                ext = x1 ? 32u + ((uint32_t)(__ffs((int)x1) - 1) >> 1) : VS_FLANK;
-                            }
-                            ext = ext < rem ? ext : rem;
-                            done = true;
-                        } else {
-                            nm.woff = P.idx.meta[node].woff;  // a long node: its text after all
-                        }
-                    }
                     const uint32_t tb = (nm.woff + (opp ? P.idx.rc_delta : 0u)) * 16u;
-                    if (done) {
-                    } else if (MODE == 2) vs_agree_long(s_words, e * wpe * 16u, tw, tb + q, cl, tb + q + wv, rem, j, wv, &left, &ext);
+                    if (MODE == 2) vs_agree_long(s_words, e * wpe * 16u, tw, tb + q, cl, tb + q + wv, rem, j, wv, &left, &ext);
                     else vs_agree_fast<STD>(s_words, e * wpe * 16u, tw, tb + q, cl, tb + q + wv, rem, j, wv, &left, &ext);
                     len = left + wv + ext;
                     if (left >= s || len < K) continue;  // an earlier probe lies inside this match and owns it / too short
@@ -952,7 +908,6 @@ k_pe_tiles(PeParams P) {
 #endif
 struct Acc32 {
     typedef uint32_t KT;
-    static constexpr bool GROUPED = false;
     static constexpr uint32_t BITS = ACC_BITS;
     static constexpr uint32_t EMPTY = 0xFFFFFFFFu;
     __device__ static uint32_t key(uint32_t mat, uint32_t x, uint32_t y, uint32_t N) { return (mat * N + x) * N + y; }
@@ -973,7 +928,6 @@ struct Acc32 {
 #endif
 struct Acc32Split {
     typedef uint32_t KT;
-    static constexpr bool GROUPED = false;
     static constexpr uint32_t BITS = ACC_BITS;
     static constexpr uint32_t HALF = 1u << (ACC_BITS - 1u);
     static constexpr uint32_t NG = ACC_NODE_GROUPS, SG = ACC_SLOTS / 16u - ACC_NODE_GROUPS;
@@ -1000,7 +954,6 @@ struct Acc32Split {
 };
 struct Acc64 {
     typedef unsigned long long KT;
-    static constexpr bool GROUPED = false;
     static constexpr uint32_t BITS = ACC_BITS - 1u;
     static constexpr unsigned long long EMPTY = ~0ull;
     __device__ static unsigned long long key(uint32_t mat, uint32_t x, uint32_t y, uint32_t N) {
@@ -1017,22 +970,6 @@ struct Acc64 {
 #endif
     __device__ static uint32_t mat_of(unsigned long long k, uint32_t, uint32_t) { return (uint32_t)(k >> 60); }
     __device__ static uint64_t cell_of(unsigned long long k, uint32_t) { return k & ((1ull << 60) - 1ull); }
-};
-
-// (r3) AccGrp (VS_ACC_WIDE=4 only -- measured slower than the tables above, see vs_pe_count): GROUPS of 16 cells -- one aligned 64-byte stretch of a matrix row --
-// under ONE tag (matrix << 28 | cell index >> 4), counts in 16 bits.  A group is 8 words of counts + 1 of tag where 16
-// cells of Acc32 take 32 words, so the same LDS holds 65 536 cells instead of 16 384; a look-up compares one tag; and a
-// write-out hands the 16 counts of a group to 16 neighbouring lanes, whose atomics leave the L2 as ONE memory-side
-// request.  A cell gets at most 2 per pair (short_mat's diagonal, PE_Inference.py:174-184), so 16 bits hold the rounds
-// between two write-outs as long as those are at most ACC_GRP_ROUNDS (31 x 1024 pairs x 2 < 65 536); two cells share a
-// word and are added to with one 32-bit LDS atomic (weight << 16 for the upper one: no carry can cross).
-#define ACC_GRP_ROUNDS 31u
-struct AccGrp {
-    typedef uint32_t KT;
-    static constexpr bool GROUPED = true;
-    static constexpr uint32_t BITS = ACC_BITS;  // (unused by the grouped paths: same LDS region)
-    static constexpr uint32_t EMPTY = 0xFFFFFFFFu;
-    __device__ static uint32_t group(uint32_t seg, uint32_t n_groups) { return (uint32_t)(((uint64_t)(seg * 0x9E3779B1u) * n_groups) >> 32); }
 };
 
 // Slow side of vs_cell_add: the slot is empty or holds another cell.  Kept out of line so that
@@ -1079,7 +1016,7 @@ __global__ void __launch_bounds__(ACC_TPB)
 k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_slots_pairs,
                 uint32_t pairs_per_wg, uint32_t N, uint32_t use_table, uint32_t fill_limit,
                 uint32_t *__restrict__ node_mat, uint32_t *__restrict__ short_mat, uint32_t *__restrict__ queue, uint32_t merge,
-                uint32_t *__restrict__ dbg, uint32_t ppw, uint32_t n_groups, uint32_t off0, uint32_t off1) {  // VS_DEBUG_ACC: [0] increments past the table, [1] write-outs, [2] cells written, [3] rounds
+                uint32_t *__restrict__ dbg, uint32_t ppw, uint32_t off0, uint32_t off1) {  // VS_DEBUG_ACC: [0] increments past the table, [1] write-outs, [2] cells written, [3] rounds
     using KT = typename TB::KT;
     constexpr uint32_t SLOTS = 1u << TB::BITS;
     KT *s_key = (KT *)vs_lds;                      // [SLOTS] keys: ACC_SLOTS words either way
@@ -1098,17 +1035,7 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
     uint32_t *s_down = s_ua + (LC + 1u) * ACC_GMAX + 4u;  // [ACC_DEDUP_SLOTS]
     uint32_t *s_dmul = s_down + ACC_DEDUP_SLOTS;          // [ACC_DEDUP_SLOTS]
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    // grouped table (AccGrp): counts = 8 words per group from the start of LDS, tags behind them -- in the dedup area when
-    // that is unused (4096 groups), else inside the table region (3584 groups: the host picks n_groups accordingly)
-    uint32_t *g_cnt = vs_lds;
-    uint32_t *g_tag = merge ? vs_lds + 8u * n_groups : s_down;
-    uint32_t rounds_since = 0;  // (uniform over the workgroup)
-    if constexpr (TB::GROUPED) {
-        for (uint32_t i = tid; i < 8u * n_groups; i += ACC_TPB) g_cnt[i] = 0u;
-        for (uint32_t i = tid; i < n_groups; i += ACC_TPB) g_tag[i] = TB::EMPTY;
-    } else {
-        for (uint32_t i = tid; i < SLOTS; i += ACC_TPB) { s_key[i] = TB::EMPTY; s_cnt[i] = 0; }
-    }
+    for (uint32_t i = tid; i < SLOTS; i += ACC_TPB) { s_key[i] = TB::EMPTY; s_cnt[i] = 0; }
     if (tid <= LC) {
         uint32_t gsum = 0;
         for (uint32_t m = 1; m <= tid; m++) gsum += (m + ACC_RUN - 1u) / ACC_RUN;
@@ -1125,34 +1052,16 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
     uint32_t &s_chunk = s_ua[(LC + 1u) * ACC_GMAX + 2u];
     // every cell of the table to its counter (one global atomic per cell), the table emptied
     auto write_out = [&]() {
-        if constexpr (TB::GROUPED) {
-            // 16 lanes per group, a lane per cell: tag and counts are read by all 16 before any of them clears (one wavefront,
-            // program order), the atomics of a group are one 64-byte stretch
-            for (uint32_t i = tid; i < 16u * n_groups; i += ACC_TPB) {
-                const uint32_t g = i >> 4, sub = i & 15u;
-                const uint32_t tag = g_tag[g];
-                if (tag != TB::EMPTY) {
-                    const uint32_t w2 = g_cnt[8u * g + (sub >> 1)];
-                    const uint32_t c = (w2 >> ((sub & 1u) * 16u)) & 0xFFFFu;
-                    const uint32_t mat = tag >> 28;
-                    if (c && use_table != 3u)
-                        atomicAdd((mat ? short_mat : node_mat) + ((((uint64_t)(tag & 0x0FFFFFFFu)) << 4) + sub - (mat ? off1 : off0)), c);
-                    if ((sub & 1u) == 0u) g_cnt[8u * g + (sub >> 1)] = 0u;
-                    if (sub == 0u) g_tag[g] = TB::EMPTY;
-                }
-            }
-        } else {
-        for (uint32_t i = tid; i < SLOTS; i += ACC_TPB) {
-            const KT key = s_key[i];
-            if (key != TB::EMPTY) {
-                if (use_table != 3u)  // (3: timing experiment without the write-outs)
-                    atomicAdd((TB::mat_of(key, N, i) ? short_mat : node_mat) + TB::cell_of(key, N), s_cnt[i]);
-                s_key[i] = TB::EMPTY;
-                s_cnt[i] = 0;
-            }
+    for (uint32_t i = tid; i < SLOTS; i += ACC_TPB) {
+        const KT key = s_key[i];
+        if (key != TB::EMPTY) {
+            if (use_table != 3u)  // (3: timing experiment without the write-outs)
+                atomicAdd((TB::mat_of(key, N, i) ? short_mat : node_mat) + TB::cell_of(key, N), s_cnt[i]);
+            s_key[i] = TB::EMPTY;
+            s_cnt[i] = 0;
         }
-        }
-        rounds_since = 0;
+    }
+    
         if (tid == 0) { s_used = 0; s_lost = 0; }
         __syncthreads();
     };
@@ -1325,77 +1234,31 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
                 if ((y0 ^ y1 ^ y2 ^ y3 ^ x) == 0xDEADBEEFu) atomicAdd(&s_lost, 1u);  // (timing experiment: decode only)
             } else if (use_table) {
                 const uint32_t ys[4] = {y0, y1, y2, y3};
-                if constexpr (TB::GROUPED) {
-                    // the four cells' group tags are read together (independent LDS loads), then counted; a group that
-                    // does not carry the cell's tag yet goes the slow way (claim / next group / global)
-                    uint32_t seg[4], sub[4], at[4], seen[4], cellv[4];
-                    bool live[4];
+            // the four cells' slots are read together (independent LDS loads), then counted; a
+            // slot that does not hold the cell yet goes the slow way (claim / probe / global)
+            KT key[4], seen[4];
+            uint32_t at[4];
+            bool live[4];
 #pragma unroll
-                    for (uint32_t j = 0; j < 4u; j++) {
-                        live[j] = bi + j < be;  // j = 0 always
-                        const uint32_t yv = ys[j];
-                        const uint32_t cx = (mat && yv < x) ? yv : x, cy = (mat && yv < x) ? x : yv;
-                        cellv[j] = cx * N + cy;  // (N <= 65535)
-                        const uint32_t c2 = cellv[j] + (mat ? off1 : off0);  // position counted from the 64-byte boundary before the matrix
-                        seg[j] = (c2 >> 4) | (mat << 28);
-                        sub[j] = c2 & 15u;
-                        at[j] = TB::group(seg[j], n_groups);
-                        seen[j] = g_tag[at[j]];
-                    }
+            for (uint32_t j = 0; j < 4u; j++) {
+                live[j] = bi + j < be;  // j = 0 always
+                const uint32_t yv = ys[j];
+                const uint32_t cx = (mat && yv < x) ? yv : x, cy = (mat && yv < x) ? x : yv;
+                key[j] = TB::key(mat, cx, cy, N);
+                at[j] = TB::slot(mat, key[j]);
+                seen[j] = s_key[at[j]];
+            }
 #pragma unroll
-                    for (uint32_t j = 0; j < 4u; j++) {
-                        if (!live[j]) continue;
-                        const uint32_t add = wgt << ((sub[j] & 1u) * 16u);
-                        if (seen[j] == seg[j]) {
-                            atomicAdd(&g_cnt[8u * at[j] + (sub[j] >> 1)], add);
-                            continue;
-                        }
-                        uint32_t g = at[j];
-                        bool done = false;
-                        for (uint32_t pr = 0; pr < 8u; pr++) {
-                            uint32_t t2 = g_tag[g];
-                            if (t2 == TB::EMPTY) {
-                                t2 = atomicCAS(&g_tag[g], TB::EMPTY, seg[j]);
-                                if (t2 == TB::EMPTY) { atomicAdd(&s_used, 1u); t2 = seg[j]; }
-                            }
-                            if (t2 == seg[j]) {
-                                atomicAdd(&g_cnt[8u * g + (sub[j] >> 1)], add);
-                                done = true;
-                                break;
-                            }
-                            g = g + 1u == n_groups ? 0u : g + 1u;
-                        }
-                        if (!done) {
-                            atomicAdd(&s_lost, 1u);
-                            atomicAdd((mat ? short_mat : node_mat) + cellv[j], wgt);
-                        }
-                    }
-                } else {
-                // the four cells' slots are read together (independent LDS loads), then counted; a
-                // slot that does not hold the cell yet goes the slow way (claim / probe / global)
-                KT key[4], seen[4];
-                uint32_t at[4];
-                bool live[4];
-#pragma unroll
-                for (uint32_t j = 0; j < 4u; j++) {
-                    live[j] = bi + j < be;  // j = 0 always
-                    const uint32_t yv = ys[j];
-                    const uint32_t cx = (mat && yv < x) ? yv : x, cy = (mat && yv < x) ? x : yv;
-                    key[j] = TB::key(mat, cx, cy, N);
-                    at[j] = TB::slot(mat, key[j]);
-                    seen[j] = s_key[at[j]];
+            for (uint32_t j = 0; j < 4u; j++) {
+                if (!live[j]) continue;
+                if (seen[j] == key[j]) {
+                    atomicAdd(&s_cnt[at[j]], wgt);
+                } else if (!vs_cell_claim<TB>(s_key, s_cnt, &s_used, key[j], at[j], wgt)) {
+                    atomicAdd(&s_lost, 1u);
+                    atomicAdd((mat ? short_mat : node_mat) + TB::cell_of(key[j], N), wgt);
                 }
-#pragma unroll
-                for (uint32_t j = 0; j < 4u; j++) {
-                    if (!live[j]) continue;
-                    if (seen[j] == key[j]) {
-                        atomicAdd(&s_cnt[at[j]], wgt);
-                    } else if (!vs_cell_claim<TB>(s_key, s_cnt, &s_used, key[j], at[j], wgt)) {
-                        atomicAdd(&s_lost, 1u);
-                        atomicAdd((mat ? short_mat : node_mat) + TB::cell_of(key[j], N), wgt);
-                    }
-                }
-                }
+            }
+            
             } else {
                 // (VS_NO_AGG=1: every increment a global atomic)
                 const uint32_t ys[4] = {y0, y1, y2, y3};
@@ -1409,8 +1272,7 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
             }
         }
         __syncthreads();
-        rounds_since++;
-        const bool spill = s_used > fill_limit || s_lost > 4096u || (TB::GROUPED && rounds_since >= ACC_GRP_ROUNDS);
+        const bool spill = s_used > fill_limit || s_lost > 4096u;
         if (dbg && tid == 0) {
             atomicAdd(dbg + 3, 1u);
             if (spill) { atomicAdd(dbg + 0, s_lost); atomicAdd(dbg + 1, 1u); atomicAdd(dbg + 2, s_used); }
@@ -1908,6 +1770,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     const VsIndexDev &idx = ctx->idx;
     const uint64_t n_ends = reads->n_ends, n_pairs = n_ends / 2;
     ctx->last_ms[0] = ctx->last_ms[1] = ctx->last_ms[2] = 0;
+    ctx->last_launched = 0;
     if (n_ends == 0) return VS_OK;
     const uint32_t maxlen = (uint32_t)reads->max_len;
     const uint32_t pmax = maxlen >= idx.w ? (maxlen - idx.w) / idx.s + 1u : 1u;
@@ -1916,10 +1779,6 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     // experiment switches: fixed defaults unless the process runs with VS_EXPERIMENT (see VsTuning)
     if (ctx->experiment_level) vs_tuning_load(ctx->tune, ctx->experiment_level);
     const VsTuning &tn = ctx->tune;
-    // VS_WALK=1 (experiment mode): certified graphs (vs_walk.h) are mapped by following the read through the graph
-    // (k_pe_walk) -- exact, but 13.7 ms against the seed kernel's 5.7 ms at configs[2]: not the default.
-    const bool use_walk = ctx->walk_ok && tn.walk && (!reads->d_mask || reads->d_inv4) && !tn.debug_stop && !tn.debug_postings &&
-                          vs_walk_lds_bytes(wpe) <= 64u * 1024u && maxlen < (1u << 20);
     uint32_t ept = tn.ept ? tn.ept : STD_EPT;
     if (ept < 2 || ept > TTPB / 2u) ept = STD_EPT;
     while (ept > 2 && (ept * pmax > NI_CAP || lds_bytes(ept, pmax, ept * wpe) > LDS_BUDGET_BYTES)) ept -= 2;
@@ -1933,9 +1792,8 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         }
     }
     size_t lds = lds_bytes(ept, pmax, ept * wpe);
-    if (!use_walk && lds > 160u * 1024u)
+    if (lds > 160u * 1024u)
         return vs_fail(ctx, VS_E_RANGE, "reads of %u bases with k+1=%u need %zu B of LDS per pair (limit 160 KiB)", maxlen, idx.K, lds);
-    if (use_walk) ept = VS_WALK_EPT;  // (tile size of k_pe_walk: the list rows below are laid out for it)
 
     // scratch: slow list (one slot per pair), counter, dense state
     if (ctx->slow_cap < n_pairs) {
@@ -2061,22 +1919,14 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     if (fast_long && ept == STD2_EPT && P.pool_bits == STD2_POOL_BITS && idx.K == STD2_K && idx.w == STD2_W && idx.s == STD2_S &&
         wpe == 16u && pmax == 3u && P.accumulate && !P.debug_stop && !P.count_postings && !P.dbg_counts && !tn.no_std)
         std_shape = 4;
-    // VS_INLINE=1 (experiment mode): 32-byte postings with the text around the seed, where most postings fit their flanks
-    // (graphs of short nodes).  Exact, but slower than the 16-byte records: a wavefront nearly always holds
-    // SOME posting that needs the node text after all, so it runs both comparisons.
-    const bool inl = fast && idx.postings32 && tn.use_inline && 2u * ctx->n_long_flank <= ctx->n_seed_pos;
-    const void *tiles_fn = inl && std_shape == 1   ? (const void *)k_pe_tiles<1, 10u, 5u, true>
-                           : inl && std_shape == 2 ? (const void *)k_pe_tiles<1, 8u, 4u, true>
-                           : inl && std_shape == 3 ? (const void *)k_pe_tiles<1, 7u, 3u, true>
-                           : inl && fast           ? (const void *)k_pe_tiles<1, 0u, 0u, true>
-                           : std_shape == 1 ? (const void *)k_pe_tiles<1, 10u, 5u>
+    const void *tiles_fn = std_shape == 1 ? (const void *)k_pe_tiles<1, 10u, 5u>
                            : std_shape == 2 ? (const void *)k_pe_tiles<1, 8u, 4u>
                            : std_shape == 3 ? (const void *)k_pe_tiles<1, 7u, 3u>
                            : fast           ? (const void *)k_pe_tiles<1, 0u, 0u>
                            : std_shape == 4 ? (const void *)k_pe_tiles<2, 16u, 3u>
                            : fast_long      ? (const void *)k_pe_tiles<2, 0u, 0u>
                                             : (const void *)k_pe_tiles<0, 0u, 0u>;
-    if (!use_walk && lds > 64u * 1024u)
+    if (lds > 64u * 1024u)
         VS_HIP(ctx, hipFuncSetAttribute(tiles_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (tn.debug_occ) {
         int nb = 0;
@@ -2095,6 +1945,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     if (use_sort) {
         const uint64_t nk = (uint64_t)idx.n_nodes + 2u;
         const bool lds_sort = nk <= LOCUS_LDS_MAX_PASSES * LOCUS_LDS_KEYS && !tn.locus_global;
+        ctx->last_launched |= lds_sort ? VS_RAN_LOCUS_LDS_SORT : VS_RAN_LOCUS_GLOBAL_SORT;
         // second key (the reverse read's locus) where the counter kernel is bound by global atomics: graphs beyond the
         // one-table shape of its cell table (VS_REFINE=0 / 1 overrides)
         const bool refine = tn.refine >= 0 ? tn.refine != 0 : 2ull * idx.n_nodes * idx.n_nodes >= 0xFFFFFFFFull;
@@ -2120,6 +1971,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
                 hipLaunchKernelGGL(k_locus_scatter, dim3(n_wg), dim3(LOCUS_TPB), lds_keys, st, key_lo, n_here, n_pairs, chunk, n_wg,
                                    (const uint32_t *)ctx->d_locus_keys, (const uint32_t *)ctx->d_locus_hist, (uint32_t *)ctx->d_perm);
             }
+            if (refine && idx.n_nodes) ctx->last_launched |= VS_RAN_LOCUS_REFINE;
             if (refine && idx.n_nodes)
                 hipLaunchKernelGGL(k_locus_refine, dim3(idx.n_nodes), dim3(TPB), 0, st, idx, reads->dev(), n_wg, n_pairs,
                                    (const uint32_t *)ctx->d_locus_hist, (uint32_t *)ctx->d_perm);
@@ -2137,56 +1989,14 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     }
     VS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     if (!d_node_mat) VS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
-    if (use_walk) {
-        VsWalkParams W;
-        W.idx = idx;
-        W.wk = ctx->walk;
-        W.rd = reads->dev();
-        W.perm = P.perm;
-        W.n_pairs = n_pairs;
-        W.n_tiles = P.n_tiles;
-        W.wpe = wpe;
-        const uint32_t ws = wpe | 1u;
-        W.magic_ws = ws > 1u ? (uint32_t)(0x100000000ull / ws) + 1u : 0u;
-        W.no_xcd_map = P.no_xcd_map;
-        W.accumulate = P.accumulate;
-        W.dbg_cap = dbg_cap;
-        W.out_lists = P.out_lists;
-        W.out_counts = P.out_counts;
-        W.stats = P.stats;
-        W.slow_list = P.slow_list;
-        W.slow_count = P.slow_count;
-        W.dbg_lists = d_dbg_lists;
-        W.dbg_counts = d_dbg_counts;
-        uint64_t wgrid = W.n_tiles;
-        const uint64_t wmax = (uint64_t)ctx->n_cu * (tn.grid_per_cu < 32u ? tn.grid_per_cu : 32u);
-        if (wgrid > wmax) wgrid = wmax;
-        W.tiles_per_wg = (uint32_t)((W.n_tiles + wgrid - 1) / wgrid);
-        wgrid = (W.n_tiles + W.tiles_per_wg - 1) / W.tiles_per_wg;
-        ctx->last_kernel = vs_walk_kernel_name(ctx->walk.nw);
-        int wrc = vs_walk_launch(ctx, W, (uint32_t)wgrid, st);
-        if (wrc) return wrc;
-    } else {
-    ctx->last_kernel = inl && std_shape == 1   ? "k_pe_tiles<1, 10u, 5u, true>"
-                       : inl && std_shape == 2 ? "k_pe_tiles<1, 8u, 4u, true>"
-                       : inl && std_shape == 3 ? "k_pe_tiles<1, 7u, 3u, true>"
-                       : inl && fast           ? "k_pe_tiles<1, 0u, 0u, true>"
-                       : std_shape == 1 ? "k_pe_tiles<1, 10u, 5u>"
+    ctx->last_kernel = std_shape == 1 ? "k_pe_tiles<1, 10u, 5u>"
                        : std_shape == 2 ? "k_pe_tiles<1, 8u, 4u>"
                        : std_shape == 3 ? "k_pe_tiles<1, 7u, 3u>"
                        : fast           ? "k_pe_tiles<1, 0u, 0u>"
                        : std_shape == 4 ? "k_pe_tiles<2, 16u, 3u>"
                        : fast_long      ? "k_pe_tiles<2, 0u, 0u>"
                                         : "k_pe_tiles<0, 0u, 0u>";
-    if (inl && std_shape == 1)
-        hipLaunchKernelGGL((k_pe_tiles<1, 10u, 5u, true>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
-    else if (inl && std_shape == 2)
-        hipLaunchKernelGGL((k_pe_tiles<1, 8u, 4u, true>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
-    else if (inl && std_shape == 3)
-        hipLaunchKernelGGL((k_pe_tiles<1, 7u, 3u, true>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
-    else if (inl && fast)
-        hipLaunchKernelGGL((k_pe_tiles<1, 0u, 0u, true>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
-    else if (std_shape == 1)
+    if (std_shape == 1)
         hipLaunchKernelGGL((k_pe_tiles<1, 10u, 5u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
     else if (std_shape == 2)
         hipLaunchKernelGGL((k_pe_tiles<1, 8u, 4u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
@@ -2200,7 +2010,6 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         hipLaunchKernelGGL((k_pe_tiles<2, 0u, 0u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
     else
         hipLaunchKernelGGL((k_pe_tiles<0, 0u, 0u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
-    }
     if (d_node_mat) {
         // the last tile may be partly empty: its unused rows must read as length 0
         const uint64_t used_ends = 2ull * n_pairs;
@@ -2225,19 +2034,15 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         // 32-bit cell keys while 2*N*N fits, 64-bit keys (half the slots) above; VS_ACC_WIDE=1 forces
         // the wide table, VS_NO_AGG=1 turns the table off (every increment a global atomic)
         // table shape (see Acc32 / Acc32Split / Acc64); VS_ACC_WIDE=1 forces the 64-bit keys, =2 the split tables
-        // VS_ACC_WIDE=1 forces the 64-bit keys, =2 the split 32-bit tables, =4 the grouped table (AccGrp, shape 3: exact,
-        // 65 536 cells in the same LDS, and slower -- 47 against 35 ms at configs[4], 3.5 against 2.3 at configs[2]: a group of
-        // 16 cells is claimed whole and a round's cells fill 1.5-2 of the 16, so it holds fewer cells, not more)
         const int force_shape = tn.acc_wide;
         const bool fits32 = 2ull * idx.n_nodes * idx.n_nodes < 0xFFFFFFFFull, fits_split = idx.n_nodes <= 65535u;
-        const int shape = force_shape == 1 ? 2 : (force_shape == 2 && fits_split) ? 1 : (force_shape == 4 && fits_split) ? 3 : fits32 ? 0 : fits_split ? 1 : 2;
+        const int shape = force_shape == 1 ? 2 : (force_shape == 2 && fits_split) ? 1 : fits32 ? 0 : fits_split ? 1 : 2;
         const bool wide = shape == 2;
         const uint32_t merge = (tn.acc_merge || shape == 1) ? 1u : 0u;
-        const uint32_t n_groups = merge ? 3584u : 4096u;  // (with the dedup area in use the tags move into the table region)
-        const uint32_t slots = shape == 3 ? n_groups : wide ? ACC_SLOTS / 2u : ACC_SLOTS;
+        const uint32_t slots = wide ? ACC_SLOTS / 2u : ACC_SLOTS;
         // the table is written out once this many of its slots (groups) are taken: probing stays
         // short at a low fill, and cells of loci the run has left do not pile up (VS_ACC_FILL: percent)
-        uint32_t fill_limit = shape == 3 ? slots / 8u : slots / 16u;
+        uint32_t fill_limit = slots / 16u;
         if (tn.acc_fill_pct >= 0) fill_limit = (uint32_t)((uint64_t)slots * (uint32_t)tn.acc_fill_pct / 100u);
         uint32_t use_table = tn.no_agg ? 0u : 1u;
         if (tn.acc_ablate >= 0) use_table = (uint32_t)tn.acc_ablate;  // 2: decode only, 3: no write-outs (VS_EXPERIMENT=timing only)
@@ -2249,22 +2054,22 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         uint32_t *acc_dbg = tn.debug_acc ? (uint32_t *)ctx->d_slow_count + 4 : nullptr;
         const uint32_t acc_ppw = tn.acc_round ? tn.acc_round / (ACC_TPB / 64u) : 64u;  // VS_ACC_ROUND: pairs per round
         VS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
-        const void *acc_fn = shape == 3 ? (const void *)k_pe_accumulate<AccGrp> : shape == 2 ? (const void *)k_pe_accumulate<Acc64>
+        const void *acc_fn = shape == 2 ? (const void *)k_pe_accumulate<Acc64>
                              : shape == 1 ? (const void *)k_pe_accumulate<Acc32Split> : (const void *)k_pe_accumulate<Acc32>;
         const uint32_t off0 = (uint32_t)(((uintptr_t)d_node_mat >> 2) & 15u), off1 = (uint32_t)(((uintptr_t)d_short_mat >> 2) & 15u);
         VS_HIP(ctx, hipFuncSetAttribute(acc_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES));
 #define VS_ACC_LAUNCH(TB)                                                                                                         \
     hipLaunchKernelGGL(k_pe_accumulate<TB>, dim3(acc_grid), dim3(ACC_TPB), ACC_LDS_BYTES, st, (const uint32_t *)ctx->d_lists,     \
                        (const uint32_t *)ctx->d_list_counts, slots_pairs, per_wg, idx.n_nodes, use_table, fill_limit, d_node_mat, \
-                       d_short_mat, acc_queue, merge, acc_dbg, acc_ppw, n_groups, off0, off1)
-        if (shape == 3) VS_ACC_LAUNCH(AccGrp);
-        else if (shape == 2) VS_ACC_LAUNCH(Acc64);
+                       d_short_mat, acc_queue, merge, acc_dbg, acc_ppw, off0, off1)
+        if (shape == 2) VS_ACC_LAUNCH(Acc64);
         else if (shape == 1) VS_ACC_LAUNCH(Acc32Split);
         else VS_ACC_LAUNCH(Acc32);
 #undef VS_ACC_LAUNCH
     }
     VS_HIP(ctx, hipEventRecord(ctx->ev[1], st));
     // overflow pairs: one wavefront per pair with its state in LDS first, the general kernel for what that cannot hold
+    ctx->last_launched |= tn.no_mid ? 0u : VS_RAN_PE_MID;
     if (!tn.no_mid) {
         hipLaunchKernelGGL(k_pe_mid, dim3((unsigned)ctx->n_cu * 8u), dim3(TPB), 0, st, P, (const uint32_t *)ctx->d_slow_list,
                            (const uint32_t *)ctx->d_slow_count, (uint32_t)n_pairs, (uint32_t *)ctx->d_slow_list2, (uint32_t *)ctx->d_slow_count + 8);
@@ -2285,6 +2090,7 @@ extern "C" int vs_pe_count(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_
 }
 
 extern "C" const char *vs_pe_last_kernel(const vs_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
+extern "C" uint32_t vs_pe_last_launched(const vs_ctx *ctx) { return ctx ? ctx->last_launched : 0u; }
 
 extern "C" int vs_pe_last_timing(vs_ctx *ctx, double ms[5]) {
     if (!ctx || !ms) return VS_E_ARG;

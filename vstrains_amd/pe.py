@@ -199,34 +199,6 @@ def node_order(seqs: Sequence[str], ksize: int, _encoded=None) -> np.ndarray:
     return order[: len(seqs)].astype(np.int64)
 
 
-def certify_walk_host(seqs: Sequence[str], ksize: int) -> dict:
-    """Host-only run of the walk-index certification (no device): what ``Context.build_index`` would decide."""
-    data, off = encode_seqs(seqs)
-    a = (C.c_uint64 * 8)()
-    why = C.create_string_buffer(256)
-    rc = nat.lib().vs_walk_certify_host(data.ctypes.data, off.ctypes.data, len(seqs), ksize, a, why, 256)
-    if rc != nat.VS_OK:
-        raise nat.NativeError(rc, "vs_walk_certify_host")
-    return dict(certified=bool(a[0]), kmers=int(a[1]), presence_mers=int(a[2]), successor_links=int(a[3]), kmer_slots=int(a[4]),
-                presence_slots=int(a[5]), device_bytes=int(a[6]), presence_mer_len=int(a[7]), why_not=why.value.decode())
-
-
-def walk_map_ends_host(seqs: Sequence[str], ksize: int, reads: Sequence[str], cap: int = 16):
-    """Host twin of k_pe_walk's per-end work (tests): per read end the sorted accepted node indices, or None where the
-    kernel would hand the pair to the overflow kernel.  Returns None when the node set does not certify."""
-    data, off = encode_seqs(seqs)
-    rdata, roff = encode_seqs(reads)
-    lists = np.zeros((max(len(reads), 1), cap), dtype=np.uint32)
-    counts = np.zeros(max(len(reads), 1), dtype=np.uint32)
-    rc = nat.lib().vs_walk_map_ends_host(data.ctypes.data, off.ctypes.data, len(seqs), ksize, rdata.ctypes.data, roff.ctypes.data,
-                                         len(reads), cap, lists.ctypes.data, counts.ctypes.data)
-    if rc == 1:
-        return None
-    if rc != 0:
-        raise nat.NativeError(rc, "vs_walk_map_ends_host")
-    return [None if counts[e] == 0xFFFFFFFF else sorted(int(x) for x in lists[e, : counts[e]]) for e in range(len(reads))]
-
-
 # ---- device objects ------------------------------------------------------------------------------
 class ReadBlock:
     def __init__(self, ctx: "Context", handle):
@@ -350,15 +322,6 @@ class Context:
         nat.check(self._h, nat.lib().vs_index_info(self._h, a))
         return dict(seed_len=a[0], stride=a[1], seed_positions=a[2], slots=a[3], distinct_seeds=a[4], device_bytes=a[5])
 
-    @property
-    def walk_info(self):
-        """Did the node set certify for the graph-following kernel (csrc/vs_walk.h), and the size of its tables."""
-        a = (C.c_uint64 * 8)()
-        why = C.create_string_buffer(256)
-        nat.check(self._h, nat.lib().vs_walk_info(self._h, a, why, 256))
-        return dict(certified=bool(a[0]), kmers=int(a[1]), presence_mers=int(a[2]), successor_links=int(a[3]), kmer_slots=int(a[4]),
-                    presence_slots=int(a[5]), device_bytes=int(a[6]), presence_mer_len=int(a[7]), why_not=why.value.decode())
-
     def pack(self, ascii_bytes: np.ndarray, off: np.ndarray) -> ReadBlock:
         ascii_bytes = np.ascontiguousarray(ascii_bytes, dtype=np.uint8)
         off = np.ascontiguousarray(off, dtype=np.uint64)
@@ -399,6 +362,13 @@ class Context:
     def last_kernel(self) -> str:
         """Name of the mapping-kernel instantiation the last ``pe_count`` launched."""
         return (nat.lib().vs_pe_last_kernel(self._h) or b"").decode()
+
+    RAN_LOCUS_LDS_SORT, RAN_LOCUS_GLOBAL_SORT, RAN_LOCUS_REFINE, RAN_PE_MID = 1, 2, 4, 8
+
+    @property
+    def last_launched(self) -> int:
+        """VS_RAN_* bits: which optional kernels the most recent ``pe_count`` launched."""
+        return int(nat.lib().vs_pe_last_launched(self._h))
 
     def map_ends(self, reads: ReadBlock, cap: int = 64) -> List[List[int]]:
         n = reads.info["ends"]
