@@ -165,6 +165,17 @@ int vs_synth_pairs(vs_ctx *ctx, const uint8_t *genomes, const uint64_t *goff,
 int vs_pe_count(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, uint32_t *d_short_mat,
                 uint64_t *d_stats);
 
+/* The same with a record of WHERE the counts went: d_tile_map holds one byte per 64 x 64 tile of node_mat followed by one
+ * per tile of short_mat (2 * T * T bytes, T = ceil(N / 64), DEVICE memory, zero before the first call); the tiles the
+ * block adds to are set to 1.  A caller that wants empty counters for the next block then calls vs_counts_zero_tracked
+ * -- zero every marked tile, clear the map -- instead of clearing 2 * N * N cells: the counters of a 50 k-node graph are
+ * 23.7 GB and a block touches a few per cent of them.  (The reference allocates its matrices once, PE_Inference.py:
+ * 139-140; per-block zeroing exists only where a caller counts blocks separately, as bench.py's steps do.)  Ranks that
+ * sum their counters must OR their maps too before they zero (a maximum over the bytes). */
+int vs_pe_count_tracked(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, uint32_t *d_short_mat,
+                        uint64_t *d_stats, uint8_t *d_tile_map);
+int vs_counts_zero_tracked(vs_ctx *ctx, uint32_t *d_node_mat, uint32_t *d_short_mat, uint32_t n, uint8_t *d_tile_map);
+
 /* d_wide[i] += d_counts[i] (read as uint32); d_counts[i] = 0, for i < n.  DEVICE pointers.  The
  * reference's matrices are numpy.zeros(..., dtype=int) = int64 (PE_Inference.py:139-140): a caller
  * that counts more pairs than a uint32 cell can hold folds into int64 totals in between. */

@@ -146,3 +146,37 @@ def compare(case, out_dir, skip=()):
     if extra:
         problems.append("unexpected files " + ",".join(extra))
     return problems, got
+
+
+def reference_command_inputs(work):
+    """The inputs tools/time_reference.py gave the REAL reference command at BASELINE configs[0] (and the digests it
+    committed, tests/golden/reference_digests.json "configs[0]_whole_command"): the config's assembler-style GFA + contig
+    paths and its 100 000 read pairs as FASTQ text (the CPU twin of the device generator, the same stream the bench counts)."""
+    import json
+
+    from oracle import pe_oracle_c
+    from vstrains_amd.workloads import CONFIGS, workload_for
+
+    with open(os.path.join(HERE, "golden", "reference_digests.json")) as fh:
+        want = json.load(fh)["configs[0]_whole_command"]
+    cfg = CONFIGS[0]
+    st, pre, names, seqs, cum, logger, _ = workload_for(0, work)
+    L = cfg["read_len"]
+    fw, rv = pe_oracle_c.synth_pairs(st.genomes, cum, want["stream_seed"], 0, want["pairs"], L, int(0.005 * 2 ** 32), int(0.001 * 2 ** 32))
+    paths = {"gfa": os.path.join(work, "input.gfa"), "paths": os.path.join(work, "input.paths")}
+    qual = b"I" * L
+    for key, arr, tag in (("fwd", fw, b"f"), ("rve", rv, b"r")):
+        paths[key] = os.path.join(work, key + ".fq")
+        with open(paths[key], "wb") as fh:
+            fh.write(b"".join(b"@%s%d\n%s\n+\n%s\n" % (tag, i, arr[i].tobytes(), qual) for i in range(arr.shape[0])))
+    return paths, want
+
+
+def reference_command_problems(out_dir, want):
+    """Files of ``want["files_sha256"]`` (the ones all eight runs of the real command agree on: both in-edge models of the
+    stand-in, hash seeds 0-3) that ``out_dir`` does not reproduce."""
+    import hashlib
+
+    got = gold.collect(out_dir)
+    return ["%s %s" % ("missing" if rel not in got else "differs", rel) for rel, sha in sorted(want["files_sha256"].items())
+            if rel not in got or hashlib.sha256(got[rel].encode()).hexdigest() != sha]

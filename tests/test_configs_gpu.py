@@ -195,6 +195,23 @@ def test_hip_path_reproduces_the_files_of_the_real_reference_script(host, ctx, t
         assert sha(path) == want[name + "_sha256"], name
 
 
+def test_cli_reproduces_the_real_reference_command_at_configs0(tmp_path):
+    """BASELINE configs[0] through the whole `vstrains`-compatible command on the device -- FASTQ ingest, PE-link inference,
+    the native stage handle, the final files -- against what the REAL reference command wrote on the same inputs
+    (tools/time_reference.py, build container: /root/reference/vstrains behind the graph-tool stand-in under both in-edge
+    models and hash seeds 0-3).  The 29 files all eight reference runs agree on, strain.paths / strain.fasta /
+    split_graph_final.gfa among them, must come out the same."""
+    from graph_case import reference_command_inputs, reference_command_problems
+    from vstrains_amd import cli
+
+    inp, want = reference_command_inputs(str(tmp_path / "work"))
+    out = str(tmp_path / "out")
+    cli.main(["-a", "spades", "-g", inp["gfa"], "-p", inp["paths"], "-o", out, "-fwd", inp["fwd"], "-rve", inp["rve"]])
+    assert len(want["files_sha256"]) >= 25 and "strain.paths" in want["files_sha256"]
+    problems = reference_command_problems(out, want)
+    assert not problems, problems
+
+
 def test_second_sort_key_with_loci_longer_than_its_workgroup_buffer(host, xctx, tmp_path, monkeypatch):
     """VS_REFINE=1 (the default for graphs beyond 46 k nodes: inside a forward-read locus the pairs are ordered by the
     reverse read's locus, one workgroup per locus with a bitonic sort in LDS) on configs[0]'s 216-node graph with 1.2 M

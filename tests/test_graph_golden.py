@@ -81,6 +81,74 @@ def test_pipeline_matches_reference_outputs(name, engine, tmp_path):
     assert not binding, binding
 
 
+# Files of the committed (rotate in-edge model, PYTHONHASHSEED 0) reference run that this build does NOT reproduce -- all of
+# them in one case, all of them files the reference itself writes differently under another hash seed (it iterates sets of
+# contig names, Decomposition.py:188,444; this build iterates in insertion order).  Everything else is held to the
+# committed run file by file, so that the cases whose binding set is small (hiv_like_k55 binds 4 of 59 files) still fail
+# when something regresses.
+KNOWN_SEED_DEPENDENT_DIFFERENCES = {"inv5_k31_mc_s219": 27}
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_every_file_equals_the_committed_rotate_model_run(name, tmp_path):
+    case = Case(name)
+    inp = case.inputs(str(tmp_path))
+    out = str(tmp_path / "out")
+    args = case.args(inp, out)
+    logger = file_logger(out)
+    try:
+        pipeline.run(args, logger, NativeBackend(case))
+    except KeyError:
+        assert case.meta["returncode"] != 0
+    for h in list(logger.handlers):
+        h.flush()
+    problems, _ = compare(case, out)
+    allowed = KNOWN_SEED_DEPENDENT_DIFFERENCES.get(name, 0)
+    assert len(problems) == allowed, problems
+    if allowed:
+        seed_dependent = set(case.meta["differs_under_other_hashseeds"])
+        assert all(p.split(" ", 1)[1] in seed_dependent for p in problems), problems
+
+
+def test_native_engine_reproduces_the_real_reference_command_at_configs0(tmp_path):
+    """The same pin as tests/test_configs_gpu.py::test_cli_reproduces_the_real_reference_command_at_configs0 on a box
+    without a GPU: the C oracle counts the 100 000 pairs, the native stage engine runs over the CPU checker of its device
+    operations, and the 29 files every run of the REAL reference command agrees on must come out the same."""
+    import numpy as np
+
+    from graph_case import reference_command_inputs, reference_command_problems
+    from oracle import pe_oracle_c
+    from vstrains_amd.graph.hip_ops import HipPeLinks  # noqa: F401  (only to show what the product would use)
+
+    inp, want = reference_command_inputs(str(tmp_path / "work"))
+
+    class OracleCountsNativeStages:
+        def pe_links(self, gfa, aln_dir, fwd, rve, ksize, names):
+            ids, seqs = pe_oracle.read_gfa_segments(gfa)
+            assert list(ids) == list(names)
+            f, r = pe_oracle.fastq_sequences(fwd), pe_oracle.fastq_sequences(rve)
+            node_mat, short_mat, _ = pe_oracle_c.Oracle(seqs, ksize).count_pairs(f, r)
+            os.makedirs(aln_dir, exist_ok=True)
+            for fname, mat in (("pe_info", node_mat), ("st_info", short_mat)):
+                with open(os.path.join(aln_dir, fname), "w") as fh:
+                    fh.write(pe_oracle.matrix_text(ids, mat))
+            return chk.DictPeLinks(names, node_mat, short_mat)
+
+        def native_stage(self, table):
+            return native_check.stage_over_checker(table.names, native_check.dense_links(table))
+
+    import argparse
+
+    out = str(tmp_path / "out")
+    for sub in ("gfa", "tmp", "paf", "aln"):
+        os.makedirs(os.path.join(out, sub))
+    args = argparse.Namespace(gfa_file=inp["gfa"], path_file=inp["paths"], fwd=inp["fwd"], rve=inp["rve"], output_dir=out,
+                              min_cov=None, min_len=250, ref_file=None, dev=False)
+    pipeline.run(args, quiet_logger(), OracleCountsNativeStages())
+    problems = reference_command_problems(out, want)
+    assert not problems, problems
+
+
 def test_report_which_golden_files_do_not_depend_on_the_in_edge_model(capsys):
     """The graph fixtures come from the real reference CLI behind a model of graph-tool's adjacency
     order (SURVEY.md 8c: unpinned).  Every case was generated under both in-edge-order models;

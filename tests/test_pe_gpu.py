@@ -182,6 +182,66 @@ def test_overflow_pairs_take_slow_path_and_stay_exact(host, xctx, no_mid, monkey
         assert lists[2 * p + 1] == orc.map_end(r[p])
 
 
+@pytest.mark.parametrize("case", ["dense_k11", "chain_k20", "strains_k55"])
+def test_tracked_counting_marks_every_touched_tile_and_zeroes_only_those(host, ctx, case):
+    """vs_pe_count_tracked / vs_counts_zero_tracked (PeCounter(track_tiles=True)): after a block every non-zero cell of both
+    matrices lies in a marked 64 x 64 tile -- the main path marks from the list rows, the overflow kernels (k_pe_mid,
+    k_pe_slow: the first two cases) where they add --, a reset leaves all-zero counters and an empty map, and a second
+    block counted after it equals the oracle: nothing of the first one is left."""
+    import torch
+
+    from vstrains_amd import synth
+
+    if case == "dense_k11":
+        g, f, r = _dense_case(11, 1500, 100, seed=301, snp=0.2)
+        seqs, k = g.seqs, 11
+    elif case == "chain_k20":
+        rng = np.random.default_rng(17)
+        k = 20
+        genome = "".join("ACGT"[i] for i in rng.integers(0, 4, size=700))
+        seqs = [genome[i: i + k + 1] for i in range(len(genome) - k)]
+        f, r = [], []
+        for i in range(400):
+            L = 120 if i % 3 else 50
+            a = int(rng.integers(0, len(genome) - 300))
+            f.append(genome[a: a + L])
+            r.append(synth.revcomp(genome[a + 150: a + 150 + L]))
+    else:
+        st = synth.make_strains(6, 5000, 0.05, seed=91)
+        g = synth.compact_dbg(st, 55)
+        f, r = synth.sample_pairs(st, 20000, 150, seed=92, sub_rate=0.01, n_rate=0.01)
+        seqs, k = g.seqs, 55
+    n = len(seqs)
+    assert n > 128  # (several tiles per side)
+    ctx.build_index(seqs, k)
+    orc = pe_oracle_c.Oracle(seqs, k)
+    half = len(f) // 2
+    counter = host.PeCounter(ctx, track_tiles=True)
+    counter.add(ctx.pack_pairs(f[:half], r[:half]))
+    torch.cuda.synchronize()
+    if case != "strains_k55":
+        assert ctx.last_timing()["slow_pairs"] > 0, "case does not exercise the overflow kernels"
+    T = (n + 63) // 64
+    marked = counter.tile_map.view(2, T, T).bool()
+    nz = counter.mats[:, :n, :n] != 0
+    tiles_nz = torch.zeros((2, T, T), dtype=torch.bool, device=nz.device)
+    idx = nz.nonzero()
+    tiles_nz[idx[:, 0], idx[:, 1] // 64, idx[:, 2] // 64] = True
+    assert bool((tiles_nz & ~marked).sum() == 0), "a non-zero cell lies in an unmarked tile"
+    assert int(marked.sum()) < 2 * T * T or n < 400  # (a banded matrix leaves tiles untouched)
+    first = counter.result()
+    want = orc.count_pairs(f[:half], r[:half])
+    assert np.array_equal(first[0], want[0]) and np.array_equal(first[1], want[1])
+    counter.reset()
+    torch.cuda.synchronize()
+    assert int(counter.mats.abs().sum()) == 0 and int(counter.tile_map.sum()) == 0
+    counter.add(ctx.pack_pairs(f[half:], r[half:]))
+    second = counter.result()
+    want = orc.count_pairs(f[half:], r[half:])
+    assert np.array_equal(second[0], want[0]) and np.array_equal(second[1], want[1])
+    assert second[2] == tuple(int(x) for x in want[2])
+
+
 def test_ends_with_a_hundred_nodes_pass_through_both_overflow_kernels(host, ctx):
     """A chain of nodes that advance ONE base each (every node k + 1 bases long): a 120-base read is accepted by 100 nodes
     -- beyond a list row (16) and beyond k_pe_mid's per-end list (64), so the pairs end in the general kernel; shorter reads

@@ -74,7 +74,16 @@ struct PeParams {
     uint64_t n_pairs;
     uint32_t no_xcd_map;             // VS_NO_XCD_MAP=1: workgroup b takes run b (experiments)
     uint32_t shortcut;               // overlapping-seed ownership shortcut for single postings (P3 stage A)
+    uint8_t *tile_map;               // vs_pe_count_tracked: one byte per 64 x 64 tile of node_mat, then of short_mat; NULL = none
+    uint32_t tile_T;                 // tiles per matrix side = ceil(N / 64)
 };
+
+// A counter cell is about to be added to: its tile is marked (a plain store of 1; racing stores write the same value).
+__device__ __forceinline__ void vs_mark_tile(uint8_t *map, uint32_t T, uint32_t mat, uint32_t x, uint32_t y) {
+    if (!map) return;
+    const uint64_t t = ((uint64_t)mat * T + (x >> 6)) * T + (y >> 6);
+    if (!map[t]) map[t] = 1;
+}
 
 struct Mem {  // one credited maximal exact match
     uint32_t cnt, minp, minj;
@@ -1290,6 +1299,106 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
     write_out();
 }
 
+// ---- which tiles of the counters a block touches (vs_pe_count_tracked) -------------------------------------------------
+// A pair adds to node_mat[l][r] for l in its left list, r in its right list, and to short_mat[min][max] for the pairs of
+// nodes of either list (PE_Inference.py:174-188): one lane per pair marks the 64 x 64 tiles those cells lie in, from the
+// same list rows k_pe_accumulate counts (the overflow kernels mark theirs where they add).  A caller that zeroes its
+// counters before every block then zeroes these tiles only (k_zero_tiles) -- a few per cent of a 50 k-node matrix.
+__global__ void __launch_bounds__(256) k_mark_tiles(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts,
+                                                   uint64_t n_slots_pairs, uint8_t *__restrict__ map, uint32_t T) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_slots_pairs) return;
+    const uint32_t nl = counts[2u * p], nr = counts[2u * p + 1u];
+    if (!nl && !nr) return;
+    const uint32_t *rl = lists + 2u * p * LC, *rr = rl + LC;
+    uint8_t *smap = map + (uint64_t)T * T;
+    // The distinct tile coordinates (node >> 6) of a list, up to eight of them, in registers (every index below is a
+    // compile-time constant: no scratch memory).  The rows come as 16-byte loads, only as many as the list is long.  A list
+    // with more than eight distinct coordinates takes the plain way.
+    uint32_t tl[8], tr[8], kl = 0, kr = 0;
+    bool over = false;
+    auto put = [&](uint32_t (&tt)[8], uint32_t &k, uint32_t t) {
+        bool seen = false;
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) seen |= j < k && tt[j] == t;
+        if (seen) return;
+        if (k >= 8u) { over = true; return; }
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++)
+            if (j == k) tt[j] = t;
+        k++;
+    };
+#pragma unroll
+    for (uint32_t j = 0; j < 8u; j++) { tl[j] = 0u; tr[j] = 0u; }
+#pragma unroll
+    for (uint32_t q = 0; q < LC / 4u; q++) {
+        if (4u * q < nl) {
+            const VsQuad v = *(const VsQuad *)(rl + 4u * q);
+            const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; i++)
+                if (4u * q + i < nl) put(tl, kl, e[i] >> 6);
+        }
+        if (4u * q < nr) {
+            const VsQuad v = *(const VsQuad *)(rr + 4u * q);
+            const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; i++)
+                if (4u * q + i < nr) put(tr, kr, e[i] >> 6);
+        }
+    }
+    if (over) {
+        for (uint32_t i = 0; i < nl; i++)
+            for (uint32_t j = 0; j < nr; j++) vs_mark_tile(map, T, 0u, rl[i], rr[j]);
+        for (uint32_t side = 0; side < 2u; side++) {
+            const uint32_t *row = side ? rr : rl;
+            const uint32_t n = side ? nr : nl;
+            for (uint32_t i = 0; i < n; i++)
+                for (uint32_t j = 0; j < n; j++) {
+                    const uint32_t x = row[i], y = row[j];
+                    if (x <= y) vs_mark_tile(map, T, 1u, x, y);
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (uint32_t a = 0; a < 8u; a++)
+#pragma unroll
+        for (uint32_t b = 0; b < 8u; b++)
+            if (a < kl && b < kr) {
+                const uint64_t t = (uint64_t)tl[a] * T + tr[b];
+                if (!map[t]) map[t] = 1;
+            }
+    // short_mat: a cell sits at (smaller node, larger node), its tile at (smaller, larger) tile coordinates
+#pragma unroll
+    for (uint32_t a = 0; a < 8u; a++)
+#pragma unroll
+        for (uint32_t b = 0; b < 8u; b++) {
+            if (a < kl && b < kl && tl[a] <= tl[b]) {
+                const uint64_t t = (uint64_t)tl[a] * T + tl[b];
+                if (!smap[t]) smap[t] = 1;
+            }
+            if (a < kr && b < kr && tr[a] <= tr[b]) {
+                const uint64_t t = (uint64_t)tr[a] * T + tr[b];
+                if (!smap[t]) smap[t] = 1;
+            }
+        }
+}
+
+// every marked tile of both matrices to zero, the map cleared: one wavefront per tile, a lane per column
+__global__ void __launch_bounds__(64) k_zero_tiles(uint32_t *__restrict__ node_mat, uint32_t *__restrict__ short_mat, uint32_t N, uint32_t T,
+                                                  uint8_t *__restrict__ map) {
+    const uint64_t t = blockIdx.x;
+    if (!map[t]) return;
+    const uint32_t mat = (uint32_t)(t / ((uint64_t)T * T));
+    const uint64_t r = t - (uint64_t)mat * T * T;
+    const uint32_t x0 = (uint32_t)(r / T) << 6, y = (((uint32_t)(r % T)) << 6) + threadIdx.x;
+    uint32_t *m = mat ? short_mat : node_mat;
+    if (y < N)
+        for (uint32_t x = x0; x < x0 + 64u && x < N; x++) m[(uint64_t)x * N + y] = 0u;
+    if (threadIdx.x == 0) map[t] = 0;
+}
+
 // ---- locus order -----------------------------------------------------------------------------------
 // Pairs are handed to k_pe_tiles sorted by the first node their forward read's seeds hit, so that
 // a tile holds pairs from one locus: they touch the same few node_mat / short_mat cells (summed in
@@ -1575,13 +1684,19 @@ k_pe_mid(PeParams P, const uint32_t *__restrict__ in_list, const uint32_t *__res
                 if (lane < n) sv[lane] = v;
             }
             vs_wave_sync();
-            for (uint32_t i = lane; i < nl * nr; i += 64u) atomicAdd(&P.node_mat[(uint64_t)L[i / nr] * N + R[i % nr]], 1u);
+            for (uint32_t i = lane; i < nl * nr; i += 64u) {
+                vs_mark_tile(P.tile_map, P.tile_T, 0u, L[i / nr], R[i % nr]);
+                atomicAdd(&P.node_mat[(uint64_t)L[i / nr] * N + R[i % nr]], 1u);
+            }
             for (uint32_t side = 0; side < 2u; side++) {
                 const uint32_t *sv = side ? R : L;
                 const uint32_t n = side ? nr : nl;
                 for (uint32_t i = lane; i < n * n; i += 64u) {
                     const uint32_t a = i / n, b = i % n, x = sv[a], y = sv[b];
-                    if (x < y || a == b) atomicAdd(&P.short_mat[(uint64_t)x * N + y], 1u);
+                    if (x < y || a == b) {
+                        vs_mark_tile(P.tile_map, P.tile_T, 1u, x, y);
+                        atomicAdd(&P.short_mat[(uint64_t)x * N + y], 1u);
+                    }
                 }
             }
         }
@@ -1706,8 +1821,10 @@ k_pe_slow(PeParams P, uint32_t *dense, uint32_t n_slow_cap, const uint32_t *__re
         if (P.accumulate) {
             for (uint64_t i = tid; i < (uint64_t)nl * nr; i += TPB) {
                 uint32_t a = (uint32_t)(i / nr), b = (uint32_t)(i - (uint64_t)a * nr);
-                atomicAdd(&P.node_mat[(uint64_t)__hip_atomic_load(&surv0[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * N +
-                                      __hip_atomic_load(&surv1[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)], 1u);
+                const uint32_t x = __hip_atomic_load(&surv0[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t y = __hip_atomic_load(&surv1[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                vs_mark_tile(P.tile_map, P.tile_T, 0u, x, y);
+                atomicAdd(&P.node_mat[(uint64_t)x * N + y], 1u);
             }
             for (uint32_t side = 0; side < 2; side++) {
                 const uint32_t *sv = side ? surv1 : surv0;
@@ -1716,7 +1833,10 @@ k_pe_slow(PeParams P, uint32_t *dense, uint32_t n_slow_cap, const uint32_t *__re
                     uint32_t a = (uint32_t)(i / n), b = (uint32_t)(i - (uint64_t)a * n);
                     uint32_t x = __hip_atomic_load(&sv[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     uint32_t y = __hip_atomic_load(&sv[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (x < y || a == b) atomicAdd(&P.short_mat[(uint64_t)x * N + y], 1u);
+                    if (x < y || a == b) {
+                        vs_mark_tile(P.tile_map, P.tile_T, 1u, x, y);
+                        atomicAdd(&P.short_mat[(uint64_t)x * N + y], 1u);
+                    }
                 }
             }
         }
@@ -1763,7 +1883,7 @@ static size_t lds_bytes(uint32_t ept, uint32_t pmax, uint32_t words_cap) {
 }
 
 static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, uint32_t *d_short_mat, uint64_t *d_stats,
-                     uint32_t *d_dbg_lists, uint32_t *d_dbg_counts, uint32_t dbg_cap) {
+                     uint32_t *d_dbg_lists, uint32_t *d_dbg_counts, uint32_t dbg_cap, uint8_t *d_tile_map = nullptr) {
     if (!ctx->has_index) return vs_fail(ctx, VS_E_STATE, "vs_pe_count: build an index first (vs_index_build)");
     VS_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -1891,6 +2011,8 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     P.dbg_counts = d_dbg_counts;
     P.dbg_cap = dbg_cap;
     P.accumulate = d_node_mat ? 1u : 0u;
+    P.tile_map = d_node_mat ? d_tile_map : nullptr;
+    P.tile_T = (idx.n_nodes + 63u) >> 6;
     P.no_xcd_map = tn.no_xcd_map ? 1u : 0u;
     // The shortcut spares a single posting its extension when the previous probe already owns the
     // match; it pays on graphs whose seeds are mostly unique.  Where seeds repeat (a compacted de
@@ -2054,6 +2176,9 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         uint32_t *acc_dbg = tn.debug_acc ? (uint32_t *)ctx->d_slow_count + 4 : nullptr;
         const uint32_t acc_ppw = tn.acc_round ? tn.acc_round / (ACC_TPB / 64u) : 64u;  // VS_ACC_ROUND: pairs per round
         VS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
+        if (d_tile_map && slots_pairs)  // (timed with the counter kernel: it is part of the counting)
+            hipLaunchKernelGGL(k_mark_tiles, dim3((unsigned)((slots_pairs + 255u) / 256u)), dim3(256), 0, st, (const uint32_t *)ctx->d_lists,
+                               (const uint32_t *)ctx->d_list_counts, slots_pairs, d_tile_map, P.tile_T);
         const void *acc_fn = shape == 2 ? (const void *)k_pe_accumulate<Acc64>
                              : shape == 1 ? (const void *)k_pe_accumulate<Acc32Split> : (const void *)k_pe_accumulate<Acc32>;
         const uint32_t off0 = (uint32_t)(((uintptr_t)d_node_mat >> 2) & 15u), off1 = (uint32_t)(((uintptr_t)d_short_mat >> 2) & 15u);
@@ -2087,6 +2212,24 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
 extern "C" int vs_pe_count(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, uint32_t *d_short_mat, uint64_t *d_stats) {
     if (!ctx || !reads || !d_node_mat || !d_short_mat || !d_stats) return VS_E_ARG;
     return pe_launch(ctx, reads, d_node_mat, d_short_mat, d_stats, nullptr, nullptr, 0);
+}
+
+extern "C" int vs_pe_count_tracked(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, uint32_t *d_short_mat, uint64_t *d_stats,
+                                   uint8_t *d_tile_map) {
+    if (!ctx || !reads || !d_node_mat || !d_short_mat || !d_stats || !d_tile_map) return VS_E_ARG;
+    return pe_launch(ctx, reads, d_node_mat, d_short_mat, d_stats, nullptr, nullptr, 0, d_tile_map);
+}
+
+extern "C" int vs_counts_zero_tracked(vs_ctx *ctx, uint32_t *d_node_mat, uint32_t *d_short_mat, uint32_t n, uint8_t *d_tile_map) {
+    if (!ctx || (n && (!d_node_mat || !d_short_mat || !d_tile_map))) return vs_fail(ctx, VS_E_ARG, "vs_counts_zero_tracked: bad argument");
+    if (!n) return VS_OK;
+    VS_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t T = (n + 63u) >> 6;
+    const uint64_t tiles = 2ull * T * T;
+    if (tiles > 0x7FFFFFFFull) return vs_fail(ctx, VS_E_RANGE, "vs_counts_zero_tracked: %u nodes make more tiles than one launch takes", n);
+    hipLaunchKernelGGL(k_zero_tiles, dim3((unsigned)tiles), dim3(64), 0, ctx->stream, d_node_mat, d_short_mat, n, T, d_tile_map);
+    VS_HIP(ctx, hipGetLastError());
+    return VS_OK;
 }
 
 extern "C" const char *vs_pe_last_kernel(const vs_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }

@@ -349,7 +349,11 @@ class Context:
                                                     sub_thresh, n_thresh, C.byref(h)))
         return ReadBlock(self, h)
 
-    def pe_count(self, reads: ReadBlock, node_mat_ptr: int, short_mat_ptr: int, stats_ptr: int):
+    def pe_count(self, reads: ReadBlock, node_mat_ptr: int, short_mat_ptr: int, stats_ptr: int, tile_map_ptr: Optional[int] = None):
+        if tile_map_ptr is not None:  # also mark the 64 x 64 counter tiles the block adds to
+            nat.check(self._h, nat.lib().vs_pe_count_tracked(self._h, reads._h, C.c_void_p(node_mat_ptr), C.c_void_p(short_mat_ptr),
+                                                             C.c_void_p(stats_ptr), C.c_void_p(tile_map_ptr)))
+            return
         nat.check(self._h, nat.lib().vs_pe_count(self._h, reads._h, C.c_void_p(node_mat_ptr),
                                                  C.c_void_p(short_mat_ptr), C.c_void_p(stats_ptr)))
 
@@ -398,7 +402,11 @@ class PeCounter:
     that bound is reached the buffer is folded into int64 totals on the device (``vs_counts_fold``),
     the reference's own cell type (``numpy.zeros(..., dtype=int)``, :139-140)."""
 
-    def __init__(self, ctx: Context, device: Optional[str] = None):
+    # counters at least this large keep a map of the 64 x 64 tiles their blocks touch, and ``reset`` zeroes those tiles
+    # only (vs_pe_count_tracked / vs_counts_zero_tracked); below it clearing the whole buffer is the cheaper way
+    TRACK_TILES_MIN_BYTES = 2 << 30
+
+    def __init__(self, ctx: Context, device: Optional[str] = None, track_tiles: Optional[bool] = None):
         import torch
 
         self.torch = torch
@@ -407,6 +415,10 @@ class PeCounter:
         n = ctx.n_nodes
         self.n = n
         self.mats = torch.zeros((2, max(n, 1), max(n, 1)), dtype=torch.int32, device=self.device)
+        if track_tiles is None:
+            track_tiles = self.device.type == "cuda" and self.mats.numel() * 4 >= self.TRACK_TILES_MIN_BYTES
+        tiles = (max(n, 1) + 63) // 64
+        self.tile_map = torch.zeros(2 * tiles * tiles, dtype=torch.uint8, device=self.device) if track_tiles else None
         self.stats = torch.zeros(3, dtype=torch.int64, device=self.device)
         self.wide = None          # int64 totals, allocated by the first fold
         self.pairs_in_buffer = 0  # pairs counted into ``mats`` since it was last empty (all ranks, after a sum)
@@ -418,7 +430,17 @@ class PeCounter:
         self.node_rank = getattr(ctx, "node_rank", None)
 
     def reset(self):
-        self.mats.zero_()
+        if self.tile_map is not None:
+            # only the tiles the blocks since the last reset touched (every add marks them, every sum over the ranks ORs the
+            # ranks' maps): the invariant is that a cell outside the marked tiles is zero
+            torch = self.torch
+            with torch.cuda.device(self.device):
+                self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+                nat.check(self.ctx._h, nat.lib().vs_counts_zero_tracked(self.ctx._h, C.c_void_p(self.mats[0].data_ptr()),
+                                                                        C.c_void_p(self.mats[1].data_ptr()), self.n,
+                                                                        C.c_void_p(self.tile_map.data_ptr())))
+        else:
+            self.mats.zero_()
         self.stats.zero_()
         if self.wide is not None:
             self.wide.zero_()
@@ -434,6 +456,8 @@ class PeCounter:
             self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
             nat.check(self.ctx._h, nat.lib().vs_counts_fold(self.ctx._h, C.c_void_p(self.mats.data_ptr()),
                                                             C.c_void_p(self.wide.data_ptr()), self.mats.numel()))
+        if self.tile_map is not None:
+            self.tile_map.zero_()  # (the fold left every uint32 cell at zero)
         self.pairs_in_buffer = 0
 
     def add(self, reads: ReadBlock):
@@ -447,7 +471,8 @@ class PeCounter:
         self.pairs_seen += n_pairs
         with torch.cuda.device(self.device):
             self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-            self.ctx.pe_count(reads, self.mats[0].data_ptr(), self.mats[1].data_ptr(), self.stats.data_ptr())
+            self.ctx.pe_count(reads, self.mats[0].data_ptr(), self.mats[1].data_ptr(), self.stats.data_ptr(),
+                              tile_map_ptr=self.tile_map.data_ptr() if self.tile_map is not None else None)
 
     def all_reduce(self):
         """Sum over the ranks of the process group, in place.  The ranks first agree (one small
@@ -475,6 +500,8 @@ class PeCounter:
         # counters are dense: dist.sum_counts_compact decides from the union, which every rank sees alike)
         self.last_all_reduce = vdist.sum_counts_compact(target, allow_compact=compact_votes == world)
         all_reduce_counts(None, self.stats)
+        if self.tile_map is not None:
+            vdist.all_reduce_max(self.tile_map)  # (the sum brought the other ranks' cells: their tiles are dirty here too)
         if not fold:
             self.pairs_in_buffer = total_in_buffers
 
@@ -488,6 +515,10 @@ class PeCounter:
             raise OverflowError("all_reduce_async sums uint32 buffers: 2 * %d pairs * %d ranks does not fit; use all_reduce()"
                                 % (self.pairs_in_buffer, world))
         work = all_reduce_counts_async(self.mats, self.stats)
+        if self.tile_map is not None:
+            import torch.distributed as dist
+
+            work.append(dist.all_reduce(self.tile_map, op=dist.ReduceOp.MAX, async_op=True))
         self.pairs_in_buffer *= world
         return work
 
