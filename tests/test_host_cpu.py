@@ -522,8 +522,36 @@ def _open_all_shards(host, fwd, rve, world):
             out = (C.c_uint64 * 3)()
             assert nat.lib().vs_fastq_count_part(path.encode(), rk, world, out) == 0
             vals += [int(out[0]), int(out[1]), int(out[2])]
-        per_rank.append(vals)
-    return [host.FastqPair.open_shard(fwd, rve, None, rk, world, all_gather=lambda mine: per_rank) for rk in range(world)]
+        per_rank.append(vals + [0])  # (seventh integer: this rank's failure flag)
+    # (the second exchange of open_shard is one status integer per rank)
+    return [host.FastqPair.open_shard(fwd, rve, None, rk, world, all_gather=lambda mine: per_rank if len(mine) > 1 else [[0]] * world)
+            for rk in range(world)]
+
+
+def test_a_rank_that_cannot_open_its_files_fails_every_rank(tmp_path):
+    """FastqPair.open_shard: the failure of one rank (a file it cannot open) travels with the exchanged counts, so its
+    peers raise instead of waiting in the next collective."""
+    from vstrains_amd import pe as host
+
+    fwd, rve = str(tmp_path / "f.fq"), str(tmp_path / "r.fq")
+    for path in (fwd, rve):
+        with open(path, "w") as fh:
+            fh.write("@a\nACGT\n+\nIIII\n" * 40)
+    seen = {}
+
+    def gather_for(rank):
+        def all_gather(mine):
+            seen[rank] = list(mine)
+            other = [10, 80, 0, 10, 80, 0, 1]  # rank 1 reports that it could not open a file
+            return [mine, other] if rank == 0 else [other, mine]
+        return all_gather
+
+    with pytest.raises(RuntimeError, match="rank"):
+        host.FastqPair.open_shard(fwd, rve, None, 0, 2, all_gather=gather_for(0))
+    assert seen[0][6] == 0
+    with pytest.raises(FileNotFoundError):
+        host.FastqPair.open_shard(str(tmp_path / "missing.fq"), rve, None, 1, 2, all_gather=gather_for(1))
+    assert seen[1][6] == 1  # (it still took part in the exchange before raising)
 
 
 def test_cooperative_fastq_open_gives_every_rank_its_block_and_only_its_bytes(tmp_path):

@@ -2021,6 +2021,9 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     // 5.8 ms without.  VS_SHORTCUT=0/1 overrides.
     P.shortcut = ctx->n_distinct && ctx->n_seed_pos < 2 * ctx->n_distinct ? 1u : 0u;
     if (tn.shortcut >= 0) P.shortcut = (uint32_t)tn.shortcut;
+    // (63-base seeds have MIXED keys: equal keys do not prove equal seeds, so "the bases in between match too" does not
+    // follow from two key hits on one diagonal -- the shortcut is for exact keys only, whatever the switch says)
+    if (VS_SEED_VERIFIED(idx.w) == 0u) P.shortcut = 0u;
 
     // straight-line extension when the whole block qualifies (see vs_extend_fast)
     // (reads with bytes outside ACGT qualify through their position lists, see k_inv4 / vs_seed_limits)

@@ -71,14 +71,18 @@ class FastqPair:
         from .dist import shard_range
 
         L = nat.lib()
-        mine = []
+        # A rank that fails (a missing file, a stale count) must not leave its peers waiting in the exchange: the failure
+        # travels WITH the counts (a seventh integer) and with a second, one-integer exchange after the open, and every
+        # rank raises.
+        mine, failure = [], None
         for path in (fwd, rve):
             out = (C.c_uint64 * 3)()
             rc = L.vs_fastq_count_part(path.encode(), rank, world, out)
-            if rc != nat.VS_OK:
+            if rc != nat.VS_OK and failure is None:
                 msg = L.vs_last_error(None).decode("utf-8", "replace")
-                raise FileNotFoundError(msg) if "cannot open" in msg else nat.NativeError(rc, msg)
-            mine += [int(out[0]), int(out[1]), int(out[2])]
+                failure = FileNotFoundError(msg) if "cannot open" in msg else nat.NativeError(rc, msg)
+            mine += [int(out[0]), int(out[1]), int(out[2])] if rc == nat.VS_OK else [0, 0, 0]
+        mine.append(0 if failure is None else 1)
         if all_gather is None:
             import torch
             import torch.distributed as dist
@@ -92,6 +96,11 @@ class FastqPair:
                 return [[int(x) for x in g.cpu().tolist()] for g in got]
 
         everyone = all_gather(mine)
+        if failure is not None:
+            raise failure
+        failed = [r for r, vals in enumerate(everyone) if len(vals) > 6 and vals[6]]
+        if failed:
+            raise RuntimeError("FASTQ open failed on rank(s) %s" % failed)
         flags = 0
         for vals in everyone:
             flags |= vals[2] | vals[5]
@@ -112,8 +121,17 @@ class FastqPair:
         h = C.c_void_p()
         rc = L.vs_fastq_open_records(ctx._h if ctx is not None else None, fwd.encode(), rve.encode(), world, counts[0].ctypes.data,
                                      counts[1].ctypes.data, first, last, C.byref(h))
+        err = None
         if rc != nat.VS_OK:
-            raise nat.NativeError(rc, L.vs_last_error(ctx._h if ctx is not None else None).decode("utf-8", "replace"))
+            err = nat.NativeError(rc, L.vs_last_error(ctx._h if ctx is not None else None).decode("utf-8", "replace"))
+        status = all_gather([0 if err is None else 1])
+        if err is not None:
+            raise err
+        failed = [r for r, vals in enumerate(status) if vals[0]]
+        if failed:
+            if h:
+                L.vs_fastq_close(h)
+            raise RuntimeError("FASTQ open failed on rank(s) %s" % failed)
         self._h = h
         self.n_pairs = last - first
         self.lines = tuple(lines)
