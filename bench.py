@@ -579,14 +579,14 @@ def cpu_baseline(ctx, host, st, g, cum, seed, L, k, sub_thresh, n_thresh, R, tar
     # how this box's port relates to the reference script itself (which cannot travel here): measured
     # in the build container by tools/time_reference.py on the same workload
     try:
-        with open(os.path.join(ROOT, "profiles", "r3", "cpu_reference.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r4", "cpu_reference.json")) as fh:
             ref = json.load(fh)["configs"].get("configs[%d]" % config)
         if ref:
             out["reference_ratio"] = ref["port_over_reference"]
             out["reference"] = {"pairs_per_s_build_container": ref["reference"]["pairs_per_s"],
                                 "port_pairs_per_s_build_container": ref["port"]["pairs_per_s"],
                                 "estimated_pairs_per_s_on_this_host": out["value"] / ref["port_over_reference"],
-                                "source": "profiles/r3/cpu_reference.json: real VStrains_PE_Inference.py vs the port on the same "
+                                "source": "profiles/r4/cpu_reference.json: real VStrains_PE_Inference.py vs the port on the same "
                                           "%d pairs, same box, 1 core each" % ref["pairs"]}
     except Exception:
         pass

@@ -823,7 +823,7 @@ void vs_stage::reinit(const std::string &filename) {
         ng.etgt.push_back((uint32_t)t);
         ng.eovl.push_back(g.eovl[ent.v]);
         ng.eline.push_back(g.eline[ent.v]);
-        ne_map.set(ent.k, ei);
+        ne_map.append_new(ent.k, ei);  // (the keys of a map are distinct)
         deg[s]++;
         deg[t]++;
     }
@@ -1668,10 +1668,19 @@ void vs_stage::remap_contigs(const NameMap<std::vector<Nid>> &id_mapping, Closur
         for (auto &c : contigs.ents) {
             if (!c.live) continue;
             if (c.v.ids.empty()) throw StageError{VS_E_KEY, "IndexError", "list index out of range"};
-            bool alive = true;  // (the reference looks an id up only while some image is still being threaded)
+            // The reference looks an id up only while some image is still being threaded, i.e. while every step so far was an
+            // edge.  Whether a step is an edge otherwise only decides a DEBUG line, so the edge map is consulted only when
+            // DEBUG lines are collected -- or when an id turns out unknown and it matters whether the walk got that far.
+            bool alive = true;
             for (size_t i = 0; i < c.v.ids.size() && alive; i++) {
-                if (!closure.is_known(c.v.ids[i])) key_error(names[c.v.ids[i]]);
-                if (i > 0 && !edges.has(pair_key(c.v.ids[i - 1], c.v.ids[i]))) alive = false;
+                if (!closure.is_known(c.v.ids[i])) {
+                    bool reached = true;
+                    for (size_t j = 1; j <= i && reached; j++) reached = edges.has(pair_key(c.v.ids[j - 1], c.v.ids[j]));
+                    if (reached) key_error(names[c.v.ids[i]]);
+                    alive = false;
+                    break;
+                }
+                if (debug_log && i > 0 && !edges.has(pair_key(c.v.ids[i - 1], c.v.ids[i]))) alive = false;
             }
             if (!alive) debug("error, contig missed: " + names[c.k]);
         }

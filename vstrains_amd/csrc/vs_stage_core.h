@@ -189,7 +189,9 @@ inline Nid key_second(uint64_t k) { return (Nid)k; }
 
 // ---- dict keyed by a pair of names --------------------------------------------------------------------------------------
 // Entries in insertion order plus an open-address table of 32-bit entry numbers (0 = empty, ~0 = deleted): a lookup
-// costs one probe into a table a quarter the size of a key table, and the keys are read where the entries are.
+// costs one probe into a table a quarter the size of a key table, and the keys are read where the entries are.  The
+// table is built by the first lookup after `clear` / `append_new`: a map that is filled and only iterated (the edge map
+// of a re-initialised stage graph between two extracted paths) never pays for it.
 template <class V>
 struct PairMap {
     struct Ent {
@@ -198,12 +200,14 @@ struct PairMap {
         bool live;
     };
     std::vector<Ent> ents;
-    std::vector<uint32_t> tab;
-    size_t n_live = 0, n_filled = 0;  // live keys; occupied slots (live + deleted)
+    mutable std::vector<uint32_t> tab;
+    mutable size_t n_filled = 0;   // occupied slots (live + deleted)
+    mutable bool tab_valid = true;  // the table holds every live entry
+    size_t n_live = 0;
     static const uint32_t DELETED = 0xFFFFFFFFu;
 
     size_t size() const { return n_live; }
-    void rebuild_table(size_t cap) {
+    void rebuild_table(size_t cap) const {
         tab.assign(cap, 0u);
         n_filled = 0;
         const size_t mask = cap - 1;
@@ -214,9 +218,17 @@ struct PairMap {
             tab[i] = (uint32_t)e + 1u;
             n_filled++;
         }
+        tab_valid = true;
+    }
+    void need_table() const {
+        if (tab_valid) return;
+        size_t cap = tab.size() < 16 ? 16 : tab.size();
+        while (cap < 4 * (n_live + 1)) cap <<= 1;
+        rebuild_table(cap);
     }
     // slot of key k, or -1
     int64_t find_slot(uint64_t k) const {
+        need_table();
         if (tab.empty()) return -1;
         const size_t mask = tab.size() - 1;
         for (size_t i = (size_t)FlatIdx::mix(k) & mask;; i = (i + 1) & mask) {
@@ -235,6 +247,7 @@ struct PairMap {
         return i >= 0 ? &ents[tab[i] - 1u].v : nullptr;
     }
     void set(uint64_t k, V v) {
+        need_table();
         if (tab.empty() || 2 * (n_filled + 1) > tab.size()) {
             size_t cap = tab.empty() ? 16 : tab.size();
             while (cap < 4 * (n_live + 1)) cap <<= 1;
@@ -261,6 +274,13 @@ struct PairMap {
         ents.push_back(Ent{k, std::move(v), true});
         n_live++;
     }
+    // a key the caller knows to be absent (the edges of a re-initialised graph, each once): no lookup, the table is left
+    // to the first reader
+    void append_new(uint64_t k, V v) {
+        ents.push_back(Ent{k, std::move(v), true});
+        n_live++;
+        tab_valid = false;
+    }
     bool pop(uint64_t k, V *out = nullptr) {
         const int64_t i = find_slot(k);
         if (i < 0) return false;
@@ -273,15 +293,11 @@ struct PairMap {
     }
     void clear() {
         ents.clear();
-        std::fill(tab.begin(), tab.end(), 0u);
-        n_live = n_filled = 0;
+        n_live = 0;
+        n_filled = 0;
+        tab_valid = false;  // (the stale table is overwritten by the rebuild the first lookup asks for)
     }
-    void reserve(size_t n) {
-        ents.reserve(n);
-        size_t cap = 16;
-        while (cap < 4 * (n + 1)) cap <<= 1;
-        if (cap > tab.size()) rebuild_table(cap);
-    }
+    void reserve(size_t n) { ents.reserve(n); }
     void compact() {
         if (ents.size() == n_live) return;
         size_t w = 0;
@@ -291,7 +307,7 @@ struct PairMap {
             w++;
         }
         ents.resize(w);
-        rebuild_table(tab.empty() ? 16 : tab.size());
+        tab_valid = false;
     }
     std::vector<uint64_t> keys() const {
         std::vector<uint64_t> out;
