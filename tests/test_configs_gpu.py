@@ -82,6 +82,7 @@ def test_config4_50k_nodes_wide_cell_keys_and_global_sort(host, ctx, tmp_path):
     whole = _count(host, ctx, st, cum, seed, L, [(0, R)], sub, nth)
     t = ctx.last_timing()
     assert ctx.last_kernel.startswith("k_pe_tiles<1")  # the straight-line instantiation serves this config
+    assert ctx.last_launched & ctx.RAN_NODE_ROWS, "a graph beyond 46 340 nodes counts node_mat by row owners (k_node_rows)"
     parts = _count(host, ctx, st, cum, seed, L, [(0, 1), (1, 4999), (5000, 1_000_001), (1_005_001, R - 1_005_001)], sub, nth)
     assert torch.equal(whole.mats, parts.mats) and torch.equal(whole.stats, parts.stats)
     stats = whole.stats.cpu().tolist()
@@ -104,6 +105,67 @@ def test_config4_50k_nodes_wide_cell_keys_and_global_sort(host, ctx, tmp_path):
     orc = pe_oracle_c.Oracle(seqs, cfg["k"])
     _assert_equals_oracle(prefix, orc, st, cum, seed, L, M, sub, nth)
     assert t["slow_pairs"] >= 0
+
+
+def test_row_owner_counting_equals_the_cell_table_path_at_config4_size(host, xctx, tmp_path, monkeypatch):
+    """node_mat by row owners (k_rows_count / k_rows_fill / k_node_rows + the short_mat-only pass; the default beyond 46 340
+    nodes) against the path it replaces there (both matrices through the split cell table, VS_ACC_ROWS=0) on 2 M pairs of
+    configs[4]'s graph, with strips of 8 (default), 1 and 64 rows and a table that spills constantly."""
+    import torch
+
+    from vstrains_amd.workloads import CONFIGS, workload_for
+
+    cfg = CONFIGS[4]
+    ctx = xctx
+    st, pre, names, seqs, cum, logger, n_in = workload_for(4, str(tmp_path))
+    ctx.build_index(seqs, cfg["k"])
+    L, seed, R = cfg["read_len"], 4545, 2_000_000
+    sub, nth = int(0.005 * 2 ** 32), int(0.001 * 2 ** 32)
+    monkeypatch.setenv("VS_ACC_ROWS", "0")
+    old = _count(host, ctx, st, cum, seed, L, [(0, R)], sub, nth)
+    assert not ctx.last_launched & ctx.RAN_NODE_ROWS
+    for env in ({}, {"VS_ROWS_PER_STRIP": "1"}, {"VS_ROWS_PER_STRIP": "64", "VS_ACC_FILL": "1"}, {"VS_NO_SORT": "1"}):
+        monkeypatch.setenv("VS_ACC_ROWS", "1")
+        for k2, v in env.items():
+            monkeypatch.setenv(k2, v)
+        new = _count(host, ctx, st, cum, seed, L, [(0, R)], sub, nth)
+        assert ctx.last_launched & ctx.RAN_NODE_ROWS
+        assert torch.equal(old.mats, new.mats) and torch.equal(old.stats, new.stats), env
+        if new.tile_map is not None:  # every non-zero cell lies in a marked tile
+            n = new.n
+            T = (n + 63) // 64
+            tm = new.tile_map.view(2, T, T).bool()
+            for mat in (0, 1):
+                for lo in range(0, n, 4096):
+                    blk = new.mats[mat, lo:lo + 4096] != 0
+                    pad = torch.zeros((blk.shape[0] + 63) // 64 * 64, T * 64, dtype=torch.bool, device=blk.device)
+                    pad[:blk.shape[0], :n] = blk
+                    touched = pad.view(-1, 64, T, 64).any(dim=3).any(dim=1)
+                    assert not (touched & ~tm[mat, lo // 64:lo // 64 + touched.shape[0]]).any(), (env, mat, lo)
+        del new
+        torch.cuda.empty_cache()
+        for k2 in env:
+            monkeypatch.delenv(k2)
+
+
+def test_row_owner_counting_with_more_rows_per_chunk_than_lds_cursors(host, xctx, tmp_path, monkeypatch):
+    """VS_ACC_ROWS=1 on configs[2]'s 5 039-node graph in INPUT order (VS_NO_SORT=1): a chunk of 16 384 pairs then holds
+    nearly every node, more than the 4 096 rows k_rows_fill keeps an LDS cursor for -- the rest place their pairs through a
+    global cursor per entry.  Against the C oracle."""
+    from vstrains_amd.workloads import CONFIGS, workload_for
+
+    cfg = CONFIGS[2]
+    ctx = xctx
+    st, pre, names, seqs, cum, logger, n_in = workload_for(2, str(tmp_path))
+    ctx.build_index(seqs, cfg["k"])
+    L, seed, M = cfg["read_len"], 4646, 60_000
+    sub, nth = int(0.005 * 2 ** 32), int(0.001 * 2 ** 32)
+    monkeypatch.setenv("VS_ACC_ROWS", "1")
+    monkeypatch.setenv("VS_NO_SORT", "1")
+    got = _count(host, ctx, st, cum, seed, L, [(0, M)], sub, nth)
+    assert ctx.last_launched & ctx.RAN_NODE_ROWS
+    orc = pe_oracle_c.Oracle(seqs, cfg["k"])
+    _assert_equals_oracle(got, orc, st, cum, seed, L, M, sub, nth)
 
 
 def test_config3_10k_nodes_k127_reads_of_250(host, ctx, tmp_path):

@@ -527,6 +527,8 @@ def test_device_read_generator_equals_cpu_twin(host, ctx):
     {"VS_ACC_WIDE": "2"}, {"VS_ACC_WIDE": "2", "VS_ACC_FILL": "1"}, {"VS_ACC_WIDE": "2", "VS_ACC_FILL": "100", "VS_ACC_MERGE": "1"},
     {"VS_ACC_ROUND": "128"},
     {"VS_REFINE": "1"}, {"VS_REFINE": "1", "VS_EPT": "32", "VS_ACC_WIDE": "2"}, {"VS_NO_MID": "1"},
+    {"VS_ACC_ROWS": "1"}, {"VS_ACC_ROWS": "1", "VS_ROWS_PER_STRIP": "1"}, {"VS_ACC_ROWS": "1", "VS_ROWS_PER_STRIP": "64", "VS_ACC_FILL": "1"},
+    {"VS_ACC_ROWS": "1", "VS_NO_SORT": "1", "VS_ACC_QUEUE": "0"},
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_every_kernel_variant_gives_the_same_counters(host, xctx, env, monkeypatch):
     """The tuning switches select other code paths (input order instead of locus order, global
@@ -549,6 +551,8 @@ def test_every_kernel_variant_gives_the_same_counters(host, xctx, env, monkeypat
     assert np.array_equal(short_mat, want[1])
     assert stats == tuple(int(x) for x in want[2])
     assert ctx.last_kernel.startswith("k_pe_tiles"), ctx.last_kernel
+    # (node_mat goes to the row owners where asked, and by itself where the split table shape is forced)
+    assert bool(ctx.last_launched & ctx.RAN_NODE_ROWS) == (env.get("VS_ACC_ROWS") == "1" or env.get("VS_ACC_WIDE") == "2")
 
 
 def test_switches_do_not_exist_outside_experiment_mode(tmp_path):

@@ -35,6 +35,8 @@ void vs_tuning_load(VsTuning &t, int level) {
     if (const char *v = getenv("VS_SHORTCUT")) t.shortcut = atoi(v) != 0 ? 1 : 0;
     if (const char *v = getenv("VS_TABLE_SHIFT")) t.table_shift = atoi(v) < 1 ? 1u : atoi(v) > 8 ? 8u : (uint32_t)atoi(v);
     if (const char *v = getenv("VS_REFINE")) t.refine = atoi(v) != 0 ? 1 : 0;
+    if (const char *v = getenv("VS_ACC_ROWS")) t.acc_rows = atoi(v) != 0 ? 1 : 0;
+    if (const char *v = getenv("VS_ROWS_PER_STRIP")) t.rows_per_strip = atoi(v) > 0 && atoi(v) <= 64 ? (uint32_t)atoi(v) : 0u;
     t.no_sort = env_on("VS_NO_SORT");
     t.locus_global = env_on("VS_LOCUS_GLOBAL");
     t.no_xcd_map = env_on("VS_NO_XCD_MAP");
@@ -145,7 +147,7 @@ void vs_ctx_destroy(vs_ctx *ctx) {
     if (ctx->d_slow_count) (void)hipFree(ctx->d_slow_count);
     if (ctx->d_slow_list2) (void)hipFree(ctx->d_slow_list2);
     if (ctx->d_dense) (void)hipFree(ctx->d_dense);
-    for (void *q : {ctx->d_locus_keys, ctx->d_perm, ctx->d_locus_hist, ctx->d_scan_tmp, ctx->d_lists, ctx->d_list_counts})
+    for (void *q : {ctx->d_locus_keys, ctx->d_perm, ctx->d_locus_hist, ctx->d_scan_tmp, ctx->d_lists, ctx->d_list_counts, ctx->d_rows, ctx->d_row_entries})
         if (q) (void)hipFree(q);
     for (void *q : ctx->scratch)
         if (q) (void)hipFree(q);

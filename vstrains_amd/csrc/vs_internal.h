@@ -112,6 +112,8 @@ struct VsTuning {
     int shortcut = -1;              // VS_SHORTCUT (-1 = by index statistics)
     uint32_t table_shift = 3;       // VS_TABLE_SHIFT: seed table of >= (distinct seeds << shift) slots (3: at most an eighth full)
     int refine = -1;                // VS_REFINE (-1 = by graph size): second sort key, the reverse read's locus
+    int acc_rows = -1;              // VS_ACC_ROWS (-1 = by graph size): node_mat summed by row owners (k_node_rows)
+    uint32_t rows_per_strip = 0;    // VS_ROWS_PER_STRIP (0 = automatic): matrix rows one workgroup of k_node_rows owns at a time
     bool no_sort = false, locus_global = false, no_xcd_map = false, no_fast = false, no_std = false, no_agg = false;
     bool acc_queue = true, acc_merge = false;
     bool no_mid = false;            // VS_NO_MID: overflow pairs straight to k_pe_slow
@@ -152,6 +154,10 @@ struct vs_ctx {
     // per-end accepted lists between k_pe_tiles and k_pe_accumulate
     void *d_lists = nullptr, *d_list_counts = nullptr;
     uint64_t lists_cap = 0;
+    // row-owner counting of node_mat (k_rows_count / k_rows_fill / k_node_rows): per-row counts, cursors and offsets
+    // (3 x (N + 2) words), and the pairs of every row (one word per accepted node of a forward read)
+    void *d_rows = nullptr, *d_row_entries = nullptr;
+    uint64_t rows_cap = 0, row_entries_cap = 0;
     // grow-only device scratch slots of the graph-stage entry points (no hipMalloc per call)
     void *scratch[32] = {};
     size_t scratch_cap[32] = {};

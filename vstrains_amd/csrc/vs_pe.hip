@@ -981,6 +981,18 @@ struct Acc64 {
     __device__ static uint64_t cell_of(unsigned long long k, uint32_t) { return k & ((1ull << 60) - 1ull); }
 };
 
+// short_mat alone (node_mat goes through k_node_rows, see below): every slot is short_mat's, 32-bit keys x * N + y (N <= 65535)
+struct Acc32Short {
+    typedef uint32_t KT;
+    static constexpr uint32_t BITS = ACC_BITS;
+    static constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+    __device__ static uint32_t key(uint32_t, uint32_t x, uint32_t y, uint32_t N) { return x * N + y; }
+    __device__ static uint32_t slot(uint32_t, uint32_t k) { return Acc32::slot(0u, k); }
+    __device__ static uint32_t next(uint32_t at) { return Acc32::next(at); }
+    __device__ static uint32_t mat_of(uint32_t, uint32_t, uint32_t) { return 1u; }
+    __device__ static uint64_t cell_of(uint32_t k, uint32_t) { return (uint64_t)k; }
+};
+
 // Slow side of vs_cell_add: the slot is empty or holds another cell.  Kept out of line so that
 // the common case (the cell is already in the table) stays a short straight-line sequence.
 template <typename TB>
@@ -1025,7 +1037,7 @@ __global__ void __launch_bounds__(ACC_TPB)
 k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_slots_pairs,
                 uint32_t pairs_per_wg, uint32_t N, uint32_t use_table, uint32_t fill_limit,
                 uint32_t *__restrict__ node_mat, uint32_t *__restrict__ short_mat, uint32_t *__restrict__ queue, uint32_t merge,
-                uint32_t *__restrict__ dbg, uint32_t ppw, uint32_t off0, uint32_t off1) {  // VS_DEBUG_ACC: [0] increments past the table, [1] write-outs, [2] cells written, [3] rounds
+                uint32_t *__restrict__ dbg, uint32_t ppw, uint32_t skip_node, uint32_t off1) {  // skip_node: short_mat only (k_node_rows counts node_mat); VS_DEBUG_ACC: [0] increments past the table, [1] write-outs, [2] cells written, [3] rounds
     using KT = typename TB::KT;
     constexpr uint32_t SLOTS = 1u << TB::BITS;
     KT *s_key = (KT *)vs_lds;                      // [SLOTS] keys: ACC_SLOTS words either way
@@ -1168,7 +1180,7 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
         }
         // (list length, multiplicity) travel together through the cross-lane reads below
         const uint32_t nlw = nl | (ml << 8), nrw = nr | (mr << 8);
-        const uint32_t u = nl * ((nr + ACC_RUN - 1u) / ACC_RUN) + (ml ? s_g[nl] : 0u) + (mr ? s_g[nr] : 0u);
+        const uint32_t u = (skip_node ? 0u : nl * ((nr + ACC_RUN - 1u) / ACC_RUN)) + (ml ? s_g[nl] : 0u) + (mr ? s_g[nr] : 0u);
         uint32_t incl = u;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -1208,13 +1220,14 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
             const uint32_t ql = qlw & 0xFFu, qr = qrw & 0xFFu;
             const uint32_t row = 2u * a0 * LC;
             const uint32_t cq = (qr + ACC_RUN - 1u) / ACC_RUN;
+            const uint32_t node_runs = skip_node ? 0u : ql * cq;
             uint32_t off;
             R.wgt = 1u;
-            if (r < ql * cq) {  // node_mat: left node a, right positions of run c
+            if (r < node_runs) {  // node_mat: left node a, right positions of run c
                 const uint32_t a = cq == 1u ? r : cq == 2u ? r >> 1 : cq == 4u ? r >> 2 : (r * 43691u) >> 17;
                 R.x = wlists[row + a]; R.mat = 0u; off = row + LC; R.bi = ACC_RUN * (r - a * cq); R.be = qr;
             } else {
-                r -= ql * cq;
+                r -= node_runs;
                 uint32_t n = ql;
                 off = row;
                 R.wgt = qlw >> 8;
@@ -1305,7 +1318,8 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
 // same list rows k_pe_accumulate counts (the overflow kernels mark theirs where they add).  A caller that zeroes its
 // counters before every block then zeroes these tiles only (k_zero_tiles) -- a few per cent of a 50 k-node matrix.
 __global__ void __launch_bounds__(256) k_mark_tiles(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts,
-                                                   uint64_t n_slots_pairs, uint8_t *__restrict__ map, uint32_t T) {
+                                                   uint64_t n_slots_pairs, uint8_t *__restrict__ map, uint32_t T, uint32_t short_only) {
+    // (short_only: node_mat's tiles are marked by k_node_rows where it writes)
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_slots_pairs) return;
     const uint32_t nl = counts[2u * p], nr = counts[2u * p + 1u];
@@ -1348,7 +1362,7 @@ __global__ void __launch_bounds__(256) k_mark_tiles(const uint32_t *__restrict__
         }
     }
     if (over) {
-        for (uint32_t i = 0; i < nl; i++)
+        for (uint32_t i = 0; i < nl && !short_only; i++)
             for (uint32_t j = 0; j < nr; j++) vs_mark_tile(map, T, 0u, rl[i], rr[j]);
         for (uint32_t side = 0; side < 2u; side++) {
             const uint32_t *row = side ? rr : rl;
@@ -1361,14 +1375,16 @@ __global__ void __launch_bounds__(256) k_mark_tiles(const uint32_t *__restrict__
         }
         return;
     }
+    if (!short_only) {
 #pragma unroll
-    for (uint32_t a = 0; a < 8u; a++)
+        for (uint32_t a = 0; a < 8u; a++)
 #pragma unroll
-        for (uint32_t b = 0; b < 8u; b++)
-            if (a < kl && b < kr) {
-                const uint64_t t = (uint64_t)tl[a] * T + tr[b];
-                if (!map[t]) map[t] = 1;
-            }
+            for (uint32_t b = 0; b < 8u; b++)
+                if (a < kl && b < kr) {
+                    const uint64_t t = (uint64_t)tl[a] * T + tr[b];
+                    if (!map[t]) map[t] = 1;
+                }
+    }
     // short_mat: a cell sits at (smaller node, larger node), its tile at (smaller, larger) tile coordinates
 #pragma unroll
     for (uint32_t a = 0; a < 8u; a++)
@@ -1397,6 +1413,223 @@ __global__ void __launch_bounds__(64) k_zero_tiles(uint32_t *__restrict__ node_m
     if (y < N)
         for (uint32_t x = x0; x < x0 + 64u && x < N; x++) m[(uint64_t)x * N + y] = 0u;
     if (threadIdx.x == 0) map[t] = 0;
+}
+
+// ---- node_mat by ROW OWNERS (graphs beyond the one-table shape of the cell table) ---------------------------------------
+// In locus order a round of 1 024 pairs of a 54 k-node graph brings ~30 k distinct cells, more than the LDS table holds, and
+// the same cell comes back from loci hundreds of rounds apart: 1.9e9 node_mat increments leave k_pe_accumulate as several
+// 1e8 memory-side atomics for 2.5e7 distinct cells (configs[4]; tools/cell_probe.py).  Turned round -- output-stationary --
+// the sums fit: ONE matrix row has a few hundred distinct cells however many pairs add to it.  So the left lists are
+// transposed (row x -> the pairs whose forward read holds x: a counting sort of one word per accepted node), a workgroup
+// owns a strip of rows at a time, adds the right lists of the strip's pairs into its LDS cell table, and writes every cell
+// ONCE.  PE_Inference.py:185-188 is the loop being reordered; integer sums do not care.
+//   k_rows_count  histogram of the left lists per chunk of pairs (LDS, 16-bit counts), added to row_count
+//   (scan)        row_ptr = exclusive sums
+//   k_rows_fill   the same histogram again; a chunk reserves its stretch of every row it holds with one global atomic,
+//                 then places its pairs through LDS cursors
+//   k_node_rows   strips of rows off a queue; a lane per (pair of the row, quad of its right list)
+#define ROWS_CHUNK 16384u  // pairs per chunk: a node is in a left list at most once, so a 16-bit count cannot wrap
+#define ROWS_TPB 1024u
+#define ROWS_CAP 4096u     // distinct rows of a chunk that get an LDS cursor (the rest: a global atomic per entry)
+#define ROWS_MAX_N 65535u
+static inline size_t rows_lds_bytes(uint32_t N) { return sizeof(uint32_t) * (((size_t)N + 2u) / 2u + ROWS_CAP + ROWS_CAP / 2u + 4u); }
+
+// one lane per (pair, quad of its left list): the 16-bit bin of every listed node + 1
+__device__ __forceinline__ void vs_rows_histogram(uint32_t *h32, const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts,
+                                                  uint64_t lo, uint64_t hi) {
+    for (uint64_t i = lo * 4u + threadIdx.x; i < hi * 4u; i += ROWS_TPB) {
+        const uint64_t p = i >> 2;
+        const uint32_t q = (uint32_t)i & 3u, nl = counts[2u * p];
+        if (4u * q >= nl) continue;
+        const VsQuad v = *(const VsQuad *)(lists + 2u * p * LC + 4u * q);
+        const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++)
+            if (4u * q + j < nl) atomicAdd(&h32[e[j] >> 1], 1u << ((e[j] & 1u) * 16u));
+    }
+}
+
+__global__ void __launch_bounds__(ROWS_TPB)
+k_rows_count(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_slots_pairs, uint32_t N,
+             uint32_t *__restrict__ row_count) {
+    uint32_t *h32 = vs_lds;
+    const uint32_t words = (N + 2u) >> 1, tid = threadIdx.x;
+    for (uint32_t i = tid; i < words; i += ROWS_TPB) h32[i] = 0u;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * ROWS_CHUNK, hi = lo + ROWS_CHUNK < n_slots_pairs ? lo + ROWS_CHUNK : n_slots_pairs;
+    vs_rows_histogram(h32, lists, counts, lo, hi);
+    __syncthreads();
+    for (uint32_t i = tid; i < words; i += ROWS_TPB) {
+        const uint32_t v = h32[i];
+        if (v & 0xFFFFu) atomicAdd(&row_count[2u * i], v & 0xFFFFu);
+        if (v >> 16) atomicAdd(&row_count[2u * i + 1u], v >> 16);
+    }
+}
+
+__global__ void __launch_bounds__(ROWS_TPB)
+k_rows_fill(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_slots_pairs, uint32_t N,
+            const uint32_t *__restrict__ row_ptr, uint32_t *__restrict__ row_cursor, uint32_t *__restrict__ entries) {
+    uint32_t *h32 = vs_lds;
+    const uint32_t words = (N + 2u) >> 1, tid = threadIdx.x;
+    uint32_t *s_base = h32 + words;          // [ROWS_CAP] where this chunk's stretch of the row starts
+    uint32_t *s_fill = s_base + ROWS_CAP;    // [ROWS_CAP / 2] 16-bit cursors inside the stretch
+    uint32_t &s_nc = s_fill[ROWS_CAP / 2u];
+    for (uint32_t i = tid; i < words; i += ROWS_TPB) h32[i] = 0u;
+    for (uint32_t i = tid; i < ROWS_CAP / 2u; i += ROWS_TPB) s_fill[i] = 0u;
+    if (tid == 0) s_nc = 0u;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * ROWS_CHUNK, hi = lo + ROWS_CHUNK < n_slots_pairs ? lo + ROWS_CHUNK : n_slots_pairs;
+    vs_rows_histogram(h32, lists, counts, lo, hi);
+    __syncthreads();
+    // a bin that is not empty: reserve the chunk's stretch of that row, and turn the bin into the number of its cursor
+    for (uint32_t i = tid; i < words; i += ROWS_TPB) {
+        const uint32_t v = h32[i];
+        if (!v) continue;
+        uint32_t out = v;
+#pragma unroll
+        for (uint32_t half = 0; half < 2u; half++) {
+            const uint32_t c = (v >> (16u * half)) & 0xFFFFu;
+            if (!c) continue;
+            const uint32_t x = 2u * i + half;
+            const uint32_t ci = atomicAdd(&s_nc, 1u);
+            uint32_t code = 0xFFFFu;
+            if (ci < ROWS_CAP) {
+                s_base[ci] = row_ptr[x] + atomicAdd(&row_cursor[x], c);
+                code = ci;
+            }
+            out = (out & ~(0xFFFFu << (16u * half))) | (code << (16u * half));
+        }
+        h32[i] = out;
+    }
+    __syncthreads();
+    for (uint64_t i = lo * 4u + tid; i < hi * 4u; i += ROWS_TPB) {
+        const uint64_t p = i >> 2;
+        const uint32_t q = (uint32_t)i & 3u, nl = counts[2u * p];
+        if (4u * q >= nl) continue;
+        const VsQuad v = *(const VsQuad *)(lists + 2u * p * LC + 4u * q);
+        const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) {
+            if (4u * q + j >= nl) continue;
+            const uint32_t x = e[j];
+            const uint32_t code = (h32[x >> 1] >> ((x & 1u) * 16u)) & 0xFFFFu;
+            uint32_t pos;
+            if (code != 0xFFFFu) {
+                const uint32_t sh = (code & 1u) * 16u;
+                const uint32_t old = atomicAdd(&s_fill[code >> 1], 1u << sh);
+                pos = s_base[code] + ((old >> sh) & 0xFFFFu);
+            } else {
+                pos = row_ptr[x] + atomicAdd(&row_cursor[x], 1u);
+            }
+            entries[pos] = (uint32_t)p;
+        }
+    }
+}
+
+#define NROWS_LDS_BYTES ((2u * ACC_SLOTS + 64u + 8u) * 4u)
+__global__ void __launch_bounds__(ACC_TPB)
+k_node_rows(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint32_t N, const uint32_t *__restrict__ row_ptr,
+            const uint32_t *__restrict__ entries, uint32_t R, uint32_t n_strips, uint32_t fill_limit, uint32_t *__restrict__ node_mat,
+            uint32_t off0, uint8_t *__restrict__ tile_map, uint32_t T, uint32_t *__restrict__ queue, uint32_t *__restrict__ dbg) {
+    using TB = Acc32;
+    uint32_t *s_key = vs_lds, *s_cnt = vs_lds + ACC_SLOTS, *s_rowend = vs_lds + 2u * ACC_SLOTS;  // [64]
+    uint32_t &s_used = s_rowend[64], &s_lost = s_rowend[65], &s_strip = s_rowend[66];
+    const uint32_t tid = threadIdx.x, q = tid & 3u;
+    constexpr uint32_t STEP = ACC_TPB / 4u;  // entries per pass of the workgroup
+    for (uint32_t i = tid; i < ACC_SLOTS; i += ACC_TPB) { s_key[i] = TB::EMPTY; s_cnt[i] = 0u; }
+    if (tid == 0) { s_used = 0u; s_lost = 0u; }
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_strip = atomicAdd(queue, 1u);
+        __syncthreads();
+        const uint32_t strip = s_strip;
+        if (strip >= n_strips) break;
+        const uint32_t first = strip * R, nrows = first + R <= N ? R : N - first;
+        if (tid < nrows) s_rowend[tid] = row_ptr[first + tid + 1u];
+        const uint32_t e0 = row_ptr[first], e1 = row_ptr[first + nrows];
+        // keys are cell indices relative to the strip's first row, shifted so that key >> 4 is one 64-byte stretch of the matrix
+        const uint32_t align = (uint32_t)(((uint64_t)first * N + off0) & 15u);
+        const uint64_t cell0 = (uint64_t)first * N;
+        __syncthreads();
+        auto write_out = [&]() {
+            for (uint32_t i = tid; i < ACC_SLOTS; i += ACC_TPB) {
+                const uint32_t key = s_key[i];
+                if (key != TB::EMPTY) {
+                    const uint32_t k2 = key - align;
+                    atomicAdd(node_mat + cell0 + k2, s_cnt[i]);
+                    if (tile_map) {
+                        const uint32_t xl = k2 / N;
+                        vs_mark_tile(tile_map, T, 0u, first + xl, k2 - xl * N);
+                    }
+                    s_key[i] = TB::EMPTY;
+                    s_cnt[i] = 0u;
+                }
+            }
+            if (dbg && tid == 0) { atomicAdd(dbg + 0, s_lost); atomicAdd(dbg + 1, 1u); atomicAdd(dbg + 2, s_used); }
+            __syncthreads();
+            if (tid == 0) { s_used = 0u; s_lost = 0u; }
+            __syncthreads();
+        };
+        // the pair of entry i two passes ahead, its right list one pass ahead (two dependent loads off the critical path)
+        auto load_pair = [&](uint32_t base) -> uint32_t {
+            const uint32_t i = base + (tid >> 2);
+            return i < e1 ? entries[i] : 0xFFFFFFFFu;
+        };
+        auto load_list = [&](uint32_t p, uint32_t &nr, VsQuad &yq) {
+            nr = 0u;
+            yq = VsQuad{0u, 0u, 0u, 0u};
+            if (p != 0xFFFFFFFFu) {
+                nr = counts[2u * (uint64_t)p + 1u];
+                yq = *(const VsQuad *)(lists + (2u * (uint64_t)p + 1u) * LC + 4u * q);
+            }
+        };
+        uint32_t p1 = e0 < e1 ? load_pair(e0) : 0xFFFFFFFFu;
+        uint32_t p2 = e1 - e0 > STEP ? load_pair(e0 + STEP) : 0xFFFFFFFFu;
+        uint32_t n1;
+        VsQuad y1;
+        load_list(p1, n1, y1);
+        uint32_t pass = 0;
+        for (uint32_t base = e0; base < e1; base += STEP, pass++) {
+            const uint32_t nr = n1;
+            const VsQuad yq = y1;
+            p1 = p2;
+            load_list(p1, n1, y1);
+            p2 = e1 - base > 2u * STEP ? load_pair(base + 2u * STEP) : 0xFFFFFFFFu;
+            if (4u * q < nr) {
+                const uint32_t i = base + (tid >> 2);
+                uint32_t xl = 0;
+                for (uint32_t j = 0; j + 1u < nrows; j++) xl += s_rowend[j] <= i ? 1u : 0u;
+                const uint32_t kbase = xl * N + align;
+                const uint32_t ys[4] = {yq.x, yq.y, yq.z, yq.w};
+                uint32_t key[4], seen[4], at[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++) {
+                    key[j] = kbase + ys[j];
+                    at[j] = TB::slot(0u, key[j]);
+                    seen[j] = s_key[at[j]];
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++) {
+                    if (4u * q + j >= nr) continue;
+                    if (seen[j] == key[j]) {
+                        atomicAdd(&s_cnt[at[j]], 1u);
+                    } else if (!vs_cell_claim<TB>(s_key, s_cnt, &s_used, key[j], at[j], 1u)) {
+                        atomicAdd(&s_lost, 1u);
+                        vs_mark_tile(tile_map, T, 0u, first + xl, ys[j]);
+                        atomicAdd(node_mat + cell0 + (key[j] - align), 1u);
+                    }
+                }
+            }
+            if ((pass & 3u) == 3u) {  // (four passes bring at most 4 096 new cells: the limit leaves that much room)
+                __syncthreads();
+                const bool spill = s_used > fill_limit || s_lost > 4096u;
+                __syncthreads();
+                if (spill) write_out();
+            }
+        }
+        __syncthreads();
+        write_out();
+    }
 }
 
 // ---- locus order -----------------------------------------------------------------------------------
@@ -1922,7 +2155,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         VS_HIP(ctx, hipMalloc(&ctx->d_slow_list, sizeof(uint32_t) * n_pairs));
         ctx->slow_cap = n_pairs;
     }
-    if (!ctx->d_slow_count) VS_HIP(ctx, hipMalloc(&ctx->d_slow_count, 64));  // [0] pairs for k_pe_mid, [1] queue, [2..3] postings, [4..7] acc, [8] pairs for k_pe_slow
+    if (!ctx->d_slow_count) VS_HIP(ctx, hipMalloc(&ctx->d_slow_count, 64));  // [0] pairs for k_pe_mid, [1] queue, [2..3] postings, [4..7] acc, [8] pairs for k_pe_slow, [9] strip queue, [10..12] k_node_rows debug
     if (ctx->slow2_cap < n_pairs) {
         if (ctx->d_slow_list2) VS_HIP(ctx, hipFree(ctx->d_slow_list2));
         ctx->d_slow_list2 = nullptr;
@@ -2163,7 +2396,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         const bool fits32 = 2ull * idx.n_nodes * idx.n_nodes < 0xFFFFFFFFull, fits_split = idx.n_nodes <= 65535u;
         const int shape = force_shape == 1 ? 2 : (force_shape == 2 && fits_split) ? 1 : fits32 ? 0 : fits_split ? 1 : 2;
         const bool wide = shape == 2;
-        const uint32_t merge = (tn.acc_merge || shape == 1) ? 1u : 0u;
+        const uint32_t merge = (tn.acc_merge || shape == 1) ? 1u : 0u;  // (also what the short_mat-only pass of the row-owner path runs with)
         const uint32_t slots = wide ? ACC_SLOTS / 2u : ACC_SLOTS;
         // the table is written out once this many of its slots (groups) are taken: probing stays
         // short at a low fill, and cells of loci the run has left do not pile up (VS_ACC_FILL: percent)
@@ -2179,18 +2412,74 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         uint32_t *acc_dbg = tn.debug_acc ? (uint32_t *)ctx->d_slow_count + 4 : nullptr;
         const uint32_t acc_ppw = tn.acc_round ? tn.acc_round / (ACC_TPB / 64u) : 64u;  // VS_ACC_ROUND: pairs per round
         VS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
+        // node_mat by row owners (see k_node_rows) where the one-table shape no longer fits -- the graphs whose rounds bring
+        // more distinct cells than the table holds; VS_ACC_ROWS=0 / 1 overrides (1: any graph of at most 65 535 nodes)
+        bool use_rows = tn.acc_rows >= 0 ? tn.acc_rows != 0 : shape == 1;
+        if (idx.n_nodes > ROWS_MAX_N || idx.n_nodes == 0 || slots_pairs * LC >= 0xF0000000ull || use_table != 1u) use_rows = false;
+        if (use_rows) {
+            const uint32_t N = idx.n_nodes;
+            if (ctx->rows_cap < (uint64_t)N + 2u) {
+                if (ctx->d_rows) VS_HIP(ctx, hipFree(ctx->d_rows));
+                ctx->d_rows = nullptr;
+                ctx->rows_cap = 0;
+                // (+ the block sums of the scan: 2 048 values per block, 64 bits each)
+                VS_HIP(ctx, hipMalloc(&ctx->d_rows, sizeof(uint32_t) * 3u * ((uint64_t)N + 2u) + sizeof(uint64_t) * ((uint64_t)N / 2048u + 8u)));
+                ctx->rows_cap = (uint64_t)N + 2u;
+            }
+            if (ctx->row_entries_cap < slots_pairs * LC) {
+                if (ctx->d_row_entries) VS_HIP(ctx, hipFree(ctx->d_row_entries));
+                ctx->d_row_entries = nullptr;
+                ctx->row_entries_cap = 0;
+                VS_HIP(ctx, hipMalloc(&ctx->d_row_entries, sizeof(uint32_t) * (slots_pairs * LC + 16u)));
+                ctx->row_entries_cap = slots_pairs * LC;
+            }
+            uint32_t *row_count = (uint32_t *)ctx->d_rows, *row_cursor = row_count + ctx->rows_cap, *row_ptr = row_cursor + ctx->rows_cap;
+            VS_HIP(ctx, hipMemsetAsync(row_count, 0, sizeof(uint32_t) * 2u * ctx->rows_cap, st));
+            const unsigned n_chunks = (unsigned)((slots_pairs + ROWS_CHUNK - 1u) / ROWS_CHUNK);
+            const size_t rl = rows_lds_bytes(N);
+            VS_HIP(ctx, hipFuncSetAttribute((const void *)k_rows_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
+            VS_HIP(ctx, hipFuncSetAttribute((const void *)k_rows_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
+            VS_HIP(ctx, hipFuncSetAttribute((const void *)k_node_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NROWS_LDS_BYTES));
+            hipLaunchKernelGGL(k_rows_count, dim3(n_chunks), dim3(ROWS_TPB), rl, st, (const uint32_t *)ctx->d_lists,
+                               (const uint32_t *)ctx->d_list_counts, slots_pairs, N, row_count);
+            // (3 * rows_cap words: rows_cap = N + 2 is even or odd -- the 64-bit block sums start on the next even word)
+            uint64_t *scan_tmp = (uint64_t *)(row_count + ((3u * ctx->rows_cap + 1u) & ~1ull));
+            int rc = vs_scan_u32(ctx, row_count, row_ptr, (uint64_t)N + 1u, scan_tmp, nullptr);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_rows_fill, dim3(n_chunks), dim3(ROWS_TPB), rl, st, (const uint32_t *)ctx->d_lists,
+                               (const uint32_t *)ctx->d_list_counts, slots_pairs, N, (const uint32_t *)row_ptr, row_cursor,
+                               (uint32_t *)ctx->d_row_entries);
+            // rows per strip: a strip's distinct cells should fill the table less than half (configs[4]: 8 rows hold 3.3 k
+            // cells at the median, 11.8 k at most); VS_ROWS_PER_STRIP overrides
+            const uint32_t R = tn.rows_per_strip ? tn.rows_per_strip : 8u;
+            const uint32_t n_strips = (N + R - 1u) / R;
+            uint32_t rows_fill = ACC_SLOTS / 2u + ACC_SLOTS / 8u;
+            if (tn.acc_fill_pct >= 0) rows_fill = (uint32_t)((uint64_t)ACC_SLOTS * (uint32_t)tn.acc_fill_pct / 100u);
+            if (rows_fill > ACC_SLOTS - 4096u) rows_fill = ACC_SLOTS - 4096u;
+            uint32_t *rows_queue = (uint32_t *)ctx->d_slow_count + 9;
+            const uint32_t off0 = (uint32_t)(((uintptr_t)d_node_mat >> 2) & 15u);
+            uint32_t rows_grid = (uint32_t)ctx->n_cu * 2u;
+            if (rows_grid > n_strips) rows_grid = n_strips;
+            hipLaunchKernelGGL(k_node_rows, dim3(rows_grid), dim3(ACC_TPB), NROWS_LDS_BYTES, st, (const uint32_t *)ctx->d_lists,
+                               (const uint32_t *)ctx->d_list_counts, N, (const uint32_t *)row_ptr, (const uint32_t *)ctx->d_row_entries, R,
+                               n_strips, rows_fill, d_node_mat, off0, d_tile_map, P.tile_T, rows_queue,
+                               tn.debug_acc ? (uint32_t *)ctx->d_slow_count + 10 : (uint32_t *)nullptr);
+            ctx->last_launched |= VS_RAN_NODE_ROWS;
+        }
         if (d_tile_map && slots_pairs)  // (timed with the counter kernel: it is part of the counting)
             hipLaunchKernelGGL(k_mark_tiles, dim3((unsigned)((slots_pairs + 255u) / 256u)), dim3(256), 0, st, (const uint32_t *)ctx->d_lists,
-                               (const uint32_t *)ctx->d_list_counts, slots_pairs, d_tile_map, P.tile_T);
-        const void *acc_fn = shape == 2 ? (const void *)k_pe_accumulate<Acc64>
+                               (const uint32_t *)ctx->d_list_counts, slots_pairs, d_tile_map, P.tile_T, use_rows ? 1u : 0u);
+        const void *acc_fn = use_rows     ? (const void *)k_pe_accumulate<Acc32Short>
+                             : shape == 2 ? (const void *)k_pe_accumulate<Acc64>
                              : shape == 1 ? (const void *)k_pe_accumulate<Acc32Split> : (const void *)k_pe_accumulate<Acc32>;
-        const uint32_t off0 = (uint32_t)(((uintptr_t)d_node_mat >> 2) & 15u), off1 = (uint32_t)(((uintptr_t)d_short_mat >> 2) & 15u);
+        const uint32_t off1 = (uint32_t)(((uintptr_t)d_short_mat >> 2) & 15u);
         VS_HIP(ctx, hipFuncSetAttribute(acc_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES));
 #define VS_ACC_LAUNCH(TB)                                                                                                         \
     hipLaunchKernelGGL(k_pe_accumulate<TB>, dim3(acc_grid), dim3(ACC_TPB), ACC_LDS_BYTES, st, (const uint32_t *)ctx->d_lists,     \
                        (const uint32_t *)ctx->d_list_counts, slots_pairs, per_wg, idx.n_nodes, use_table, fill_limit, d_node_mat, \
-                       d_short_mat, acc_queue, merge, acc_dbg, acc_ppw, off0, off1)
-        if (shape == 2) VS_ACC_LAUNCH(Acc64);
+                       d_short_mat, acc_queue, merge, acc_dbg, acc_ppw, use_rows ? 1u : 0u, off1)
+        if (use_rows) VS_ACC_LAUNCH(Acc32Short);
+        else if (shape == 2) VS_ACC_LAUNCH(Acc64);
         else if (shape == 1) VS_ACC_LAUNCH(Acc32Split);
         else VS_ACC_LAUNCH(Acc32);
 #undef VS_ACC_LAUNCH
@@ -2262,6 +2551,11 @@ extern "C" int vs_pe_last_timing(vs_ctx *ctx, double ms[5]) {
         uint32_t d4[4] = {0, 0, 0, 0};
         VS_HIP(ctx, hipMemcpy(d4, (char *)ctx->d_slow_count + 16, sizeof d4, hipMemcpyDeviceToHost));
         fprintf(stderr, "[vs] k_pe_accumulate: %u increments went past the cell table, %u write-outs of %u cells, %u rounds\n", d4[0], d4[1], d4[2], d4[3]);
+        if (ctx->last_launched & VS_RAN_NODE_ROWS) {
+            uint32_t r3[3] = {0, 0, 0};
+            VS_HIP(ctx, hipMemcpy(r3, (char *)ctx->d_slow_count + 40, sizeof r3, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[vs] k_node_rows: %u increments went past the cell table, %u write-outs of %u cells\n", r3[0], r3[1], r3[2]);
+        }
     }
     ctx->last_ms[0] = a; ctx->last_ms[1] = b; ctx->last_ms[2] = n_slow;
     return VS_OK;
