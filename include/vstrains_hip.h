@@ -219,7 +219,7 @@ enum {
     VS_RAN_LOCUS_GLOBAL_SORT = 2, /* ... by global atomics (k_pe_locus / k_pe_permute): graphs beyond 147 k nodes */
     VS_RAN_LOCUS_REFINE = 4,      /* second sort key, the reverse read's locus (k_locus_refine): graphs beyond 46 340 nodes */
     VS_RAN_PE_MID = 8,            /* overflow pairs through the wavefront-per-pair kernel first (k_pe_mid) */
-    VS_RAN_NODE_ROWS = 16         /* node_mat summed by row owners (k_rows_count / k_rows_fill / k_node_rows): graphs beyond 46 340 nodes */
+    VS_RAN_ROW_OWNERS = 16        /* counters summed by row owners (k_list_owners / k_rows_count / k_rows_fill / k_rows_sum): graphs beyond 46 340 nodes */
 };
 uint32_t vs_pe_last_launched(const vs_ctx *ctx);
 

@@ -82,7 +82,7 @@ def test_config4_50k_nodes_wide_cell_keys_and_global_sort(host, ctx, tmp_path):
     whole = _count(host, ctx, st, cum, seed, L, [(0, R)], sub, nth)
     t = ctx.last_timing()
     assert ctx.last_kernel.startswith("k_pe_tiles<1")  # the straight-line instantiation serves this config
-    assert ctx.last_launched & ctx.RAN_NODE_ROWS, "a graph beyond 46 340 nodes counts node_mat by row owners (k_node_rows)"
+    assert ctx.last_launched & ctx.RAN_ROW_OWNERS, "a graph beyond 46 340 nodes counts node_mat by row owners (k_node_rows)"
     parts = _count(host, ctx, st, cum, seed, L, [(0, 1), (1, 4999), (5000, 1_000_001), (1_005_001, R - 1_005_001)], sub, nth)
     assert torch.equal(whole.mats, parts.mats) and torch.equal(whole.stats, parts.stats)
     stats = whole.stats.cpu().tolist()
@@ -123,13 +123,13 @@ def test_row_owner_counting_equals_the_cell_table_path_at_config4_size(host, xct
     sub, nth = int(0.005 * 2 ** 32), int(0.001 * 2 ** 32)
     monkeypatch.setenv("VS_ACC_ROWS", "0")
     old = _count(host, ctx, st, cum, seed, L, [(0, R)], sub, nth)
-    assert not ctx.last_launched & ctx.RAN_NODE_ROWS
+    assert not ctx.last_launched & ctx.RAN_ROW_OWNERS
     for env in ({}, {"VS_ROWS_PER_STRIP": "1"}, {"VS_ROWS_PER_STRIP": "64", "VS_ACC_FILL": "1"}, {"VS_NO_SORT": "1"}):
         monkeypatch.setenv("VS_ACC_ROWS", "1")
         for k2, v in env.items():
             monkeypatch.setenv(k2, v)
         new = _count(host, ctx, st, cum, seed, L, [(0, R)], sub, nth)
-        assert ctx.last_launched & ctx.RAN_NODE_ROWS
+        assert ctx.last_launched & ctx.RAN_ROW_OWNERS
         assert torch.equal(old.mats, new.mats) and torch.equal(old.stats, new.stats), env
         if new.tile_map is not None:  # every non-zero cell lies in a marked tile
             n = new.n
@@ -163,7 +163,7 @@ def test_row_owner_counting_with_more_rows_per_chunk_than_lds_cursors(host, xctx
     monkeypatch.setenv("VS_ACC_ROWS", "1")
     monkeypatch.setenv("VS_NO_SORT", "1")
     got = _count(host, ctx, st, cum, seed, L, [(0, M)], sub, nth)
-    assert ctx.last_launched & ctx.RAN_NODE_ROWS
+    assert ctx.last_launched & ctx.RAN_ROW_OWNERS
     orc = pe_oracle_c.Oracle(seqs, cfg["k"])
     _assert_equals_oracle(got, orc, st, cum, seed, L, M, sub, nth)
 

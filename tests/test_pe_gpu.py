@@ -521,14 +521,12 @@ def test_device_read_generator_equals_cpu_twin(host, ctx):
 
 @pytest.mark.parametrize("env", [
     {"VS_NO_SORT": "1"}, {"VS_NO_AGG": "1"}, {"VS_LOCUS_GLOBAL": "1"}, {"VS_EPT": "32"}, {"VS_EPT": "128"},
-    {"VS_EPT": "6", "VS_GRID_PER_CU": "1"}, {"VS_ACC_FILL": "1"}, {"VS_ACC_FILL": "100"}, {"VS_NO_FAST": "1"}, {"VS_ACC_WIDE": "1"},
+    {"VS_EPT": "6", "VS_GRID_PER_CU": "1"}, {"VS_ACC_FILL": "1"}, {"VS_ACC_FILL": "100"}, {"VS_NO_FAST": "1"},
     {"VS_ACC_QUEUE": "0"}, {"VS_ACC_GRID_PER_CU": "1", "VS_ACC_QUEUE": "0"}, {"VS_NO_XCD_MAP": "1"}, {"VS_GRID_PER_CU": "8"}, {"VS_NO_STD": "1"}, {"VS_SHORTCUT": "1"}, {"VS_SHORTCUT": "0"},
-    {"VS_ACC_MERGE": "1"}, {"VS_ACC_MERGE": "1", "VS_NO_AGG": "1"}, {"VS_ACC_MERGE": "1", "VS_ACC_WIDE": "1", "VS_ACC_FILL": "1"},
-    {"VS_ACC_WIDE": "2"}, {"VS_ACC_WIDE": "2", "VS_ACC_FILL": "1"}, {"VS_ACC_WIDE": "2", "VS_ACC_FILL": "100", "VS_ACC_MERGE": "1"},
     {"VS_ACC_ROUND": "128"},
-    {"VS_REFINE": "1"}, {"VS_REFINE": "1", "VS_EPT": "32", "VS_ACC_WIDE": "2"}, {"VS_NO_MID": "1"},
+    {"VS_REFINE": "1"}, {"VS_REFINE": "1", "VS_EPT": "32", "VS_ACC_ROWS": "1"}, {"VS_NO_MID": "1"},
     {"VS_ACC_ROWS": "1"}, {"VS_ACC_ROWS": "1", "VS_ROWS_PER_STRIP": "1"}, {"VS_ACC_ROWS": "1", "VS_ROWS_PER_STRIP": "64", "VS_ACC_FILL": "1"},
-    {"VS_ACC_ROWS": "1", "VS_NO_SORT": "1", "VS_ACC_QUEUE": "0"},
+    {"VS_ACC_ROWS": "1", "VS_NO_SORT": "1"}, {"VS_ACC_ROWS": "1", "VS_ROWS_KEYS": "100"}, {"VS_ACC_ROWS": "1", "VS_ROWS_SUB": "2048", "VS_ROWS_KEYS": "7"},
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_every_kernel_variant_gives_the_same_counters(host, xctx, env, monkeypatch):
     """The tuning switches select other code paths (input order instead of locus order, global
@@ -551,8 +549,7 @@ def test_every_kernel_variant_gives_the_same_counters(host, xctx, env, monkeypat
     assert np.array_equal(short_mat, want[1])
     assert stats == tuple(int(x) for x in want[2])
     assert ctx.last_kernel.startswith("k_pe_tiles"), ctx.last_kernel
-    # (node_mat goes to the row owners where asked, and by itself where the split table shape is forced)
-    assert bool(ctx.last_launched & ctx.RAN_NODE_ROWS) == (env.get("VS_ACC_ROWS") == "1" or env.get("VS_ACC_WIDE") == "2")
+    assert bool(ctx.last_launched & ctx.RAN_ROW_OWNERS) == (env.get("VS_ACC_ROWS") == "1")
 
 
 def test_switches_do_not_exist_outside_experiment_mode(tmp_path):

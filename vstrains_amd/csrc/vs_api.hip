@@ -31,11 +31,12 @@ void vs_tuning_load(VsTuning &t, int level) {
     if (const char *v = getenv("VS_ACC_GRID_PER_CU")) t.acc_grid_per_cu = atoi(v) > 0 ? (uint32_t)atoi(v) : 32u;
     if (const char *v = getenv("VS_ACC_FILL")) t.acc_fill_pct = atoi(v);
     if (const char *v = getenv("VS_ACC_ROUND")) { const int r = atoi(v); t.acc_round = (r == 64 || r == 128 || r == 256 || r == 512 || r == 1024) ? (uint32_t)r : 0u; }
-    if (const char *v = getenv("VS_ACC_WIDE")) t.acc_wide = atoi(v);
     if (const char *v = getenv("VS_SHORTCUT")) t.shortcut = atoi(v) != 0 ? 1 : 0;
     if (const char *v = getenv("VS_TABLE_SHIFT")) t.table_shift = atoi(v) < 1 ? 1u : atoi(v) > 8 ? 8u : (uint32_t)atoi(v);
     if (const char *v = getenv("VS_REFINE")) t.refine = atoi(v) != 0 ? 1 : 0;
     if (const char *v = getenv("VS_ACC_ROWS")) t.acc_rows = atoi(v) != 0 ? 1 : 0;
+    if (const char *v = getenv("VS_ROWS_KEYS")) t.rows_keys = atoi(v) >= 2 && atoi(v) <= 65536 ? (uint32_t)atoi(v) : 0u;
+    if (const char *v = getenv("VS_ROWS_SUB")) t.rows_sub = atoi(v) >= 1024 ? (uint32_t)atoi(v) : 0u;
     if (const char *v = getenv("VS_ROWS_PER_STRIP")) t.rows_per_strip = atoi(v) > 0 && atoi(v) <= 64 ? (uint32_t)atoi(v) : 0u;
     t.no_sort = env_on("VS_NO_SORT");
     t.locus_global = env_on("VS_LOCUS_GLOBAL");
@@ -45,7 +46,6 @@ void vs_tuning_load(VsTuning &t, int level) {
     t.no_agg = env_on("VS_NO_AGG");
     t.no_mid = env_on("VS_NO_MID");
     if (const char *v = getenv("VS_ACC_QUEUE")) t.acc_queue = atoi(v) != 0;
-    t.acc_merge = env_on("VS_ACC_MERGE");
     t.debug_postings = getenv("VS_DEBUG_POSTINGS") != nullptr;
     t.debug_occ = getenv("VS_DEBUG_OCC") != nullptr;
     t.debug_acc = getenv("VS_DEBUG_ACC") != nullptr;
@@ -147,7 +147,7 @@ void vs_ctx_destroy(vs_ctx *ctx) {
     if (ctx->d_slow_count) (void)hipFree(ctx->d_slow_count);
     if (ctx->d_slow_list2) (void)hipFree(ctx->d_slow_list2);
     if (ctx->d_dense) (void)hipFree(ctx->d_dense);
-    for (void *q : {ctx->d_locus_keys, ctx->d_perm, ctx->d_locus_hist, ctx->d_scan_tmp, ctx->d_lists, ctx->d_list_counts, ctx->d_rows, ctx->d_row_entries})
+    for (void *q : {ctx->d_locus_keys, ctx->d_perm, ctx->d_locus_hist, ctx->d_scan_tmp, ctx->d_lists, ctx->d_list_counts, ctx->d_rows, ctx->d_row_entries, ctx->d_mult})
         if (q) (void)hipFree(q);
     for (void *q : ctx->scratch)
         if (q) (void)hipFree(q);

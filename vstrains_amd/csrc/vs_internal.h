@@ -108,14 +108,14 @@ struct VsTuning {
     uint32_t acc_grid_per_cu = 32;  // VS_ACC_GRID_PER_CU
     int acc_fill_pct = -1;          // VS_ACC_FILL (-1 = 1/16 of the slots)
     uint32_t acc_round = 0;         // VS_ACC_ROUND: pairs per round of the counter kernel (0 = automatic; 64 .. 1024, power of two)
-    int acc_wide = 0;               // VS_ACC_WIDE (1: 64-bit keys, 2: split tables)
     int shortcut = -1;              // VS_SHORTCUT (-1 = by index statistics)
     uint32_t table_shift = 3;       // VS_TABLE_SHIFT: seed table of >= (distinct seeds << shift) slots (3: at most an eighth full)
     int refine = -1;                // VS_REFINE (-1 = by graph size): second sort key, the reverse read's locus
-    int acc_rows = -1;              // VS_ACC_ROWS (-1 = by graph size): node_mat summed by row owners (k_node_rows)
-    uint32_t rows_per_strip = 0;    // VS_ROWS_PER_STRIP (0 = automatic): matrix rows one workgroup of k_node_rows owns at a time
+    int acc_rows = -1;              // VS_ACC_ROWS (-1 = by graph size): counters summed by row owners (k_rows_sum) instead of pair-major (k_pe_accumulate)
+    uint32_t rows_keys = 0, rows_sub = 0;  // VS_ROWS_KEYS / VS_ROWS_SUB: rows per histogram pass, pairs per transposition (0 = the constants; tests shrink them)
+    uint32_t rows_per_strip = 0;    // VS_ROWS_PER_STRIP (0 = automatic): matrix rows one workgroup of k_rows_sum owns at a time
     bool no_sort = false, locus_global = false, no_xcd_map = false, no_fast = false, no_std = false, no_agg = false;
-    bool acc_queue = true, acc_merge = false;
+    bool acc_queue = true;
     bool no_mid = false;            // VS_NO_MID: overflow pairs straight to k_pe_slow
     bool debug_postings = false, debug_occ = false, debug_acc = false;
     // timing only (VS_EXPERIMENT=timing): wrong counters by design
@@ -154,10 +154,10 @@ struct vs_ctx {
     // per-end accepted lists between k_pe_tiles and k_pe_accumulate
     void *d_lists = nullptr, *d_list_counts = nullptr;
     uint64_t lists_cap = 0;
-    // row-owner counting of node_mat (k_rows_count / k_rows_fill / k_node_rows): per-row counts, cursors and offsets
-    // (3 x (N + 2) words), and the pairs of every row (one word per accepted node of a forward read)
-    void *d_rows = nullptr, *d_row_entries = nullptr;
-    uint64_t rows_cap = 0, row_entries_cap = 0;
+    // row-owner counting (k_list_owners / k_rows_count / k_rows_fill / k_rows_sum): per matrix and row the counts, cursors
+    // and offsets (6 x (N + 2) words), the items of every row (one word per listed node), the multiplicity of every end's list
+    void *d_rows = nullptr, *d_row_entries = nullptr, *d_mult = nullptr;
+    uint64_t rows_cap = 0, row_entries_cap = 0, mult_cap = 0;
     // grow-only device scratch slots of the graph-stage entry points (no hipMalloc per call)
     void *scratch[32] = {};
     size_t scratch_cap[32] = {};

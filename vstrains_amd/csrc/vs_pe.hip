@@ -882,10 +882,12 @@ k_pe_tiles(PeParams P) {
 // short_mat increments: positions a <= b give the cell (min, max) of the two node ids -- the
 // reference's "i <= i2 over ascending indices" (:174-184).
 // Scattered global atomics run at ~2e10/s chip-wide and would bound the whole step (5.4e8 increments
-// at configs[2]), so a workgroup (1024 threads, one per CU, a contiguous run of pairs = a few loci)
-// first sums increments per cell in a 16k-slot LDS table and issues ONE global atomic per cell when
-// the table is written out.  One wavefront expands 64 pairs at a time, one lane per run of at
-// most four increments.
+// at configs[2]), so increments are summed per cell in LDS before they reach memory.  Two loop orders:
+//   * k_pe_accumulate (graphs of at most 46 340 nodes): pair-major.  A workgroup (1024 threads, one per CU, a
+//     contiguous run of pairs = a few loci) sums in a 16k-slot cell table and issues ONE global atomic per cell when the
+//     table is written out.  One wavefront expands 64 pairs at a time, one lane per run of at most four increments.
+//   * the row owners below (larger graphs): output-major.  There a round of locus-ordered pairs brings more distinct
+//     cells than the table holds, and the same cell returns from loci hundreds of rounds apart.
 #ifndef ACC_TPB
 #define ACC_TPB 1024
 #endif
@@ -893,8 +895,7 @@ k_pe_tiles(PeParams P) {
 #define ACC_BITS 14
 #endif
 #define ACC_SLOTS (1u << ACC_BITS)
-#define ACC_DEDUP_SLOTS (2u * ACC_TPB)  // one slot per read end of a round: at most a fifth of them get claimed
-#define ACC_LDS_BYTES ((2u * ACC_SLOTS + (ACC_TPB / 64) * 66u + (LC + 1u) + (LC + 1u) * 40u + 4u + 2u * ACC_DEDUP_SLOTS) * 4u)
+#define ACC_LDS_BYTES ((2u * ACC_SLOTS + (ACC_TPB / 64) * 66u + (LC + 1u) + (LC + 1u) * 40u + 4u) * 4u)
 // Work units: a list row is cut into runs of at most ACC_RUN partners, one lane per run, so that
 // every lane of a wavefront has about the same (small, fully unrolled) amount of work:
 //   node_mat : left node a against right positions [4c, 4c+4)           -> nl * ceil(nr/4) runs
@@ -902,161 +903,53 @@ k_pe_tiles(PeParams P) {
 //              g(n) = sum_{m=1..n} ceil(m/4)
 #define ACC_RUN 4u
 #define ACC_GMAX 40u  // g(16)
-// The cell table comes in three shapes (16 k words of keys + 16 k words of counts either way):
-//   Acc32      one table of 16 k slots, 32-bit keys mat * N*N + x * N + y, while 2*N*N fits 32 bits (N <= 46340)
-//   Acc32Split one 8 k-slot table per matrix, 32-bit keys x * N + y, while N*N fits (N <= 65535): the matrix is
-//              the upper bit of the slot index, a probe sequence stays inside its half
-//   Acc64      8 k slots, 64-bit keys mat << 60 | x * N + y, above that
-// (r3) ACC_SEG: the 16 cells of one 64-byte stretch of a matrix row sit in 16 NEIGHBOURING slots (the hash picks a
-// group of 16 slots from the cell index >> 4, the low four bits pick the slot inside it; a taken slot sends the probe to
-// the same position of the next group).  A write-out walks the slots in order, a lane per slot, so the lanes of a
-// wavefront that hold cells of one stretch issue their atomics side by side -- and integer atomics, like the float
-// ones of MI355X_MICROARCH.md, leave the L2 as one memory-side request per 64-byte stretch a wave instruction touches.
-#ifndef ACC_SEG
-#define ACC_SEG 1
-#endif
+// The cell table: 16 k slots, 32-bit keys (k_pe_accumulate: mat * N*N + x * N + y, while 2*N*N fits 32 bits, N <= 46340;
+// the row owners: cell index relative to the strip's first row).  The 16 cells of one 64-byte stretch of a matrix row
+// sit in 16 NEIGHBOURING slots (the hash picks a group of 16 slots from the key >> 4, the low four bits pick the slot
+// inside it; a taken slot sends the probe to the same position of the next group).  A write-out walks the slots in
+// order, a lane per slot, so the lanes of a wavefront that hold cells of one stretch issue their atomics side by side
+// -- and integer atomics, like the float ones of MI355X_MICROARCH.md, leave the L2 as one memory-side request per
+// 64-byte stretch a wave instruction touches.
 struct Acc32 {
-    typedef uint32_t KT;
-    static constexpr uint32_t BITS = ACC_BITS;
     static constexpr uint32_t EMPTY = 0xFFFFFFFFu;
     __device__ static uint32_t key(uint32_t mat, uint32_t x, uint32_t y, uint32_t N) { return (mat * N + x) * N + y; }
-#if ACC_SEG
-    __device__ static uint32_t slot(uint32_t, uint32_t k) { return ((((k >> 4) * 0x9E3779B1u) >> (36u - BITS)) << 4) | (k & 15u); }
-    __device__ static uint32_t next(uint32_t at) { return (at + 16u) & ((1u << BITS) - 1u); }
-#else
-    __device__ static uint32_t slot(uint32_t, uint32_t k) { return (k * 0x9E3779B1u) >> (32u - BITS); }
-    __device__ static uint32_t next(uint32_t at) { return (at + 1u) & ((1u << BITS) - 1u); }
-#endif
-    __device__ static uint32_t mat_of(uint32_t k, uint32_t N, uint32_t) { return k >= N * N ? 1u : 0u; }
-    __device__ static uint64_t cell_of(uint32_t k, uint32_t N) { return k >= N * N ? (uint64_t)(k - N * N) : (uint64_t)k; }
-};
-// ACC_NODE_GROUPS of the ACC_SLOTS / 16 groups of 16 slots belong to node_mat, the rest to short_mat (an even split by
-// default; short_mat's cells -- pairs of nodes under ONE read -- repeat far more than node_mat's)
-#ifndef ACC_NODE_GROUPS
-#define ACC_NODE_GROUPS (ACC_SLOTS / 32u)
-#endif
-struct Acc32Split {
-    typedef uint32_t KT;
-    static constexpr uint32_t BITS = ACC_BITS;
-    static constexpr uint32_t HALF = 1u << (ACC_BITS - 1u);
-    static constexpr uint32_t NG = ACC_NODE_GROUPS, SG = ACC_SLOTS / 16u - ACC_NODE_GROUPS;
-    static constexpr uint32_t EMPTY = 0xFFFFFFFFu;  // (N <= 65535: the largest cell is N*N - 1 < 2^32 - 1)
-    __device__ static uint32_t key(uint32_t, uint32_t x, uint32_t y, uint32_t N) { return x * N + y; }
-#if ACC_SEG
-    __device__ static uint32_t slot(uint32_t mat, uint32_t k) {
-        const uint32_t h = (k >> 4) * 0x9E3779B1u;
-        const uint32_t g = mat ? NG + (uint32_t)(((uint64_t)h * SG) >> 32) : (uint32_t)(((uint64_t)h * NG) >> 32);
-        return (g << 4) | (k & 15u);
-    }
-    __device__ static uint32_t next(uint32_t at) {
-        const uint32_t g = at >> 4, sub = at & 15u;
-        const uint32_t g2 = g + 1u == NG ? 0u : g + 1u == NG + SG ? NG : g + 1u;
-        return (g2 << 4) | sub;
-    }
-    __device__ static uint32_t mat_of(uint32_t, uint32_t, uint32_t i) { return (i >> 4) >= NG ? 1u : 0u; }
-#else
-    __device__ static uint32_t slot(uint32_t mat, uint32_t k) { return (mat ? HALF : 0u) | ((k * 0x9E3779B1u) >> (33u - BITS)); }
-    __device__ static uint32_t next(uint32_t at) { return (at & HALF) | ((at + 1u) & (HALF - 1u)); }
-    __device__ static uint32_t mat_of(uint32_t, uint32_t, uint32_t i) { return i >> (BITS - 1u); }
-#endif
-    __device__ static uint64_t cell_of(uint32_t k, uint32_t) { return (uint64_t)k; }
-};
-struct Acc64 {
-    typedef unsigned long long KT;
-    static constexpr uint32_t BITS = ACC_BITS - 1u;
-    static constexpr unsigned long long EMPTY = ~0ull;
-    __device__ static unsigned long long key(uint32_t mat, uint32_t x, uint32_t y, uint32_t N) {
-        return ((unsigned long long)mat << 60) | ((unsigned long long)x * N + y);
-    }
-#if ACC_SEG
-    __device__ static uint32_t slot(uint32_t, unsigned long long k) {
-        return ((uint32_t)(((k >> 4) * 0x9E3779B97F4A7C15ull) >> (68u - BITS)) << 4) | ((uint32_t)k & 15u);
-    }
-    __device__ static uint32_t next(uint32_t at) { return (at + 16u) & ((1u << BITS) - 1u); }
-#else
-    __device__ static uint32_t slot(uint32_t, unsigned long long k) { return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> (64u - BITS)); }
-    __device__ static uint32_t next(uint32_t at) { return (at + 1u) & ((1u << BITS) - 1u); }
-#endif
-    __device__ static uint32_t mat_of(unsigned long long k, uint32_t, uint32_t) { return (uint32_t)(k >> 60); }
-    __device__ static uint64_t cell_of(unsigned long long k, uint32_t) { return k & ((1ull << 60) - 1ull); }
+    __device__ static uint32_t slot(uint32_t k) { return ((((k >> 4) * 0x9E3779B1u) >> (36u - ACC_BITS)) << 4) | (k & 15u); }
+    __device__ static uint32_t next(uint32_t at) { return (at + 16u) & (ACC_SLOTS - 1u); }
 };
 
-// short_mat alone (node_mat goes through k_node_rows, see below): every slot is short_mat's, 32-bit keys x * N + y (N <= 65535)
-struct Acc32Short {
-    typedef uint32_t KT;
-    static constexpr uint32_t BITS = ACC_BITS;
-    static constexpr uint32_t EMPTY = 0xFFFFFFFFu;
-    __device__ static uint32_t key(uint32_t, uint32_t x, uint32_t y, uint32_t N) { return x * N + y; }
-    __device__ static uint32_t slot(uint32_t, uint32_t k) { return Acc32::slot(0u, k); }
-    __device__ static uint32_t next(uint32_t at) { return Acc32::next(at); }
-    __device__ static uint32_t mat_of(uint32_t, uint32_t, uint32_t) { return 1u; }
-    __device__ static uint64_t cell_of(uint32_t k, uint32_t) { return (uint64_t)k; }
-};
-
-// Slow side of vs_cell_add: the slot is empty or holds another cell.  Kept out of line so that
-// the common case (the cell is already in the table) stays a short straight-line sequence.
-template <typename TB>
-__device__ __forceinline__ bool vs_cell_claim(typename TB::KT *s_key, uint32_t *s_cnt, uint32_t *s_used, typename TB::KT key, uint32_t at, uint32_t wgt) {
+// The slot a key hashes to is empty or holds another cell: claim / probe on.  Kept out of line of the common case (the
+// cell is already in the table), which stays a short straight-line sequence.  false: no place within eight probes.
+__device__ __forceinline__ bool vs_cell_claim(uint32_t *s_key, uint32_t *s_cnt, uint32_t *s_used, uint32_t key, uint32_t at, uint32_t wgt) {
     for (uint32_t pr = 0; pr < 8u; pr++) {
-        typename TB::KT kx = s_key[at];
-        if (kx == TB::EMPTY) {
-            kx = atomicCAS(&s_key[at], TB::EMPTY, key);
-            if (kx == TB::EMPTY) { atomicAdd(s_used, 1u); kx = key; }
+        uint32_t kx = s_key[at];
+        if (kx == Acc32::EMPTY) {
+            kx = atomicCAS(&s_key[at], Acc32::EMPTY, key);
+            if (kx == Acc32::EMPTY) { atomicAdd(s_used, 1u); kx = key; }
         }
         if (kx == key) {
             atomicAdd(&s_cnt[at], wgt);
             return true;
         }
-        at = TB::next(at);
+        at = Acc32::next(at);
     }
     return false;
 }
 
-template <typename TB>
-__device__ __forceinline__ void vs_cell_add(typename TB::KT *s_key, uint32_t *s_cnt, uint32_t &s_used, uint32_t &s_lost, bool use_table,
-                                            uint32_t mat, uint32_t x, uint32_t yv, uint32_t N,
-                                            uint32_t *node_mat, uint32_t *short_mat, uint32_t wgt) {
-    const uint32_t cx = (mat && yv < x) ? yv : x, cy = (mat && yv < x) ? x : yv;
-    bool done = false;
-    if (use_table) {
-        const typename TB::KT key = TB::key(mat, cx, cy, N);
-        const uint32_t at = TB::slot(mat, key);
-        if (s_key[at] == key) {
-            atomicAdd(&s_cnt[at], wgt);
-            done = true;
-        } else {
-            done = vs_cell_claim<TB>(s_key, s_cnt, &s_used, key, at, wgt);
-            if (!done) atomicAdd(&s_lost, 1u);
-        }
-    }
-    if (!done) atomicAdd((mat ? short_mat : node_mat) + (uint64_t)cx * N + cy, wgt);
-}
-
-template <typename TB>
 __global__ void __launch_bounds__(ACC_TPB)
 k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_slots_pairs,
                 uint32_t pairs_per_wg, uint32_t N, uint32_t use_table, uint32_t fill_limit,
-                uint32_t *__restrict__ node_mat, uint32_t *__restrict__ short_mat, uint32_t *__restrict__ queue, uint32_t merge,
-                uint32_t *__restrict__ dbg, uint32_t ppw, uint32_t skip_node, uint32_t off1) {  // skip_node: short_mat only (k_node_rows counts node_mat); VS_DEBUG_ACC: [0] increments past the table, [1] write-outs, [2] cells written, [3] rounds
-    using KT = typename TB::KT;
-    constexpr uint32_t SLOTS = 1u << TB::BITS;
-    KT *s_key = (KT *)vs_lds;                      // [SLOTS] keys: ACC_SLOTS words either way
-    uint32_t *s_cnt = vs_lds + ACC_SLOTS;          // [SLOTS]
+                uint32_t *__restrict__ node_mat, uint32_t *__restrict__ short_mat, uint32_t *__restrict__ queue,
+                uint32_t *__restrict__ dbg, uint32_t ppw) {  // VS_DEBUG_ACC: [0] increments past the table, [1] write-outs, [2] cells written, [3] rounds
+    uint32_t *s_key = vs_lds;                      // [ACC_SLOTS]
+    uint32_t *s_cnt = vs_lds + ACC_SLOTS;          // [ACC_SLOTS]
     uint32_t(*s_pref)[66] = (uint32_t(*)[66])(vs_lds + 2u * ACC_SLOTS);  // [ACC_TPB / 64][66]
     uint32_t *s_g = vs_lds + 2u * ACC_SLOTS + (ACC_TPB / 64) * 66u;      // [LC + 1]: g(n)
     uint32_t *s_ua = s_g + (LC + 1u);                                     // [LC + 1][ACC_GMAX]: run -> position a
     uint32_t &s_used = s_ua[(LC + 1u) * ACC_GMAX];
     uint32_t &s_lost = s_ua[(LC + 1u) * ACC_GMAX + 1u];
-    // Equal end lists of a round (1024 locus-ordered pairs: four of five ends repeat the list of another
-    // end) are merged: the first end that brings a list owns it, the others only add to its multiplicity,
-    // and the owner's short_mat cells (PE_Inference.py:174-184: one increment per end holding both nodes)
-    // are incremented once, by that multiplicity.  s_down[slot] = tag << 11 | owner end, s_dmul[slot] =
-    // how many further ends hold the same list.  The tag is an order-independent fingerprint (the lists
-    // arrive in no particular order); a tag match is confirmed node by node against the owner's row.
-    uint32_t *s_down = s_ua + (LC + 1u) * ACC_GMAX + 4u;  // [ACC_DEDUP_SLOTS]
-    uint32_t *s_dmul = s_down + ACC_DEDUP_SLOTS;          // [ACC_DEDUP_SLOTS]
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    for (uint32_t i = tid; i < SLOTS; i += ACC_TPB) { s_key[i] = TB::EMPTY; s_cnt[i] = 0; }
+    const uint32_t NN = N * N;  // (use_table: 2 * N * N fits 32 bits)
+    for (uint32_t i = tid; i < ACC_SLOTS; i += ACC_TPB) { s_key[i] = Acc32::EMPTY; s_cnt[i] = 0; }
     if (tid <= LC) {
         uint32_t gsum = 0;
         for (uint32_t m = 1; m <= tid; m++) gsum += (m + ACC_RUN - 1u) / ACC_RUN;
@@ -1073,16 +966,15 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
     uint32_t &s_chunk = s_ua[(LC + 1u) * ACC_GMAX + 2u];
     // every cell of the table to its counter (one global atomic per cell), the table emptied
     auto write_out = [&]() {
-    for (uint32_t i = tid; i < SLOTS; i += ACC_TPB) {
-        const KT key = s_key[i];
-        if (key != TB::EMPTY) {
-            if (use_table != 3u)  // (3: timing experiment without the write-outs)
-                atomicAdd((TB::mat_of(key, N, i) ? short_mat : node_mat) + TB::cell_of(key, N), s_cnt[i]);
-            s_key[i] = TB::EMPTY;
-            s_cnt[i] = 0;
+        for (uint32_t i = tid; i < ACC_SLOTS; i += ACC_TPB) {
+            const uint32_t key = s_key[i];
+            if (key != Acc32::EMPTY) {
+                if (use_table != 3u)  // (3: timing experiment without the write-outs)
+                    atomicAdd(key >= NN ? short_mat + (key - NN) : node_mat + key, s_cnt[i]);
+                s_key[i] = Acc32::EMPTY;
+                s_cnt[i] = 0;
+            }
         }
-    }
-    
         if (tid == 0) { s_used = 0; s_lost = 0; }
         __syncthreads();
     };
@@ -1097,8 +989,7 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
     const uint64_t lo = chunk * pairs_per_wg;
     if (lo >= n_slots_pairs) break;
     const uint64_t hi = lo + pairs_per_wg < n_slots_pairs ? lo + pairs_per_wg : n_slots_pairs;
-    // a round = ppw pairs per wavefront (64: one per lane; fewer where the lists are long, so that a round's cells fit the
-    // table and leave it through a write-out, whose atomics travel a 64-byte stretch at a time, instead of one by one)
+    // a round = ppw pairs per wavefront (64: one per lane; VS_ACC_ROUND for fewer)
     for (uint64_t base = lo; base < hi; base += (ACC_TPB / 64u) * ppw) {
         const uint64_t wbase = base + wv * ppw;             // wave-uniform
         const uint32_t *wcounts = counts + 2u * wbase;
@@ -1108,79 +999,7 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
             const uint2 c = *(const uint2 *)(wcounts + 2u * lane);
             nl = c.x; nr = c.y;
         }
-        // multiplicity of this pair's two lists: 0 = merged into another end's list (no short_mat work
-        // of its own), m >= 1 = this end expands its list m-fold
-        uint32_t ml = nl ? 1u : 0u, mr = nr ? 1u : 0u;
-        if (merge) {
-            for (uint32_t i = tid; i < ACC_DEDUP_SLOTS; i += ACC_TPB) { s_down[i] = 0xFFFFFFFFu; s_dmul[i] = 0u; }
-            __syncthreads();
-            uint32_t slot_of[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
-#pragma unroll
-            for (uint32_t side = 0; side < 2u; side++) {
-                const uint32_t n = side ? nr : nl;
-                if (n == 0u) continue;
-                const uint32_t me = 2u * (wv * ppw + lane) + side;  // end index within the round
-                const uint32_t *row = wlists + (2u * lane + side) * LC;
-                uint32_t mine[LC];
-                {
-                    const VsQuad a = *(const VsQuad *)row, b = n > 4u ? *(const VsQuad *)(row + 4) : VsQuad{0, 0, 0, 0};
-                    const VsQuad c = n > 8u ? *(const VsQuad *)(row + 8) : VsQuad{0, 0, 0, 0}, d = n > 12u ? *(const VsQuad *)(row + 12) : VsQuad{0, 0, 0, 0};
-                    const uint32_t v[LC] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-#pragma unroll
-                    for (uint32_t i = 0; i < LC; i++) mine[i] = i < n ? v[i] : 0xFFFFFFFFu;
-                }
-                uint32_t fp = n * 0x9E3779B1u;
-#pragma unroll
-                for (uint32_t i = 0; i < LC; i++)
-                    if (i < n) {
-                        uint32_t h = mine[i] * 0x85EBCA6Bu;
-                        h ^= h >> 15;
-                        fp += h * 0xC2B2AE35u;  // (a sum: the order of the nodes does not matter)
-                    }
-                // tag: 17 bits of the fingerprint and the list length (the owner's length comes with the table
-                // word: no load for it); all ones with owner 2047 would read as an empty slot -- n - 1 <= 15
-                // only together with tag bits all ones, so clear one
-                uint32_t tag = (((fp ^ (fp >> 13)) & 0x1FFFFu) << 4) | (n - 1u);
-                if (tag == 0x1FFFFFu) tag ^= 0x10u;
-                uint32_t at = (fp * 0x9E3779B1u) >> (32u - 11u);  // ACC_DEDUP_SLOTS = 2048
-                for (uint32_t pr = 0; pr < 6u; pr++) {
-                    uint32_t w0 = s_down[at];
-                    if (w0 == 0xFFFFFFFFu) {
-                        w0 = atomicCAS(&s_down[at], 0xFFFFFFFFu, (tag << 11) | me);
-                        if (w0 == 0xFFFFFFFFu) { slot_of[side] = at; break; }  // this end owns the list
-                    }
-                    if ((w0 >> 11) == tag) {
-                        // same fingerprint and length: the same set of nodes?  (the owner's row is input data,
-                        // nobody writes it; its quads are fetched together)
-                        const uint32_t oe = w0 & 0x7FFu;
-                        const uint32_t *orow = lists + (2u * base + oe) * (uint64_t)LC;
-                        const VsQuad o0 = *(const VsQuad *)orow, o1 = n > 4u ? *(const VsQuad *)(orow + 4) : VsQuad{0, 0, 0, 0};
-                        const VsQuad o2 = n > 8u ? *(const VsQuad *)(orow + 8) : VsQuad{0, 0, 0, 0}, o3 = n > 12u ? *(const VsQuad *)(orow + 12) : VsQuad{0, 0, 0, 0};
-                        const uint32_t ov[LC] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w, o2.x, o2.y, o2.z, o2.w, o3.x, o3.y, o3.z, o3.w};
-                        bool same = true;
-#pragma unroll
-                        for (uint32_t k2 = 0; k2 < LC; k2++) {
-                            bool found = false;
-#pragma unroll
-                            for (uint32_t i = 0; i < LC; i++) found |= mine[i] == ov[k2];
-                            same &= found || k2 >= n;
-                        }
-                        if (same) {  // merged: the owner expands for this end too
-                            atomicAdd(&s_dmul[at], 1u);
-                            if (side) mr = 0u; else ml = 0u;
-                            break;
-                        }
-                    }
-                    at = (at + 1u) & (ACC_DEDUP_SLOTS - 1u);
-                }
-            }
-            __syncthreads();
-            if (slot_of[0] != 0xFFFFFFFFu) ml += s_dmul[slot_of[0]];
-            if (slot_of[1] != 0xFFFFFFFFu) mr += s_dmul[slot_of[1]];
-        }
-        // (list length, multiplicity) travel together through the cross-lane reads below
-        const uint32_t nlw = nl | (ml << 8), nrw = nr | (mr << 8);
-        const uint32_t u = (skip_node ? 0u : nl * ((nr + ACC_RUN - 1u) / ACC_RUN)) + (ml ? s_g[nl] : 0u) + (mr ? s_g[nr] : 0u);
+        const uint32_t u = nl * ((nr + ACC_RUN - 1u) / ACC_RUN) + s_g[nl] + s_g[nr];
         uint32_t incl = u;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -1199,7 +1018,7 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
         // its (up to) four partners.  The two list loads of window i+1 are issued before window i is
         // counted, so their round trip (L2) is covered by the cell-table work instead of preceding it.
         struct Run {
-            uint32_t x, mat, bi, be, wgt;
+            uint32_t x, mat, bi, be;
             VsQuad yq;
             bool ok;
         };
@@ -1215,24 +1034,20 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
             while (s_pref[wv][a0 + 1u] <= t) a0++;
             uint32_t r = t - s_pref[wv][a0];
             // list lengths of pair a0: lane a0 holds them (cross-lane read, no memory round trip)
-            const uint32_t qlw = __shfl(nlw, (int)a0, 64), qrw = __shfl(nrw, (int)a0, 64);
+            const uint32_t ql = __shfl(nl, (int)a0, 64), qr = __shfl(nr, (int)a0, 64);
             R.ok = t_raw < U;
-            const uint32_t ql = qlw & 0xFFu, qr = qrw & 0xFFu;
             const uint32_t row = 2u * a0 * LC;
             const uint32_t cq = (qr + ACC_RUN - 1u) / ACC_RUN;
-            const uint32_t node_runs = skip_node ? 0u : ql * cq;
             uint32_t off;
-            R.wgt = 1u;
-            if (r < node_runs) {  // node_mat: left node a, right positions of run c
+            if (r < ql * cq) {  // node_mat: left node a, right positions of run c
                 const uint32_t a = cq == 1u ? r : cq == 2u ? r >> 1 : cq == 4u ? r >> 2 : (r * 43691u) >> 17;
                 R.x = wlists[row + a]; R.mat = 0u; off = row + LC; R.bi = ACC_RUN * (r - a * cq); R.be = qr;
             } else {
-                r -= node_runs;
+                r -= ql * cq;
                 uint32_t n = ql;
                 off = row;
-                R.wgt = qlw >> 8;
-                const uint32_t gl = R.wgt ? s_g[ql] : 0u;  // (a merged left list has no runs of its own)
-                if (r >= gl) { r -= gl; n = qr; off = row + LC; R.wgt = qrw >> 8; }
+                const uint32_t gl = s_g[ql];
+                if (r >= gl) { r -= gl; n = qr; off = row + LC; }
                 const uint32_t a = s_ua[n * ACC_GMAX + r];
                 const uint32_t crun = r - (s_g[n] - s_g[n - a]);  // runs of positions before a: g(n) - g(n-a)
                 R.x = wlists[off + a]; R.mat = 1u; R.bi = a + ACC_RUN * crun; R.be = n;
@@ -1249,47 +1064,40 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
             const Run c = nxt;
             if (t0 + 64u < U) nxt = fetch(t0 + 64u);
             if (!c.ok) continue;
-            const uint32_t x = c.x, mat = c.mat, bi = c.bi, be = c.be, wgt = c.wgt;
-            const VsQuad yq = c.yq;
-            const uint32_t y0 = yq.x, y1 = yq.y, y2 = yq.z, y3 = yq.w;
+            const uint32_t x = c.x, mat = c.mat, bi = c.bi, be = c.be;
+            const uint32_t ys[4] = {c.yq.x, c.yq.y, c.yq.z, c.yq.w};
             if (use_table == 2u) {
-                if ((y0 ^ y1 ^ y2 ^ y3 ^ x) == 0xDEADBEEFu) atomicAdd(&s_lost, 1u);  // (timing experiment: decode only)
+                if ((ys[0] ^ ys[1] ^ ys[2] ^ ys[3] ^ x) == 0xDEADBEEFu) atomicAdd(&s_lost, 1u);  // (timing experiment: decode only)
             } else if (use_table) {
-                const uint32_t ys[4] = {y0, y1, y2, y3};
-            // the four cells' slots are read together (independent LDS loads), then counted; a
-            // slot that does not hold the cell yet goes the slow way (claim / probe / global)
-            KT key[4], seen[4];
-            uint32_t at[4];
-            bool live[4];
+                // the four cells' slots are read together (independent LDS loads), then counted; a
+                // slot that does not hold the cell yet goes the slow way (claim / probe / global)
+                uint32_t key[4], seen[4], at[4];
 #pragma unroll
-            for (uint32_t j = 0; j < 4u; j++) {
-                live[j] = bi + j < be;  // j = 0 always
-                const uint32_t yv = ys[j];
-                const uint32_t cx = (mat && yv < x) ? yv : x, cy = (mat && yv < x) ? x : yv;
-                key[j] = TB::key(mat, cx, cy, N);
-                at[j] = TB::slot(mat, key[j]);
-                seen[j] = s_key[at[j]];
-            }
-#pragma unroll
-            for (uint32_t j = 0; j < 4u; j++) {
-                if (!live[j]) continue;
-                if (seen[j] == key[j]) {
-                    atomicAdd(&s_cnt[at[j]], wgt);
-                } else if (!vs_cell_claim<TB>(s_key, s_cnt, &s_used, key[j], at[j], wgt)) {
-                    atomicAdd(&s_lost, 1u);
-                    atomicAdd((mat ? short_mat : node_mat) + TB::cell_of(key[j], N), wgt);
+                for (uint32_t j = 0; j < 4u; j++) {
+                    const uint32_t yv = ys[j];
+                    const uint32_t cx = (mat && yv < x) ? yv : x, cy = (mat && yv < x) ? x : yv;
+                    key[j] = Acc32::key(mat, cx, cy, N);
+                    at[j] = Acc32::slot(key[j]);
+                    seen[j] = s_key[at[j]];
                 }
-            }
-            
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++) {
+                    if (bi + j >= be) continue;  // (j = 0 always counts)
+                    if (seen[j] == key[j]) {
+                        atomicAdd(&s_cnt[at[j]], 1u);
+                    } else if (!vs_cell_claim(s_key, s_cnt, &s_used, key[j], at[j], 1u)) {
+                        atomicAdd(&s_lost, 1u);
+                        atomicAdd(key[j] >= NN ? short_mat + (key[j] - NN) : node_mat + key[j], 1u);
+                    }
+                }
             } else {
                 // (VS_NO_AGG=1: every increment a global atomic)
-                const uint32_t ys[4] = {y0, y1, y2, y3};
 #pragma unroll
                 for (uint32_t j = 0; j < 4u; j++) {
                     if (bi + j >= be) continue;
                     const uint32_t yv = ys[j];
                     const uint32_t cx = (mat && yv < x) ? yv : x, cy = (mat && yv < x) ? x : yv;
-                    atomicAdd((mat ? short_mat : node_mat) + (uint64_t)cx * N + cy, wgt);
+                    atomicAdd((mat ? short_mat : node_mat) + (uint64_t)cx * N + cy, 1u);
                 }
             }
         }
@@ -1315,11 +1123,10 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
 // ---- which tiles of the counters a block touches (vs_pe_count_tracked) -------------------------------------------------
 // A pair adds to node_mat[l][r] for l in its left list, r in its right list, and to short_mat[min][max] for the pairs of
 // nodes of either list (PE_Inference.py:174-188): one lane per pair marks the 64 x 64 tiles those cells lie in, from the
-// same list rows k_pe_accumulate counts (the overflow kernels mark theirs where they add).  A caller that zeroes its
+// same list rows k_pe_accumulate counts (the overflow kernels and the row owners mark theirs where they add).  A caller that zeroes its
 // counters before every block then zeroes these tiles only (k_zero_tiles) -- a few per cent of a 50 k-node matrix.
 __global__ void __launch_bounds__(256) k_mark_tiles(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts,
-                                                   uint64_t n_slots_pairs, uint8_t *__restrict__ map, uint32_t T, uint32_t short_only) {
-    // (short_only: node_mat's tiles are marked by k_node_rows where it writes)
+                                                   uint64_t n_slots_pairs, uint8_t *__restrict__ map, uint32_t T) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_slots_pairs) return;
     const uint32_t nl = counts[2u * p], nr = counts[2u * p + 1u];
@@ -1362,7 +1169,7 @@ __global__ void __launch_bounds__(256) k_mark_tiles(const uint32_t *__restrict__
         }
     }
     if (over) {
-        for (uint32_t i = 0; i < nl && !short_only; i++)
+        for (uint32_t i = 0; i < nl; i++)
             for (uint32_t j = 0; j < nr; j++) vs_mark_tile(map, T, 0u, rl[i], rr[j]);
         for (uint32_t side = 0; side < 2u; side++) {
             const uint32_t *row = side ? rr : rl;
@@ -1375,16 +1182,14 @@ __global__ void __launch_bounds__(256) k_mark_tiles(const uint32_t *__restrict__
         }
         return;
     }
-    if (!short_only) {
 #pragma unroll
-        for (uint32_t a = 0; a < 8u; a++)
+    for (uint32_t a = 0; a < 8u; a++)
 #pragma unroll
-            for (uint32_t b = 0; b < 8u; b++)
-                if (a < kl && b < kr) {
-                    const uint64_t t = (uint64_t)tl[a] * T + tr[b];
-                    if (!map[t]) map[t] = 1;
-                }
-    }
+        for (uint32_t b = 0; b < 8u; b++)
+            if (a < kl && b < kr) {
+                const uint64_t t = (uint64_t)tl[a] * T + tr[b];
+                if (!map[t]) map[t] = 1;
+            }
     // short_mat: a cell sits at (smaller node, larger node), its tile at (smaller, larger) tile coordinates
 #pragma unroll
     for (uint32_t a = 0; a < 8u; a++)
@@ -1415,62 +1220,173 @@ __global__ void __launch_bounds__(64) k_zero_tiles(uint32_t *__restrict__ node_m
     if (threadIdx.x == 0) map[t] = 0;
 }
 
-// ---- node_mat by ROW OWNERS (graphs beyond the one-table shape of the cell table) ---------------------------------------
-// In locus order a round of 1 024 pairs of a 54 k-node graph brings ~30 k distinct cells, more than the LDS table holds, and
-// the same cell comes back from loci hundreds of rounds apart: 1.9e9 node_mat increments leave k_pe_accumulate as several
-// 1e8 memory-side atomics for 2.5e7 distinct cells (configs[4]; tools/cell_probe.py).  Turned round -- output-stationary --
-// the sums fit: ONE matrix row has a few hundred distinct cells however many pairs add to it.  So the left lists are
-// transposed (row x -> the pairs whose forward read holds x: a counting sort of one word per accepted node), a workgroup
-// owns a strip of rows at a time, adds the right lists of the strip's pairs into its LDS cell table, and writes every cell
-// ONCE.  PE_Inference.py:185-188 is the loop being reordered; integer sums do not care.
-//   k_rows_count  histogram of the left lists per chunk of pairs (LDS, 16-bit counts), added to row_count
-//   (scan)        row_ptr = exclusive sums
-//   k_rows_fill   the same histogram again; a chunk reserves its stretch of every row it holds with one global atomic,
-//                 then places its pairs through LDS cursors
-//   k_node_rows   strips of rows off a queue; a lane per (pair of the row, quad of its right list)
-#define ROWS_CHUNK 16384u  // pairs per chunk: a node is in a left list at most once, so a 16-bit count cannot wrap
+// ---- both matrices by ROW OWNERS (graphs beyond the one-table shape of the cell table) ---------------------------------
+// In locus order a round of 1 024 pairs of a 54 k-node graph brings ~30 k distinct cells, more than an LDS table holds,
+// and the same cell comes back from loci hundreds of rounds apart: 4.4e9 increments left the pair-major kernel as 7.9e8
+// memory-side atomics for 2.9e7 distinct cells (configs[4]; tools/cell_probe.py).  Turned round -- output-major -- the
+// sums fit: ONE matrix row has a few hundred distinct cells however many pairs add to it.  So the lists are transposed
+// (row x -> the items whose list holds x: a counting sort of one word per accepted node), a workgroup owns a strip of
+// rows at a time, adds the partner lists of the strip's items into its LDS cell table, and writes every cell ONCE.
+// PE_Inference.py:174-188 is the loop nest being reordered; integer sums do not care.
+//   node_mat  (mode 0): item = pair, row x in its LEFT list, partners = its RIGHT list             (:185-188)
+//   short_mat (mode 1): item = read end, row x in its list, partners = the nodes y >= x of the SAME list; an end whose
+//                       list equals that of an earlier end of its round is not an item of its own -- the first one
+//                       carries the multiplicity (k_list_owners), and adds it instead of 1           (:174-184)
+//   k_list_owners  per round of 1 024 pairs: which ends own their list, and how many ends share it
+//   k_rows_count   histogram of the items' lists per chunk (LDS, 16-bit counts), added to row_count
+//   (scan)         row_ptr = exclusive sums
+//   k_rows_fill    the same histogram again; a chunk reserves its stretch of every row it holds with one global atomic,
+//                  then places its items through LDS cursors
+//   k_rows_sum     strips of rows off a queue; a lane per (item of the row, quad of its partner list)
+#define OWN_SLOTS 2048u    // dedup slots of a round (2 048 ends: at most a fifth of them claim one)
+#define ROWS_CHUNK 16384u  // pairs per chunk: a node is in a list at most once, so a 16-bit count (<= 32 768 ends) cannot wrap
 #define ROWS_TPB 1024u
 #define ROWS_CAP 4096u     // distinct rows of a chunk that get an LDS cursor (the rest: a global atomic per entry)
-#define ROWS_MAX_N 65535u
-static inline size_t rows_lds_bytes(uint32_t N) { return sizeof(uint32_t) * (((size_t)N + 2u) / 2u + ROWS_CAP + ROWS_CAP / 2u + 4u); }
+#define ROWS_KEYS 65536u   // rows per histogram pass (larger graphs take several passes over the lists)
+#define ROWS_SUB (1u << 27)  // pairs per transposition (entry indices and row offsets are 32-bit)
+static inline size_t rows_lds_bytes(uint32_t n_keys) { return sizeof(uint32_t) * (((size_t)n_keys + 2u) / 2u + ROWS_CAP + ROWS_CAP / 2u + 4u); }
 
-// one lane per (pair, quad of its left list): the 16-bit bin of every listed node + 1
+// Equal end lists of a round (1 024 locus-ordered pairs: four of five ends repeat the list of another end) are merged:
+// the first end that brings a list owns it, the others only add to its multiplicity.  mult[end] = 0 (merged into another
+// end's list, or empty) or the number of ends the list stands for.  s_down[slot] = tag << 11 | owner end, s_dmul[slot] =
+// how many further ends hold the same list.  The tag is an order-independent fingerprint (the lists arrive in no
+// particular order); a tag match is confirmed node by node against the owner's row.
+__global__ void __launch_bounds__(ACC_TPB)
+k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_slots_pairs, uint32_t *__restrict__ mult) {
+    uint32_t *s_down = vs_lds, *s_dmul = vs_lds + OWN_SLOTS;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * ACC_TPB, p = base + tid;
+    for (uint32_t i = tid; i < OWN_SLOTS; i += ACC_TPB) { s_down[i] = 0xFFFFFFFFu; s_dmul[i] = 0u; }
+    __syncthreads();
+    uint32_t nl = 0, nr = 0;
+    if (p < n_slots_pairs) {
+        const uint2 c = *(const uint2 *)(counts + 2u * p);
+        nl = c.x; nr = c.y;
+    }
+    uint32_t ml = nl ? 1u : 0u, mr = nr ? 1u : 0u;
+    uint32_t slot_of[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
+    for (uint32_t side = 0; side < 2u; side++) {
+        const uint32_t n = side ? nr : nl;
+        if (n == 0u) continue;
+        const uint32_t me = 2u * tid + side;  // end index within the round
+        const uint32_t *row = lists + (2u * p + side) * LC;
+        uint32_t mine[LC];
+        {
+            const VsQuad a = *(const VsQuad *)row, b = n > 4u ? *(const VsQuad *)(row + 4) : VsQuad{0, 0, 0, 0};
+            const VsQuad c = n > 8u ? *(const VsQuad *)(row + 8) : VsQuad{0, 0, 0, 0}, d = n > 12u ? *(const VsQuad *)(row + 12) : VsQuad{0, 0, 0, 0};
+            const uint32_t v[LC] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (uint32_t i = 0; i < LC; i++) mine[i] = i < n ? v[i] : 0xFFFFFFFFu;
+        }
+        uint32_t fp = n * 0x9E3779B1u;
+#pragma unroll
+        for (uint32_t i = 0; i < LC; i++)
+            if (i < n) {
+                uint32_t h = mine[i] * 0x85EBCA6Bu;
+                h ^= h >> 15;
+                fp += h * 0xC2B2AE35u;  // (a sum: the order of the nodes does not matter)
+            }
+        // tag: 17 bits of the fingerprint and the list length (the owner's length comes with the table
+        // word: no load for it); all ones with owner 2047 would read as an empty slot -- n - 1 <= 15
+        // only together with tag bits all ones, so clear one
+        uint32_t tag = (((fp ^ (fp >> 13)) & 0x1FFFFu) << 4) | (n - 1u);
+        if (tag == 0x1FFFFFu) tag ^= 0x10u;
+        uint32_t at = (fp * 0x9E3779B1u) >> (32u - 11u);  // OWN_SLOTS = 2048
+        for (uint32_t pr = 0; pr < 6u; pr++) {
+            uint32_t w0 = s_down[at];
+            if (w0 == 0xFFFFFFFFu) {
+                w0 = atomicCAS(&s_down[at], 0xFFFFFFFFu, (tag << 11) | me);
+                if (w0 == 0xFFFFFFFFu) { slot_of[side] = at; break; }  // this end owns the list
+            }
+            if ((w0 >> 11) == tag) {
+                // same fingerprint and length: the same set of nodes?  (the owner's row is input data,
+                // nobody writes it; its quads are fetched together)
+                const uint32_t oe = w0 & 0x7FFu;
+                const uint32_t *orow = lists + (2u * base + oe) * (uint64_t)LC;
+                const VsQuad o0 = *(const VsQuad *)orow, o1 = n > 4u ? *(const VsQuad *)(orow + 4) : VsQuad{0, 0, 0, 0};
+                const VsQuad o2 = n > 8u ? *(const VsQuad *)(orow + 8) : VsQuad{0, 0, 0, 0}, o3 = n > 12u ? *(const VsQuad *)(orow + 12) : VsQuad{0, 0, 0, 0};
+                const uint32_t ov[LC] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w, o2.x, o2.y, o2.z, o2.w, o3.x, o3.y, o3.z, o3.w};
+                bool same = true;
+#pragma unroll
+                for (uint32_t k2 = 0; k2 < LC; k2++) {
+                    bool found = false;
+#pragma unroll
+                    for (uint32_t i = 0; i < LC; i++) found |= mine[i] == ov[k2];
+                    same &= found || k2 >= n;
+                }
+                if (same) {  // merged: the owner stands for this end too
+                    atomicAdd(&s_dmul[at], 1u);
+                    if (side) mr = 0u; else ml = 0u;
+                    break;
+                }
+            }
+            at = (at + 1u) & (OWN_SLOTS - 1u);
+        }
+    }
+    __syncthreads();
+    if (slot_of[0] != 0xFFFFFFFFu) ml += s_dmul[slot_of[0]];
+    if (slot_of[1] != 0xFFFFFFFFu) mr += s_dmul[slot_of[1]];
+    if (p < n_slots_pairs) *(uint2 *)(mult + 2u * p) = make_uint2(ml, mr);
+}
+
+// The list of item i that is transposed, and its length (0: not an item).  Mode 0: pair i, its left list -- only if the
+// right list holds anything; mode 1: read end i, if it owns its list.
+template <int MODE>
+__device__ __forceinline__ uint32_t vs_rows_item(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ mult, uint64_t i, uint64_t &row) {
+    if (MODE == 0) {
+        const uint2 c = *(const uint2 *)(counts + 2u * i);
+        row = 2u * i;
+        return c.y ? c.x : 0u;
+    }
+    row = i;
+    return mult[i] ? counts[i] : 0u;
+}
+
+// one lane per (item, quad of its list): the 16-bit bin of every listed node in [key_lo, key_lo + n_keys) + 1
+template <int MODE>
 __device__ __forceinline__ void vs_rows_histogram(uint32_t *h32, const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts,
-                                                  uint64_t lo, uint64_t hi) {
+                                                  const uint32_t *__restrict__ mult, uint64_t lo, uint64_t hi, uint32_t key_lo, uint32_t n_keys) {
     for (uint64_t i = lo * 4u + threadIdx.x; i < hi * 4u; i += ROWS_TPB) {
-        const uint64_t p = i >> 2;
-        const uint32_t q = (uint32_t)i & 3u, nl = counts[2u * p];
-        if (4u * q >= nl) continue;
-        const VsQuad v = *(const VsQuad *)(lists + 2u * p * LC + 4u * q);
+        uint64_t row;
+        const uint32_t q = (uint32_t)i & 3u, n = vs_rows_item<MODE>(counts, mult, i >> 2, row);
+        if (4u * q >= n) continue;
+        const VsQuad v = *(const VsQuad *)(lists + row * LC + 4u * q);
         const uint32_t e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (uint32_t j = 0; j < 4u; j++)
-            if (4u * q + j < nl) atomicAdd(&h32[e[j] >> 1], 1u << ((e[j] & 1u) * 16u));
+        for (uint32_t j = 0; j < 4u; j++) {
+            const uint32_t x = e[j] - key_lo;
+            if (4u * q + j < n && x < n_keys) atomicAdd(&h32[x >> 1], 1u << ((x & 1u) * 16u));
+        }
     }
 }
 
+template <int MODE>
 __global__ void __launch_bounds__(ROWS_TPB)
-k_rows_count(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_slots_pairs, uint32_t N,
-             uint32_t *__restrict__ row_count) {
+k_rows_count(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ mult, uint64_t n_items,
+             uint32_t key_lo, uint32_t n_keys, uint32_t *__restrict__ row_count) {
     uint32_t *h32 = vs_lds;
-    const uint32_t words = (N + 2u) >> 1, tid = threadIdx.x;
+    const uint32_t words = (n_keys + 1u) >> 1, tid = threadIdx.x;
     for (uint32_t i = tid; i < words; i += ROWS_TPB) h32[i] = 0u;
     __syncthreads();
-    const uint64_t lo = (uint64_t)blockIdx.x * ROWS_CHUNK, hi = lo + ROWS_CHUNK < n_slots_pairs ? lo + ROWS_CHUNK : n_slots_pairs;
-    vs_rows_histogram(h32, lists, counts, lo, hi);
+    const uint64_t per = MODE ? 2u * ROWS_CHUNK : ROWS_CHUNK;
+    const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n_items ? lo + per : n_items;
+    vs_rows_histogram<MODE>(h32, lists, counts, mult, lo, hi, key_lo, n_keys);
     __syncthreads();
     for (uint32_t i = tid; i < words; i += ROWS_TPB) {
         const uint32_t v = h32[i];
-        if (v & 0xFFFFu) atomicAdd(&row_count[2u * i], v & 0xFFFFu);
-        if (v >> 16) atomicAdd(&row_count[2u * i + 1u], v >> 16);
+        if (v & 0xFFFFu) atomicAdd(&row_count[key_lo + 2u * i], v & 0xFFFFu);
+        if (v >> 16) atomicAdd(&row_count[key_lo + 2u * i + 1u], v >> 16);
     }
 }
 
+template <int MODE>
 __global__ void __launch_bounds__(ROWS_TPB)
-k_rows_fill(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_slots_pairs, uint32_t N,
-            const uint32_t *__restrict__ row_ptr, uint32_t *__restrict__ row_cursor, uint32_t *__restrict__ entries) {
+k_rows_fill(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ mult, uint64_t n_items,
+            uint32_t key_lo, uint32_t n_keys, const uint32_t *__restrict__ row_ptr, uint32_t *__restrict__ row_cursor,
+            uint32_t *__restrict__ entries) {
     uint32_t *h32 = vs_lds;
-    const uint32_t words = (N + 2u) >> 1, tid = threadIdx.x;
+    const uint32_t words = (n_keys + 1u) >> 1, tid = threadIdx.x;
     uint32_t *s_base = h32 + words;          // [ROWS_CAP] where this chunk's stretch of the row starts
     uint32_t *s_fill = s_base + ROWS_CAP;    // [ROWS_CAP / 2] 16-bit cursors inside the stretch
     uint32_t &s_nc = s_fill[ROWS_CAP / 2u];
@@ -1478,8 +1394,9 @@ k_rows_fill(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ cou
     for (uint32_t i = tid; i < ROWS_CAP / 2u; i += ROWS_TPB) s_fill[i] = 0u;
     if (tid == 0) s_nc = 0u;
     __syncthreads();
-    const uint64_t lo = (uint64_t)blockIdx.x * ROWS_CHUNK, hi = lo + ROWS_CHUNK < n_slots_pairs ? lo + ROWS_CHUNK : n_slots_pairs;
-    vs_rows_histogram(h32, lists, counts, lo, hi);
+    const uint64_t per = MODE ? 2u * ROWS_CHUNK : ROWS_CHUNK;
+    const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n_items ? lo + per : n_items;
+    vs_rows_histogram<MODE>(h32, lists, counts, mult, lo, hi, key_lo, n_keys);
     __syncthreads();
     // a bin that is not empty: reserve the chunk's stretch of that row, and turn the bin into the number of its cursor
     for (uint32_t i = tid; i < words; i += ROWS_TPB) {
@@ -1490,7 +1407,7 @@ k_rows_fill(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ cou
         for (uint32_t half = 0; half < 2u; half++) {
             const uint32_t c = (v >> (16u * half)) & 0xFFFFu;
             if (!c) continue;
-            const uint32_t x = 2u * i + half;
+            const uint32_t x = key_lo + 2u * i + half;
             const uint32_t ci = atomicAdd(&s_nc, 1u);
             uint32_t code = 0xFFFFu;
             if (ci < ROWS_CAP) {
@@ -1503,15 +1420,15 @@ k_rows_fill(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ cou
     }
     __syncthreads();
     for (uint64_t i = lo * 4u + tid; i < hi * 4u; i += ROWS_TPB) {
-        const uint64_t p = i >> 2;
-        const uint32_t q = (uint32_t)i & 3u, nl = counts[2u * p];
-        if (4u * q >= nl) continue;
-        const VsQuad v = *(const VsQuad *)(lists + 2u * p * LC + 4u * q);
+        uint64_t row;
+        const uint32_t q = (uint32_t)i & 3u, n = vs_rows_item<MODE>(counts, mult, i >> 2, row);
+        if (4u * q >= n) continue;
+        const VsQuad v = *(const VsQuad *)(lists + row * LC + 4u * q);
         const uint32_t e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (uint32_t j = 0; j < 4u; j++) {
-            if (4u * q + j >= nl) continue;
-            const uint32_t x = e[j];
+            const uint32_t x = e[j] - key_lo;
+            if (4u * q + j >= n || x >= n_keys) continue;
             const uint32_t code = (h32[x >> 1] >> ((x & 1u) * 16u)) & 0xFFFFu;
             uint32_t pos;
             if (code != 0xFFFFu) {
@@ -1519,24 +1436,26 @@ k_rows_fill(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ cou
                 const uint32_t old = atomicAdd(&s_fill[code >> 1], 1u << sh);
                 pos = s_base[code] + ((old >> sh) & 0xFFFFu);
             } else {
-                pos = row_ptr[x] + atomicAdd(&row_cursor[x], 1u);
+                pos = row_ptr[e[j]] + atomicAdd(&row_cursor[e[j]], 1u);
             }
-            entries[pos] = (uint32_t)p;
+            entries[pos] = (uint32_t)(i >> 2);
         }
     }
 }
 
-#define NROWS_LDS_BYTES ((2u * ACC_SLOTS + 64u + 8u) * 4u)
+#define RSUM_LDS_BYTES ((2u * ACC_SLOTS + 64u + 8u) * 4u)
+#define RSUM_MAX_ROWS 64u
+template <int MODE>
 __global__ void __launch_bounds__(ACC_TPB)
-k_node_rows(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint32_t N, const uint32_t *__restrict__ row_ptr,
-            const uint32_t *__restrict__ entries, uint32_t R, uint32_t n_strips, uint32_t fill_limit, uint32_t *__restrict__ node_mat,
-            uint32_t off0, uint8_t *__restrict__ tile_map, uint32_t T, uint32_t *__restrict__ queue, uint32_t *__restrict__ dbg) {
-    using TB = Acc32;
-    uint32_t *s_key = vs_lds, *s_cnt = vs_lds + ACC_SLOTS, *s_rowend = vs_lds + 2u * ACC_SLOTS;  // [64]
+k_rows_sum(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ mult, uint32_t N,
+           const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ entries, uint32_t R, uint32_t n_strips, uint32_t fill_limit,
+           uint32_t *__restrict__ mat, uint32_t off, uint8_t *__restrict__ tile_map, uint32_t T, uint32_t *__restrict__ queue,
+           uint32_t *__restrict__ dbg) {
+    uint32_t *s_key = vs_lds, *s_cnt = vs_lds + ACC_SLOTS, *s_rowend = vs_lds + 2u * ACC_SLOTS;  // [RSUM_MAX_ROWS]
     uint32_t &s_used = s_rowend[64], &s_lost = s_rowend[65], &s_strip = s_rowend[66];
     const uint32_t tid = threadIdx.x, q = tid & 3u;
     constexpr uint32_t STEP = ACC_TPB / 4u;  // entries per pass of the workgroup
-    for (uint32_t i = tid; i < ACC_SLOTS; i += ACC_TPB) { s_key[i] = TB::EMPTY; s_cnt[i] = 0u; }
+    for (uint32_t i = tid; i < ACC_SLOTS; i += ACC_TPB) { s_key[i] = Acc32::EMPTY; s_cnt[i] = 0u; }
     if (tid == 0) { s_used = 0u; s_lost = 0u; }
     for (;;) {
         __syncthreads();
@@ -1548,20 +1467,20 @@ k_node_rows(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ cou
         if (tid < nrows) s_rowend[tid] = row_ptr[first + tid + 1u];
         const uint32_t e0 = row_ptr[first], e1 = row_ptr[first + nrows];
         // keys are cell indices relative to the strip's first row, shifted so that key >> 4 is one 64-byte stretch of the matrix
-        const uint32_t align = (uint32_t)(((uint64_t)first * N + off0) & 15u);
+        const uint32_t align = (uint32_t)(((uint64_t)first * N + off) & 15u);
         const uint64_t cell0 = (uint64_t)first * N;
         __syncthreads();
         auto write_out = [&]() {
             for (uint32_t i = tid; i < ACC_SLOTS; i += ACC_TPB) {
                 const uint32_t key = s_key[i];
-                if (key != TB::EMPTY) {
+                if (key != Acc32::EMPTY) {
                     const uint32_t k2 = key - align;
-                    atomicAdd(node_mat + cell0 + k2, s_cnt[i]);
+                    atomicAdd(mat + cell0 + k2, s_cnt[i]);
                     if (tile_map) {
                         const uint32_t xl = k2 / N;
-                        vs_mark_tile(tile_map, T, 0u, first + xl, k2 - xl * N);
+                        vs_mark_tile(tile_map, T, (uint32_t)MODE, first + xl, k2 - xl * N);
                     }
-                    s_key[i] = TB::EMPTY;
+                    s_key[i] = Acc32::EMPTY;
                     s_cnt[i] = 0u;
                 }
             }
@@ -1570,53 +1489,61 @@ k_node_rows(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ cou
             if (tid == 0) { s_used = 0u; s_lost = 0u; }
             __syncthreads();
         };
-        // the pair of entry i two passes ahead, its right list one pass ahead (two dependent loads off the critical path)
-        auto load_pair = [&](uint32_t base) -> uint32_t {
+        // the item of entry i is loaded two passes ahead, its partner list one pass ahead (two dependent loads off the
+        // critical path)
+        auto load_item = [&](uint32_t base) -> uint32_t {
             const uint32_t i = base + (tid >> 2);
             return i < e1 ? entries[i] : 0xFFFFFFFFu;
         };
-        auto load_list = [&](uint32_t p, uint32_t &nr, VsQuad &yq) {
-            nr = 0u;
+        auto load_list = [&](uint32_t it, uint32_t &n, uint32_t &wgt, VsQuad &yq) {
+            n = 0u;
+            wgt = 1u;
             yq = VsQuad{0u, 0u, 0u, 0u};
-            if (p != 0xFFFFFFFFu) {
-                nr = counts[2u * (uint64_t)p + 1u];
-                yq = *(const VsQuad *)(lists + (2u * (uint64_t)p + 1u) * LC + 4u * q);
+            if (it != 0xFFFFFFFFu) {
+                const uint64_t row = MODE ? (uint64_t)it : 2u * (uint64_t)it + 1u;
+                n = counts[row];
+                if (MODE) wgt = mult[it];
+                yq = *(const VsQuad *)(lists + row * LC + 4u * q);
             }
         };
-        uint32_t p1 = e0 < e1 ? load_pair(e0) : 0xFFFFFFFFu;
-        uint32_t p2 = e1 - e0 > STEP ? load_pair(e0 + STEP) : 0xFFFFFFFFu;
-        uint32_t n1;
+        uint32_t p1 = e0 < e1 ? load_item(e0) : 0xFFFFFFFFu;
+        uint32_t p2 = e1 - e0 > STEP ? load_item(e0 + STEP) : 0xFFFFFFFFu;
+        uint32_t n1, w1;
         VsQuad y1;
-        load_list(p1, n1, y1);
+        load_list(p1, n1, w1, y1);
         uint32_t pass = 0;
         for (uint32_t base = e0; base < e1; base += STEP, pass++) {
-            const uint32_t nr = n1;
+            const uint32_t n = n1, wgt = w1;
             const VsQuad yq = y1;
             p1 = p2;
-            load_list(p1, n1, y1);
-            p2 = e1 - base > 2u * STEP ? load_pair(base + 2u * STEP) : 0xFFFFFFFFu;
-            if (4u * q < nr) {
+            load_list(p1, n1, w1, y1);
+            p2 = e1 - base > 2u * STEP ? load_item(base + 2u * STEP) : 0xFFFFFFFFu;
+            if (4u * q < n) {
                 const uint32_t i = base + (tid >> 2);
-                uint32_t xl = 0;
-                for (uint32_t j = 0; j + 1u < nrows; j++) xl += s_rowend[j] <= i ? 1u : 0u;
-                const uint32_t kbase = xl * N + align;
+                uint32_t xl = 0;  // rows of the strip that end at or before entry i
+#pragma unroll
+                for (uint32_t step = RSUM_MAX_ROWS / 2u; step; step >>= 1) {
+                    const uint32_t t = xl + step;
+                    if (t < nrows && s_rowend[t - 1u] <= i) xl = t;
+                }
+                const uint32_t kbase = xl * N + align, x = first + xl;
                 const uint32_t ys[4] = {yq.x, yq.y, yq.z, yq.w};
                 uint32_t key[4], seen[4], at[4];
 #pragma unroll
                 for (uint32_t j = 0; j < 4u; j++) {
                     key[j] = kbase + ys[j];
-                    at[j] = TB::slot(0u, key[j]);
+                    at[j] = Acc32::slot(key[j]);
                     seen[j] = s_key[at[j]];
                 }
 #pragma unroll
                 for (uint32_t j = 0; j < 4u; j++) {
-                    if (4u * q + j >= nr) continue;
+                    if (4u * q + j >= n || (MODE && ys[j] < x)) continue;  // (short_mat: the cell (x, y) belongs to the smaller node's row)
                     if (seen[j] == key[j]) {
-                        atomicAdd(&s_cnt[at[j]], 1u);
-                    } else if (!vs_cell_claim<TB>(s_key, s_cnt, &s_used, key[j], at[j], 1u)) {
+                        atomicAdd(&s_cnt[at[j]], wgt);
+                    } else if (!vs_cell_claim(s_key, s_cnt, &s_used, key[j], at[j], wgt)) {
                         atomicAdd(&s_lost, 1u);
-                        vs_mark_tile(tile_map, T, 0u, first + xl, ys[j]);
-                        atomicAdd(node_mat + cell0 + (key[j] - align), 1u);
+                        vs_mark_tile(tile_map, T, (uint32_t)MODE, x, ys[j]);
+                        atomicAdd(mat + cell0 + (key[j] - align), wgt);
                     }
                 }
             }
@@ -2115,6 +2042,103 @@ static size_t lds_bytes(uint32_t ept, uint32_t pmax, uint32_t words_cap) {
     return (size_t)tile_layout(ept, pmax, words_cap, pool).total * sizeof(uint32_t);
 }
 
+// The row-owner path: both counters of one block from the per-end lists (see "both matrices by ROW OWNERS").
+static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_mat, uint32_t *d_short_mat, uint8_t *d_tile_map, uint32_t T) {
+    hipStream_t st = ctx->stream;
+    const VsTuning &tn = ctx->tune;
+    const uint32_t N = ctx->idx.n_nodes;
+    const uint64_t list_ends = 2u * slots_pairs;
+    const uint64_t sub_max = tn.rows_sub ? (uint64_t)tn.rows_sub / ACC_TPB * ACC_TPB : (uint64_t)ROWS_SUB;  // (whole rounds of k_list_owners)
+    const uint64_t sub_pairs = slots_pairs < sub_max ? slots_pairs : sub_max;  // pairs per transposition
+    if (ctx->rows_cap < (uint64_t)N + 2u) {
+        if (ctx->d_rows) VS_HIP(ctx, hipFree(ctx->d_rows));
+        ctx->d_rows = nullptr;
+        ctx->rows_cap = 0;
+        // per mode: counts, cursors, offsets; then the block sums of the scan (2 048 values per block, 64 bits each)
+        VS_HIP(ctx, hipMalloc(&ctx->d_rows, sizeof(uint32_t) * 6u * ((uint64_t)N + 2u) + sizeof(uint64_t) * ((uint64_t)N / 2048u + 8u)));
+        ctx->rows_cap = (uint64_t)N + 2u;
+    }
+    // entries: one word per listed node -- the left lists (node_mat) and the lists of the owning ends (short_mat)
+    if (ctx->row_entries_cap < 3u * sub_pairs * LC || ctx->mult_cap < list_ends) {
+        if (ctx->d_row_entries) VS_HIP(ctx, hipFree(ctx->d_row_entries));
+        if (ctx->d_mult) VS_HIP(ctx, hipFree(ctx->d_mult));
+        ctx->d_row_entries = ctx->d_mult = nullptr;
+        ctx->row_entries_cap = ctx->mult_cap = 0;
+        VS_HIP(ctx, hipMalloc(&ctx->d_row_entries, sizeof(uint32_t) * (3u * sub_pairs * LC + 16u)));
+        VS_HIP(ctx, hipMalloc(&ctx->d_mult, sizeof(uint32_t) * (list_ends + 2u)));
+        ctx->row_entries_cap = 3u * sub_pairs * LC;
+        ctx->mult_cap = list_ends;
+    }
+    const uint64_t cap = ctx->rows_cap;
+    uint32_t *rows = (uint32_t *)ctx->d_rows;
+    uint64_t *scan_tmp = (uint64_t *)(rows + ((6u * cap + 1u) & ~1ull));
+    const uint32_t keys_max = tn.rows_keys ? tn.rows_keys : ROWS_KEYS;
+    const uint32_t n_keys = N < keys_max ? N : keys_max;
+    const size_t rl = rows_lds_bytes(n_keys);
+    for (const void *fn : {(const void *)k_rows_count<0>, (const void *)k_rows_count<1>, (const void *)k_rows_fill<0>, (const void *)k_rows_fill<1>})
+        VS_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
+    for (const void *fn : {(const void *)k_rows_sum<0>, (const void *)k_rows_sum<1>})
+        VS_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RSUM_LDS_BYTES));
+    const uint32_t *lists = (const uint32_t *)ctx->d_lists, *counts = (const uint32_t *)ctx->d_list_counts;
+    uint32_t *mult = (uint32_t *)ctx->d_mult;
+    hipLaunchKernelGGL(k_list_owners, dim3((unsigned)((slots_pairs + ACC_TPB - 1u) / ACC_TPB)), dim3(ACC_TPB), 2u * OWN_SLOTS * sizeof(uint32_t), st,
+                       lists, counts, slots_pairs, mult);
+    // the table is written out once this share of its slots is taken (a strip that holds more cells than that is written
+    // in pieces: still one atomic per cell and piece); VS_ACC_FILL: percent
+    uint32_t fill = ACC_SLOTS / 2u + ACC_SLOTS / 8u;
+    if (tn.acc_fill_pct >= 0) fill = (uint32_t)((uint64_t)ACC_SLOTS * (uint32_t)tn.acc_fill_pct / 100u);
+    if (fill > ACC_SLOTS - 4096u) fill = ACC_SLOTS - 4096u;
+    // rows per strip: a strip's distinct cells should fill the table less than half.  configs[4]: 4 rows of node_mat hold
+    // 1.7 k cells at the median and 6 k at most, 32 rows of short_mat 2.1 k and 6.6 k.  VS_ROWS_PER_STRIP overrides both.
+    const uint32_t R[2] = {tn.rows_per_strip ? tn.rows_per_strip : 4u, tn.rows_per_strip ? tn.rows_per_strip : 32u};
+    uint32_t *dbg = tn.debug_acc ? (uint32_t *)ctx->d_slow_count + 10 : nullptr;
+    for (uint64_t p0 = 0; p0 < slots_pairs; p0 += sub_pairs) {
+        const uint64_t np = slots_pairs - p0 < sub_pairs ? slots_pairs - p0 : sub_pairs;
+        const uint32_t *sl = lists + 2u * p0 * LC, *sc = counts + 2u * p0, *sm = mult + 2u * p0;
+        const unsigned n_chunks = (unsigned)((np + ROWS_CHUNK - 1u) / ROWS_CHUNK);
+        VS_HIP(ctx, hipMemsetAsync(rows, 0, sizeof(uint32_t) * 6u * cap, st));
+        VS_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->d_slow_count + 9, 0, sizeof(uint32_t), st));
+        for (int mode = 0; mode < 2; mode++) {
+            uint32_t *row_count = rows + 3u * mode * cap, *row_cursor = row_count + cap, *row_ptr = row_cursor + cap;
+            uint32_t *entries = (uint32_t *)ctx->d_row_entries + (mode ? np * LC : 0u);
+            const uint64_t n_items = mode ? 2u * np : np;
+            for (uint32_t key_lo = 0; key_lo < N; key_lo += n_keys) {
+                const uint32_t nk = N - key_lo < n_keys ? N - key_lo : n_keys;
+                if (mode) hipLaunchKernelGGL(k_rows_count<1>, dim3(n_chunks), dim3(ROWS_TPB), rl, st, sl, sc, sm, n_items, key_lo, nk, row_count);
+                else hipLaunchKernelGGL(k_rows_count<0>, dim3(n_chunks), dim3(ROWS_TPB), rl, st, sl, sc, sm, n_items, key_lo, nk, row_count);
+            }
+            int rc = vs_scan_u32(ctx, row_count, row_ptr, (uint64_t)N + 1u, scan_tmp, nullptr);
+            if (rc) return rc;
+            for (uint32_t key_lo = 0; key_lo < N; key_lo += n_keys) {
+                const uint32_t nk = N - key_lo < n_keys ? N - key_lo : n_keys;
+                if (mode) hipLaunchKernelGGL(k_rows_fill<1>, dim3(n_chunks), dim3(ROWS_TPB), rl, st, sl, sc, sm, n_items, key_lo, nk, (const uint32_t *)row_ptr, row_cursor, entries);
+                else hipLaunchKernelGGL(k_rows_fill<0>, dim3(n_chunks), dim3(ROWS_TPB), rl, st, sl, sc, sm, n_items, key_lo, nk, (const uint32_t *)row_ptr, row_cursor, entries);
+            }
+        }
+        for (int mode = 0; mode < 2; mode++) {
+            const uint32_t *row_ptr = rows + 3u * mode * cap + 2u * cap;
+            const uint32_t *entries = (const uint32_t *)ctx->d_row_entries + (mode ? np * LC : 0u);
+            const uint32_t n_strips = (N + R[mode] - 1u) / R[mode];
+            uint32_t grid = (uint32_t)ctx->n_cu * 2u;
+            if (grid > n_strips) grid = n_strips;
+            uint32_t *m = mode ? d_short_mat : d_node_mat;
+            const uint32_t off = (uint32_t)(((uintptr_t)m >> 2) & 15u);
+            uint32_t *queue = (uint32_t *)ctx->d_slow_count + 9;
+            if (mode) {
+                // (the queue of mode 0 has run past n_strips of mode 0: start again)
+                VS_HIP(ctx, hipMemsetAsync(queue, 0, sizeof(uint32_t), st));
+                hipLaunchKernelGGL(k_rows_sum<1>, dim3(grid), dim3(ACC_TPB), RSUM_LDS_BYTES, st, sl, sc, sm, N, row_ptr, entries, R[1], n_strips, fill, m, off,
+                                   d_tile_map, T, queue, dbg);
+            } else {
+                hipLaunchKernelGGL(k_rows_sum<0>, dim3(grid), dim3(ACC_TPB), RSUM_LDS_BYTES, st, sl, sc, sm, N, row_ptr, entries, R[0], n_strips, fill, m, off,
+                                   d_tile_map, T, queue, dbg);
+            }
+        }
+    }
+    VS_HIP(ctx, hipGetLastError());
+    return VS_OK;
+}
+
 static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, uint32_t *d_short_mat, uint64_t *d_stats,
                      uint32_t *d_dbg_lists, uint32_t *d_dbg_counts, uint32_t dbg_cap, uint8_t *d_tile_map = nullptr) {
     if (!ctx->has_index) return vs_fail(ctx, VS_E_STATE, "vs_pe_count: build an index first (vs_index_build)");
@@ -2374,115 +2398,50 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         if (list_ends > used_ends)
             VS_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->d_list_counts + used_ends, 0, sizeof(uint32_t) * (list_ends - used_ends), st));
         const uint64_t slots_pairs = list_ends / 2;
-        // one workgroup fits per CU (the cell table); 32 per CU queued, for the same reason as above
-        // (4.9 -> 3.9 ms), each at least one round of ACC_TPB pairs
-        uint32_t acc_grid = (uint32_t)ctx->n_cu * tn.acc_grid_per_cu;
-        uint32_t per_wg = (uint32_t)((slots_pairs + acc_grid - 1) / acc_grid);
-        per_wg = (per_wg + ACC_TPB - 1) / ACC_TPB * ACC_TPB;
-        acc_grid = (uint32_t)((slots_pairs + per_wg - 1) / per_wg);
-        // the chunks are not bound to workgroups: two workgroups per CU take the next chunk off a
-        // counter whenever they are free, so a cell table lives across chunks and is written out on
-        // fill only (3.85 -> 3.6 ms against one workgroup per chunk; VS_ACC_QUEUE=0 for that)
-        uint32_t *acc_queue = nullptr;
-        if (tn.acc_queue) {
-            acc_queue = (uint32_t *)ctx->d_slow_count + 1;
-            const uint32_t wgs = (uint32_t)ctx->n_cu * 2u;
-            if (acc_grid > wgs) acc_grid = wgs;
-        }
-        // 32-bit cell keys while 2*N*N fits, 64-bit keys (half the slots) above; VS_ACC_WIDE=1 forces
-        // the wide table, VS_NO_AGG=1 turns the table off (every increment a global atomic)
-        // table shape (see Acc32 / Acc32Split / Acc64); VS_ACC_WIDE=1 forces the 64-bit keys, =2 the split tables
-        const int force_shape = tn.acc_wide;
-        const bool fits32 = 2ull * idx.n_nodes * idx.n_nodes < 0xFFFFFFFFull, fits_split = idx.n_nodes <= 65535u;
-        const int shape = force_shape == 1 ? 2 : (force_shape == 2 && fits_split) ? 1 : fits32 ? 0 : fits_split ? 1 : 2;
-        const bool wide = shape == 2;
-        const uint32_t merge = (tn.acc_merge || shape == 1) ? 1u : 0u;  // (also what the short_mat-only pass of the row-owner path runs with)
-        const uint32_t slots = wide ? ACC_SLOTS / 2u : ACC_SLOTS;
-        // the table is written out once this many of its slots (groups) are taken: probing stays
-        // short at a low fill, and cells of loci the run has left do not pile up (VS_ACC_FILL: percent)
-        uint32_t fill_limit = slots / 16u;
-        if (tn.acc_fill_pct >= 0) fill_limit = (uint32_t)((uint64_t)slots * (uint32_t)tn.acc_fill_pct / 100u);
+        // VS_NO_AGG=1 turns the summing in LDS off (every increment a global atomic)
         uint32_t use_table = tn.no_agg ? 0u : 1u;
         if (tn.acc_ablate >= 0) use_table = (uint32_t)tn.acc_ablate;  // 2: decode only, 3: no write-outs (VS_EXPERIMENT=timing only)
-        // VS_ACC_MERGE=1: equal end lists of a round are merged (one weighted short_mat expansion per distinct
-        // list).  Exact and tested, but off by default: it removes 47 % of the increments at configs[2] and
-        // the kernel takes the same time -- the cell table is not what the time goes into there -- while it
-        // costs 8-20 % on graphs with short lists (configs[1], [3]); the split-table shape (VS_ACC_WIDE=2) gains 4 % from it
-        // at configs[4] and turns it on by itself.
-        uint32_t *acc_dbg = tn.debug_acc ? (uint32_t *)ctx->d_slow_count + 4 : nullptr;
-        const uint32_t acc_ppw = tn.acc_round ? tn.acc_round / (ACC_TPB / 64u) : 64u;  // VS_ACC_ROUND: pairs per round
+        // pair-major with one cell table while 2*N*N fits its 32-bit keys, by row owners above; VS_ACC_ROWS=0 / 1
+        // overrides (0 beyond 46 340 nodes: no table, every increment a global atomic)
+        const bool fits32 = 2ull * idx.n_nodes * idx.n_nodes < 0xFFFFFFFFull;
+        bool use_rows = tn.acc_rows >= 0 ? tn.acc_rows != 0 : !fits32;
+        if (idx.n_nodes == 0 || use_table != 1u) use_rows = false;
+        if (!use_rows && !fits32 && use_table == 1u) use_table = 0u;
         VS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
-        // node_mat by row owners (see k_node_rows) where the one-table shape no longer fits -- the graphs whose rounds bring
-        // more distinct cells than the table holds; VS_ACC_ROWS=0 / 1 overrides (1: any graph of at most 65 535 nodes)
-        bool use_rows = tn.acc_rows >= 0 ? tn.acc_rows != 0 : shape == 1;
-        if (idx.n_nodes > ROWS_MAX_N || idx.n_nodes == 0 || slots_pairs * LC >= 0xF0000000ull || use_table != 1u) use_rows = false;
         if (use_rows) {
-            const uint32_t N = idx.n_nodes;
-            if (ctx->rows_cap < (uint64_t)N + 2u) {
-                if (ctx->d_rows) VS_HIP(ctx, hipFree(ctx->d_rows));
-                ctx->d_rows = nullptr;
-                ctx->rows_cap = 0;
-                // (+ the block sums of the scan: 2 048 values per block, 64 bits each)
-                VS_HIP(ctx, hipMalloc(&ctx->d_rows, sizeof(uint32_t) * 3u * ((uint64_t)N + 2u) + sizeof(uint64_t) * ((uint64_t)N / 2048u + 8u)));
-                ctx->rows_cap = (uint64_t)N + 2u;
-            }
-            if (ctx->row_entries_cap < slots_pairs * LC) {
-                if (ctx->d_row_entries) VS_HIP(ctx, hipFree(ctx->d_row_entries));
-                ctx->d_row_entries = nullptr;
-                ctx->row_entries_cap = 0;
-                VS_HIP(ctx, hipMalloc(&ctx->d_row_entries, sizeof(uint32_t) * (slots_pairs * LC + 16u)));
-                ctx->row_entries_cap = slots_pairs * LC;
-            }
-            uint32_t *row_count = (uint32_t *)ctx->d_rows, *row_cursor = row_count + ctx->rows_cap, *row_ptr = row_cursor + ctx->rows_cap;
-            VS_HIP(ctx, hipMemsetAsync(row_count, 0, sizeof(uint32_t) * 2u * ctx->rows_cap, st));
-            const unsigned n_chunks = (unsigned)((slots_pairs + ROWS_CHUNK - 1u) / ROWS_CHUNK);
-            const size_t rl = rows_lds_bytes(N);
-            VS_HIP(ctx, hipFuncSetAttribute((const void *)k_rows_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
-            VS_HIP(ctx, hipFuncSetAttribute((const void *)k_rows_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
-            VS_HIP(ctx, hipFuncSetAttribute((const void *)k_node_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NROWS_LDS_BYTES));
-            hipLaunchKernelGGL(k_rows_count, dim3(n_chunks), dim3(ROWS_TPB), rl, st, (const uint32_t *)ctx->d_lists,
-                               (const uint32_t *)ctx->d_list_counts, slots_pairs, N, row_count);
-            // (3 * rows_cap words: rows_cap = N + 2 is even or odd -- the 64-bit block sums start on the next even word)
-            uint64_t *scan_tmp = (uint64_t *)(row_count + ((3u * ctx->rows_cap + 1u) & ~1ull));
-            int rc = vs_scan_u32(ctx, row_count, row_ptr, (uint64_t)N + 1u, scan_tmp, nullptr);
+            const int rc = pe_count_by_rows(ctx, slots_pairs, d_node_mat, d_short_mat, d_tile_map, P.tile_T);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_rows_fill, dim3(n_chunks), dim3(ROWS_TPB), rl, st, (const uint32_t *)ctx->d_lists,
-                               (const uint32_t *)ctx->d_list_counts, slots_pairs, N, (const uint32_t *)row_ptr, row_cursor,
-                               (uint32_t *)ctx->d_row_entries);
-            // rows per strip: a strip's distinct cells should fill the table less than half (configs[4]: 8 rows hold 3.3 k
-            // cells at the median, 11.8 k at most); VS_ROWS_PER_STRIP overrides
-            const uint32_t R = tn.rows_per_strip ? tn.rows_per_strip : 8u;
-            const uint32_t n_strips = (N + R - 1u) / R;
-            uint32_t rows_fill = ACC_SLOTS / 2u + ACC_SLOTS / 8u;
-            if (tn.acc_fill_pct >= 0) rows_fill = (uint32_t)((uint64_t)ACC_SLOTS * (uint32_t)tn.acc_fill_pct / 100u);
-            if (rows_fill > ACC_SLOTS - 4096u) rows_fill = ACC_SLOTS - 4096u;
-            uint32_t *rows_queue = (uint32_t *)ctx->d_slow_count + 9;
-            const uint32_t off0 = (uint32_t)(((uintptr_t)d_node_mat >> 2) & 15u);
-            uint32_t rows_grid = (uint32_t)ctx->n_cu * 2u;
-            if (rows_grid > n_strips) rows_grid = n_strips;
-            hipLaunchKernelGGL(k_node_rows, dim3(rows_grid), dim3(ACC_TPB), NROWS_LDS_BYTES, st, (const uint32_t *)ctx->d_lists,
-                               (const uint32_t *)ctx->d_list_counts, N, (const uint32_t *)row_ptr, (const uint32_t *)ctx->d_row_entries, R,
-                               n_strips, rows_fill, d_node_mat, off0, d_tile_map, P.tile_T, rows_queue,
-                               tn.debug_acc ? (uint32_t *)ctx->d_slow_count + 10 : (uint32_t *)nullptr);
-            ctx->last_launched |= VS_RAN_NODE_ROWS;
+            ctx->last_launched |= VS_RAN_ROW_OWNERS;
+        } else {
+            // one workgroup fits per CU (the cell table); 32 per CU queued, for the same reason as above
+            // (4.9 -> 3.9 ms), each at least one round of ACC_TPB pairs
+            uint32_t acc_grid = (uint32_t)ctx->n_cu * tn.acc_grid_per_cu;
+            uint32_t per_wg = (uint32_t)((slots_pairs + acc_grid - 1) / acc_grid);
+            per_wg = (per_wg + ACC_TPB - 1) / ACC_TPB * ACC_TPB;
+            acc_grid = (uint32_t)((slots_pairs + per_wg - 1) / per_wg);
+            // the chunks are not bound to workgroups: two workgroups per CU take the next chunk off a
+            // counter whenever they are free, so a cell table lives across chunks and is written out on
+            // fill only (3.85 -> 3.6 ms against one workgroup per chunk; VS_ACC_QUEUE=0 for that)
+            uint32_t *acc_queue = nullptr;
+            if (tn.acc_queue) {
+                acc_queue = (uint32_t *)ctx->d_slow_count + 1;
+                const uint32_t wgs = (uint32_t)ctx->n_cu * 2u;
+                if (acc_grid > wgs) acc_grid = wgs;
+            }
+            // the table is written out once this many of its slots are taken: probing stays short at a low
+            // fill, and cells of loci the run has left do not pile up (VS_ACC_FILL: percent)
+            uint32_t fill_limit = ACC_SLOTS / 16u;
+            if (tn.acc_fill_pct >= 0) fill_limit = (uint32_t)((uint64_t)ACC_SLOTS * (uint32_t)tn.acc_fill_pct / 100u);
+            uint32_t *acc_dbg = tn.debug_acc ? (uint32_t *)ctx->d_slow_count + 4 : nullptr;
+            const uint32_t acc_ppw = tn.acc_round ? tn.acc_round / (ACC_TPB / 64u) : 64u;  // VS_ACC_ROUND: pairs per round
+            if (d_tile_map && slots_pairs)  // (timed with the counter kernel: it is part of the counting)
+                hipLaunchKernelGGL(k_mark_tiles, dim3((unsigned)((slots_pairs + 255u) / 256u)), dim3(256), 0, st, (const uint32_t *)ctx->d_lists,
+                                   (const uint32_t *)ctx->d_list_counts, slots_pairs, d_tile_map, P.tile_T);
+            VS_HIP(ctx, hipFuncSetAttribute((const void *)k_pe_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES));
+            hipLaunchKernelGGL(k_pe_accumulate, dim3(acc_grid), dim3(ACC_TPB), ACC_LDS_BYTES, st, (const uint32_t *)ctx->d_lists,
+                               (const uint32_t *)ctx->d_list_counts, slots_pairs, per_wg, idx.n_nodes, use_table, fill_limit, d_node_mat,
+                               d_short_mat, acc_queue, acc_dbg, acc_ppw);
         }
-        if (d_tile_map && slots_pairs)  // (timed with the counter kernel: it is part of the counting)
-            hipLaunchKernelGGL(k_mark_tiles, dim3((unsigned)((slots_pairs + 255u) / 256u)), dim3(256), 0, st, (const uint32_t *)ctx->d_lists,
-                               (const uint32_t *)ctx->d_list_counts, slots_pairs, d_tile_map, P.tile_T, use_rows ? 1u : 0u);
-        const void *acc_fn = use_rows     ? (const void *)k_pe_accumulate<Acc32Short>
-                             : shape == 2 ? (const void *)k_pe_accumulate<Acc64>
-                             : shape == 1 ? (const void *)k_pe_accumulate<Acc32Split> : (const void *)k_pe_accumulate<Acc32>;
-        const uint32_t off1 = (uint32_t)(((uintptr_t)d_short_mat >> 2) & 15u);
-        VS_HIP(ctx, hipFuncSetAttribute(acc_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES));
-#define VS_ACC_LAUNCH(TB)                                                                                                         \
-    hipLaunchKernelGGL(k_pe_accumulate<TB>, dim3(acc_grid), dim3(ACC_TPB), ACC_LDS_BYTES, st, (const uint32_t *)ctx->d_lists,     \
-                       (const uint32_t *)ctx->d_list_counts, slots_pairs, per_wg, idx.n_nodes, use_table, fill_limit, d_node_mat, \
-                       d_short_mat, acc_queue, merge, acc_dbg, acc_ppw, use_rows ? 1u : 0u, off1)
-        if (use_rows) VS_ACC_LAUNCH(Acc32Short);
-        else if (shape == 2) VS_ACC_LAUNCH(Acc64);
-        else if (shape == 1) VS_ACC_LAUNCH(Acc32Split);
-        else VS_ACC_LAUNCH(Acc32);
-#undef VS_ACC_LAUNCH
     }
     VS_HIP(ctx, hipEventRecord(ctx->ev[1], st));
     // overflow pairs: one wavefront per pair with its state in LDS first, the general kernel for what that cannot hold
@@ -2551,10 +2510,15 @@ extern "C" int vs_pe_last_timing(vs_ctx *ctx, double ms[5]) {
         uint32_t d4[4] = {0, 0, 0, 0};
         VS_HIP(ctx, hipMemcpy(d4, (char *)ctx->d_slow_count + 16, sizeof d4, hipMemcpyDeviceToHost));
         fprintf(stderr, "[vs] k_pe_accumulate: %u increments went past the cell table, %u write-outs of %u cells, %u rounds\n", d4[0], d4[1], d4[2], d4[3]);
-        if (ctx->last_launched & VS_RAN_NODE_ROWS) {
+        if (ctx->last_launched & VS_RAN_ROW_OWNERS) {
             uint32_t r3[3] = {0, 0, 0};
             VS_HIP(ctx, hipMemcpy(r3, (char *)ctx->d_slow_count + 40, sizeof r3, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[vs] k_node_rows: %u increments went past the cell table, %u write-outs of %u cells\n", r3[0], r3[1], r3[2]);
+            fprintf(stderr, "[vs] k_rows_sum (both matrices): %u increments went past the cell table, %u write-outs of %u cells\n", r3[0], r3[1], r3[2]);
+            uint32_t e2[2] = {0, 0};  // entries of the last transposition: row_ptr[N] of either mode
+            const uint32_t *rows = (const uint32_t *)ctx->d_rows;
+            VS_HIP(ctx, hipMemcpy(&e2[0], rows + 2u * ctx->rows_cap + ctx->idx.n_nodes, sizeof(uint32_t), hipMemcpyDeviceToHost));
+            VS_HIP(ctx, hipMemcpy(&e2[1], rows + 5u * ctx->rows_cap + ctx->idx.n_nodes, sizeof(uint32_t), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[vs] row entries: node_mat %u, short_mat %u\n", e2[0], e2[1]);
         }
     }
     ctx->last_ms[0] = a; ctx->last_ms[1] = b; ctx->last_ms[2] = n_slow;
