@@ -124,7 +124,8 @@ def test_row_owner_counting_equals_the_cell_table_path_at_config4_size(host, xct
     monkeypatch.setenv("VS_ACC_ROWS", "0")
     old = _count(host, ctx, st, cum, seed, L, [(0, R)], sub, nth)
     assert not ctx.last_launched & ctx.RAN_ROW_OWNERS
-    for env in ({}, {"VS_ROWS_PER_STRIP": "1"}, {"VS_ROWS_PER_STRIP": "64", "VS_ACC_FILL": "1"}, {"VS_NO_SORT": "1"}):
+    for env in ({}, {"VS_ROWS_PER_STRIP": "1"}, {"VS_ROWS_PER_STRIP": "64", "VS_ACC_FILL": "1"}, {"VS_NO_SORT": "1"}, {"VS_LTAB_BITS": "0"},
+                {"VS_LTAB_BITS": "12"}, {"VS_ROWS_SUB": "300000", "VS_ROWS_KEYS": "20000"}):
         monkeypatch.setenv("VS_ACC_ROWS", "1")
         for k2, v in env.items():
             monkeypatch.setenv(k2, v)

@@ -527,6 +527,7 @@ def test_device_read_generator_equals_cpu_twin(host, ctx):
     {"VS_REFINE": "1"}, {"VS_REFINE": "1", "VS_EPT": "32", "VS_ACC_ROWS": "1"}, {"VS_NO_MID": "1"},
     {"VS_ACC_ROWS": "1"}, {"VS_ACC_ROWS": "1", "VS_ROWS_PER_STRIP": "1"}, {"VS_ACC_ROWS": "1", "VS_ROWS_PER_STRIP": "64", "VS_ACC_FILL": "1"},
     {"VS_ACC_ROWS": "1", "VS_NO_SORT": "1"}, {"VS_ACC_ROWS": "1", "VS_ROWS_KEYS": "100"}, {"VS_ACC_ROWS": "1", "VS_ROWS_SUB": "2048", "VS_ROWS_KEYS": "7"},
+    {"VS_ACC_ROWS": "1", "VS_LTAB_BITS": "0"}, {"VS_ACC_ROWS": "1", "VS_LTAB_BITS": "3"}, {"VS_ACC_ROWS": "1", "VS_LTAB_BITS": "7", "VS_ROWS_SUB": "1024"},
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_every_kernel_variant_gives_the_same_counters(host, xctx, env, monkeypatch):
     """The tuning switches select other code paths (input order instead of locus order, global

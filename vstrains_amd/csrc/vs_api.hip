@@ -35,6 +35,7 @@ void vs_tuning_load(VsTuning &t, int level) {
     if (const char *v = getenv("VS_TABLE_SHIFT")) t.table_shift = atoi(v) < 1 ? 1u : atoi(v) > 8 ? 8u : (uint32_t)atoi(v);
     if (const char *v = getenv("VS_REFINE")) t.refine = atoi(v) != 0 ? 1 : 0;
     if (const char *v = getenv("VS_ACC_ROWS")) t.acc_rows = atoi(v) != 0 ? 1 : 0;
+    if (const char *v = getenv("VS_LTAB_BITS")) t.ltab_bits = atoi(v) >= 0 && atoi(v) <= 31 ? atoi(v) : -1;
     if (const char *v = getenv("VS_ROWS_KEYS")) t.rows_keys = atoi(v) >= 2 && atoi(v) <= 65536 ? (uint32_t)atoi(v) : 0u;
     if (const char *v = getenv("VS_ROWS_SUB")) t.rows_sub = atoi(v) >= 1024 ? (uint32_t)atoi(v) : 0u;
     if (const char *v = getenv("VS_ROWS_PER_STRIP")) t.rows_per_strip = atoi(v) > 0 && atoi(v) <= 64 ? (uint32_t)atoi(v) : 0u;
@@ -147,7 +148,7 @@ void vs_ctx_destroy(vs_ctx *ctx) {
     if (ctx->d_slow_count) (void)hipFree(ctx->d_slow_count);
     if (ctx->d_slow_list2) (void)hipFree(ctx->d_slow_list2);
     if (ctx->d_dense) (void)hipFree(ctx->d_dense);
-    for (void *q : {ctx->d_locus_keys, ctx->d_perm, ctx->d_locus_hist, ctx->d_scan_tmp, ctx->d_lists, ctx->d_list_counts, ctx->d_rows, ctx->d_row_entries, ctx->d_mult})
+    for (void *q : {ctx->d_locus_keys, ctx->d_perm, ctx->d_locus_hist, ctx->d_scan_tmp, ctx->d_lists, ctx->d_list_counts, ctx->d_rows, ctx->d_row_entries, ctx->d_mult, ctx->d_ltab})
         if (q) (void)hipFree(q);
     for (void *q : ctx->scratch)
         if (q) (void)hipFree(q);

@@ -112,6 +112,7 @@ struct VsTuning {
     uint32_t table_shift = 3;       // VS_TABLE_SHIFT: seed table of >= (distinct seeds << shift) slots (3: at most an eighth full)
     int refine = -1;                // VS_REFINE (-1 = by graph size): second sort key, the reverse read's locus
     int acc_rows = -1;              // VS_ACC_ROWS (-1 = by graph size): counters summed by row owners (k_rows_sum) instead of pair-major (k_pe_accumulate)
+    int ltab_bits = -1;             // VS_LTAB_BITS: log2 slots of the block's list table (-1 = by block size, 0 = no table: round owners only)
     uint32_t rows_keys = 0, rows_sub = 0;  // VS_ROWS_KEYS / VS_ROWS_SUB: rows per histogram pass, pairs per transposition (0 = the constants; tests shrink them)
     uint32_t rows_per_strip = 0;    // VS_ROWS_PER_STRIP (0 = automatic): matrix rows one workgroup of k_rows_sum owns at a time
     bool no_sort = false, locus_global = false, no_xcd_map = false, no_fast = false, no_std = false, no_agg = false;
@@ -156,8 +157,8 @@ struct vs_ctx {
     uint64_t lists_cap = 0;
     // row-owner counting (k_list_owners / k_rows_count / k_rows_fill / k_rows_sum): per matrix and row the counts, cursors
     // and offsets (6 x (N + 2) words), the items of every row (one word per listed node), the multiplicity of every end's list
-    void *d_rows = nullptr, *d_row_entries = nullptr, *d_mult = nullptr;
-    uint64_t rows_cap = 0, row_entries_cap = 0, mult_cap = 0;
+    void *d_rows = nullptr, *d_row_entries = nullptr, *d_mult = nullptr, *d_ltab = nullptr;
+    uint64_t rows_cap = 0, row_entries_cap = 0 /* pairs */, ltab_cap = 0 /* slots */;
     // grow-only device scratch slots of the graph-stage entry points (no hipMalloc per call)
     void *scratch[32] = {};
     size_t scratch_cap[32] = {};

@@ -1240,19 +1240,51 @@ __global__ void __launch_bounds__(64) k_zero_tiles(uint32_t *__restrict__ node_m
 //   k_rows_sum     strips of rows off a queue; a lane per (item of the row, quad of its partner list)
 #define OWN_SLOTS 2048u    // dedup slots of a round (2 048 ends: at most a fifth of them claim one)
 #define ROWS_CHUNK 16384u  // pairs per chunk: a node is in a list at most once, so a 16-bit count (<= 32 768 ends) cannot wrap
+#define ROWS_CHUNK1 8192u  // owning ends per chunk (mode 1: few items, spread over more workgroups)
 #define ROWS_TPB 1024u
 #define ROWS_CAP 4096u     // distinct rows of a chunk that get an LDS cursor (the rest: a global atomic per entry)
 #define ROWS_KEYS 65536u   // rows per histogram pass (larger graphs take several passes over the lists)
 #define ROWS_SUB (1u << 27)  // pairs per transposition (entry indices and row offsets are 32-bit)
 static inline size_t rows_lds_bytes(uint32_t n_keys) { return sizeof(uint32_t) * (((size_t)n_keys + 2u) / 2u + ROWS_CAP + ROWS_CAP / 2u + 4u); }
 
-// Equal end lists of a round (1 024 locus-ordered pairs: four of five ends repeat the list of another end) are merged:
-// the first end that brings a list owns it, the others only add to its multiplicity.  mult[end] = 0 (merged into another
-// end's list, or empty) or the number of ends the list stands for.  s_down[slot] = tag << 11 | owner end, s_dmul[slot] =
-// how many further ends hold the same list.  The tag is an order-independent fingerprint (the lists arrive in no
-// particular order); a tag match is confirmed node by node against the owner's row.
+// Which read ends stand for a list of their own, and for how many ends (short_mat takes one weighted pass per DISTINCT
+// list).  Two stages in one kernel:
+//   round  equal end lists of a round (1 024 locus-ordered pairs) are merged in LDS: the first end that brings a list owns
+//          it, the others only add to its multiplicity.  Forward reads of one locus repeat each other's lists nine times
+//          in ten; their mates, spread over the insert-size range, rarely do (configs[4]: 58 % of the ends stay owners).
+//   block  every round owner looks its list up in a table of the whole block (device memory, one 64-bit word per slot:
+//          tag << 32 | owner end + 1, claimed by compare-and-swap; a separate word per slot sums the multiplicities).  A
+//          lookup reads with plain loads -- a word never changes once claimed, a stale zero only sends the lane into a CAS
+//          that returns the real word.
+// Fingerprints are order-independent (the lists arrive in no particular order); a tag match is confirmed node by node
+// against the owner's row, which is input data.  mult[end] = 0 for an end that is merged into another one; the ends that
+// claimed a table slot get theirs, and their place in `owners`, from k_owners_collect; an end that finds no place within
+// LTAB_PROBES slots stays the owner of what its round gave it.
+#define LTAB_PROBES 16u
+__device__ __forceinline__ void vs_load_list(const uint32_t *__restrict__ row, uint32_t n, uint32_t (&v)[LC]) {
+    const VsQuad a = *(const VsQuad *)row, b = n > 4u ? *(const VsQuad *)(row + 4) : VsQuad{0, 0, 0, 0};
+    const VsQuad c = n > 8u ? *(const VsQuad *)(row + 8) : VsQuad{0, 0, 0, 0}, d = n > 12u ? *(const VsQuad *)(row + 12) : VsQuad{0, 0, 0, 0};
+    const uint32_t w[LC] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (uint32_t i = 0; i < LC; i++) v[i] = i < n ? w[i] : 0xFFFFFFFFu;
+}
+// the same set of n nodes?  (both padded with 0xFFFFFFFF)
+__device__ __forceinline__ bool vs_same_list(const uint32_t (&mine)[LC], const uint32_t (&other)[LC], uint32_t n) {
+    bool same = true;
+#pragma unroll
+    for (uint32_t k2 = 0; k2 < LC; k2++) {
+        bool found = false;
+#pragma unroll
+        for (uint32_t i = 0; i < LC; i++) found |= mine[i] == other[k2];
+        same &= found || k2 >= n;
+    }
+    return same;
+}
+
 __global__ void __launch_bounds__(ACC_TPB)
-k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_slots_pairs, uint32_t *__restrict__ mult) {
+k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_slots_pairs, uint32_t *__restrict__ mult,
+              unsigned long long *__restrict__ ltab, uint32_t *__restrict__ lmult, uint32_t ltab_bits, uint32_t *__restrict__ owners,
+              uint32_t *__restrict__ n_owners) {
     uint32_t *s_down = vs_lds, *s_dmul = vs_lds + OWN_SLOTS;
     const uint32_t tid = threadIdx.x;
     const uint64_t base = (uint64_t)blockIdx.x * ACC_TPB, p = base + tid;
@@ -1263,30 +1295,28 @@ k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ c
         const uint2 c = *(const uint2 *)(counts + 2u * p);
         nl = c.x; nr = c.y;
     }
-    uint32_t ml = nl ? 1u : 0u, mr = nr ? 1u : 0u;
     uint32_t slot_of[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+    unsigned long long fp64[2] = {0ull, 0ull};
 #pragma unroll
     for (uint32_t side = 0; side < 2u; side++) {
         const uint32_t n = side ? nr : nl;
         if (n == 0u) continue;
         const uint32_t me = 2u * tid + side;  // end index within the round
-        const uint32_t *row = lists + (2u * p + side) * LC;
         uint32_t mine[LC];
-        {
-            const VsQuad a = *(const VsQuad *)row, b = n > 4u ? *(const VsQuad *)(row + 4) : VsQuad{0, 0, 0, 0};
-            const VsQuad c = n > 8u ? *(const VsQuad *)(row + 8) : VsQuad{0, 0, 0, 0}, d = n > 12u ? *(const VsQuad *)(row + 12) : VsQuad{0, 0, 0, 0};
-            const uint32_t v[LC] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-#pragma unroll
-            for (uint32_t i = 0; i < LC; i++) mine[i] = i < n ? v[i] : 0xFFFFFFFFu;
-        }
+        vs_load_list(lists + (2u * p + side) * LC, n, mine);
         uint32_t fp = n * 0x9E3779B1u;
+        unsigned long long f2 = n;
 #pragma unroll
         for (uint32_t i = 0; i < LC; i++)
             if (i < n) {
                 uint32_t h = mine[i] * 0x85EBCA6Bu;
                 h ^= h >> 15;
                 fp += h * 0xC2B2AE35u;  // (a sum: the order of the nodes does not matter)
+                unsigned long long g = (mine[i] + 1ull) * 0x9E3779B97F4A7C15ull;
+                g ^= g >> 29;
+                f2 += g * 0xBF58476D1CE4E5B9ull;
             }
+        fp64[side] = f2;
         // tag: 17 bits of the fingerprint and the list length (the owner's length comes with the table
         // word: no load for it); all ones with owner 2047 would read as an empty slot -- n - 1 <= 15
         // only together with tag bits all ones, so clear one
@@ -1297,27 +1327,14 @@ k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ c
             uint32_t w0 = s_down[at];
             if (w0 == 0xFFFFFFFFu) {
                 w0 = atomicCAS(&s_down[at], 0xFFFFFFFFu, (tag << 11) | me);
-                if (w0 == 0xFFFFFFFFu) { slot_of[side] = at; break; }  // this end owns the list
+                if (w0 == 0xFFFFFFFFu) { slot_of[side] = at; break; }  // this end owns the list in its round
             }
             if ((w0 >> 11) == tag) {
-                // same fingerprint and length: the same set of nodes?  (the owner's row is input data,
-                // nobody writes it; its quads are fetched together)
-                const uint32_t oe = w0 & 0x7FFu;
-                const uint32_t *orow = lists + (2u * base + oe) * (uint64_t)LC;
-                const VsQuad o0 = *(const VsQuad *)orow, o1 = n > 4u ? *(const VsQuad *)(orow + 4) : VsQuad{0, 0, 0, 0};
-                const VsQuad o2 = n > 8u ? *(const VsQuad *)(orow + 8) : VsQuad{0, 0, 0, 0}, o3 = n > 12u ? *(const VsQuad *)(orow + 12) : VsQuad{0, 0, 0, 0};
-                const uint32_t ov[LC] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w, o2.x, o2.y, o2.z, o2.w, o3.x, o3.y, o3.z, o3.w};
-                bool same = true;
-#pragma unroll
-                for (uint32_t k2 = 0; k2 < LC; k2++) {
-                    bool found = false;
-#pragma unroll
-                    for (uint32_t i = 0; i < LC; i++) found |= mine[i] == ov[k2];
-                    same &= found || k2 >= n;
-                }
-                if (same) {  // merged: the owner stands for this end too
+                uint32_t other[LC];
+                vs_load_list(lists + (2u * base + (w0 & 0x7FFu)) * (uint64_t)LC, n, other);
+                if (vs_same_list(mine, other, n)) {  // merged: the owner stands for this end too
                     atomicAdd(&s_dmul[at], 1u);
-                    if (side) mr = 0u; else ml = 0u;
+                    slot_of[side] = 0xFFFFFFFEu;
                     break;
                 }
             }
@@ -1325,31 +1342,112 @@ k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ c
         }
     }
     __syncthreads();
-    if (slot_of[0] != 0xFFFFFFFFu) ml += s_dmul[slot_of[0]];
-    if (slot_of[1] != 0xFFFFFFFFu) mr += s_dmul[slot_of[1]];
-    if (p < n_slots_pairs) *(uint2 *)(mult + 2u * p) = make_uint2(ml, mr);
+    uint32_t out[2] = {0u, 0u};
+#pragma unroll
+    for (uint32_t side = 0; side < 2u; side++) {
+        const uint32_t n = side ? nr : nl;
+        if (n == 0u || slot_of[side] == 0xFFFFFFFEu) continue;  // nothing listed / merged in the round
+        const uint32_t m = 1u + (slot_of[side] != 0xFFFFFFFFu ? s_dmul[slot_of[side]] : 0u);  // (no dedup slot found: an owner all the same)
+        const uint32_t e = (uint32_t)(2u * p + side);
+        out[side] = m;
+        if (!ltab) continue;
+        const unsigned long long f2 = fp64[side];
+        const uint32_t tag = ((uint32_t)(f2 >> 32) & ~15u) | (n - 1u);  // (the list length rides in the tag: no load for the owner's)
+        const unsigned long long word = ((unsigned long long)tag << 32) | (e + 1u);
+        uint32_t h = (uint32_t)((f2 * 0xD6E8FEB86659FD93ull) >> (64u - ltab_bits));
+        bool placed = false;
+        uint32_t mine[LC];
+        vs_load_list(lists + (uint64_t)e * LC, n, mine);
+        for (uint32_t pr = 0; pr < LTAB_PROBES && !placed; pr++) {
+            unsigned long long cur = ltab[h];
+            if (cur == 0ull) {
+                cur = atomicCAS(&ltab[h], 0ull, word);
+                if (cur == 0ull) {  // claimed: k_owners_collect hands this end the slot's total
+                    atomicAdd(&lmult[h], m);
+                    out[side] = 0u;
+                    placed = true;
+                    break;
+                }
+            }
+            if ((uint32_t)(cur >> 32) == tag) {
+                uint32_t other[LC];
+                vs_load_list(lists + (uint64_t)((uint32_t)cur - 1u) * LC, n, other);
+                if (vs_same_list(mine, other, n)) {
+                    atomicAdd(&lmult[h], m);
+                    out[side] = 0u;
+                    placed = true;
+                    break;
+                }
+            }
+            h = (h + 1u) & ((1u << ltab_bits) - 1u);
+        }
+        if (!placed) owners[atomicAdd(n_owners, 1u)] = e;  // (a crowded table: the round's owner stays one)
+    }
+    if (p < n_slots_pairs) *(uint2 *)(mult + 2u * p) = make_uint2(out[0], out[1]);
+    if (!ltab && p < n_slots_pairs) {  // (no block table: every round owner is an item)
+        if (out[0]) owners[atomicAdd(n_owners, 1u)] = (uint32_t)(2u * p);
+        if (out[1]) owners[atomicAdd(n_owners, 1u)] = (uint32_t)(2u * p + 1u);
+    }
+}
+
+// every claimed slot of the block's list table: its owner gets the slot's multiplicity and a place in `owners`.  A
+// workgroup takes a stretch of slots, counts the claimed ones, reserves their places with ONE atomic (the counter is a
+// single word: an atomic per wavefront would queue up behind each other), then reads the stretch again and writes.
+#define COLLECT_TPB 256u
+__global__ void __launch_bounds__(COLLECT_TPB)
+k_owners_collect(const unsigned long long *__restrict__ ltab, const uint32_t *__restrict__ lmult, uint64_t n_slots, uint64_t per_wg,
+                 uint32_t *__restrict__ mult, uint32_t *__restrict__ owners, uint32_t *__restrict__ n_owners) {
+    __shared__ uint32_t s_wave[COLLECT_TPB / 64u], s_base;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint64_t lo = (uint64_t)blockIdx.x * per_wg, hi = lo + per_wg < n_slots ? lo + per_wg : n_slots;
+    uint32_t mine = 0;
+    for (uint64_t h = lo + tid; h < hi; h += COLLECT_TPB) mine += ltab[h] != 0ull ? 1u : 0u;
+#pragma unroll
+    for (int d = 32; d; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if (lane == 0) s_wave[wv] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t tot = 0;
+        for (uint32_t i = 0; i < COLLECT_TPB / 64u; i++) tot += s_wave[i];
+        s_base = tot ? atomicAdd(n_owners, tot) : 0u;
+        s_wave[0] = 0u;  // (now the running offset inside the reservation)
+    }
+    __syncthreads();
+    for (uint64_t h0 = lo; h0 < hi; h0 += COLLECT_TPB) {  // (uniform trip count: the ballots and the barrier below see every lane)
+        const uint64_t h = h0 + tid;
+        const unsigned long long w = h < hi ? ltab[h] : 0ull;
+        const unsigned long long live = __ballot(w != 0ull);
+        uint32_t wbase = 0;
+        if (lane == 0 && live) wbase = atomicAdd(&s_wave[0], (uint32_t)__popcll(live));  // (LDS)
+        wbase = __shfl(wbase, 0, 64);
+        if (w != 0ull) {
+            const uint32_t e = (uint32_t)w - 1u;
+            mult[e] = lmult[h];
+            owners[s_base + wbase + (uint32_t)__popcll(live & ((1ull << lane) - 1ull))] = e;
+        }
+    }
 }
 
 // The list of item i that is transposed, and its length (0: not an item).  Mode 0: pair i, its left list -- only if the
-// right list holds anything; mode 1: read end i, if it owns its list.
+// right list holds anything; mode 1: the i-th owning read end.
 template <int MODE>
-__device__ __forceinline__ uint32_t vs_rows_item(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ mult, uint64_t i, uint64_t &row) {
+__device__ __forceinline__ uint32_t vs_rows_item(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ owners, uint64_t i, uint64_t &row) {
     if (MODE == 0) {
         const uint2 c = *(const uint2 *)(counts + 2u * i);
         row = 2u * i;
         return c.y ? c.x : 0u;
     }
-    row = i;
-    return mult[i] ? counts[i] : 0u;
+    row = owners[i];
+    return counts[row];
 }
 
 // one lane per (item, quad of its list): the 16-bit bin of every listed node in [key_lo, key_lo + n_keys) + 1
 template <int MODE>
 __device__ __forceinline__ void vs_rows_histogram(uint32_t *h32, const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts,
-                                                  const uint32_t *__restrict__ mult, uint64_t lo, uint64_t hi, uint32_t key_lo, uint32_t n_keys) {
+                                                  const uint32_t *__restrict__ owners, uint64_t lo, uint64_t hi, uint32_t key_lo, uint32_t n_keys) {
     for (uint64_t i = lo * 4u + threadIdx.x; i < hi * 4u; i += ROWS_TPB) {
         uint64_t row;
-        const uint32_t q = (uint32_t)i & 3u, n = vs_rows_item<MODE>(counts, mult, i >> 2, row);
+        const uint32_t q = (uint32_t)i & 3u, n = vs_rows_item<MODE>(counts, owners, i >> 2, row);
         if (4u * q >= n) continue;
         const VsQuad v = *(const VsQuad *)(lists + row * LC + 4u * q);
         const uint32_t e[4] = {v.x, v.y, v.z, v.w};
@@ -1363,15 +1461,17 @@ __device__ __forceinline__ void vs_rows_histogram(uint32_t *h32, const uint32_t 
 
 template <int MODE>
 __global__ void __launch_bounds__(ROWS_TPB)
-k_rows_count(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ mult, uint64_t n_items,
-             uint32_t key_lo, uint32_t n_keys, uint32_t *__restrict__ row_count) {
+k_rows_count(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ owners, uint64_t n_items,
+             const uint32_t *__restrict__ n_owners, uint32_t key_lo, uint32_t n_keys, uint32_t *__restrict__ row_count) {
     uint32_t *h32 = vs_lds;
     const uint32_t words = (n_keys + 1u) >> 1, tid = threadIdx.x;
+    if (MODE) n_items = *n_owners;  // (mode 1: the launch covers every end, the items are the owners among them)
+    const uint64_t per = MODE ? ROWS_CHUNK1 : ROWS_CHUNK;
+    const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n_items ? lo + per : n_items;
+    if (lo >= n_items) return;
     for (uint32_t i = tid; i < words; i += ROWS_TPB) h32[i] = 0u;
     __syncthreads();
-    const uint64_t per = MODE ? 2u * ROWS_CHUNK : ROWS_CHUNK;
-    const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n_items ? lo + per : n_items;
-    vs_rows_histogram<MODE>(h32, lists, counts, mult, lo, hi, key_lo, n_keys);
+    vs_rows_histogram<MODE>(h32, lists, counts, owners, lo, hi, key_lo, n_keys);
     __syncthreads();
     for (uint32_t i = tid; i < words; i += ROWS_TPB) {
         const uint32_t v = h32[i];
@@ -1382,11 +1482,13 @@ k_rows_count(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ co
 
 template <int MODE>
 __global__ void __launch_bounds__(ROWS_TPB)
-k_rows_fill(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ mult, uint64_t n_items,
-            uint32_t key_lo, uint32_t n_keys, const uint32_t *__restrict__ row_ptr, uint32_t *__restrict__ row_cursor,
-            uint32_t *__restrict__ entries) {
+k_rows_fill(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ owners, uint64_t n_items,
+            const uint32_t *__restrict__ n_owners, uint32_t key_lo, uint32_t n_keys, const uint32_t *__restrict__ row_ptr,
+            uint32_t *__restrict__ row_cursor, uint32_t *__restrict__ entries) {
     uint32_t *h32 = vs_lds;
     const uint32_t words = (n_keys + 1u) >> 1, tid = threadIdx.x;
+    if (MODE) n_items = *n_owners;
+    if ((uint64_t)blockIdx.x * (MODE ? ROWS_CHUNK1 : ROWS_CHUNK) >= n_items) return;
     uint32_t *s_base = h32 + words;          // [ROWS_CAP] where this chunk's stretch of the row starts
     uint32_t *s_fill = s_base + ROWS_CAP;    // [ROWS_CAP / 2] 16-bit cursors inside the stretch
     uint32_t &s_nc = s_fill[ROWS_CAP / 2u];
@@ -1394,9 +1496,9 @@ k_rows_fill(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ cou
     for (uint32_t i = tid; i < ROWS_CAP / 2u; i += ROWS_TPB) s_fill[i] = 0u;
     if (tid == 0) s_nc = 0u;
     __syncthreads();
-    const uint64_t per = MODE ? 2u * ROWS_CHUNK : ROWS_CHUNK;
+    const uint64_t per = MODE ? ROWS_CHUNK1 : ROWS_CHUNK;
     const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n_items ? lo + per : n_items;
-    vs_rows_histogram<MODE>(h32, lists, counts, mult, lo, hi, key_lo, n_keys);
+    vs_rows_histogram<MODE>(h32, lists, counts, owners, lo, hi, key_lo, n_keys);
     __syncthreads();
     // a bin that is not empty: reserve the chunk's stretch of that row, and turn the bin into the number of its cursor
     for (uint32_t i = tid; i < words; i += ROWS_TPB) {
@@ -1421,7 +1523,7 @@ k_rows_fill(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ cou
     __syncthreads();
     for (uint64_t i = lo * 4u + tid; i < hi * 4u; i += ROWS_TPB) {
         uint64_t row;
-        const uint32_t q = (uint32_t)i & 3u, n = vs_rows_item<MODE>(counts, mult, i >> 2, row);
+        const uint32_t q = (uint32_t)i & 3u, n = vs_rows_item<MODE>(counts, owners, i >> 2, row);
         if (4u * q >= n) continue;
         const VsQuad v = *(const VsQuad *)(lists + row * LC + 4u * q);
         const uint32_t e[4] = {v.x, v.y, v.z, v.w};
@@ -1438,7 +1540,7 @@ k_rows_fill(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ cou
             } else {
                 pos = row_ptr[e[j]] + atomicAdd(&row_cursor[e[j]], 1u);
             }
-            entries[pos] = (uint32_t)(i >> 2);
+            entries[pos] = MODE ? (uint32_t)row : (uint32_t)(i >> 2);  // the pair / the read end
         }
     }
 }
@@ -2047,7 +2149,6 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
     hipStream_t st = ctx->stream;
     const VsTuning &tn = ctx->tune;
     const uint32_t N = ctx->idx.n_nodes;
-    const uint64_t list_ends = 2u * slots_pairs;
     const uint64_t sub_max = tn.rows_sub ? (uint64_t)tn.rows_sub / ACC_TPB * ACC_TPB : (uint64_t)ROWS_SUB;  // (whole rounds of k_list_owners)
     const uint64_t sub_pairs = slots_pairs < sub_max ? slots_pairs : sub_max;  // pairs per transposition
     if (ctx->rows_cap < (uint64_t)N + 2u) {
@@ -2058,16 +2159,23 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
         VS_HIP(ctx, hipMalloc(&ctx->d_rows, sizeof(uint32_t) * 6u * ((uint64_t)N + 2u) + sizeof(uint64_t) * ((uint64_t)N / 2048u + 8u)));
         ctx->rows_cap = (uint64_t)N + 2u;
     }
-    // entries: one word per listed node -- the left lists (node_mat) and the lists of the owning ends (short_mat)
-    if (ctx->row_entries_cap < 3u * sub_pairs * LC || ctx->mult_cap < list_ends) {
-        if (ctx->d_row_entries) VS_HIP(ctx, hipFree(ctx->d_row_entries));
-        if (ctx->d_mult) VS_HIP(ctx, hipFree(ctx->d_mult));
-        ctx->d_row_entries = ctx->d_mult = nullptr;
-        ctx->row_entries_cap = ctx->mult_cap = 0;
+    // the list table of a transposition: a power of two of slots, at least one per read end (VS_LTAB_BITS: tests crowd it)
+    uint32_t ltab_bits = 10;
+    while ((1ull << ltab_bits) < 2u * sub_pairs && ltab_bits < 31u) ltab_bits++;
+    if (tn.ltab_bits >= 0) ltab_bits = (uint32_t)tn.ltab_bits;
+    const bool use_ltab = ltab_bits > 0;
+    const uint64_t ltab_slots = use_ltab ? 1ull << ltab_bits : 0;
+    // entries: one word per listed node -- the left lists (node_mat) and the lists of the owning ends (short_mat); the
+    // multiplicity of every end, the owning ends, the table (a 64-bit word and a 32-bit sum per slot)
+    if (ctx->row_entries_cap < sub_pairs || ctx->ltab_cap < ltab_slots) {
+        for (void **q : {&ctx->d_row_entries, &ctx->d_mult, &ctx->d_ltab})
+            if (*q) { VS_HIP(ctx, hipFree(*q)); *q = nullptr; }
+        ctx->row_entries_cap = ctx->ltab_cap = 0;
         VS_HIP(ctx, hipMalloc(&ctx->d_row_entries, sizeof(uint32_t) * (3u * sub_pairs * LC + 16u)));
-        VS_HIP(ctx, hipMalloc(&ctx->d_mult, sizeof(uint32_t) * (list_ends + 2u)));
-        ctx->row_entries_cap = 3u * sub_pairs * LC;
-        ctx->mult_cap = list_ends;
+        VS_HIP(ctx, hipMalloc(&ctx->d_mult, sizeof(uint32_t) * (4u * sub_pairs + 4u)));  // mult[2 np], owners[2 np]
+        VS_HIP(ctx, hipMalloc(&ctx->d_ltab, (sizeof(uint64_t) + sizeof(uint32_t)) * ltab_slots + 16u));
+        ctx->row_entries_cap = sub_pairs;
+        ctx->ltab_cap = ltab_slots;
     }
     const uint64_t cap = ctx->rows_cap;
     uint32_t *rows = (uint32_t *)ctx->d_rows;
@@ -2079,10 +2187,6 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
         VS_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
     for (const void *fn : {(const void *)k_rows_sum<0>, (const void *)k_rows_sum<1>})
         VS_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RSUM_LDS_BYTES));
-    const uint32_t *lists = (const uint32_t *)ctx->d_lists, *counts = (const uint32_t *)ctx->d_list_counts;
-    uint32_t *mult = (uint32_t *)ctx->d_mult;
-    hipLaunchKernelGGL(k_list_owners, dim3((unsigned)((slots_pairs + ACC_TPB - 1u) / ACC_TPB)), dim3(ACC_TPB), 2u * OWN_SLOTS * sizeof(uint32_t), st,
-                       lists, counts, slots_pairs, mult);
     // the table is written out once this share of its slots is taken (a strip that holds more cells than that is written
     // in pieces: still one atomic per cell and piece); VS_ACC_FILL: percent
     uint32_t fill = ACC_SLOTS / 2u + ACC_SLOTS / 8u;
@@ -2092,27 +2196,39 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
     // 1.7 k cells at the median and 6 k at most, 32 rows of short_mat 2.1 k and 6.6 k.  VS_ROWS_PER_STRIP overrides both.
     const uint32_t R[2] = {tn.rows_per_strip ? tn.rows_per_strip : 4u, tn.rows_per_strip ? tn.rows_per_strip : 32u};
     uint32_t *dbg = tn.debug_acc ? (uint32_t *)ctx->d_slow_count + 10 : nullptr;
+    uint32_t *queue = (uint32_t *)ctx->d_slow_count + 9, *n_owners = (uint32_t *)ctx->d_slow_count + 13;
+    unsigned long long *ltab = use_ltab ? (unsigned long long *)ctx->d_ltab : nullptr;
+    uint32_t *lmult = use_ltab ? (uint32_t *)((unsigned long long *)ctx->d_ltab + ltab_slots) : nullptr;
     for (uint64_t p0 = 0; p0 < slots_pairs; p0 += sub_pairs) {
         const uint64_t np = slots_pairs - p0 < sub_pairs ? slots_pairs - p0 : sub_pairs;
-        const uint32_t *sl = lists + 2u * p0 * LC, *sc = counts + 2u * p0, *sm = mult + 2u * p0;
+        const uint32_t *sl = (const uint32_t *)ctx->d_lists + 2u * p0 * LC, *sc = (const uint32_t *)ctx->d_list_counts + 2u * p0;
+        uint32_t *mult = (uint32_t *)ctx->d_mult, *owners = mult + 2u * sub_pairs;
         const unsigned n_chunks = (unsigned)((np + ROWS_CHUNK - 1u) / ROWS_CHUNK);
+        const unsigned n_chunks1 = (unsigned)((2u * np + ROWS_CHUNK1 - 1u) / ROWS_CHUNK1);  // (every end could be an owner; a chunk past the last owner returns at once)
         VS_HIP(ctx, hipMemsetAsync(rows, 0, sizeof(uint32_t) * 6u * cap, st));
-        VS_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->d_slow_count + 9, 0, sizeof(uint32_t), st));
+        VS_HIP(ctx, hipMemsetAsync(n_owners, 0, sizeof(uint32_t), st));
+        if (use_ltab) VS_HIP(ctx, hipMemsetAsync(ctx->d_ltab, 0, (sizeof(uint64_t) + sizeof(uint32_t)) * ltab_slots, st));
+        hipLaunchKernelGGL(k_list_owners, dim3((unsigned)((np + ACC_TPB - 1u) / ACC_TPB)), dim3(ACC_TPB), 2u * OWN_SLOTS * sizeof(uint32_t), st, sl, sc, np,
+                           mult, ltab, lmult, ltab_bits, owners, n_owners);
+        if (use_ltab) {
+            const uint64_t per_wg = (ltab_slots + ctx->n_cu * 8ull - 1u) / (ctx->n_cu * 8ull);
+            hipLaunchKernelGGL(k_owners_collect, dim3((unsigned)((ltab_slots + per_wg - 1u) / per_wg)), dim3(COLLECT_TPB), 0, st,
+                               (const unsigned long long *)ltab, (const uint32_t *)lmult, ltab_slots, per_wg, mult, owners, n_owners);
+        }
         for (int mode = 0; mode < 2; mode++) {
             uint32_t *row_count = rows + 3u * mode * cap, *row_cursor = row_count + cap, *row_ptr = row_cursor + cap;
             uint32_t *entries = (uint32_t *)ctx->d_row_entries + (mode ? np * LC : 0u);
-            const uint64_t n_items = mode ? 2u * np : np;
             for (uint32_t key_lo = 0; key_lo < N; key_lo += n_keys) {
                 const uint32_t nk = N - key_lo < n_keys ? N - key_lo : n_keys;
-                if (mode) hipLaunchKernelGGL(k_rows_count<1>, dim3(n_chunks), dim3(ROWS_TPB), rl, st, sl, sc, sm, n_items, key_lo, nk, row_count);
-                else hipLaunchKernelGGL(k_rows_count<0>, dim3(n_chunks), dim3(ROWS_TPB), rl, st, sl, sc, sm, n_items, key_lo, nk, row_count);
+                if (mode) hipLaunchKernelGGL(k_rows_count<1>, dim3(n_chunks1), dim3(ROWS_TPB), rl, st, sl, sc, (const uint32_t *)owners, 0ull, (const uint32_t *)n_owners, key_lo, nk, row_count);
+                else hipLaunchKernelGGL(k_rows_count<0>, dim3(n_chunks), dim3(ROWS_TPB), rl, st, sl, sc, (const uint32_t *)nullptr, np, (const uint32_t *)nullptr, key_lo, nk, row_count);
             }
             int rc = vs_scan_u32(ctx, row_count, row_ptr, (uint64_t)N + 1u, scan_tmp, nullptr);
             if (rc) return rc;
             for (uint32_t key_lo = 0; key_lo < N; key_lo += n_keys) {
                 const uint32_t nk = N - key_lo < n_keys ? N - key_lo : n_keys;
-                if (mode) hipLaunchKernelGGL(k_rows_fill<1>, dim3(n_chunks), dim3(ROWS_TPB), rl, st, sl, sc, sm, n_items, key_lo, nk, (const uint32_t *)row_ptr, row_cursor, entries);
-                else hipLaunchKernelGGL(k_rows_fill<0>, dim3(n_chunks), dim3(ROWS_TPB), rl, st, sl, sc, sm, n_items, key_lo, nk, (const uint32_t *)row_ptr, row_cursor, entries);
+                if (mode) hipLaunchKernelGGL(k_rows_fill<1>, dim3(n_chunks1), dim3(ROWS_TPB), rl, st, sl, sc, (const uint32_t *)owners, 0ull, (const uint32_t *)n_owners, key_lo, nk, (const uint32_t *)row_ptr, row_cursor, entries);
+                else hipLaunchKernelGGL(k_rows_fill<0>, dim3(n_chunks), dim3(ROWS_TPB), rl, st, sl, sc, (const uint32_t *)nullptr, np, (const uint32_t *)nullptr, key_lo, nk, (const uint32_t *)row_ptr, row_cursor, entries);
             }
         }
         for (int mode = 0; mode < 2; mode++) {
@@ -2123,16 +2239,13 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
             if (grid > n_strips) grid = n_strips;
             uint32_t *m = mode ? d_short_mat : d_node_mat;
             const uint32_t off = (uint32_t)(((uintptr_t)m >> 2) & 15u);
-            uint32_t *queue = (uint32_t *)ctx->d_slow_count + 9;
-            if (mode) {
-                // (the queue of mode 0 has run past n_strips of mode 0: start again)
-                VS_HIP(ctx, hipMemsetAsync(queue, 0, sizeof(uint32_t), st));
-                hipLaunchKernelGGL(k_rows_sum<1>, dim3(grid), dim3(ACC_TPB), RSUM_LDS_BYTES, st, sl, sc, sm, N, row_ptr, entries, R[1], n_strips, fill, m, off,
-                                   d_tile_map, T, queue, dbg);
-            } else {
-                hipLaunchKernelGGL(k_rows_sum<0>, dim3(grid), dim3(ACC_TPB), RSUM_LDS_BYTES, st, sl, sc, sm, N, row_ptr, entries, R[0], n_strips, fill, m, off,
-                                   d_tile_map, T, queue, dbg);
-            }
+            VS_HIP(ctx, hipMemsetAsync(queue, 0, sizeof(uint32_t), st));
+            if (mode)
+                hipLaunchKernelGGL(k_rows_sum<1>, dim3(grid), dim3(ACC_TPB), RSUM_LDS_BYTES, st, sl, sc, (const uint32_t *)mult, N, row_ptr, entries, R[1], n_strips, fill, m,
+                                   off, d_tile_map, T, queue, dbg);
+            else
+                hipLaunchKernelGGL(k_rows_sum<0>, dim3(grid), dim3(ACC_TPB), RSUM_LDS_BYTES, st, sl, sc, (const uint32_t *)mult, N, row_ptr, entries, R[0], n_strips, fill, m,
+                                   off, d_tile_map, T, queue, dbg);
         }
     }
     VS_HIP(ctx, hipGetLastError());
@@ -2179,7 +2292,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         VS_HIP(ctx, hipMalloc(&ctx->d_slow_list, sizeof(uint32_t) * n_pairs));
         ctx->slow_cap = n_pairs;
     }
-    if (!ctx->d_slow_count) VS_HIP(ctx, hipMalloc(&ctx->d_slow_count, 64));  // [0] pairs for k_pe_mid, [1] queue, [2..3] postings, [4..7] acc, [8] pairs for k_pe_slow, [9] strip queue, [10..12] k_node_rows debug
+    if (!ctx->d_slow_count) VS_HIP(ctx, hipMalloc(&ctx->d_slow_count, 64));  // [0] pairs for k_pe_mid, [1] queue, [2..3] postings, [4..7] acc, [8] pairs for k_pe_slow, [9] strip queue, [10..12] k_rows_sum debug, [13] owning ends
     if (ctx->slow2_cap < n_pairs) {
         if (ctx->d_slow_list2) VS_HIP(ctx, hipFree(ctx->d_slow_list2));
         ctx->d_slow_list2 = nullptr;
