@@ -217,7 +217,6 @@ const char *vs_pe_last_kernel(const vs_ctx *ctx);
 enum {
     VS_RAN_LOCUS_LDS_SORT = 1,    /* locus order by per-workgroup LDS histograms (k_locus_count / k_locus_scatter) */
     VS_RAN_LOCUS_GLOBAL_SORT = 2, /* ... by global atomics (k_pe_locus / k_pe_permute): graphs beyond 147 k nodes */
-    VS_RAN_LOCUS_REFINE = 4,      /* second sort key, the reverse read's locus (k_locus_refine): graphs beyond 46 340 nodes */
     VS_RAN_PE_MID = 8,            /* overflow pairs through the wavefront-per-pair kernel first (k_pe_mid) */
     VS_RAN_ROW_OWNERS = 16        /* counters summed by row owners (k_list_owners / k_rows_count / k_rows_fill / k_rows_sum): graphs beyond 46 340 nodes */
 };

@@ -97,7 +97,7 @@ def main():
         want = pe_oracle_c.Oracle(g.seqs, p["k"]).count_pairs(fwd, rve)
         env = {}
         if rng.random() < 0.3:
-            env = dict([[("VS_NO_STD", "1")], [("VS_NO_FAST", "1")], [("VS_EPT", "6")], [("VS_ACC_ROWS", "1"), ("VS_ROWS_KEYS", "64")], [("VS_REFINE", "1")], [("VS_ACC_ROWS", "1"), ("VS_ROWS_SUB", "1024")], [("VS_ACC_ROWS", "1"), ("VS_ACC_FILL", "1")], [("VS_ACC_FILL", "100")],
+            env = dict([[("VS_NO_STD", "1")], [("VS_NO_FAST", "1")], [("VS_EPT", "6")], [("VS_ACC_ROWS", "1"), ("VS_ROWS_KEYS", "64")], [("VS_ACC_ROWS", "1"), ("VS_LTAB_BITS", "0")], [("VS_ACC_ROWS", "1"), ("VS_ROWS_SUB", "1024")], [("VS_ACC_ROWS", "1"), ("VS_ACC_FILL", "1")], [("VS_ACC_FILL", "100")],
                         [("VS_NO_SORT", "1")], [("VS_LOCUS_GLOBAL", "1")], [("VS_ACC_ROWS", "1")], [("VS_ACC_ROWS", "1"), ("VS_ROWS_PER_STRIP", "3"), ("VS_LTAB_BITS", "4")]][int(rng.integers(0, 12))])
         if rng.random() < 0.15:
             env["VS_NO_MID"] = "1"  # overflow pairs straight to the general kernel

@@ -273,25 +273,3 @@ def test_cli_reproduces_the_real_reference_command_at_configs0(tmp_path):
     assert len(want["files_sha256"]) >= 25 and "strain.paths" in want["files_sha256"]
     problems = reference_command_problems(out, want)
     assert not problems, problems
-
-
-def test_second_sort_key_with_loci_longer_than_its_workgroup_buffer(host, xctx, tmp_path, monkeypatch):
-    """VS_REFINE=1 (the default for graphs beyond 46 k nodes: inside a forward-read locus the pairs are ordered by the
-    reverse read's locus, one workgroup per locus with a bitonic sort in LDS) on configs[0]'s 216-node graph with 1.2 M
-    pairs: most loci hold more pairs than the 4 096 the workgroup buffer takes and stay in first-key order, the others are
-    re-ordered -- the counters equal the oracle's either way (any order gives the same sums)."""
-    from vstrains_amd.workloads import CONFIGS, workload_for
-
-    cfg = CONFIGS[0]
-    ctx = xctx
-    st, pre, names, seqs, cum, logger, n_in = workload_for(0, str(tmp_path))
-    ctx.build_index(seqs, cfg["k"])
-    L, seed, R = cfg["read_len"], 5151, 1_200_000
-    sub, nth = int(0.005 * 2 ** 32), int(0.001 * 2 ** 32)
-    plain = _count(host, ctx, st, cum, seed, L, [(0, 1000)], sub, nth)
-    assert not ctx.last_launched & ctx.RAN_LOCUS_REFINE  # (a 216-node graph does not take the second key by itself)
-    monkeypatch.setenv("VS_REFINE", "1")
-    refined = _count(host, ctx, st, cum, seed, L, [(0, R)], sub, nth)
-    assert ctx.last_launched & ctx.RAN_LOCUS_REFINE, "VS_REFINE=1 did not launch k_locus_refine"
-    orc = pe_oracle_c.Oracle(seqs, cfg["k"])
-    _assert_equals_oracle(refined, orc, st, cum, seed, L, R, sub, nth)

@@ -524,7 +524,7 @@ def test_device_read_generator_equals_cpu_twin(host, ctx):
     {"VS_EPT": "6", "VS_GRID_PER_CU": "1"}, {"VS_ACC_FILL": "1"}, {"VS_ACC_FILL": "100"}, {"VS_NO_FAST": "1"},
     {"VS_ACC_QUEUE": "0"}, {"VS_ACC_GRID_PER_CU": "1", "VS_ACC_QUEUE": "0"}, {"VS_NO_XCD_MAP": "1"}, {"VS_GRID_PER_CU": "8"}, {"VS_NO_STD": "1"}, {"VS_SHORTCUT": "1"}, {"VS_SHORTCUT": "0"},
     {"VS_ACC_ROUND": "128"},
-    {"VS_REFINE": "1"}, {"VS_REFINE": "1", "VS_EPT": "32", "VS_ACC_ROWS": "1"}, {"VS_NO_MID": "1"},
+    {"VS_EPT": "32", "VS_ACC_ROWS": "1"}, {"VS_NO_MID": "1"},
     {"VS_ACC_ROWS": "1"}, {"VS_ACC_ROWS": "1", "VS_ROWS_PER_STRIP": "1"}, {"VS_ACC_ROWS": "1", "VS_ROWS_PER_STRIP": "64", "VS_ACC_FILL": "1"},
     {"VS_ACC_ROWS": "1", "VS_NO_SORT": "1"}, {"VS_ACC_ROWS": "1", "VS_ROWS_KEYS": "100"}, {"VS_ACC_ROWS": "1", "VS_ROWS_SUB": "2048", "VS_ROWS_KEYS": "7"},
     {"VS_ACC_ROWS": "1", "VS_LTAB_BITS": "0"}, {"VS_ACC_ROWS": "1", "VS_LTAB_BITS": "3"}, {"VS_ACC_ROWS": "1", "VS_LTAB_BITS": "7", "VS_ROWS_SUB": "1024"},

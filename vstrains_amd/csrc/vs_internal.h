@@ -110,7 +110,6 @@ struct VsTuning {
     uint32_t acc_round = 0;         // VS_ACC_ROUND: pairs per round of the counter kernel (0 = automatic; 64 .. 1024, power of two)
     int shortcut = -1;              // VS_SHORTCUT (-1 = by index statistics)
     uint32_t table_shift = 3;       // VS_TABLE_SHIFT: seed table of >= (distinct seeds << shift) slots (3: at most an eighth full)
-    int refine = -1;                // VS_REFINE (-1 = by graph size): second sort key, the reverse read's locus
     int acc_rows = -1;              // VS_ACC_ROWS (-1 = by graph size): counters summed by row owners (k_rows_sum) instead of pair-major (k_pe_accumulate)
     int ltab_bits = -1;             // VS_LTAB_BITS: log2 slots of the block's list table (-1 = by block size, 0 = no table: round owners only)
     uint32_t rows_keys = 0, rows_sub = 0;  // VS_ROWS_KEYS / VS_ROWS_SUB: rows per histogram pass, pairs per transposition (0 = the constants; tests shrink them)

@@ -1244,7 +1244,7 @@ __global__ void __launch_bounds__(64) k_zero_tiles(uint32_t *__restrict__ node_m
 #define ROWS_TPB 1024u
 #define ROWS_CAP 4096u     // distinct rows of a chunk that get an LDS cursor (the rest: a global atomic per entry)
 #define ROWS_KEYS 65536u   // rows per histogram pass (larger graphs take several passes over the lists)
-#define ROWS_SUB (1u << 27)  // pairs per transposition (entry indices and row offsets are 32-bit)
+#define ROWS_SUB ((1u << 27) - 1024u)  // pairs per transposition (an entry names a read end in 28 bits; row offsets are 32-bit)
 static inline size_t rows_lds_bytes(uint32_t n_keys) { return sizeof(uint32_t) * (((size_t)n_keys + 2u) / 2u + ROWS_CAP + ROWS_CAP / 2u + 4u); }
 
 // Which read ends stand for a list of their own, and for how many ends (short_mat takes one weighted pass per DISTINCT
@@ -1283,9 +1283,9 @@ __device__ __forceinline__ bool vs_same_list(const uint32_t (&mine)[LC], const u
 
 __global__ void __launch_bounds__(ACC_TPB)
 k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_slots_pairs, uint32_t *__restrict__ mult,
-              unsigned long long *__restrict__ ltab, uint32_t *__restrict__ lmult, uint32_t ltab_bits, uint32_t *__restrict__ owners,
-              uint32_t *__restrict__ n_owners) {
-    uint32_t *s_down = vs_lds, *s_dmul = vs_lds + OWN_SLOTS;
+              uint32_t *__restrict__ gown, unsigned long long *__restrict__ ltab, uint32_t *__restrict__ lmult, uint32_t ltab_bits,
+              uint32_t *__restrict__ owners, uint32_t *__restrict__ n_owners) {
+    uint32_t *s_down = vs_lds, *s_dmul = vs_lds + OWN_SLOTS, *s_gown = vs_lds + 2u * OWN_SLOTS;  // [2 * ACC_TPB]: the block's owner of a round owner's list
     const uint32_t tid = threadIdx.x;
     const uint64_t base = (uint64_t)blockIdx.x * ACC_TPB, p = base + tid;
     for (uint32_t i = tid; i < OWN_SLOTS; i += ACC_TPB) { s_down[i] = 0xFFFFFFFFu; s_dmul[i] = 0u; }
@@ -1295,7 +1295,7 @@ k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ c
         const uint2 c = *(const uint2 *)(counts + 2u * p);
         nl = c.x; nr = c.y;
     }
-    uint32_t slot_of[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+    uint32_t slot_of[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, round_owner[2] = {0u, 0u};
     unsigned long long fp64[2] = {0ull, 0ull};
 #pragma unroll
     for (uint32_t side = 0; side < 2u; side++) {
@@ -1335,6 +1335,7 @@ k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ c
                 if (vs_same_list(mine, other, n)) {  // merged: the owner stands for this end too
                     atomicAdd(&s_dmul[at], 1u);
                     slot_of[side] = 0xFFFFFFFEu;
+                    round_owner[side] = w0 & 0x7FFu;
                     break;
                 }
             }
@@ -1342,7 +1343,7 @@ k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ c
         }
     }
     __syncthreads();
-    uint32_t out[2] = {0u, 0u};
+    uint32_t out[2] = {0u, 0u}, own[2] = {0u, 0u};  // own: the end whose row stands for this end's list in the whole block
 #pragma unroll
     for (uint32_t side = 0; side < 2u; side++) {
         const uint32_t n = side ? nr : nl;
@@ -1350,6 +1351,8 @@ k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ c
         const uint32_t m = 1u + (slot_of[side] != 0xFFFFFFFFu ? s_dmul[slot_of[side]] : 0u);  // (no dedup slot found: an owner all the same)
         const uint32_t e = (uint32_t)(2u * p + side);
         out[side] = m;
+        own[side] = e;
+        s_gown[2u * tid + side] = e;
         if (!ltab) continue;
         const unsigned long long f2 = fp64[side];
         const uint32_t tag = ((uint32_t)(f2 >> 32) & ~15u) | (n - 1u);  // (the list length rides in the tag: no load for the owner's)
@@ -1375,6 +1378,8 @@ k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ c
                 if (vs_same_list(mine, other, n)) {
                     atomicAdd(&lmult[h], m);
                     out[side] = 0u;
+                    own[side] = (uint32_t)cur - 1u;
+                    s_gown[2u * tid + side] = own[side];
                     placed = true;
                     break;
                 }
@@ -1383,7 +1388,13 @@ k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ c
         }
         if (!placed) owners[atomicAdd(n_owners, 1u)] = e;  // (a crowded table: the round's owner stays one)
     }
-    if (p < n_slots_pairs) *(uint2 *)(mult + 2u * p) = make_uint2(out[0], out[1]);
+    __syncthreads();
+    if (slot_of[0] == 0xFFFFFFFEu) own[0] = s_gown[round_owner[0]];
+    if (slot_of[1] == 0xFFFFFFFEu) own[1] = s_gown[round_owner[1]];
+    if (p < n_slots_pairs) {
+        *(uint2 *)(mult + 2u * p) = make_uint2(out[0], out[1]);
+        *(uint2 *)(gown + 2u * p) = make_uint2(own[0], own[1]);
+    }
     if (!ltab && p < n_slots_pairs) {  // (no block table: every round owner is an item)
         if (out[0]) owners[atomicAdd(n_owners, 1u)] = (uint32_t)(2u * p);
         if (out[1]) owners[atomicAdd(n_owners, 1u)] = (uint32_t)(2u * p + 1u);
@@ -1483,8 +1494,8 @@ k_rows_count(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ co
 template <int MODE>
 __global__ void __launch_bounds__(ROWS_TPB)
 k_rows_fill(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ owners, uint64_t n_items,
-            const uint32_t *__restrict__ n_owners, uint32_t key_lo, uint32_t n_keys, const uint32_t *__restrict__ row_ptr,
-            uint32_t *__restrict__ row_cursor, uint32_t *__restrict__ entries) {
+            const uint32_t *__restrict__ n_owners, const uint32_t *__restrict__ gown, uint32_t key_lo, uint32_t n_keys,
+            const uint32_t *__restrict__ row_ptr, uint32_t *__restrict__ row_cursor, uint32_t *__restrict__ entries) {
     uint32_t *h32 = vs_lds;
     const uint32_t words = (n_keys + 1u) >> 1, tid = threadIdx.x;
     if (MODE) n_items = *n_owners;
@@ -1527,6 +1538,15 @@ k_rows_fill(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ cou
         if (4u * q >= n) continue;
         const VsQuad v = *(const VsQuad *)(lists + row * LC + 4u * q);
         const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+        // what an entry says: whose list row k_rows_sum reads, and that list's length - 1 in the top four bits -- the block's
+        // owner of the pair's RIGHT list (a few hundred distinct rows per matrix row, cached, instead of one row per pair) /
+        // the owning end itself
+        uint32_t payload;
+        if (MODE) payload = (uint32_t)row | ((n - 1u) << 28);
+        else {
+            const uint64_t re = 2u * (i >> 2) + 1u;
+            payload = gown[re] | ((counts[re] - 1u) << 28);
+        }
 #pragma unroll
         for (uint32_t j = 0; j < 4u; j++) {
             const uint32_t x = e[j] - key_lo;
@@ -1540,7 +1560,7 @@ k_rows_fill(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ cou
             } else {
                 pos = row_ptr[e[j]] + atomicAdd(&row_cursor[e[j]], 1u);
             }
-            entries[pos] = MODE ? (uint32_t)row : (uint32_t)(i >> 2);  // the pair / the read end
+            entries[pos] = payload;
         }
     }
 }
@@ -1602,9 +1622,9 @@ k_rows_sum(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ coun
             wgt = 1u;
             yq = VsQuad{0u, 0u, 0u, 0u};
             if (it != 0xFFFFFFFFu) {
-                const uint64_t row = MODE ? (uint64_t)it : 2u * (uint64_t)it + 1u;
-                n = counts[row];
-                if (MODE) wgt = mult[it];
+                const uint64_t row = it & 0x0FFFFFFFu;  // (a read end of the transposition)
+                n = (it >> 28) + 1u;
+                if (MODE) wgt = mult[row];
                 yq = *(const VsQuad *)(lists + row * LC + 4u * q);
             }
         };
@@ -1699,45 +1719,6 @@ __device__ __forceinline__ uint32_t vs_locus_key_end(const VsIndexDev &idx, cons
         if (c) return c == 1u ? pa : (idx.postings[pa].x & 0x01FFFFFFu);
     }
     return N;
-}
-
-// Second sort key (large graphs): inside the run of pairs that share the forward read's locus, order by the REVERSE read's
-// locus.  Pairs that are neighbours in that order come from the same strain and insert size far more often, hit the same
-// counter cells, and the cell table of k_pe_accumulate sums them before they become global atomics.  One workgroup per
-// locus: its pairs and their second keys go to LDS, a bitonic sort orders them, the run of `perm` is rewritten in place
-// (runs longer than REFINE_CAP stay as they are).  Any order gives the same counters.
-#define REFINE_CAP 4096u
-__global__ void __launch_bounds__(TPB)
-k_locus_refine(VsIndexDev idx, VsReadsDev rd, uint32_t n_wg, uint64_t n_pairs, const uint32_t *__restrict__ first, uint32_t *__restrict__ perm) {
-    __shared__ unsigned long long s_kv[REFINE_CAP];
-    const uint32_t key = blockIdx.x;  // 0 .. N-1 (the runs of unmapped / dropped pairs are left alone)
-    const uint64_t lo = first[(uint64_t)key * n_wg];
-    const uint64_t hi = first[(uint64_t)(key + 1u) * n_wg];  // (key + 1 <= N: the table holds N + 2 keys)
-    const uint32_t n = (uint32_t)(hi - lo);
-    if (n < 2u || n > REFINE_CAP) return;
-    uint32_t m = 1u;
-    while (m < n) m <<= 1;
-    for (uint32_t i = threadIdx.x; i < m; i += TPB) {
-        unsigned long long kv = ~0ull;  // padding sorts to the end
-        if (i < n) {
-            const uint32_t pair = perm[lo + i];
-            kv = ((unsigned long long)vs_locus_key_end(idx, rd, 2ull * pair + 1u) << 32) | pair;
-        }
-        s_kv[i] = kv;
-    }
-    __syncthreads();
-    for (uint32_t size = 2u; size <= m; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0u; stride >>= 1) {
-            for (uint32_t i = threadIdx.x; i < (m >> 1); i += TPB) {
-                const uint32_t a = 2u * i - (i & (stride - 1u)), b = a + stride;
-                const bool up = (a & size) == 0u;
-                const unsigned long long x = s_kv[a], y = s_kv[b];
-                if ((x > y) == up) { s_kv[a] = y; s_kv[b] = x; }
-            }
-            __syncthreads();
-        }
-    }
-    for (uint32_t i = threadIdx.x; i < n; i += TPB) perm[lo + i] = (uint32_t)s_kv[i];
 }
 
 // Counting sort without global atomics (used while the N+2 keys fit an LDS histogram):
@@ -2172,7 +2153,7 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
             if (*q) { VS_HIP(ctx, hipFree(*q)); *q = nullptr; }
         ctx->row_entries_cap = ctx->ltab_cap = 0;
         VS_HIP(ctx, hipMalloc(&ctx->d_row_entries, sizeof(uint32_t) * (3u * sub_pairs * LC + 16u)));
-        VS_HIP(ctx, hipMalloc(&ctx->d_mult, sizeof(uint32_t) * (4u * sub_pairs + 4u)));  // mult[2 np], owners[2 np]
+        VS_HIP(ctx, hipMalloc(&ctx->d_mult, sizeof(uint32_t) * (6u * sub_pairs + 4u)));  // mult[2 np], owners[2 np], gown[2 np]
         VS_HIP(ctx, hipMalloc(&ctx->d_ltab, (sizeof(uint64_t) + sizeof(uint32_t)) * ltab_slots + 16u));
         ctx->row_entries_cap = sub_pairs;
         ctx->ltab_cap = ltab_slots;
@@ -2202,14 +2183,14 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
     for (uint64_t p0 = 0; p0 < slots_pairs; p0 += sub_pairs) {
         const uint64_t np = slots_pairs - p0 < sub_pairs ? slots_pairs - p0 : sub_pairs;
         const uint32_t *sl = (const uint32_t *)ctx->d_lists + 2u * p0 * LC, *sc = (const uint32_t *)ctx->d_list_counts + 2u * p0;
-        uint32_t *mult = (uint32_t *)ctx->d_mult, *owners = mult + 2u * sub_pairs;
+        uint32_t *mult = (uint32_t *)ctx->d_mult, *owners = mult + 2u * sub_pairs, *gown = owners + 2u * sub_pairs;
         const unsigned n_chunks = (unsigned)((np + ROWS_CHUNK - 1u) / ROWS_CHUNK);
         const unsigned n_chunks1 = (unsigned)((2u * np + ROWS_CHUNK1 - 1u) / ROWS_CHUNK1);  // (every end could be an owner; a chunk past the last owner returns at once)
         VS_HIP(ctx, hipMemsetAsync(rows, 0, sizeof(uint32_t) * 6u * cap, st));
         VS_HIP(ctx, hipMemsetAsync(n_owners, 0, sizeof(uint32_t), st));
         if (use_ltab) VS_HIP(ctx, hipMemsetAsync(ctx->d_ltab, 0, (sizeof(uint64_t) + sizeof(uint32_t)) * ltab_slots, st));
-        hipLaunchKernelGGL(k_list_owners, dim3((unsigned)((np + ACC_TPB - 1u) / ACC_TPB)), dim3(ACC_TPB), 2u * OWN_SLOTS * sizeof(uint32_t), st, sl, sc, np,
-                           mult, ltab, lmult, ltab_bits, owners, n_owners);
+        hipLaunchKernelGGL(k_list_owners, dim3((unsigned)((np + ACC_TPB - 1u) / ACC_TPB)), dim3(ACC_TPB), (2u * OWN_SLOTS + 2u * ACC_TPB) * sizeof(uint32_t), st, sl, sc, np,
+                           mult, gown, ltab, lmult, ltab_bits, owners, n_owners);
         if (use_ltab) {
             const uint64_t per_wg = (ltab_slots + ctx->n_cu * 8ull - 1u) / (ctx->n_cu * 8ull);
             hipLaunchKernelGGL(k_owners_collect, dim3((unsigned)((ltab_slots + per_wg - 1u) / per_wg)), dim3(COLLECT_TPB), 0, st,
@@ -2227,8 +2208,8 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
             if (rc) return rc;
             for (uint32_t key_lo = 0; key_lo < N; key_lo += n_keys) {
                 const uint32_t nk = N - key_lo < n_keys ? N - key_lo : n_keys;
-                if (mode) hipLaunchKernelGGL(k_rows_fill<1>, dim3(n_chunks1), dim3(ROWS_TPB), rl, st, sl, sc, (const uint32_t *)owners, 0ull, (const uint32_t *)n_owners, key_lo, nk, (const uint32_t *)row_ptr, row_cursor, entries);
-                else hipLaunchKernelGGL(k_rows_fill<0>, dim3(n_chunks), dim3(ROWS_TPB), rl, st, sl, sc, (const uint32_t *)nullptr, np, (const uint32_t *)nullptr, key_lo, nk, (const uint32_t *)row_ptr, row_cursor, entries);
+                if (mode) hipLaunchKernelGGL(k_rows_fill<1>, dim3(n_chunks1), dim3(ROWS_TPB), rl, st, sl, sc, (const uint32_t *)owners, 0ull, (const uint32_t *)n_owners, (const uint32_t *)gown, key_lo, nk, (const uint32_t *)row_ptr, row_cursor, entries);
+                else hipLaunchKernelGGL(k_rows_fill<0>, dim3(n_chunks), dim3(ROWS_TPB), rl, st, sl, sc, (const uint32_t *)nullptr, np, (const uint32_t *)nullptr, (const uint32_t *)gown, key_lo, nk, (const uint32_t *)row_ptr, row_cursor, entries);
             }
         }
         for (int mode = 0; mode < 2; mode++) {
@@ -2441,9 +2422,6 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         const uint64_t nk = (uint64_t)idx.n_nodes + 2u;
         const bool lds_sort = nk <= LOCUS_LDS_MAX_PASSES * LOCUS_LDS_KEYS && !tn.locus_global;
         ctx->last_launched |= lds_sort ? VS_RAN_LOCUS_LDS_SORT : VS_RAN_LOCUS_GLOBAL_SORT;
-        // second key (the reverse read's locus) where the counter kernel is bound by global atomics: graphs beyond the
-        // one-table shape of its cell table (VS_REFINE=0 / 1 overrides)
-        const bool refine = tn.refine >= 0 ? tn.refine != 0 : 2ull * idx.n_nodes * idx.n_nodes >= 0xFFFFFFFFull;
         if (lds_sort) {
             const uint32_t n_wg = LOCUS_WGS;
             const uint32_t chunk = (uint32_t)((n_pairs + n_wg - 1) / n_wg);
@@ -2466,10 +2444,6 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
                 hipLaunchKernelGGL(k_locus_scatter, dim3(n_wg), dim3(LOCUS_TPB), lds_keys, st, key_lo, n_here, n_pairs, chunk, n_wg,
                                    (const uint32_t *)ctx->d_locus_keys, (const uint32_t *)ctx->d_locus_hist, (uint32_t *)ctx->d_perm);
             }
-            if (refine && idx.n_nodes) ctx->last_launched |= VS_RAN_LOCUS_REFINE;
-            if (refine && idx.n_nodes)
-                hipLaunchKernelGGL(k_locus_refine, dim3(idx.n_nodes), dim3(TPB), 0, st, idx, reads->dev(), n_wg, n_pairs,
-                                   (const uint32_t *)ctx->d_locus_hist, (uint32_t *)ctx->d_perm);
         } else {
             VS_HIP(ctx, hipMemsetAsync(ctx->d_locus_hist, 0, sizeof(uint32_t) * nk, st));
             const unsigned pg = (unsigned)((n_pairs + TPB - 1) / TPB);

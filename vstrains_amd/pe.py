@@ -385,7 +385,7 @@ class Context:
         """Name of the mapping-kernel instantiation the last ``pe_count`` launched."""
         return (nat.lib().vs_pe_last_kernel(self._h) or b"").decode()
 
-    RAN_LOCUS_LDS_SORT, RAN_LOCUS_GLOBAL_SORT, RAN_LOCUS_REFINE, RAN_PE_MID, RAN_ROW_OWNERS = 1, 2, 4, 8, 16
+    RAN_LOCUS_LDS_SORT, RAN_LOCUS_GLOBAL_SORT, RAN_PE_MID, RAN_ROW_OWNERS = 1, 2, 8, 16
 
     @property
     def last_launched(self) -> int:
