@@ -1283,8 +1283,7 @@ __device__ __forceinline__ bool vs_same_list(const uint32_t (&mine)[LC], const u
 
 __global__ void __launch_bounds__(ACC_TPB)
 k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_slots_pairs, uint32_t *__restrict__ mult,
-              uint32_t *__restrict__ gown, unsigned long long *__restrict__ ltab, uint32_t *__restrict__ lmult, uint32_t ltab_bits,
-              uint32_t *__restrict__ owners, uint32_t *__restrict__ n_owners) {
+              uint32_t *__restrict__ gown, unsigned long long *__restrict__ ltab, uint32_t *__restrict__ lmult, uint32_t ltab_bits) {
     uint32_t *s_down = vs_lds, *s_dmul = vs_lds + OWN_SLOTS, *s_gown = vs_lds + 2u * OWN_SLOTS;  // [2 * ACC_TPB]: the block's owner of a round owner's list
     const uint32_t tid = threadIdx.x;
     const uint64_t base = (uint64_t)blockIdx.x * ACC_TPB, p = base + tid;
@@ -1386,7 +1385,7 @@ k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ c
             }
             h = (h + 1u) & ((1u << ltab_bits) - 1u);
         }
-        if (!placed) owners[atomicAdd(n_owners, 1u)] = e;  // (a crowded table: the round's owner stays one)
+        // (not placed -- a crowded table: the round's owner stays one, with the multiplicity its round gave it)
     }
     __syncthreads();
     if (slot_of[0] == 0xFFFFFFFEu) own[0] = s_gown[round_owner[0]];
@@ -1395,24 +1394,28 @@ k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ c
         *(uint2 *)(mult + 2u * p) = make_uint2(out[0], out[1]);
         *(uint2 *)(gown + 2u * p) = make_uint2(own[0], own[1]);
     }
-    if (!ltab && p < n_slots_pairs) {  // (no block table: every round owner is an item)
-        if (out[0]) owners[atomicAdd(n_owners, 1u)] = (uint32_t)(2u * p);
-        if (out[1]) owners[atomicAdd(n_owners, 1u)] = (uint32_t)(2u * p + 1u);
-    }
 }
 
-// every claimed slot of the block's list table: its owner gets the slot's multiplicity and a place in `owners`.  A
-// workgroup takes a stretch of slots, counts the claimed ones, reserves their places with ONE atomic (the counter is a
-// single word: an atomic per wavefront would queue up behind each other), then reads the stretch again and writes.
+// every claimed slot of the block's list table: its owner gets the slot's multiplicity
+__global__ void __launch_bounds__(256)
+k_owners_mult(const unsigned long long *__restrict__ ltab, const uint32_t *__restrict__ lmult, uint64_t n_slots, uint32_t *__restrict__ mult) {
+    const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n_slots) return;
+    const unsigned long long w = ltab[h];
+    if (w != 0ull) mult[(uint32_t)w - 1u] = lmult[h];
+}
+
+// The owning ends (mult > 0) in END order -- locus order, so that a chunk of them touches few matrix rows, as a chunk of
+// pairs does.  A workgroup takes a stretch of ends, counts the owners, reserves their places with ONE atomic (the counter is
+// a single word: an atomic per wavefront would queue up behind each other), then reads the stretch again and writes.
 #define COLLECT_TPB 256u
 __global__ void __launch_bounds__(COLLECT_TPB)
-k_owners_collect(const unsigned long long *__restrict__ ltab, const uint32_t *__restrict__ lmult, uint64_t n_slots, uint64_t per_wg,
-                 uint32_t *__restrict__ mult, uint32_t *__restrict__ owners, uint32_t *__restrict__ n_owners) {
+k_owners_collect(const uint32_t *__restrict__ mult, uint64_t n_ends, uint64_t per_wg, uint32_t *__restrict__ owners, uint32_t *__restrict__ n_owners) {
     __shared__ uint32_t s_wave[COLLECT_TPB / 64u], s_base;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    const uint64_t lo = (uint64_t)blockIdx.x * per_wg, hi = lo + per_wg < n_slots ? lo + per_wg : n_slots;
+    const uint64_t lo = (uint64_t)blockIdx.x * per_wg, hi = lo + per_wg < n_ends ? lo + per_wg : n_ends;
     uint32_t mine = 0;
-    for (uint64_t h = lo + tid; h < hi; h += COLLECT_TPB) mine += ltab[h] != 0ull ? 1u : 0u;
+    for (uint64_t e = lo + tid; e < hi; e += COLLECT_TPB) mine += mult[e] != 0u ? 1u : 0u;
 #pragma unroll
     for (int d = 32; d; d >>= 1) mine += __shfl_xor(mine, d, 64);
     if (lane == 0) s_wave[wv] = mine;
@@ -1424,18 +1427,14 @@ k_owners_collect(const unsigned long long *__restrict__ ltab, const uint32_t *__
         s_wave[0] = 0u;  // (now the running offset inside the reservation)
     }
     __syncthreads();
-    for (uint64_t h0 = lo; h0 < hi; h0 += COLLECT_TPB) {  // (uniform trip count: the ballots and the barrier below see every lane)
-        const uint64_t h = h0 + tid;
-        const unsigned long long w = h < hi ? ltab[h] : 0ull;
-        const unsigned long long live = __ballot(w != 0ull);
+    for (uint64_t e0 = lo; e0 < hi; e0 += COLLECT_TPB) {  // (uniform trip count: the ballot sees every lane)
+        const uint64_t e = e0 + tid;
+        const bool own = e < hi && mult[e] != 0u;
+        const unsigned long long live = __ballot(own);
         uint32_t wbase = 0;
         if (lane == 0 && live) wbase = atomicAdd(&s_wave[0], (uint32_t)__popcll(live));  // (LDS)
         wbase = __shfl(wbase, 0, 64);
-        if (w != 0ull) {
-            const uint32_t e = (uint32_t)w - 1u;
-            mult[e] = lmult[h];
-            owners[s_base + wbase + (uint32_t)__popcll(live & ((1ull << lane) - 1ull))] = e;
-        }
+        if (own) owners[s_base + wbase + (uint32_t)__popcll(live & ((1ull << lane) - 1ull))] = (uint32_t)e;
     }
 }
 
@@ -2177,7 +2176,7 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
     // 1.7 k cells at the median and 6 k at most, 32 rows of short_mat 2.1 k and 6.6 k.  VS_ROWS_PER_STRIP overrides both.
     const uint32_t R[2] = {tn.rows_per_strip ? tn.rows_per_strip : 4u, tn.rows_per_strip ? tn.rows_per_strip : 32u};
     uint32_t *dbg = tn.debug_acc ? (uint32_t *)ctx->d_slow_count + 10 : nullptr;
-    uint32_t *queue = (uint32_t *)ctx->d_slow_count + 9, *n_owners = (uint32_t *)ctx->d_slow_count + 13;
+    uint32_t *queue = (uint32_t *)ctx->d_slow_count + 9, *n_owners = (uint32_t *)ctx->d_slow_count + 15;
     unsigned long long *ltab = use_ltab ? (unsigned long long *)ctx->d_ltab : nullptr;
     uint32_t *lmult = use_ltab ? (uint32_t *)((unsigned long long *)ctx->d_ltab + ltab_slots) : nullptr;
     for (uint64_t p0 = 0; p0 < slots_pairs; p0 += sub_pairs) {
@@ -2190,11 +2189,14 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
         VS_HIP(ctx, hipMemsetAsync(n_owners, 0, sizeof(uint32_t), st));
         if (use_ltab) VS_HIP(ctx, hipMemsetAsync(ctx->d_ltab, 0, (sizeof(uint64_t) + sizeof(uint32_t)) * ltab_slots, st));
         hipLaunchKernelGGL(k_list_owners, dim3((unsigned)((np + ACC_TPB - 1u) / ACC_TPB)), dim3(ACC_TPB), (2u * OWN_SLOTS + 2u * ACC_TPB) * sizeof(uint32_t), st, sl, sc, np,
-                           mult, gown, ltab, lmult, ltab_bits, owners, n_owners);
-        if (use_ltab) {
-            const uint64_t per_wg = (ltab_slots + ctx->n_cu * 8ull - 1u) / (ctx->n_cu * 8ull);
-            hipLaunchKernelGGL(k_owners_collect, dim3((unsigned)((ltab_slots + per_wg - 1u) / per_wg)), dim3(COLLECT_TPB), 0, st,
-                               (const unsigned long long *)ltab, (const uint32_t *)lmult, ltab_slots, per_wg, mult, owners, n_owners);
+                           mult, gown, ltab, lmult, ltab_bits);
+        if (use_ltab)
+            hipLaunchKernelGGL(k_owners_mult, dim3((unsigned)((ltab_slots + 255u) / 256u)), dim3(256), 0, st, (const unsigned long long *)ltab,
+                               (const uint32_t *)lmult, ltab_slots, mult);
+        {
+            const uint64_t per_wg = ((2u * np + ctx->n_cu * 8ull - 1u) / (ctx->n_cu * 8ull) + COLLECT_TPB - 1u) / COLLECT_TPB * COLLECT_TPB;
+            hipLaunchKernelGGL(k_owners_collect, dim3((unsigned)((2u * np + per_wg - 1u) / per_wg)), dim3(COLLECT_TPB), 0, st, (const uint32_t *)mult, 2u * np, per_wg,
+                               owners, n_owners);
         }
         for (int mode = 0; mode < 2; mode++) {
             uint32_t *row_count = rows + 3u * mode * cap, *row_cursor = row_count + cap, *row_ptr = row_cursor + cap;
@@ -2273,7 +2275,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         VS_HIP(ctx, hipMalloc(&ctx->d_slow_list, sizeof(uint32_t) * n_pairs));
         ctx->slow_cap = n_pairs;
     }
-    if (!ctx->d_slow_count) VS_HIP(ctx, hipMalloc(&ctx->d_slow_count, 64));  // [0] pairs for k_pe_mid, [1] queue, [2..3] postings, [4..7] acc, [8] pairs for k_pe_slow, [9] strip queue, [10..12] k_rows_sum debug, [13] owning ends
+    if (!ctx->d_slow_count) VS_HIP(ctx, hipMalloc(&ctx->d_slow_count, 64));  // [0] pairs for k_pe_mid, [1] queue, [2..3] postings, [4..7] acc, [8] pairs for k_pe_slow, [9] strip queue, [10..14] k_rows_sum debug, [15] owning ends
     if (ctx->slow2_cap < n_pairs) {
         if (ctx->d_slow_list2) VS_HIP(ctx, hipFree(ctx->d_slow_list2));
         ctx->d_slow_list2 = nullptr;
@@ -2601,6 +2603,7 @@ extern "C" int vs_pe_last_timing(vs_ctx *ctx, double ms[5]) {
             uint32_t r3[3] = {0, 0, 0};
             VS_HIP(ctx, hipMemcpy(r3, (char *)ctx->d_slow_count + 40, sizeof r3, hipMemcpyDeviceToHost));
             fprintf(stderr, "[vs] k_rows_sum (both matrices): %u increments went past the cell table, %u write-outs of %u cells\n", r3[0], r3[1], r3[2]);
+
             uint32_t e2[2] = {0, 0};  // entries of the last transposition: row_ptr[N] of either mode
             const uint32_t *rows = (const uint32_t *)ctx->d_rows;
             VS_HIP(ctx, hipMemcpy(&e2[0], rows + 2u * ctx->rows_cap + ctx->idx.n_nodes, sizeof(uint32_t), hipMemcpyDeviceToHost));
