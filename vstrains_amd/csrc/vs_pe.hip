@@ -1238,7 +1238,6 @@ __global__ void __launch_bounds__(64) k_zero_tiles(uint32_t *__restrict__ node_m
 //   k_rows_fill    the same histogram again; a chunk reserves its stretch of every row it holds with one global atomic,
 //                  then places its items through LDS cursors
 //   k_rows_sum     strips of rows off a queue; a lane per (item of the row, quad of its partner list)
-#define OWN_SLOTS 2048u    // dedup slots of a round (2 048 ends: at most a fifth of them claim one)
 #define ROWS_CHUNK 16384u  // pairs per chunk: a node is in a list at most once, so a 16-bit count (<= 32 768 ends) cannot wrap
 #define ROWS_CHUNK1 8192u  // owning ends per chunk (mode 1: few items, spread over more workgroups)
 #define ROWS_TPB 1024u
@@ -1247,19 +1246,17 @@ __global__ void __launch_bounds__(64) k_zero_tiles(uint32_t *__restrict__ node_m
 #define ROWS_SUB ((1u << 27) - 1024u)  // pairs per transposition (an entry names a read end in 28 bits; row offsets are 32-bit)
 static inline size_t rows_lds_bytes(uint32_t n_keys) { return sizeof(uint32_t) * (((size_t)n_keys + 2u) / 2u + ROWS_CAP + ROWS_CAP / 2u + 4u); }
 
-// Which read ends stand for a list of their own, and for how many ends (short_mat takes one weighted pass per DISTINCT
-// list).  Two stages in one kernel:
-//   round  equal end lists of a round (1 024 locus-ordered pairs) are merged in LDS: the first end that brings a list owns
-//          it, the others only add to its multiplicity.  Forward reads of one locus repeat each other's lists nine times
-//          in ten; their mates, spread over the insert-size range, rarely do (configs[4]: 58 % of the ends stay owners).
-//   block  every round owner looks its list up in a table of the whole block (device memory, one 64-bit word per slot:
-//          tag << 32 | owner end + 1, claimed by compare-and-swap; a separate word per slot sums the multiplicities).  A
-//          lookup reads with plain loads -- a word never changes once claimed, a stale zero only sends the lane into a CAS
-//          that returns the real word.
-// Fingerprints are order-independent (the lists arrive in no particular order); a tag match is confirmed node by node
-// against the owner's row, which is input data.  mult[end] = 0 for an end that is merged into another one; the ends that
-// claimed a table slot get theirs, and their place in `owners`, from k_owners_collect; an end that finds no place within
-// LTAB_PROBES slots stays the owner of what its round gave it.
+// Which read ends stand for a list of their own, and for how many ends: short_mat takes one weighted pass per DISTINCT
+// list of the block, and node_mat's entries name distinct lists (cached rows) instead of one row per pair.  Every end
+// looks its list up in a table of the whole block (device memory, one 64-bit word per slot: tag << 32 | owner end + 1,
+// claimed by compare-and-swap; a separate word per slot counts the ends).  A lookup reads with plain loads -- a word never
+// changes once claimed, a stale zero only sends the lane into a CAS that returns the real word.  Fingerprints are
+// order-independent (the lists arrive in no particular order); a tag match is confirmed node by node against the owner's
+// row, which is input data.  mult[end] = 0 for an end that is merged into another one; an end that claimed a slot gets the
+// slot's count from k_owners_mult; an end that finds no place within LTAB_PROBES slots stands for itself alone.
+// gown[end] = the end whose row holds this end's list.  (Merging the ends of a round in LDS first was measured: forward
+// reads of one locus repeat each other nine times in ten, their mates rarely; with it the kernel took 5.6 ms at
+// configs[4], without 4.1.)
 #define LTAB_PROBES 16u
 __device__ __forceinline__ void vs_load_list(const uint32_t *__restrict__ row, uint32_t n, uint32_t (&v)[LC]) {
     const VsQuad a = *(const VsQuad *)row, b = n > 4u ? *(const VsQuad *)(row + 4) : VsQuad{0, 0, 0, 0};
@@ -1281,93 +1278,34 @@ __device__ __forceinline__ bool vs_same_list(const uint32_t (&mine)[LC], const u
     return same;
 }
 
-__global__ void __launch_bounds__(ACC_TPB)
-k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_slots_pairs, uint32_t *__restrict__ mult,
+__global__ void __launch_bounds__(256)
+k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_ends, uint32_t *__restrict__ mult,
               uint32_t *__restrict__ gown, unsigned long long *__restrict__ ltab, uint32_t *__restrict__ lmult, uint32_t ltab_bits) {
-    uint32_t *s_down = vs_lds, *s_dmul = vs_lds + OWN_SLOTS, *s_gown = vs_lds + 2u * OWN_SLOTS;  // [2 * ACC_TPB]: the block's owner of a round owner's list
-    const uint32_t tid = threadIdx.x;
-    const uint64_t base = (uint64_t)blockIdx.x * ACC_TPB, p = base + tid;
-    for (uint32_t i = tid; i < OWN_SLOTS; i += ACC_TPB) { s_down[i] = 0xFFFFFFFFu; s_dmul[i] = 0u; }
-    __syncthreads();
-    uint32_t nl = 0, nr = 0;
-    if (p < n_slots_pairs) {
-        const uint2 c = *(const uint2 *)(counts + 2u * p);
-        nl = c.x; nr = c.y;
-    }
-    uint32_t slot_of[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, round_owner[2] = {0u, 0u};
-    unsigned long long fp64[2] = {0ull, 0ull};
-#pragma unroll
-    for (uint32_t side = 0; side < 2u; side++) {
-        const uint32_t n = side ? nr : nl;
-        if (n == 0u) continue;
-        const uint32_t me = 2u * tid + side;  // end index within the round
+    const uint64_t e64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e64 >= n_ends) return;
+    const uint32_t e = (uint32_t)e64, n = counts[e];
+    uint32_t m = n ? 1u : 0u, own = e;
+    if (n && ltab) {
         uint32_t mine[LC];
-        vs_load_list(lists + (2u * p + side) * LC, n, mine);
-        uint32_t fp = n * 0x9E3779B1u;
+        vs_load_list(lists + e64 * LC, n, mine);
         unsigned long long f2 = n;
 #pragma unroll
         for (uint32_t i = 0; i < LC; i++)
             if (i < n) {
-                uint32_t h = mine[i] * 0x85EBCA6Bu;
-                h ^= h >> 15;
-                fp += h * 0xC2B2AE35u;  // (a sum: the order of the nodes does not matter)
                 unsigned long long g = (mine[i] + 1ull) * 0x9E3779B97F4A7C15ull;
                 g ^= g >> 29;
-                f2 += g * 0xBF58476D1CE4E5B9ull;
+                f2 += g * 0xBF58476D1CE4E5B9ull;  // (a sum: the order of the nodes does not matter)
             }
-        fp64[side] = f2;
-        // tag: 17 bits of the fingerprint and the list length (the owner's length comes with the table
-        // word: no load for it); all ones with owner 2047 would read as an empty slot -- n - 1 <= 15
-        // only together with tag bits all ones, so clear one
-        uint32_t tag = (((fp ^ (fp >> 13)) & 0x1FFFFu) << 4) | (n - 1u);
-        if (tag == 0x1FFFFFu) tag ^= 0x10u;
-        uint32_t at = (fp * 0x9E3779B1u) >> (32u - 11u);  // OWN_SLOTS = 2048
-        for (uint32_t pr = 0; pr < 6u; pr++) {
-            uint32_t w0 = s_down[at];
-            if (w0 == 0xFFFFFFFFu) {
-                w0 = atomicCAS(&s_down[at], 0xFFFFFFFFu, (tag << 11) | me);
-                if (w0 == 0xFFFFFFFFu) { slot_of[side] = at; break; }  // this end owns the list in its round
-            }
-            if ((w0 >> 11) == tag) {
-                uint32_t other[LC];
-                vs_load_list(lists + (2u * base + (w0 & 0x7FFu)) * (uint64_t)LC, n, other);
-                if (vs_same_list(mine, other, n)) {  // merged: the owner stands for this end too
-                    atomicAdd(&s_dmul[at], 1u);
-                    slot_of[side] = 0xFFFFFFFEu;
-                    round_owner[side] = w0 & 0x7FFu;
-                    break;
-                }
-            }
-            at = (at + 1u) & (OWN_SLOTS - 1u);
-        }
-    }
-    __syncthreads();
-    uint32_t out[2] = {0u, 0u}, own[2] = {0u, 0u};  // own: the end whose row stands for this end's list in the whole block
-#pragma unroll
-    for (uint32_t side = 0; side < 2u; side++) {
-        const uint32_t n = side ? nr : nl;
-        if (n == 0u || slot_of[side] == 0xFFFFFFFEu) continue;  // nothing listed / merged in the round
-        const uint32_t m = 1u + (slot_of[side] != 0xFFFFFFFFu ? s_dmul[slot_of[side]] : 0u);  // (no dedup slot found: an owner all the same)
-        const uint32_t e = (uint32_t)(2u * p + side);
-        out[side] = m;
-        own[side] = e;
-        s_gown[2u * tid + side] = e;
-        if (!ltab) continue;
-        const unsigned long long f2 = fp64[side];
         const uint32_t tag = ((uint32_t)(f2 >> 32) & ~15u) | (n - 1u);  // (the list length rides in the tag: no load for the owner's)
         const unsigned long long word = ((unsigned long long)tag << 32) | (e + 1u);
         uint32_t h = (uint32_t)((f2 * 0xD6E8FEB86659FD93ull) >> (64u - ltab_bits));
-        bool placed = false;
-        uint32_t mine[LC];
-        vs_load_list(lists + (uint64_t)e * LC, n, mine);
-        for (uint32_t pr = 0; pr < LTAB_PROBES && !placed; pr++) {
+        for (uint32_t pr = 0; pr < LTAB_PROBES; pr++) {
             unsigned long long cur = ltab[h];
             if (cur == 0ull) {
                 cur = atomicCAS(&ltab[h], 0ull, word);
-                if (cur == 0ull) {  // claimed: k_owners_collect hands this end the slot's total
-                    atomicAdd(&lmult[h], m);
-                    out[side] = 0u;
-                    placed = true;
+                if (cur == 0ull) {  // claimed: k_owners_mult hands this end the slot's count
+                    atomicAdd(&lmult[h], 1u);
+                    m = 0u;
                     break;
                 }
             }
@@ -1375,25 +1313,18 @@ k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ c
                 uint32_t other[LC];
                 vs_load_list(lists + (uint64_t)((uint32_t)cur - 1u) * LC, n, other);
                 if (vs_same_list(mine, other, n)) {
-                    atomicAdd(&lmult[h], m);
-                    out[side] = 0u;
-                    own[side] = (uint32_t)cur - 1u;
-                    s_gown[2u * tid + side] = own[side];
-                    placed = true;
+                    atomicAdd(&lmult[h], 1u);
+                    m = 0u;
+                    own = (uint32_t)cur - 1u;
                     break;
                 }
             }
             h = (h + 1u) & ((1u << ltab_bits) - 1u);
         }
-        // (not placed -- a crowded table: the round's owner stays one, with the multiplicity its round gave it)
+        // (no place within LTAB_PROBES slots -- a crowded table: m = 1, the end stands for itself)
     }
-    __syncthreads();
-    if (slot_of[0] == 0xFFFFFFFEu) own[0] = s_gown[round_owner[0]];
-    if (slot_of[1] == 0xFFFFFFFEu) own[1] = s_gown[round_owner[1]];
-    if (p < n_slots_pairs) {
-        *(uint2 *)(mult + 2u * p) = make_uint2(out[0], out[1]);
-        *(uint2 *)(gown + 2u * p) = make_uint2(own[0], own[1]);
-    }
+    mult[e] = m;
+    gown[e] = own;
 }
 
 // every claimed slot of the block's list table: its owner gets the slot's multiplicity
@@ -2129,7 +2060,7 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
     hipStream_t st = ctx->stream;
     const VsTuning &tn = ctx->tune;
     const uint32_t N = ctx->idx.n_nodes;
-    const uint64_t sub_max = tn.rows_sub ? (uint64_t)tn.rows_sub / ACC_TPB * ACC_TPB : (uint64_t)ROWS_SUB;  // (whole rounds of k_list_owners)
+    const uint64_t sub_max = tn.rows_sub ? (uint64_t)tn.rows_sub : (uint64_t)ROWS_SUB;
     const uint64_t sub_pairs = slots_pairs < sub_max ? slots_pairs : sub_max;  // pairs per transposition
     if (ctx->rows_cap < (uint64_t)N + 2u) {
         if (ctx->d_rows) VS_HIP(ctx, hipFree(ctx->d_rows));
@@ -2188,8 +2119,7 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
         VS_HIP(ctx, hipMemsetAsync(rows, 0, sizeof(uint32_t) * 6u * cap, st));
         VS_HIP(ctx, hipMemsetAsync(n_owners, 0, sizeof(uint32_t), st));
         if (use_ltab) VS_HIP(ctx, hipMemsetAsync(ctx->d_ltab, 0, (sizeof(uint64_t) + sizeof(uint32_t)) * ltab_slots, st));
-        hipLaunchKernelGGL(k_list_owners, dim3((unsigned)((np + ACC_TPB - 1u) / ACC_TPB)), dim3(ACC_TPB), (2u * OWN_SLOTS + 2u * ACC_TPB) * sizeof(uint32_t), st, sl, sc, np,
-                           mult, gown, ltab, lmult, ltab_bits);
+        hipLaunchKernelGGL(k_list_owners, dim3((unsigned)((2u * np + 255u) / 256u)), dim3(256), 0, st, sl, sc, 2u * np, mult, gown, ltab, lmult, ltab_bits);
         if (use_ltab)
             hipLaunchKernelGGL(k_owners_mult, dim3((unsigned)((ltab_slots + 255u) / 256u)), dim3(256), 0, st, (const unsigned long long *)ltab,
                                (const uint32_t *)lmult, ltab_slots, mult);
