@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VS_ABI_VERSION 6
+#define VS_ABI_VERSION 7
 
 enum {
     VS_OK = 0,
@@ -207,7 +207,8 @@ int vs_pe_map_ends(vs_ctx *ctx, const vs_reads *reads, uint32_t cap, uint32_t *l
 /* Timing of the most recent vs_pe_count on this ctx, measured with HIP events on the ctx
  * stream: ms[0] = mapping kernel (k_pe_tiles), ms[1] = overflow (slow-path) kernel, ms[2] =
  * pairs sent to the slow path, ms[3] = locus ordering of the pairs in front of the mapping
- * kernel (k_pe_locus + scan + k_pe_permute), ms[4] = counter kernel (k_pe_accumulate).
+ * kernel (k_pe_locus + scan + k_pe_permute), ms[4] = counter kernels (k_pe_accumulate, or the row
+ * owners k_list_owners .. k_rows_sum on graphs beyond 46 340 nodes).
  * Synchronises the stream. */
 int vs_pe_last_timing(vs_ctx *ctx, double ms[5]);
 /* Name of the mapping-kernel instantiation the most recent vs_pe_count launched, as a profiler

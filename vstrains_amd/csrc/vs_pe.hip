@@ -1225,19 +1225,20 @@ __global__ void __launch_bounds__(64) k_zero_tiles(uint32_t *__restrict__ node_m
 // and the same cell comes back from loci hundreds of rounds apart: 4.4e9 increments left the pair-major kernel as 7.9e8
 // memory-side atomics for 2.9e7 distinct cells (configs[4]; tools/cell_probe.py).  Turned round -- output-major -- the
 // sums fit: ONE matrix row has a few hundred distinct cells however many pairs add to it.  So the lists are transposed
-// (row x -> the items whose list holds x: a counting sort of one word per accepted node), a workgroup owns a strip of
-// rows at a time, adds the partner lists of the strip's items into its LDS cell table, and writes every cell ONCE.
+// (row x -> the items whose list holds x: a counting sort of one word per listed node), a workgroup owns a strip of rows
+// at a time, adds the partner lists of the strip's items into its LDS cell table, and writes every cell ONCE.
 // PE_Inference.py:174-188 is the loop nest being reordered; integer sums do not care.
 //   node_mat  (mode 0): item = pair, row x in its LEFT list, partners = its RIGHT list             (:185-188)
-//   short_mat (mode 1): item = read end, row x in its list, partners = the nodes y >= x of the SAME list; an end whose
-//                       list equals that of an earlier end of its round is not an item of its own -- the first one
-//                       carries the multiplicity (k_list_owners), and adds it instead of 1           (:174-184)
-//   k_list_owners  per round of 1 024 pairs: which ends own their list, and how many ends share it
-//   k_rows_count   histogram of the items' lists per chunk (LDS, 16-bit counts), added to row_count
-//   (scan)         row_ptr = exclusive sums
-//   k_rows_fill    the same histogram again; a chunk reserves its stretch of every row it holds with one global atomic,
-//                  then places its items through LDS cursors
-//   k_rows_sum     strips of rows off a queue; a lane per (item of the row, quad of its partner list)
+//   short_mat (mode 1): item = a DISTINCT end list of the block, row x in it, partners = its nodes y >= x, added as often
+//                       as the block holds that list (7 % of the ends at configs[4] bring a list of their own)   (:174-184)
+//   k_list_owners   every end against the block's list table: who stands for a list, who repeats one (gown, mult)
+//   k_owners_mult   the multiplicities from the table to the owning ends; k_owners_collect: the owning ends, in end order
+//   k_rows_count    histogram of the items' lists per chunk (LDS, 16-bit counts), added to row_count
+//   (scan)          row_ptr = exclusive sums
+//   k_rows_fill     the same histogram again; a chunk reserves its stretch of every row it holds with one global atomic,
+//                   then places its items through LDS cursors.  An entry names the ROW OF THE LIST to add -- the owner of
+//                   an equal list, so that a matrix row reads a few hundred cached rows, not one per pair -- and its length
+//   k_rows_sum      strips of rows off a queue; a lane per (entry of the row, quad of the list it names)
 #define ROWS_CHUNK 16384u  // pairs per chunk: a node is in a list at most once, so a 16-bit count (<= 32 768 ends) cannot wrap
 #define ROWS_CHUNK1 8192u  // owning ends per chunk (mode 1: few items, spread over more workgroups)
 #define ROWS_TPB 1024u
