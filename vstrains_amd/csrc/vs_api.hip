@@ -37,6 +37,7 @@ void vs_tuning_load(VsTuning &t, int level) {
     if (const char *v = getenv("VS_LTAB_BITS")) t.ltab_bits = atoi(v) >= 0 && atoi(v) <= 31 ? atoi(v) : -1;
     if (const char *v = getenv("VS_ROWS_KEYS")) t.rows_keys = atoi(v) >= 2 && atoi(v) <= 65536 ? (uint32_t)atoi(v) : 0u;
     if (const char *v = getenv("VS_ROWS_SUB")) t.rows_sub = atoi(v) >= 1024 ? (uint32_t)atoi(v) : 0u;
+    if (const char *v = getenv("VS_ROWS_PER_STRIP1")) t.rows_per_strip1 = atoi(v) > 0 && atoi(v) <= 64 ? (uint32_t)atoi(v) : 0u;
     if (const char *v = getenv("VS_ROWS_PER_STRIP")) t.rows_per_strip = atoi(v) > 0 && atoi(v) <= 64 ? (uint32_t)atoi(v) : 0u;
     t.no_sort = env_on("VS_NO_SORT");
     t.locus_global = env_on("VS_LOCUS_GLOBAL");

@@ -113,6 +113,7 @@ struct VsTuning {
     int acc_rows = -1;              // VS_ACC_ROWS (-1 = by graph size): counters summed by row owners (k_rows_sum) instead of pair-major (k_pe_accumulate)
     int ltab_bits = -1;             // VS_LTAB_BITS: log2 slots of the block's list table (-1 = by block size, 0 = no table: every end stands for itself)
     uint32_t rows_keys = 0, rows_sub = 0;  // VS_ROWS_KEYS / VS_ROWS_SUB: rows per histogram pass, pairs per transposition (0 = the constants; tests shrink them)
+    uint32_t rows_per_strip1 = 0;   // VS_ROWS_PER_STRIP1: the same for short_mat alone
     uint32_t rows_per_strip = 0;    // VS_ROWS_PER_STRIP (0 = automatic): matrix rows one workgroup of k_rows_sum owns at a time
     bool no_sort = false, locus_global = false, no_xcd_map = false, no_fast = false, no_std = false, no_agg = false;
     bool acc_queue = true;

@@ -910,27 +910,30 @@ k_pe_tiles(PeParams P) {
 // order, a lane per slot, so the lanes of a wavefront that hold cells of one stretch issue their atomics side by side
 // -- and integer atomics, like the float ones of MI355X_MICROARCH.md, leave the L2 as one memory-side request per
 // 64-byte stretch a wave instruction touches.
-struct Acc32 {
+template <uint32_t BITS>
+struct CellTable {  // 1 << BITS slots
     static constexpr uint32_t EMPTY = 0xFFFFFFFFu;
     __device__ static uint32_t key(uint32_t mat, uint32_t x, uint32_t y, uint32_t N) { return (mat * N + x) * N + y; }
-    __device__ static uint32_t slot(uint32_t k) { return ((((k >> 4) * 0x9E3779B1u) >> (36u - ACC_BITS)) << 4) | (k & 15u); }
-    __device__ static uint32_t next(uint32_t at) { return (at + 16u) & (ACC_SLOTS - 1u); }
+    __device__ static uint32_t slot(uint32_t k) { return ((((k >> 4) * 0x9E3779B1u) >> (36u - BITS)) << 4) | (k & 15u); }
+    __device__ static uint32_t next(uint32_t at) { return (at + 16u) & ((1u << BITS) - 1u); }
 };
+typedef CellTable<ACC_BITS> Acc32;  // k_pe_accumulate's
 
 // The slot a key hashes to is empty or holds another cell: claim / probe on.  Kept out of line of the common case (the
 // cell is already in the table), which stays a short straight-line sequence.  false: no place within eight probes.
+template <typename TB>
 __device__ __forceinline__ bool vs_cell_claim(uint32_t *s_key, uint32_t *s_cnt, uint32_t *s_used, uint32_t key, uint32_t at, uint32_t wgt) {
     for (uint32_t pr = 0; pr < 8u; pr++) {
         uint32_t kx = s_key[at];
-        if (kx == Acc32::EMPTY) {
-            kx = atomicCAS(&s_key[at], Acc32::EMPTY, key);
-            if (kx == Acc32::EMPTY) { atomicAdd(s_used, 1u); kx = key; }
+        if (kx == TB::EMPTY) {
+            kx = atomicCAS(&s_key[at], TB::EMPTY, key);
+            if (kx == TB::EMPTY) { atomicAdd(s_used, 1u); kx = key; }
         }
         if (kx == key) {
             atomicAdd(&s_cnt[at], wgt);
             return true;
         }
-        at = Acc32::next(at);
+        at = TB::next(at);
     }
     return false;
 }
@@ -1085,7 +1088,7 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
                     if (bi + j >= be) continue;  // (j = 0 always counts)
                     if (seen[j] == key[j]) {
                         atomicAdd(&s_cnt[at[j]], 1u);
-                    } else if (!vs_cell_claim(s_key, s_cnt, &s_used, key[j], at[j], 1u)) {
+                    } else if (!vs_cell_claim<Acc32>(s_key, s_cnt, &s_used, key[j], at[j], 1u)) {
                         atomicAdd(&s_lost, 1u);
                         atomicAdd(key[j] >= NN ? short_mat + (key[j] - NN) : node_mat + key[j], 1u);
                     }
@@ -1496,19 +1499,29 @@ k_rows_fill(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ cou
     }
 }
 
-#define RSUM_LDS_BYTES ((2u * ACC_SLOTS + 64u + 8u) * 4u)
+// The strips' cell table is smaller than the pair-major kernel's (8 k slots, 64 KB) and the strips narrower for it: two
+// workgroups share a CU, and one waits in its LDS queue while the other computes (configs[4]: 14.1 -> 11.2 ms)
+#ifndef RS_BITS
+#define RS_BITS 13
+#endif
+#ifndef RS_TPB
+#define RS_TPB 1024
+#endif
+#define RS_SLOTS (1u << RS_BITS)
+typedef CellTable<RS_BITS> RsTable;
+#define RSUM_LDS_BYTES ((2u * RS_SLOTS + 64u + 8u) * 4u)
 #define RSUM_MAX_ROWS 64u
 template <int MODE>
-__global__ void __launch_bounds__(ACC_TPB)
+__global__ void __launch_bounds__(RS_TPB)
 k_rows_sum(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ mult, uint32_t N,
            const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ entries, uint32_t R, uint32_t n_strips, uint32_t fill_limit,
            uint32_t *__restrict__ mat, uint32_t off, uint8_t *__restrict__ tile_map, uint32_t T, uint32_t *__restrict__ queue,
            uint32_t *__restrict__ dbg) {
-    uint32_t *s_key = vs_lds, *s_cnt = vs_lds + ACC_SLOTS, *s_rowend = vs_lds + 2u * ACC_SLOTS;  // [RSUM_MAX_ROWS]
+    uint32_t *s_key = vs_lds, *s_cnt = vs_lds + RS_SLOTS, *s_rowend = vs_lds + 2u * RS_SLOTS;  // [RSUM_MAX_ROWS]
     uint32_t &s_used = s_rowend[64], &s_lost = s_rowend[65], &s_strip = s_rowend[66];
     const uint32_t tid = threadIdx.x, q = tid & 3u;
-    constexpr uint32_t STEP = ACC_TPB / 4u;  // entries per pass of the workgroup
-    for (uint32_t i = tid; i < ACC_SLOTS; i += ACC_TPB) { s_key[i] = Acc32::EMPTY; s_cnt[i] = 0u; }
+    constexpr uint32_t STEP = RS_TPB / 4u;  // entries per pass of the workgroup
+    for (uint32_t i = tid; i < RS_SLOTS; i += RS_TPB) { s_key[i] = RsTable::EMPTY; s_cnt[i] = 0u; }
     if (tid == 0) { s_used = 0u; s_lost = 0u; }
     for (;;) {
         __syncthreads();
@@ -1524,16 +1537,16 @@ k_rows_sum(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ coun
         const uint64_t cell0 = (uint64_t)first * N;
         __syncthreads();
         auto write_out = [&]() {
-            for (uint32_t i = tid; i < ACC_SLOTS; i += ACC_TPB) {
+            for (uint32_t i = tid; i < RS_SLOTS; i += RS_TPB) {
                 const uint32_t key = s_key[i];
-                if (key != Acc32::EMPTY) {
+                if (key != RsTable::EMPTY) {
                     const uint32_t k2 = key - align;
                     atomicAdd(mat + cell0 + k2, s_cnt[i]);
                     if (tile_map) {
                         const uint32_t xl = k2 / N;
                         vs_mark_tile(tile_map, T, (uint32_t)MODE, first + xl, k2 - xl * N);
                     }
-                    s_key[i] = Acc32::EMPTY;
+                    s_key[i] = RsTable::EMPTY;
                     s_cnt[i] = 0u;
                 }
             }
@@ -1585,7 +1598,7 @@ k_rows_sum(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ coun
 #pragma unroll
                 for (uint32_t j = 0; j < 4u; j++) {
                     key[j] = kbase + ys[j];
-                    at[j] = Acc32::slot(key[j]);
+                    at[j] = RsTable::slot(key[j]);
                     seen[j] = s_key[at[j]];
                 }
 #pragma unroll
@@ -1593,14 +1606,14 @@ k_rows_sum(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ coun
                     if (4u * q + j >= n || (MODE && ys[j] < x)) continue;  // (short_mat: the cell (x, y) belongs to the smaller node's row)
                     if (seen[j] == key[j]) {
                         atomicAdd(&s_cnt[at[j]], wgt);
-                    } else if (!vs_cell_claim(s_key, s_cnt, &s_used, key[j], at[j], wgt)) {
+                    } else if (!vs_cell_claim<RsTable>(s_key, s_cnt, &s_used, key[j], at[j], wgt)) {
                         atomicAdd(&s_lost, 1u);
                         vs_mark_tile(tile_map, T, (uint32_t)MODE, x, ys[j]);
                         atomicAdd(mat + cell0 + (key[j] - align), wgt);
                     }
                 }
             }
-            if ((pass & 3u) == 3u) {  // (four passes bring at most 4 096 new cells: the limit leaves that much room)
+            if ((pass & 3u) == 3u) {  // (a strip that outruns the limit between two looks finds the table crowded and adds the rest to memory itself: slower, the same sums)
                 __syncthreads();
                 const bool spill = s_used > fill_limit || s_lost > 4096u;
                 __syncthreads();
@@ -2101,12 +2114,12 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
         VS_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RSUM_LDS_BYTES));
     // the table is written out once this share of its slots is taken (a strip that holds more cells than that is written
     // in pieces: still one atomic per cell and piece); VS_ACC_FILL: percent
-    uint32_t fill = ACC_SLOTS / 2u + ACC_SLOTS / 8u;
-    if (tn.acc_fill_pct >= 0) fill = (uint32_t)((uint64_t)ACC_SLOTS * (uint32_t)tn.acc_fill_pct / 100u);
-    if (fill > ACC_SLOTS - 4096u) fill = ACC_SLOTS - 4096u;
+    uint32_t fill = RS_SLOTS / 2u;
+    if (tn.acc_fill_pct >= 0) fill = (uint32_t)((uint64_t)RS_SLOTS * (uint32_t)tn.acc_fill_pct / 100u);
+    if (fill > RS_SLOTS - 1024u) fill = RS_SLOTS - 1024u;
     // rows per strip: a strip's distinct cells should fill the table less than half.  configs[4]: 4 rows of node_mat hold
     // 1.7 k cells at the median and 6 k at most, 32 rows of short_mat 2.1 k and 6.6 k.  VS_ROWS_PER_STRIP overrides both.
-    const uint32_t R[2] = {tn.rows_per_strip ? tn.rows_per_strip : 4u, tn.rows_per_strip ? tn.rows_per_strip : 32u};
+    const uint32_t R[2] = {tn.rows_per_strip ? tn.rows_per_strip : 2u, tn.rows_per_strip1 ? tn.rows_per_strip1 : tn.rows_per_strip ? tn.rows_per_strip : 2u};
     uint32_t *dbg = tn.debug_acc ? (uint32_t *)ctx->d_slow_count + 10 : nullptr;
     uint32_t *queue = (uint32_t *)ctx->d_slow_count + 9, *n_owners = (uint32_t *)ctx->d_slow_count + 15;
     unsigned long long *ltab = use_ltab ? (unsigned long long *)ctx->d_ltab : nullptr;
@@ -2149,16 +2162,16 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
             const uint32_t *row_ptr = rows + 3u * mode * cap + 2u * cap;
             const uint32_t *entries = (const uint32_t *)ctx->d_row_entries + (mode ? np * LC : 0u);
             const uint32_t n_strips = (N + R[mode] - 1u) / R[mode];
-            uint32_t grid = (uint32_t)ctx->n_cu * 2u;
+            uint32_t grid = (uint32_t)ctx->n_cu * (RSUM_LDS_BYTES <= 40000u ? 4u : 2u) * (1024u / RS_TPB);
             if (grid > n_strips) grid = n_strips;
             uint32_t *m = mode ? d_short_mat : d_node_mat;
             const uint32_t off = (uint32_t)(((uintptr_t)m >> 2) & 15u);
             VS_HIP(ctx, hipMemsetAsync(queue, 0, sizeof(uint32_t), st));
             if (mode)
-                hipLaunchKernelGGL(k_rows_sum<1>, dim3(grid), dim3(ACC_TPB), RSUM_LDS_BYTES, st, sl, sc, (const uint32_t *)mult, N, row_ptr, entries, R[1], n_strips, fill, m,
+                hipLaunchKernelGGL(k_rows_sum<1>, dim3(grid), dim3(RS_TPB), RSUM_LDS_BYTES, st, sl, sc, (const uint32_t *)mult, N, row_ptr, entries, R[1], n_strips, fill, m,
                                    off, d_tile_map, T, queue, dbg);
             else
-                hipLaunchKernelGGL(k_rows_sum<0>, dim3(grid), dim3(ACC_TPB), RSUM_LDS_BYTES, st, sl, sc, (const uint32_t *)mult, N, row_ptr, entries, R[0], n_strips, fill, m,
+                hipLaunchKernelGGL(k_rows_sum<0>, dim3(grid), dim3(RS_TPB), RSUM_LDS_BYTES, st, sl, sc, (const uint32_t *)mult, N, row_ptr, entries, R[0], n_strips, fill, m,
                                    off, d_tile_map, T, queue, dbg);
         }
     }
