@@ -2,8 +2,8 @@
 the C oracle; configs[0..2]: the HIP path against digests of the pe_info / st_info files the REAL reference script
 wrote for the bench stream (tests/golden/reference_digests.json, made by tools/time_reference.py);
 configs[3] and configs[4] at their real graph sizes (the generators bench.py
---config uses): the code paths only these sizes take -- 64-bit cell keys in the counter kernel and
-the global-atomic locus sort above 46 k / 36 k nodes, 2 x 10 GB counters, the generic-loop mapping
+--config uses): the code paths only these sizes take -- the counters by row owners (k_list_owners .. k_rows_sum) beyond
+46 340 nodes, the multi-pass locus sort above 36 k nodes, 2 x 12 GB counters with dirty-tile tracking, the generic-loop mapping
 kernel for k = 127 / 2 x 250 -- against the C oracle on a prefix of the read stream, plus the
 size-independent partition property on the whole block.  Integer work: bit-exact."""
 import numpy as np
@@ -66,7 +66,7 @@ def _assert_equals_oracle(counter, orc, st, cum, seed, L, M, sub, nth):
     assert int(node_counts.sum()) > M  # the sample says something
 
 
-def test_config4_50k_nodes_wide_cell_keys_and_global_sort(host, ctx, tmp_path):
+def test_config4_50k_nodes_row_owner_counters(host, ctx, tmp_path):
     import torch
 
     from vstrains_amd.workloads import CONFIGS, workload_for
@@ -74,7 +74,7 @@ def test_config4_50k_nodes_wide_cell_keys_and_global_sort(host, ctx, tmp_path):
     cfg = CONFIGS[4]
     st, pre, names, seqs, cum, logger, n_in = workload_for(4, str(tmp_path))
     n = len(seqs)
-    assert n >= 50000, n  # > 46340: 2*N*N no longer fits the 32-bit cell keys; > 36862: no LDS histogram for the sort
+    assert n >= 50000, n  # > 46340: 2*N*N no longer fits the pair-major kernel's cell keys -> row owners; > 36862: several passes of the locus sort
     ctx.build_index(seqs, cfg["k"])
     L, seed = cfg["read_len"], 4242
     sub, nth = int(0.005 * 2 ** 32), int(0.001 * 2 ** 32)
@@ -107,10 +107,12 @@ def test_config4_50k_nodes_wide_cell_keys_and_global_sort(host, ctx, tmp_path):
     assert t["slow_pairs"] >= 0
 
 
-def test_row_owner_counting_equals_the_cell_table_path_at_config4_size(host, xctx, tmp_path, monkeypatch):
-    """node_mat by row owners (k_rows_count / k_rows_fill / k_node_rows + the short_mat-only pass; the default beyond 46 340
-    nodes) against the path it replaces there (both matrices through the split cell table, VS_ACC_ROWS=0) on 2 M pairs of
-    configs[4]'s graph, with strips of 8 (default), 1 and 64 rows and a table that spills constantly."""
+def test_row_owner_counting_equals_plain_atomics_at_config4_size(host, xctx, tmp_path, monkeypatch):
+    """Both counters by row owners (k_list_owners .. k_rows_sum; the default beyond 46 340 nodes) against one global atomic per
+    increment (VS_ACC_ROWS=0: at this size no table shape of the pair-major kernel exists) on 2 M pairs of configs[4]'s
+    graph: default strips, strips of 1 and 64 rows with a cell table that spills constantly, input order, no list table, a
+    crowded list table, several transpositions with several histogram passes each.  Every non-zero cell lies in a marked
+    tile."""
     import torch
 
     from vstrains_amd.workloads import CONFIGS, workload_for
