@@ -242,6 +242,37 @@ def test_tracked_counting_marks_every_touched_tile_and_zeroes_only_those(host, c
     assert second[2] == tuple(int(x) for x in want[2])
 
 
+@pytest.mark.parametrize("case", ["dense_k11", "chain_k20"])
+def test_row_owners_next_to_the_overflow_kernels(host, xctx, case, monkeypatch):
+    """Row owners (VS_ACC_ROWS=1) on blocks where a third of the ends are accepted by more than 16 nodes: those pairs have
+    empty list rows and are counted by k_pe_mid / k_pe_slow, the rest by the row owners, into the same counters.  Against the
+    C oracle."""
+    from vstrains_amd import synth
+
+    ctx = xctx
+    if case == "dense_k11":
+        g, f, r = _dense_case(11, 1500, 100, seed=301, snp=0.2)
+        seqs, k = g.seqs, 11
+    else:
+        rng = np.random.default_rng(17)
+        k = 20
+        genome = "".join("ACGT"[i] for i in rng.integers(0, 4, size=700))
+        seqs = [genome[i: i + k + 1] for i in range(len(genome) - k)]
+        f, r = [], []
+        for i in range(900):
+            L = (120, 50, 62, 37, 30)[i % 5]  # 100 nodes (beyond k_pe_mid), 30, 42, 17 and 10 (a list row holds 16)
+            a = int(rng.integers(0, len(genome) - 300))
+            f.append(genome[a: a + L])
+            r.append(synth.revcomp(genome[a + 150: a + 150 + (L if i % 3 else 25)]))
+    monkeypatch.setenv("VS_ACC_ROWS", "1")
+    want = pe_oracle_c.Oracle(seqs, k).count_pairs(f, r)
+    (node_mat, short_mat, stats), block = _gpu_matrices(host, ctx, seqs, f, r, k)
+    assert ctx.last_launched & ctx.RAN_ROW_OWNERS and ctx.last_launched & ctx.RAN_PE_MID
+    assert ctx.last_timing()["slow_pairs"] > 100
+    assert np.array_equal(node_mat, want[0]) and np.array_equal(short_mat, want[1])
+    assert stats == tuple(int(x) for x in want[2])
+
+
 def test_ends_with_a_hundred_nodes_pass_through_both_overflow_kernels(host, ctx):
     """A chain of nodes that advance ONE base each (every node k + 1 bases long): a 120-base read is accepted by 100 nodes
     -- beyond a list row (16) and beyond k_pe_mid's per-end list (64), so the pairs end in the general kernel; shorter reads
