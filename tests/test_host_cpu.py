@@ -410,12 +410,29 @@ def test_native_fastq_ingest_odd_inputs(tmp_path):
         bad.write_bytes(raw)
         with pytest.raises(UnicodeDecodeError):
             raw.decode("utf-8")
-        fq = host.FastqPair(str(bad), str(bad))
+        with pytest.raises(ValueError):  # at open, as the reference fails in readlines() before it counts anything
+            host.FastqPair(str(bad), str(bad))
+    # ... and anywhere in the file, not only in sequence lines: a header, a quality line, the line past the last whole record;
+    # a character cut in two by the worker threads' ranges (a long file of two-byte characters) is not an error
+    good = tmp_path / "many_utf8.fq"
+    good.write_bytes(("@h\u00e9\nACGT\n+\n\u00e9\u00e9\u00e9\u00e9\n" * 5000).encode("utf-8"))
+    fq = host.FastqPair(str(good), str(good))
+    assert len(fq) == 5000 and fq.sequence(1, 4999) == "ACGT"
+    fq.close()
+    import ctypes as C
+
+    from vstrains_amd import _native as nat
+
+    for raw in (b"@a\xff\nACGT\n+\nIIII\n", b"@a\nACGT\n+\nII\xc3I\n", b"@a\nACGT\n+\nIIII\n@b\xa9\n", b"@a\nACGT\n+\nIIII\n" * 3000 + b"\xed\xa0\x80"):
+        bad = tmp_path / "bad2.fq"
+        bad.write_bytes(raw)
         with pytest.raises(ValueError):
-            fq.sequence(0, 0)
-        with pytest.raises(ValueError):
-            fq.gather(0, 1)
-        fq.close()
+            host.FastqPair(str(bad), str(good))
+        out = (C.c_uint64 * 3)()
+        assert nat.lib().vs_fastq_count_part(str(bad).encode(), 0, 1, out) == nat.VS_E_UTF8  # (the sharded open: every rank its byte range)
+        assert any(nat.lib().vs_fastq_count_part(str(bad).encode(), r, 3, out) == nat.VS_E_UTF8 for r in range(3))
+    out = (C.c_uint64 * 3)()
+    assert all(nat.lib().vs_fastq_count_part(str(good).encode(), r, 7, out) == nat.VS_OK for r in range(7))
     with pytest.raises(FileNotFoundError):
         host.FastqPair(str(tmp_path / "nope.fq"), str(bad))
 

@@ -762,17 +762,15 @@ def test_rccl_allreduce_through_the_c_abi_one_rank(host, ctx):
     nat.check(ctx._h, L.vs_comm_destroy(ctx._h, comm))
 
 
-def test_fastq_block_refuses_invalid_utf8_and_takes_dirty_reads(host, ctx, tmp_path):
-    """vs_fastq_block packs on the host cores: sequence bytes that are not valid UTF-8 are refused there
-    (ValueError, as the reference's text-mode read raises UnicodeDecodeError; VALID multi-byte characters are
-    read as the reference reads them -- golden case utf8_reads_k21), a block with lower-case / IUPAC bytes
+def test_fastq_open_refuses_invalid_utf8_and_blocks_take_dirty_reads(host, ctx, tmp_path):
+    """Bytes that are not valid UTF-8 are refused when the files are opened (ValueError, as the reference's text-mode
+    read raises UnicodeDecodeError before it counts anything; VALID multi-byte characters are read as the reference reads
+    them -- golden case utf8_reads_k21); vs_fastq_block packs on the host cores, a block with lower-case / IUPAC bytes
     falls back to the device packer (mask + position lists) and counts like the oracle."""
     bad = tmp_path / "bad.fq"
     bad.write_bytes("@r\u00e9ad\nACGTACGTAC\n+\nIIIIIIIIII\n@b\nAC".encode("utf-8") + b"\xc3TACGTAC\n+\nIIIIIIIIII\n")
-    fq = host.FastqPair(str(bad), str(bad), ctx)
     with pytest.raises(ValueError):
-        fq.block(0, len(fq))
-    fq.close()
+        host.FastqPair(str(bad), str(bad), ctx)
     g, f, r = _dense_case(21, 700, 90, seed=99, snp=0.03)
     rng = np.random.default_rng(1)
     for lst in (f, r):

@@ -237,6 +237,58 @@ int map_file(std::string &err, const char *path, FqFile &f) {
     return VS_OK;
 }
 
+// Python's text mode decodes the WHOLE file (PE_Inference.py:147-152: open(...).readlines()): a byte that is not valid
+// UTF-8 anywhere -- header, sequence or quality line -- raises UnicodeDecodeError before anything is counted.  Here: the
+// characters that START in [lo, hi) of txt[0, size) are checked (a caller cuts a file into ranges: a character that
+// straddles a cut belongs to the range it starts in; leading continuation bytes belong to the range before).  Words
+// without a high bit are skipped eight bytes at a time.
+inline uint32_t utf8_len_strict(const uint8_t *q, size_t n) {  // bytes of the character at q[0], 0 if invalid (no overlong forms, no surrogates, nothing above U+10FFFF)
+    const uint8_t c = q[0];
+    if (c < 0x80u) return 1u;
+    auto cont = [&](size_t i) { return i < n && (q[i] & 0xC0u) == 0x80u; };
+    if (c >= 0xC2u && c <= 0xDFu) return cont(1) ? 2u : 0u;
+    if (c >= 0xE0u && c <= 0xEFu) {
+        if (!cont(1) || !cont(2)) return 0u;
+        if (c == 0xE0u && q[1] < 0xA0u) return 0u;
+        if (c == 0xEDu && q[1] >= 0xA0u) return 0u;
+        return 3u;
+    }
+    if (c >= 0xF0u && c <= 0xF4u) {
+        if (!cont(1) || !cont(2) || !cont(3)) return 0u;
+        if (c == 0xF0u && q[1] < 0x90u) return 0u;
+        if (c == 0xF4u && q[1] >= 0x90u) return 0u;
+        return 4u;
+    }
+    return 0u;
+}
+bool utf8_range_ok(const uint8_t *txt, size_t size, size_t lo, size_t hi) {
+    size_t i = lo;
+    if (lo > 0 && lo < hi && (txt[lo] & 0xC0u) == 0x80u) {
+        // a continuation byte at the cut: the tail of a character that starts in the range before (which checks it), or a
+        // stray one.  Its lead byte lies at most three bytes back and says how far the character reaches.
+        size_t j = lo;
+        while (j > 0 && lo - j < 3u && (txt[j - 1u] & 0xC0u) == 0x80u) j--;
+        if (j == 0) return false;
+        const uint8_t lead = txt[j - 1u];
+        const size_t len = lead >= 0xF0u ? 4u : lead >= 0xE0u ? 3u : lead >= 0xC0u ? 2u : 1u;
+        if (j - 1u + len <= lo) return false;  // (no character reaches over the cut: the byte stands alone)
+        i = j - 1u + len < hi ? j - 1u + len : hi;
+    }
+    while (i < hi) {
+        if (i + 8u <= hi) {
+            uint64_t w;
+            memcpy(&w, txt + i, 8);
+            if (!(w & 0x8080808080808080ull)) { i += 8u; continue; }
+        }
+        if (txt[i] < 0x80u) { i++; continue; }
+        const uint32_t n = utf8_len_strict(txt + i, size - i);
+        if (!n) return false;
+        i += n;
+    }
+    return true;
+}
+const char *const BAD_UTF8_FILE_MSG = "%s holds bytes that are not valid UTF-8 (the reference's text-mode read raises UnicodeDecodeError)";
+
 // Index the sequence lines of one file.
 int index_file(vs_ctx *ctx, const char *path, FqFile &f) {
     const unsigned T = n_threads();
@@ -288,6 +340,12 @@ int index_file(vs_ctx *ctx, const char *path, FqFile &f) {
     }
     const uint8_t *txt = f.text();
     const size_t n = f.text_size();
+    {
+        std::vector<int> bad(T, 0);
+        parallel_for(T, [&](unsigned p) { bad[p] = utf8_range_ok(txt, n, n * p / T, n * (p + 1) / T) ? 0 : 1; });
+        for (unsigned p = 0; p < T; p++)
+            if (bad[p]) return vs_fail(ctx, VS_E_UTF8, BAD_UTF8_FILE_MSG, path);
+    }
     for (unsigned p = 0; p < T; p++) nl[p + 1] += nl[p];
     const uint64_t n_newlines = nl[T];
     const bool open_tail = n > 0 && txt[n - 1] != '\n';
@@ -475,12 +533,13 @@ int vs_fastq_count_part(const char *path, uint32_t part, uint32_t n_parts, uint6
         const size_t hi = size / n_parts * (part + 1u) + std::min<size_t>(part + 1u, size % n_parts);
         const unsigned T = n_threads();
         std::vector<uint64_t> cnt(T, 0);
-        std::vector<int> cr(T, 0);
+        std::vector<int> cr(T, 0), bad(T, 0);
         parallel_for(T, [&](unsigned t) {
             const size_t a = lo + (hi - lo) * t / T, b = lo + (hi - lo) * (t + 1) / T;
             uint64_t n = 0;
             const uint8_t *q = txt + a, *end = txt + b;
             if (a < b && memchr(q, '\r', b - a)) cr[t] = 1;
+            if (a < b && !utf8_range_ok(txt, size, a, b)) bad[t] = 1;  // (every rank its own range: together the whole file)
             while (q < end) {
                 const uint8_t *r = (const uint8_t *)memchr(q, '\n', (size_t)(end - q));
                 if (!r) break;
@@ -491,6 +550,12 @@ int vs_fastq_count_part(const char *path, uint32_t part, uint32_t n_parts, uint6
         });
         for (unsigned t = 0; t < T; t++) { out[0] += cnt[t]; if (cr[t]) out[2] |= 1u; }
         if (hi == size && txt[size - 1] != '\n') out[2] |= 4u;
+        for (unsigned t = 0; t < T; t++)
+            if (bad[t]) {
+                munmap(p, size);
+                close(fd);
+                return vs_fail(nullptr, VS_E_UTF8, BAD_UTF8_FILE_MSG, path);
+            }
     }
     munmap(p, size);
     close(fd);

@@ -253,13 +253,29 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
             bits_final = 4;
             while ((1ull << bits_final) < want) bits_final++;
             if (bits_final > 30u) bits_final = 30u;
-            n_slots_final = 1ull << bits_final;
-            d.table_bits = bits_final;
+            // (the cap, or a table the device has no room for: fewer slots per seed -- longer probe chains, the same
+            // answers -- down to three quarters full; beyond that the build fails and says why)
+            const uint64_t distinct = h_flags[3];
             if (bits_final > bits) {
                 (void)hipFree(d_keys);
                 d_keys = nullptr;
-                TRY(hipMalloc((void **)&d_keys, sizeof(unsigned long long) * n_slots_final));
+                while (hipMalloc((void **)&d_keys, sizeof(unsigned long long) << bits_final) != hipSuccess) {
+                    (void)hipGetLastError();
+                    d_keys = nullptr;
+                    if (bits_final <= bits + 1u || (3ull << (bits_final - 1u)) / 4u < distinct) break;
+                    bits_final--;
+                }
+                if (!d_keys) {
+                    bits_final = bits;
+                    TRY(hipMalloc((void **)&d_keys, sizeof(unsigned long long) << bits_final));
+                }
             }
+            if ((3ull << bits_final) / 4u < distinct) {
+                rc = vs_fail(ctx, VS_E_RANGE, "vs_index_build: %llu distinct seeds do not fit a seed table of 2^%u slots", (unsigned long long)distinct, bits_final);
+                goto done;
+            }
+            n_slots_final = 1ull << bits_final;
+            d.table_bits = bits_final;
             TRY(hipMemsetAsync(d_keys, 0xFF, sizeof(unsigned long long) * n_slots_final, st));
         }
         TRY(hipMalloc((void **)&d_cnts, sizeof(uint32_t) * n_slots_final));

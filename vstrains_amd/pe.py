@@ -53,6 +53,8 @@ class FastqPair:
             msg = nat.lib().vs_last_error(ctx._h if ctx is not None else None).decode("utf-8", "replace")
             if "cannot open" in msg:
                 raise FileNotFoundError(msg)
+            if rc == nat.VS_E_UTF8:  # the reference's readlines() raises UnicodeDecodeError, a ValueError (PE_Inference.py:147-152)
+                raise ValueError(msg)
             raise nat.NativeError(rc, msg)
         self._h = h
         info = (C.c_uint64 * 3)()
@@ -80,7 +82,7 @@ class FastqPair:
             rc = L.vs_fastq_count_part(path.encode(), rank, world, out)
             if rc != nat.VS_OK and failure is None:
                 msg = L.vs_last_error(None).decode("utf-8", "replace")
-                failure = FileNotFoundError(msg) if "cannot open" in msg else nat.NativeError(rc, msg)
+                failure = FileNotFoundError(msg) if "cannot open" in msg else ValueError(msg) if rc == nat.VS_E_UTF8 else nat.NativeError(rc, msg)
             mine += [int(out[0]), int(out[1]), int(out[2])] if rc == nat.VS_OK else [0, 0, 0]
         mine.append(0 if failure is None else 1)
         if all_gather is None:
@@ -123,7 +125,8 @@ class FastqPair:
                                      counts[1].ctypes.data, first, last, C.byref(h))
         err = None
         if rc != nat.VS_OK:
-            err = nat.NativeError(rc, L.vs_last_error(ctx._h if ctx is not None else None).decode("utf-8", "replace"))
+            msg = L.vs_last_error(ctx._h if ctx is not None else None).decode("utf-8", "replace")
+            err = ValueError(msg) if rc == nat.VS_E_UTF8 else nat.NativeError(rc, msg)
         status = all_gather([0 if err is None else 1])
         if err is not None:
             raise err
