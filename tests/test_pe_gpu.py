@@ -69,6 +69,26 @@ def test_golden_files_bit_exact(host, ctx, name, d, meta):
 
 
 @pytest.mark.parametrize("name,d,meta", pe_cases(), ids=[c[0] for c in pe_cases()])
+def test_golden_files_bit_exact_by_row_owners(host, xctx, name, d, meta, monkeypatch):
+    """The same files of the real reference script with the counters summed by row owners (VS_ACC_ROWS=1: what graphs beyond
+    46 340 nodes take by themselves), one-row strips and a list table of eight slots."""
+    monkeypatch.setenv("VS_ACC_ROWS", "1")
+    monkeypatch.setenv("VS_ROWS_PER_STRIP", "1")
+    monkeypatch.setenv("VS_LTAB_BITS", "3")
+    ctx = xctx
+    ids, seqs = host.read_gfa_segments(os.path.join(d, "graph.gfa"))
+    fq = host.FastqPair(os.path.join(d, "fwd.fq"), os.path.join(d, "rve.fq"), ctx)
+    ctx.build_index(seqs, meta["k"])
+    counter = host.PeCounter(ctx)
+    counter.add(fq.block(0, len(fq)))
+    node_mat, short_mat, stats = counter.result()
+    if len(fq) and len(seqs):
+        assert ctx.last_launched & ctx.RAN_ROW_OWNERS
+    assert pe_oracle.matrix_text(ids, node_mat) == _read(os.path.join(d, "pe_info"))
+    assert pe_oracle.matrix_text(ids, short_mat) == _read(os.path.join(d, "st_info"))
+
+
+@pytest.mark.parametrize("name,d,meta", pe_cases(), ids=[c[0] for c in pe_cases()])
 def test_per_end_lists_match_oracle(host, ctx, name, d, meta):
     K = meta["k"] + 1
     ids, seqs = host.read_gfa_segments(os.path.join(d, "graph.gfa"))
