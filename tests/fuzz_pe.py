@@ -99,6 +99,12 @@ def main():
         if rng.random() < 0.3:
             env = dict([[("VS_NO_STD", "1")], [("VS_NO_FAST", "1")], [("VS_EPT", "6")], [("VS_ACC_ROWS", "1"), ("VS_ROWS_KEYS", "64")], [("VS_ACC_ROWS", "1"), ("VS_LTAB_BITS", "0")], [("VS_ACC_ROWS", "1"), ("VS_ROWS_SUB", "1024")], [("VS_ACC_ROWS", "1"), ("VS_ACC_FILL", "1")], [("VS_ACC_FILL", "100")],
                         [("VS_NO_SORT", "1")], [("VS_LOCUS_GLOBAL", "1")], [("VS_ACC_ROWS", "1")], [("VS_ACC_ROWS", "1"), ("VS_ROWS_PER_STRIP", "3"), ("VS_LTAB_BITS", "4")]][int(rng.integers(0, 12))])
+        if os.environ.get("FUZZ_ROWS") == "1":  # a campaign on the row-owner counters alone: every draw takes them, under varying switches
+            env = {"VS_ACC_ROWS": "1"}
+            for key, choices in (("VS_ROWS_PER_STRIP", ("1", "2", "5", "64")), ("VS_ROWS_KEYS", ("7", "64", "1000")), ("VS_ROWS_SUB", ("1024", "4096")),
+                                 ("VS_LTAB_BITS", ("0", "2", "6", "12")), ("VS_ACC_FILL", ("1", "30", "100")), ("VS_NO_SORT", ("1",))):
+                if rng.random() < 0.3:
+                    env[key] = str(choices[int(rng.integers(0, len(choices)))])
         if rng.random() < 0.15:
             env["VS_NO_MID"] = "1"  # overflow pairs straight to the general kernel
         os.environ.update(env)
