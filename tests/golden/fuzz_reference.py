@@ -5,7 +5,7 @@ Every draw is a seeded synthetic case in the parameter ranges of the committed f
 (make_graph_golden.CASES).  The reference (``/root/reference/vstrains`` behind
 ``tests/golden/gt_standin``, exactly as make_graph_golden.py runs it: both in-edge-order models,
 hash seeds 0-3) writes its outputs into a scratch golden directory; this build's pipeline then runs
-on the same inputs with the checker backend (as tests/test_graph_golden.py does) and every file
+on the same inputs with the native stage engine over the CPU checker (as tests/test_graph_golden.py does) and every file
 that the reference itself produces deterministically must be identical -- stage GFAs, contig
 files, pe_info / st_info, strain.paths, strain.fasta, the INFO log lines.  Nothing is committed
 from here except the tally.
@@ -41,7 +41,7 @@ def one(job):
 
     import graph_case
     import make_graph_golden as gold
-    from test_graph_golden import CheckerBackend
+    from test_graph_golden import CheckerBackend, NativeBackend
     from vstrains_amd.graph import pipeline
 
     name = "fuzz_%04d" % idx
@@ -75,7 +75,9 @@ def one(job):
         logger = graph_case.file_logger(out, "fuzz-%d" % idx)
         err = None
         try:
-            pipeline.run(args, logger, CheckerBackend(case, False))
+            # FUZZ_ENGINE=python: the Python statement of the stages (oracle/graph_stages); default: the native stage engine
+            # (vs_stage) over the CPU checker of its device operations -- the product's decisions against the real reference
+            pipeline.run(args, logger, CheckerBackend(case, False) if os.environ.get("FUZZ_ENGINE") == "python" else NativeBackend(case))
         except BaseException as e:  # noqa: B036 (KeyError / SystemExit where the reference exits non-zero too)
             err = "%s: %s" % (type(e).__name__, e)
         for h in list(logger.handlers):
