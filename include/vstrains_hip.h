@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VS_ABI_VERSION 7
+#define VS_ABI_VERSION 8
 
 enum {
     VS_OK = 0,
@@ -35,8 +35,11 @@ enum {
                             text-mode readlines() raises UnicodeDecodeError (PE_Inference.py:147-152) */
     VS_E_KEY = -8,       /* a graph stage looked up an id / index that is not there: the reference raises
                             KeyError / IndexError / ValueError at that point (vs_stage_error names which) */
-    VS_E_FPE = -9        /* an edge flow would divide by a zero neighbour sum: FloatingPointError under the
+    VS_E_FPE = -9,       /* an edge flow would divide by a zero neighbour sum: FloatingPointError under the
                             reference's numpy.seterr(all="raise") (vstrains:25, Utilities.py:20-30) */
+    VS_E_RECURSION = -10 /* (ABI 8) a chain of forked ids is longer than the reference's recursive merge_id
+                            (Utilities.py:318-327) can follow under CPython's recursion limit: the reference
+                            ends with RecursionError there (runaway trivial splits on circular graphs) */
 };
 
 typedef struct vs_ctx vs_ctx;     /* one per device */

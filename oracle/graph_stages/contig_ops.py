@@ -15,6 +15,9 @@ from vstrains_amd.graph.contigs import contig_steps, contigs_by_node  # noqa: F4
 from vstrains_amd.graph.formats import ContigDict, path_length
 
 
+PY_MERGE_ID_FRAMES = 993  # nested merge_id frames CPython 3.10 allows the reference's CLI (limit 1000, six frames above, len() on top)
+
+
 class _Closure(dict):
     """id -> ordered set of the ids it ended up as, for the ids of the graph before the pass
     (anything else is a KeyError, as with the plain dict); filled on first use."""
@@ -53,6 +56,28 @@ def remap_contigs(g: AsmGraph, nodes: NodeMap, edges: EdgeMap, contigs: ContigDi
     if not known <= id_mapping.keys():
         for name in prev_ids:
             id_mapping[name]  # the reference indexes it directly: unknown ids are an error
+    # The reference follows the forks with a recursive function, eagerly for every id of the graph before the pass
+    # (merge_id, Utilities.py:318-334), six frames deep under CPython's recursion limit of 1 000: a fork chain that
+    # needs a 994th nested frame ends it with RecursionError (runaway trivial splits on circular graphs).  Depth of an
+    # id: 1 if it was not forked, else 1 + the deepest of its forks -- worked out here without recursion.
+    if any(len(k) for k in id_mapping.values()):
+        depth: Dict[str, int] = {}
+        for root in prev_ids:
+            stack = [root]
+            while stack:
+                name = stack[-1]
+                if name in depth:
+                    stack.pop()
+                    continue
+                kids = id_mapping.get(name, ())
+                todo = [k for k in kids if k not in depth]
+                if todo:
+                    stack.extend(todo)
+                    continue
+                depth[name] = 1 + max((depth[k] for k in kids), default=0)
+                stack.pop()
+            if depth[root] > PY_MERGE_ID_FRAMES:
+                raise RecursionError("maximum recursion depth exceeded while calling a Python object")
     # (the closure of an id is worked out when somebody asks for it: a pass forks a handful of the
     # thousands of ids, and the callers index by id only)
     closure = _Closure(leaves, known)

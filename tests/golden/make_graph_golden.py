@@ -104,6 +104,19 @@ INVARIANT_CASES.update({
     "inv3_k55t_s201": (dict(n_strains=3, genome_len=2600, snp_rate=0.009, k=55, n_pairs=5000, read_len=150, abundance_ratio=0.55, seed=201), []),
 })
 CASES.update(INVARIANT_CASES)
+# round 5: circular genomes on which the reference's global_trivial_split (Decomposition.py:691-819) runs away -- a fork of
+# "X*B" leaves an "X*B*B" that forks again -- until its N^2 bound stops it ("Strange topology detected").  On the small ones
+# the reference carries on and finishes; on the k = 55 one (draw 236 of ``fuzz_reference.py 600 778``, unresolved in round
+# 4) the fork chain is longer than merge_id (Utilities.py:318-327) can recurse and the reference ends with RecursionError.
+RUNAWAY_CASES = {
+    "circular_runaway_k55": (dict(n_strains=3, genome_len=6245, snp_rate=0.02, k=55, n_pairs=8189, read_len=150, seed=878636,
+                                  abundance_ratio=0.45, scramble=True, circular=True), ["-ml", "100"]),
+    "circular_tiny_bound_k21_s480348": (dict(n_strains=2, genome_len=494, snp_rate=0.01, k=21, n_pairs=805, read_len=100, seed=480348,
+                                             abundance_ratio=0.6, circular=True, scramble=True), ["-ml", "100"]),
+    "circular_tiny_bound_k21_s810092": (dict(n_strains=3, genome_len=353, snp_rate=0.01, k=21, n_pairs=1442, read_len=100, seed=810092,
+                                             abundance_ratio=0.45, circular=True), ["-ml", "100"]),
+}
+CASES.update(RUNAWAY_CASES)
 
 
 PHRASES = {"link_split": "->perform split, all kept links", "coverage_match": "obtain best match via coverage similarity",

@@ -1,4 +1,4 @@
-"""String-level model of the device algorithm (seed at stride s, canonical w-mer table, exact
+"""String-level model of the device algorithm (seeds at stride s from the end's phase, canonical w-mer table, exact
 extension, first-seed-owns-the-match rule).  It exists to pin the *algorithm* of
 vstrains_amd/csrc/vs_pe.hip against the oracle on the CPU, where no GPU is available; the HIP
 kernels themselves are checked against the oracle in the -m gpu tests."""
@@ -32,15 +32,23 @@ def build(seqs: Sequence[str], K: int):
     return table, w, s
 
 
+def phase(rlen: int, w: int, s: int) -> int:
+    """First probe offset of an end (vs_seed_phase in csrc/vs_internal.h): any phase of the grid is exact; this one gives
+    the fewest probes, floor((rlen - w + 1) / s)."""
+    return ((rlen - w) % s + s) // 2 if rlen >= w else 0
+
+
 def valid(ch: str) -> bool:
     return ch in _C
 
 
-def map_end(read: str, seqs: Sequence[str], rcs: Sequence[str], table, w: int, s: int, K: int) -> List[int]:
+def map_end(read: str, seqs: Sequence[str], rcs: Sequence[str], table, w: int, s: int, K: int, first=None, probes=None) -> List[int]:
     rlen = len(read)
     agg: Dict[int, List[int]] = {}
-    j = 0
+    j = phase(rlen, w, s) if first is None else first
     while j + w <= rlen:
+        if probes is not None:
+            probes.append(j)
         f = read[j : j + w]
         if all(valid(c) for c in f):
             r = rc(f)

@@ -574,6 +574,7 @@ def test_device_read_generator_equals_cpu_twin(host, ctx):
     {"VS_NO_SORT": "1"}, {"VS_NO_AGG": "1"}, {"VS_LOCUS_GLOBAL": "1"}, {"VS_EPT": "32"}, {"VS_EPT": "128"},
     {"VS_EPT": "6", "VS_GRID_PER_CU": "1"}, {"VS_ACC_FILL": "1"}, {"VS_ACC_FILL": "100"}, {"VS_NO_FAST": "1"},
     {"VS_ACC_QUEUE": "0"}, {"VS_ACC_GRID_PER_CU": "1", "VS_ACC_QUEUE": "0"}, {"VS_NO_XCD_MAP": "1"}, {"VS_GRID_PER_CU": "8"}, {"VS_NO_STD": "1"}, {"VS_SHORTCUT": "1"}, {"VS_SHORTCUT": "0"},
+    {"VS_PHASE0": "1"}, {"VS_PHASE0": "1", "VS_NO_FAST": "1"}, {"VS_PHASE0": "1", "VS_SHORTCUT": "1"},  # (r5) the probe grid from offset 0, as before vs_seed_phase
     {"VS_ACC_ROUND": "128"},
     {"VS_EPT": "32", "VS_ACC_ROWS": "1"}, {"VS_NO_MID": "1"},
     {"VS_ACC_ROWS": "1"}, {"VS_ACC_ROWS": "1", "VS_ROWS_PER_STRIP": "1"}, {"VS_ACC_ROWS": "1", "VS_ROWS_PER_STRIP": "64", "VS_ACC_FILL": "1"},

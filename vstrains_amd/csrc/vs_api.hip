@@ -44,6 +44,7 @@ void vs_tuning_load(VsTuning &t, int level) {
     t.no_xcd_map = env_on("VS_NO_XCD_MAP");
     t.no_fast = env_on("VS_NO_FAST");
     t.no_std = env_on("VS_NO_STD");
+    t.phase0 = env_on("VS_PHASE0");
     t.no_agg = env_on("VS_NO_AGG");
     t.no_mid = env_on("VS_NO_MID");
     if (const char *v = getenv("VS_ACC_QUEUE")) t.acc_queue = atoi(v) != 0;

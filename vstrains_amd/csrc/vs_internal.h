@@ -118,6 +118,7 @@ struct VsTuning {
     bool no_sort = false, locus_global = false, no_xcd_map = false, no_fast = false, no_std = false, no_agg = false;
     bool acc_queue = true;
     bool no_mid = false;            // VS_NO_MID: overflow pairs straight to k_pe_slow
+    bool phase0 = false;            // VS_PHASE0: probe grid 0, s, 2s, ... as before round 5 (vs_seed_phase); the generic kernels only (implies VS_NO_STD)
     bool debug_postings = false, debug_occ = false, debug_acc = false;
     // timing only (VS_EXPERIMENT=timing): wrong counters by design
     uint32_t debug_stop = 0;        // VS_DEBUG_STOP=1..5
@@ -188,6 +189,24 @@ struct vs_reads {
         return r;
     }
 };
+
+// The probe grid of a read end (round 5).  A match of K bases and more holds s = K - w + 1 consecutive seed starts, so any
+// grid phi, phi + s, phi + 2s, ... of read offsets finds it, and the first grid point inside it credits it (left extension
+// below s: vs_extend / k_pe_tiles).  phi = 0 spends a probe on the read's last, partly covered stride: floor((len - w) / s) + 1
+// probes.  With r = (len - w) mod s every phi in (r, s) needs one probe less -- floor((len - w + 1) / s), the fewest any
+// exact grid of stride s can have (the len - K + 1 windows of a read in runs of s) -- and the grid's seeds then lie
+// inside the read instead of flush with its first base.  phi = (r + s) / 2 is the middle of that range (and s - 1, the
+// only choice, when r = s - 1).  Measured on the configs[2] stream: 21.9 instead of 27.4 postings per end, four probes
+// instead of five (profiles/r5/phase_gate_config2.json).  Ends shorter than K are never probed (PE_Inference.py:160-163).
+__host__ __device__ inline uint32_t vs_seed_phase(uint32_t len, uint32_t w, uint32_t s, bool phase0 = false) {
+    return (phase0 || len < w) ? 0u : ((len - w) % s + s) / 2u;
+}
+__host__ __device__ inline uint32_t vs_seed_probes(uint32_t len, uint32_t w, uint32_t s, bool phase0 = false) {
+    if (len < w) return 0u;
+    if (phase0) return (len - w) / s + 1u;
+    const uint32_t n = (len - w + 1u) / s;
+    return n ? n : 1u;  // (len < K: one probe at (len - w + s) / 2 >= len - w ... such ends are dropped before any probe)
+}
 
 int vs_fail(vs_ctx *ctx, int code, const char *fmt, ...);
 // grow-only cache of device buffers (see vs_ctx::cache); NULL on allocation failure

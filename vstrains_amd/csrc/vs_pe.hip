@@ -76,6 +76,7 @@ struct PeParams {
     uint32_t shortcut;               // overlapping-seed ownership shortcut for single postings (P3 stage A)
     uint8_t *tile_map;               // vs_pe_count_tracked: one byte per 64 x 64 tile of node_mat, then of short_mat; NULL = none
     uint32_t tile_T;                 // tiles per matrix side = ceil(N / 64)
+    uint32_t phase0;                 // VS_PHASE0: probe grid 0, s, 2s, ... (generic instantiations only; see vs_seed_phase)
 };
 
 // A counter cell is about to be added to: its tile is marked (a plain store of 1; racing stores write the same value).
@@ -424,8 +425,8 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
 }
 
 // SW, SP != 0: the tile shape is a compile-time one for k = 55 -- 64 ends per tile, 1024-slot table,
-// SW packed words and SP probes per end: (10, 5) = 2 x 145..159 bases, (8, 4) = 2 x 113..128,
-// (7, 3) = 2 x 97..112.  Every LDS array then sits at a constant offset (folded into the LDS
+// SW packed words and SP probes per end (vs_seed_probes): (10, 4) = 2 x 145..159 bases, (8, 3) = 2 x 113..128,
+// (7, 2) = 2 x 97..107.  Every LDS array then sits at a constant offset (folded into the LDS
 // instructions) instead of costing a scalar register and an add, the divisions by pmax / wpe and
 // k+1 / seed length / stride become constants.  The host picks one when the block has that shape.
 #ifndef STD_EPT
@@ -435,7 +436,7 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
 #define STD_K 56u   // k + 1
 #define STD_W 31u   // seed length and probe stride that follow from it (seed_geometry)
 #define STD_S 26u
-#define STD2_EPT 58u  // the k = 127 shape (MODE 2): ends per tile, pool_for(58) = 1024 slots, k + 1, seed length, stride
+#define STD2_EPT 60u  // the k = 127 shape (MODE 2): ends per tile, pool_for(60) = 1024 slots, k + 1, seed length, stride
 #define STD2_POOL_BITS 10u
 #define STD2_K 128u
 #define STD2_W 63u
@@ -467,7 +468,7 @@ k_pe_tiles(PeParams P) {
     const bool count_postings = !STD && P.count_postings, want_dbg = !STD && P.dbg_counts != nullptr;
     const bool accumulate = STD || P.accumulate;
     // (r3) MODE 2 has one compile-time shape too: k = 127 with 2 x 241..256 bases -- 63-base seeds, stride 66, 16 words and
-    // three probes per end, 58 ends per tile (what the host's LDS budget gives that shape)
+    // two probes per end, 60 ends per tile (what the host's LDS budget gives that shape)
     constexpr uint32_t C_EPT = MODE == 2 ? STD2_EPT : STD_EPT, C_K = MODE == 2 ? STD2_K : STD_K;
     constexpr uint32_t C_W = MODE == 2 ? STD2_W : STD_W, C_S = MODE == 2 ? STD2_S : STD_S;
     constexpr uint32_t C_POOL_BITS = MODE == 2 ? STD2_POOL_BITS : STD_POOL_BITS;
@@ -493,7 +494,8 @@ k_pe_tiles(PeParams P) {
     uint32_t *s_hminp = vs_lds + T.hminp;
     uint32_t *s_hminj = vs_lds + T.hminj;
     uint32_t *s_ns = vs_lds + T.ns;        // accepted nodes per end
-    uint32_t *s_state = vs_lds + T.state;  // bit0: end belongs to a used pair, bit1: overflow
+    uint32_t *s_state = vs_lds + T.state;  // bit0: end belongs to a used pair, bit1: overflow; bits 8..: first probe offset (vs_seed_phase)
+    const bool phase0 = !STD && P.phase0;
     uint32_t *s_list = vs_lds + T.list;    // accepted node ids, LC per end
     uint32_t *s_misc = vs_lds + T.misc;
     uint32_t *s_owner = vs_lds + T.owner;
@@ -639,7 +641,9 @@ k_pe_tiles(PeParams P) {
             uint32_t st = (cls == 2) ? 1u : 0u;
             // (an end with more bytes outside ACGT than vs_seed_limits can hold: the pair takes the overflow path)
             if (FAST && st && (((mf | mr) >> 24) & VS_FLAG_MANY)) st = 3u;
-            s_state[2 * tid] = s_state[2 * tid + 1] = st;
+            // the probe grid of either end: phi, phi + s, ... (vs_seed_phase: the shortest exact grid for the end's length)
+            s_state[2 * tid] = st | (vs_seed_phase(mf & VS_LEN_MASK, w, s, phase0) << 8);
+            s_state[2 * tid + 1] = st | (vs_seed_phase(mr & VS_LEN_MASK, w, s, phase0) << 8);
             s_ns[2 * tid] = s_ns[2 * tid + 1] = 0;
         }
         __syncthreads();
@@ -648,10 +652,11 @@ k_pe_tiles(PeParams P) {
         for (uint32_t it = tid; it < NI; it += TTPB) {
             uint32_t e = STD ? it / STD_PMAX : vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
             uint32_t cnt = 0, pa = 0, pb = 0;
-            if (e < ne && (s_state[e] & 3u) == 1u) {
+            const uint32_t est = e < ne ? s_state[e] : 0u;
+            if ((est & 3u) == 1u) {
                 uint32_t meta = s_meta[e];
                 uint32_t rlen = meta & VS_LEN_MASK;
-                uint32_t j = pi * s;
+                uint32_t j = (est >> 8) + pi * s;
                 if (j + w <= rlen) {
                     uint32_t sr;
                     const uint64_t key = vs_seed_key(s_words, e * wpe * 16u + j, w, &sr);
@@ -761,7 +766,7 @@ k_pe_tiles(PeParams P) {
                 const uint32_t pa = s_pa[it], pb = s_pb[it];
                 const uint32_t e = STD ? it / STD_PMAX : vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
                 p_e[k2] = e;
-                p_j[k2] = pi * s;
+                p_j[k2] = (s_state[e] >> 8) + pi * s;
                 uint32_t node = pa, pos = pb & 0x7FFFFFFFu, opp = pb >> 31;
                 p_nm[k2].woff = 0; p_nm[k2].len = 0;
                 if (live[k2] && cnt != 1u) {  // (the record carries the node header: no second round trip)
@@ -1639,7 +1644,7 @@ __device__ __forceinline__ uint32_t vs_locus_key(const VsIndexDev &idx, const Vs
     const uint32_t rlen = mf & VS_LEN_MASK;
     const uint64_t base = (uint64_t)rd.woff[2 * p] * 16u;
     const bool inv = (mf >> 24) & VS_FLAG_INVALID;
-    for (uint32_t j = 0; j + w <= rlen; j += s) {
+    for (uint32_t j = vs_seed_phase(rlen, w, s); j + w <= rlen; j += s) {
         if (inv && vs_seed_dirty(rd.mask, base + j, w)) continue;
         uint32_t pa, pb, sr;
         const uint64_t key = vs_seed_key(rd.words, base + j, w, &sr);
@@ -1655,7 +1660,7 @@ __device__ __forceinline__ uint32_t vs_locus_key_end(const VsIndexDev &idx, cons
     const uint32_t N = idx.n_nodes, w = idx.w, s = idx.s, rlen = m & VS_LEN_MASK;
     const uint64_t base = (uint64_t)rd.woff[e] * 16u;
     const bool inv = (m >> 24) & VS_FLAG_INVALID;
-    for (uint32_t j = 0; j + w <= rlen; j += s) {
+    for (uint32_t j = vs_seed_phase(rlen, w, s); j + w <= rlen; j += s) {
         if (inv && vs_seed_dirty(rd.mask, base + j, w)) continue;
         uint32_t pa, pb, sr;
         const uint64_t key = vs_seed_key(rd.words, base + j, w, &sr);
@@ -1771,13 +1776,13 @@ k_pe_mid(PeParams P, const uint32_t *__restrict__ in_list, const uint32_t *__res
             const uint32_t rlen = meta & VS_LEN_MASK;
             const uint64_t rbase = (uint64_t)P.rd.woff[e] * 16u;
             const uint32_t *mk = ((meta >> 24) & VS_FLAG_INVALID) ? P.rd.mask : nullptr;
-            const uint32_t nprobe = rlen >= w ? (rlen - w) / s + 1u : 0u;
+            const uint32_t nprobe = vs_seed_probes(rlen, w, s, P.phase0), phase = vs_seed_phase(rlen, w, s, P.phase0);
             for (uint32_t i = lane; i < MID_SLOTS; i += 64u) { s_key[i] = EMPTY_NODE; s_cnt[i] = 0u; s_minp[i] = 0xFFFFFFFFu; s_minj[i] = 0xFFFFFFFFu; }
             if (nprobe > 64u) { if (lane == 0u) s_flag[0] = 1u; }
             // probes: one per lane
             uint32_t c = 0u, pa = 0u, pb = 0u;
             if (lane < nprobe && nprobe <= 64u) {
-                const uint32_t j = lane * s;
+                const uint32_t j = phase + lane * s;
                 if (!(mk && vs_seed_dirty(mk, rbase + j, w))) {
                     uint32_t sr;
                     const uint64_t key = vs_seed_key(P.rd.words, rbase + j, w, &sr);
@@ -1797,7 +1802,7 @@ k_pe_mid(PeParams P, const uint32_t *__restrict__ in_list, const uint32_t *__res
             const uint32_t total = s_pref[64];
             for (uint32_t t = lane; t < total; t += 64u) {
                 const uint32_t pr = vs_upper_idx(s_pref, 65u, t);
-                const uint32_t k2 = t - s_pref[pr], j = pr * s;
+                const uint32_t k2 = t - s_pref[pr], j = phase + pr * s;
                 uint32_t node, pos, opp;
                 VsNodeMeta nm;
                 if (s_pc[pr] == 1u) {
@@ -1928,7 +1933,7 @@ k_pe_slow(PeParams P, uint32_t *dense, uint32_t n_slow_cap, const uint32_t *__re
             const uint64_t rbase = (uint64_t)P.rd.woff[e] * 16u;
             const uint32_t *mk = ((meta >> 24) & VS_FLAG_INVALID) ? P.rd.mask : nullptr;
             uint32_t *surv = side ? surv1 : surv0;
-            const uint32_t nprobe = rlen >= w ? (rlen - w) / s + 1u : 0u;
+            const uint32_t nprobe = vs_seed_probes(rlen, w, s, P.phase0), phase = vs_seed_phase(rlen, w, s, P.phase0);
             if (tid == 0) s_nt = 0;
             __syncthreads();
             for (uint32_t p0 = 0; p0 < nprobe; p0 += TPB) {
@@ -1936,7 +1941,7 @@ k_pe_slow(PeParams P, uint32_t *dense, uint32_t n_slow_cap, const uint32_t *__re
                 uint32_t c = 0, pa = 0, pb = 0;
                 const uint32_t pi = p0 + tid;
                 if (pi < nprobe) {
-                    const uint32_t j = pi * s;
+                    const uint32_t j = phase + pi * s;
                     if (!(mk && vs_seed_dirty(mk, rbase + j, w))) {
                         uint32_t sr;
                         const uint64_t key = vs_seed_key(P.rd.words, rbase + j, w, &sr);
@@ -1965,7 +1970,7 @@ k_pe_slow(PeParams P, uint32_t *dense, uint32_t n_slow_cap, const uint32_t *__re
                 for (uint32_t t = tid; t < total; t += TPB) {
                     // the probe that owns posting t: last index with s_cnt[idx] <= t
                     const uint32_t pr = vs_upper_idx(s_cnt, TPB + 1u, t);
-                    const uint32_t k2 = t - s_cnt[pr], j = (p0 + pr) * s;
+                    const uint32_t k2 = t - s_cnt[pr], j = phase + (p0 + pr) * s;
                     const uint32_t qa0 = s_pa[pr], qb0 = s_pb[pr];
                     uint32_t node, pos, opp;
                     VsNodeMeta nm;
@@ -2190,12 +2195,14 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     ctx->last_launched = 0;
     if (n_ends == 0) return VS_OK;
     const uint32_t maxlen = (uint32_t)reads->max_len;
-    const uint32_t pmax = maxlen >= idx.w ? (maxlen - idx.w) / idx.s + 1u : 1u;
     const uint32_t wpe = maxlen ? (maxlen + 15u) / 16u : 1u;
     if (idx.n_nodes > 0x01FFFFFEu) return vs_fail(ctx, VS_E_RANGE, "more than 2^25-2 nodes");
     // experiment switches: fixed defaults unless the process runs with VS_EXPERIMENT (see VsTuning)
     if (ctx->experiment_level) vs_tuning_load(ctx->tune, ctx->experiment_level);
     const VsTuning &tn = ctx->tune;
+    // probes of the longest end (vs_seed_probes grows with the length): the probe slots a tile reserves per end
+    uint32_t pmax = vs_seed_probes(maxlen, idx.w, idx.s, tn.phase0);
+    if (!pmax) pmax = 1u;
     uint32_t ept = tn.ept ? tn.ept : STD_EPT;
     if (ept < 2 || ept > TTPB / 2u) ept = STD_EPT;
     while (ept > 2 && (ept * pmax > NI_CAP || lds_bytes(ept, pmax, ept * wpe) > LDS_BUDGET_BYTES)) ept -= 2;
@@ -2311,6 +2318,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     P.tile_map = d_node_mat ? d_tile_map : nullptr;
     P.tile_T = (idx.n_nodes + 63u) >> 6;
     P.no_xcd_map = tn.no_xcd_map ? 1u : 0u;
+    P.phase0 = tn.phase0 ? 1u : 0u;
     // The shortcut spares a single posting its extension when the previous probe already owns the
     // match; it pays on graphs whose seeds are mostly unique.  Where seeds repeat (a compacted de
     // Bruijn graph of many strains: 3.5 postings per distinct seed at configs[2]) nearly every
@@ -2326,26 +2334,26 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     // (reads with bytes outside ACGT qualify through their position lists, see k_inv4 / vs_seed_limits)
     const bool fast = (!reads->d_mask || reads->d_inv4) && idx.s <= 32u && maxlen <= 128u + idx.w + 32u &&
                       !tn.no_fast;
-    // compile-time-shape instantiations (see k_pe_tiles): 1 = (10, 5), 2 = (8, 4), 3 = (7, 3)
+    // compile-time-shape instantiations (see k_pe_tiles): 1 = (10, 4), 2 = (8, 3), 3 = (7, 2)
     int std_shape = 0;
     if (fast && ept == STD_EPT && P.pool_bits == STD_POOL_BITS && maxlen <= 159u && idx.K == STD_K && idx.w == STD_W &&
         idx.s == STD_S && P.accumulate && !P.debug_stop && !P.count_postings && !P.dbg_counts &&
-        !tn.no_std) {
-        if (wpe == 10u && pmax == 5u) std_shape = 1;
-        else if (wpe == 8u && pmax == 4u) std_shape = 2;
-        else if (wpe == 7u && pmax == 3u) std_shape = 3;
+        !tn.no_std && !tn.phase0) {
+        if (wpe == 10u && pmax == 4u) std_shape = 1;       // 2 x 145..159 bases
+        else if (wpe == 8u && pmax == 3u) std_shape = 2;   // 2 x 113..128
+        else if (wpe == 7u && pmax == 2u) std_shape = 3;   // 2 x 97..107
     }
     // longer strides and reads (k = 127 with 2 x 250 bases): the straight-line kernel with more windows
     const bool fast_long = !fast && (!reads->d_mask || reads->d_inv4) && idx.s <= 128u && maxlen <= VS_SEED_VERIFIED(idx.w) + 256u &&
                            ctx->max_node_len < (1u << 23) && !tn.no_fast;
     if (fast_long && ept == STD2_EPT && P.pool_bits == STD2_POOL_BITS && idx.K == STD2_K && idx.w == STD2_W && idx.s == STD2_S &&
-        wpe == 16u && pmax == 3u && P.accumulate && !P.debug_stop && !P.count_postings && !P.dbg_counts && !tn.no_std)
+        wpe == 16u && pmax == 2u && P.accumulate && !P.debug_stop && !P.count_postings && !P.dbg_counts && !tn.no_std && !tn.phase0)
         std_shape = 4;
-    const void *tiles_fn = std_shape == 1 ? (const void *)k_pe_tiles<1, 10u, 5u>
-                           : std_shape == 2 ? (const void *)k_pe_tiles<1, 8u, 4u>
-                           : std_shape == 3 ? (const void *)k_pe_tiles<1, 7u, 3u>
+    const void *tiles_fn = std_shape == 1 ? (const void *)k_pe_tiles<1, 10u, 4u>
+                           : std_shape == 2 ? (const void *)k_pe_tiles<1, 8u, 3u>
+                           : std_shape == 3 ? (const void *)k_pe_tiles<1, 7u, 2u>
                            : fast           ? (const void *)k_pe_tiles<1, 0u, 0u>
-                           : std_shape == 4 ? (const void *)k_pe_tiles<2, 16u, 3u>
+                           : std_shape == 4 ? (const void *)k_pe_tiles<2, 16u, 2u>
                            : fast_long      ? (const void *)k_pe_tiles<2, 0u, 0u>
                                             : (const void *)k_pe_tiles<0, 0u, 0u>;
     if (lds > 64u * 1024u)
@@ -2404,23 +2412,23 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     }
     VS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     if (!d_node_mat) VS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
-    ctx->last_kernel = std_shape == 1 ? "k_pe_tiles<1, 10u, 5u>"
-                       : std_shape == 2 ? "k_pe_tiles<1, 8u, 4u>"
-                       : std_shape == 3 ? "k_pe_tiles<1, 7u, 3u>"
+    ctx->last_kernel = std_shape == 1 ? "k_pe_tiles<1, 10u, 4u>"
+                       : std_shape == 2 ? "k_pe_tiles<1, 8u, 3u>"
+                       : std_shape == 3 ? "k_pe_tiles<1, 7u, 2u>"
                        : fast           ? "k_pe_tiles<1, 0u, 0u>"
-                       : std_shape == 4 ? "k_pe_tiles<2, 16u, 3u>"
+                       : std_shape == 4 ? "k_pe_tiles<2, 16u, 2u>"
                        : fast_long      ? "k_pe_tiles<2, 0u, 0u>"
                                         : "k_pe_tiles<0, 0u, 0u>";
     if (std_shape == 1)
-        hipLaunchKernelGGL((k_pe_tiles<1, 10u, 5u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
+        hipLaunchKernelGGL((k_pe_tiles<1, 10u, 4u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
     else if (std_shape == 2)
-        hipLaunchKernelGGL((k_pe_tiles<1, 8u, 4u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
+        hipLaunchKernelGGL((k_pe_tiles<1, 8u, 3u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
     else if (std_shape == 3)
-        hipLaunchKernelGGL((k_pe_tiles<1, 7u, 3u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
+        hipLaunchKernelGGL((k_pe_tiles<1, 7u, 2u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
     else if (fast)
         hipLaunchKernelGGL((k_pe_tiles<1, 0u, 0u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
     else if (std_shape == 4)
-        hipLaunchKernelGGL((k_pe_tiles<2, 16u, 3u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
+        hipLaunchKernelGGL((k_pe_tiles<2, 16u, 2u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
     else if (fast_long)
         hipLaunchKernelGGL((k_pe_tiles<2, 0u, 0u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
     else

@@ -572,6 +572,7 @@ struct vs_stage {
     void drop_duplicate_contigs(NameMap<Contig> &cd);
     struct Closure;
     void remap_contigs(const NameMap<std::vector<Nid>> &id_mapping, Closure &closure);
+    void check_fork_depth(const NameMap<std::vector<Nid>> &id_mapping, const Closure &closure);
     void best_matching();
     void increment_nt_branch_coverage();
     void walk(std::vector<uint32_t> &path, std::vector<uint8_t> &visited, uint32_t start, bool forward, const LinkTable &table,
@@ -1657,11 +1658,51 @@ struct vs_stage::Closure {
     bool is_known(Nid name) const { return name < known.size() && known[name]; }
 };
 
+// The reference works the closure out EAGERLY, for every id of the graph before the pass, by a recursive function
+// (merge_id, Utilities.py:318-327: one Python frame per link of a fork chain) under CPython's default recursion limit of
+// 1 000.  contig_dict_remapping runs six frames deep (<module>, main, run, VStrains_SPAdes.run, path_extension or
+// iter_graph_disentanglement, itself), and the first statement of merge_id calls len() -- a C call, which counts too --
+// so a chain that needs a 994th nested merge_id frame ends the reference with "RecursionError: maximum recursion depth
+// exceeded while calling a Python object" (exit status 1); 993 frames pass.  That is how the reference leaves the runaway
+// of global_trivial_split on some circular graphs (every fork of "X*B" leaves an "X*B*B" that forks again, up to the
+// N^2 bound: fuzz_reference draw 236 of campaign 778, tests/golden/graph/circular_runaway_k55).  Depth of an id = 1 for an
+// id that was not forked, else 1 + the deepest of its forks; worked out without recursion.
+static const uint32_t PY_MERGE_ID_FRAMES = 993;  // (CPython 3.10, sys.getrecursionlimit() == 1000, the CLI's call depth)
+void vs_stage::check_fork_depth(const NameMap<std::vector<Nid>> &id_mapping, const Closure &closure) {
+    std::vector<uint32_t> depth(names.size(), 0);  // 0 = not worked out yet
+    std::vector<std::pair<Nid, size_t>> stack;     // (id, next fork to look at)
+    for (Nid root = 0; root < (Nid)closure.known.size(); root++) {
+        if (!closure.known[root] || depth[root]) continue;
+        stack.assign(1, {root, 0});
+        while (!stack.empty()) {
+            const Nid id = stack.back().first;
+            const std::vector<Nid> *kids = id_mapping.get(id);
+            if (!kids || kids->empty()) {
+                depth[id] = 1;
+                stack.pop_back();
+                continue;
+            }
+            if (stack.back().second < kids->size()) {
+                const Nid kid = (*kids)[stack.back().second++];
+                if (!depth[kid]) stack.push_back({kid, 0});  // (fork names only grow: the mapping has no cycle)
+                continue;
+            }
+            uint32_t d = 0;
+            for (Nid kid : *kids) d = depth[kid] > d ? depth[kid] : d;
+            depth[id] = d + 1;
+            stack.pop_back();
+        }
+        if (depth[root] > PY_MERGE_ID_FRAMES)
+            throw StageError{VS_E_RECURSION, "RecursionError", "maximum recursion depth exceeded while calling a Python object"};
+    }
+}
+
 void vs_stage::remap_contigs(const NameMap<std::vector<Nid>> &id_mapping, Closure &closure) {
     VS_SECTION("remap_contigs");
     info("contig resolution..");
     bool any_kids = false;
     for (auto &m : id_mapping.ents) any_kids = any_kids || (m.live && !m.v.empty());
+    if (any_kids) check_fork_depth(id_mapping, closure);
     if (!any_kids) {
         // the closure of every id is the id itself: a contig has one image (itself) or none (a step that is no edge:
         // "contig missed", kept as it is) -- only the lookup of an id the graph did not hold before the pass raises

@@ -58,7 +58,7 @@ STAGE_SYMBOLS = {
 }
 
 _EXCEPTIONS = {"KeyError": KeyError, "IndexError": IndexError, "ValueError": ValueError, "FloatingPointError": FloatingPointError,
-               "OSError": OSError, "MemoryError": MemoryError}
+               "OSError": OSError, "MemoryError": MemoryError, "RecursionError": RecursionError}
 
 
 def bind(lib) -> None:
