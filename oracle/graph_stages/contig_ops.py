@@ -43,12 +43,17 @@ def remap_contigs(g: AsmGraph, nodes: NodeMap, edges: EdgeMap, contigs: ContigDi
     ordered sets (dict keys)."""
 
     def leaves(name: str) -> Dict[str, None]:
-        kids = id_mapping.get(name, ())
-        if len(kids) == 0:
-            return {name: None}
+        # (depth-first, forks in order, without recursion: the chain may be as long as the reference's limit allows, and
+        # this checker runs at whatever depth its caller happens to be)
         out: Dict[str, None] = {}
-        for kid in kids:
-            out.update(leaves(kid))
+        stack = [name]
+        while stack:
+            cur = stack.pop()
+            kids = id_mapping.get(cur, ())
+            if len(kids) == 0:
+                out.setdefault(cur, None)
+            else:
+                stack.extend(reversed(list(kids)))
         return out
 
     logger.info("contig resolution..")

@@ -191,8 +191,19 @@ def collect(out_dir):
                 text = digest_fasta(text)
             elif name in ("pe_info", "st_info"):
                 text = sparse_info(text)
-            res[rel] = text
+            res[rel] = compact_large(text)
     return res
+
+
+LARGE_TEXT = 2_000_000
+
+
+def compact_large(text):
+    """A digest-form file of more than 2 MB is kept as its SHA-256 and size (the stage graph behind a runaway trivial split
+    names 8 549 vertices with ids of up to 17 kB: 73 MB of text in ``circular_runaway_k55``)."""
+    if len(text) <= LARGE_TEXT:
+        return text
+    return "large file: sha256 %s, %d characters\n" % (hashlib.sha256(text.encode()).hexdigest(), len(text))
 
 
 def run_reference(inp, extra, variant, hashseed=0, keep_log_to=None):

@@ -61,6 +61,21 @@ class Case:
                 out.append(p)
         return out
 
+    def expected_exception(self):
+        """The exception the reference ended with on this case (``returncode`` != 0), named by the last line of its
+        traceback: KeyError from its PE subprocess (a node base outside ACGT), RecursionError from merge_id after a runaway
+        trivial split (Utilities.py:318-327) -- this build must raise the same one after writing the same files."""
+        import builtins
+
+        assert self.meta["returncode"] != 0
+        last = [l for l in self.meta.get("stderr_tail", "").strip().splitlines() if l.strip()][-1]
+        name = last.split(":", 1)[0].strip()
+        if name == "subprocess.CalledProcessError":  # (the PE script, a subprocess of the reference, died of the KeyError)
+            name = "KeyError"
+        exc = getattr(builtins, name, None)
+        assert isinstance(exc, type) and issubclass(exc, BaseException), last
+        return exc
+
     def inputs(self, tmp, with_reads=False):
         """Re-derive the inputs from the seed and check them against the pinned digests."""
         pc = synth.make_pipeline_case(**self.meta["synth"])

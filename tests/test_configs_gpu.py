@@ -275,3 +275,35 @@ def test_cli_reproduces_the_real_reference_command_at_configs0(tmp_path):
     assert len(want["files_sha256"]) >= 25 and "strain.paths" in want["files_sha256"]
     problems = reference_command_problems(out, want)
     assert not problems, problems
+
+
+def test_per_end_lists_equal_the_real_reference_function_at_config4_size(host, ctx, tmp_path):
+    """configs[4] (54 465 nodes): the whole reference script cannot run at that size (two text files of 3e9 lines), but its
+    ``single_end_read_mapping`` (PE_Inference.py:16-48) can, end by end -- tests/golden/make_pe_end_lists.py imported it from
+    /root/reference, ran it on the first 1 024 pairs of the bench stream against the table of this graph and committed the
+    lists it returned (mean 8.6 nodes per end, up to 19: ends beyond a list row's 16 are among them, so the overflow kernels
+    are held to the reference too).  The same pairs are regenerated on the device and ``vs_pe_map_ends`` must give the same
+    list for every end."""
+    import hashlib
+    import json
+    import os
+
+    from conftest import GOLDEN
+    from vstrains_amd.workloads import CONFIGS, workload_for
+
+    with open(os.path.join(GOLDEN, "pe_end_lists_config4.json")) as fh:
+        want = json.load(fh)
+    cfg = CONFIGS[4]
+    st, pre, names, seqs, cum, logger, n_in = workload_for(4, str(tmp_path))
+    with open(os.path.join(str(tmp_path), "gfa", "s_graph_L1.gfa"), "rb") as fh:
+        assert hashlib.sha256(fh.read()).hexdigest() == want["s_graph_L1_gfa_sha256"]  # the same graph, byte for byte
+    assert len(seqs) == want["nodes"] and cfg["k"] == want["k"] and cfg["read_len"] == want["read_len"]
+    ctx.build_index(list(seqs), cfg["k"])
+    block = ctx.synth_pairs(st.genomes, cum, want["stream_seed"], 0, want["pairs"], cfg["read_len"], want["sub_thresh"], want["n_thresh"])
+    got = ctx.map_ends(block, cap=64)
+    assert len(got) == len(want["lists"]) == 2 * want["pairs"]
+    n_long = 0
+    for e, (g, w) in enumerate(zip(got, want["lists"])):
+        assert g == (sorted(w) if w is not None else []), (e, g, w)  # (None: the pair loop drops the pair, :160-165)
+        n_long += w is not None and len(w) > 16
+    assert n_long > 0  # ends past the tile kernel's list rows were part of the comparison

@@ -67,7 +67,7 @@ def test_pipeline_matches_reference_outputs(name, engine, tmp_path):
     if case.meta["returncode"] != 0:
         # the reference exits non-zero (its PE subprocess raises KeyError); so must this build, after
         # writing the same files up to that point
-        with pytest.raises(KeyError):
+        with pytest.raises(case.expected_exception()):
             pipeline.run(args, logger, make_backend(case, engine))
     else:
         pipeline.run(args, logger, make_backend(case, engine))
@@ -98,8 +98,8 @@ def test_every_file_equals_the_committed_rotate_model_run(name, tmp_path):
     logger = file_logger(out)
     try:
         pipeline.run(args, logger, NativeBackend(case))
-    except KeyError:
-        assert case.meta["returncode"] != 0
+    except (KeyError, RecursionError) as err:
+        assert case.meta["returncode"] != 0 and isinstance(err, case.expected_exception())
     for h in list(logger.handlers):
         h.flush()
     problems, _ = compare(case, out)
@@ -178,3 +178,34 @@ def test_report_which_golden_files_do_not_depend_on_the_in_edge_model(capsys):
     metas = {n: Case(n).meta for n in exercised}
     assert any(m["k"] == 55 for m in metas.values()), "no fully invariant k = 55 case"
     assert any("-mc" in m["cli_extra"] for m in metas.values()), "no fully invariant case with -mc"
+
+
+@pytest.mark.parametrize("name", ["circular_tiny_bound_k21_s480348", "circular_tiny_bound_k21_s810092", "circular_runaway_k55"])
+def test_runaway_trivial_split_ends_like_the_reference_and_quickly(name, tmp_path):
+    """Round 5 (fuzz_reference draw 236 of campaign 778, unresolved in round 4): on some circular genomes the reference's
+    ``global_trivial_split`` forks "X*B" into "X*B*B" for ever and only its N^2 bound stops it (Decomposition.py:699-705,
+    "Strange topology detected").  On 9- and 12-node graphs the reference then carries on and finishes; on the 250-node
+    k = 55 draw the fork chain (8 549 links) is longer than its recursive merge_id (Utilities.py:318-327) can follow and it
+    exits with RecursionError after writing graph_S6.gfa.  This build must end the same way on each -- the files are
+    compared by the tests above -- and do so in seconds: before the recursion limit was restated the engine ran out of
+    memory on the k = 55 draw (65 GB) where the reference needs 90 s."""
+    import time
+
+    case = Case(name)
+    inp = case.inputs(str(tmp_path))
+    out = str(tmp_path / "out")
+    args = case.args(inp, out)
+    logger = file_logger(out, "runaway")
+    t0 = time.time()
+    if case.meta["returncode"] != 0:
+        assert case.expected_exception() is RecursionError
+        with pytest.raises(RecursionError, match="maximum recursion depth exceeded"):
+            pipeline.run(args, logger, NativeBackend(case))
+    else:
+        pipeline.run(args, logger, NativeBackend(case))
+    took = time.time() - t0
+    for h in list(logger.handlers):
+        h.flush()
+    with open(os.path.join(out, "vstrains.log")) as fh:
+        assert "Strange topology detected, exit trivial split immediately" in fh.read()
+    assert took < 30.0, took

@@ -225,3 +225,38 @@ def test_randomized_campaign_against_the_python_stages_short():
     import warnings
 
     warnings.warn(UserWarning("fuzz_native_cpu: %s" % [l for l in proc.stdout.splitlines() if l.startswith("draws ")][-1]))
+
+
+def test_fork_chain_limit_is_the_one_measured_on_the_real_reference_function():
+    """tests/golden/probe_merge_id_depth.py imported ``contig_dict_remapping`` from /root/reference and measured how many
+    nested ``merge_id`` frames (Utilities.py:318-327) this interpreter lets it have at the CLI's call depth: 993; the next
+    link raises RecursionError.  The native engine (check_fork_depth) and the Python checker restate that number; the golden
+    case ``circular_runaway_k55`` shows the reference ending that way (8 549 links)."""
+    import json
+    import re
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "merge_id_depth.json")) as fh:
+        want = json.load(fh)
+    assert want["error_one_beyond"].startswith("RecursionError: maximum recursion depth exceeded")
+    from oracle.graph_stages import contig_ops
+
+    assert contig_ops.PY_MERGE_ID_FRAMES == want["max_nested_merge_id_frames"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "vstrains_amd", "csrc", "vs_stage.cpp")) as fh:
+        (n,) = re.findall(r"PY_MERGE_ID_FRAMES = (\d+);", fh.read())
+    assert int(n) == want["max_nested_merge_id_frames"]
+    # the checker on chains either side of the limit (no graph needed: nothing is a contig)
+    import logging
+
+    for frames, ok in ((want["max_nested_merge_id_frames"], True), (want["max_nested_merge_id_frames"] + 1, False)):
+        ids = ["n%d" % i for i in range(frames)]
+        id_mapping = {ids[i]: {ids[i + 1]: None} for i in range(frames - 1)}
+        id_mapping[ids[-1]] = {}
+        lg = logging.getLogger("chain")
+        lg.handlers[:] = [logging.NullHandler()]
+        if ok:
+            closure = contig_ops.remap_contigs(None, {}, {}, {}, id_mapping, [ids[0]], lg)
+            assert list(closure[ids[0]]) == [ids[-1]]
+        else:
+            with pytest.raises(RecursionError):
+                contig_ops.remap_contigs(None, {}, {}, {}, id_mapping, [ids[0]], lg)

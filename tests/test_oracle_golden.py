@@ -69,3 +69,29 @@ def test_c_oracle_lowercase_node_keyerror():
     with pytest.raises(KeyError) as ei:
         pe_oracle_c.Oracle(seqs, meta["k"])
     assert "KeyError: %r" % ei.value.args[0] == meta["stderr_last"]
+
+
+def test_c_port_equals_the_real_reference_function_at_config4_size(tmp_path):
+    """The C restatement against lists the REAL ``single_end_read_mapping`` returned at the graph size of BASELINE configs[4]
+    (54 465 nodes; tests/golden/make_pe_end_lists.py imported the function from /root/reference): the port is the checker of
+    the configs[4] GPU tests, so it is pinned at that size too, not only on the small golden graphs."""
+    import hashlib
+    import json
+
+    from conftest import GOLDEN
+    from oracle import pe_oracle_c
+    from vstrains_amd.workloads import CONFIGS, workload_for
+
+    with open(os.path.join(GOLDEN, "pe_end_lists_config4.json")) as fh:
+        want = json.load(fh)
+    cfg = CONFIGS[4]
+    st, pre, names, seqs, cum, logger, n_in = workload_for(4, str(tmp_path))
+    with open(os.path.join(str(tmp_path), "gfa", "s_graph_L1.gfa"), "rb") as fh:
+        assert hashlib.sha256(fh.read()).hexdigest() == want["s_graph_L1_gfa_sha256"]
+    orc = pe_oracle_c.Oracle(list(seqs), cfg["k"])
+    fw, rv = pe_oracle_c.synth_pairs(st.genomes, cum, want["stream_seed"], 0, want["pairs"], cfg["read_len"], want["sub_thresh"], want["n_thresh"])
+    for p in range(want["pairs"]):
+        for side, arr in ((0, fw), (1, rv)):
+            w = want["lists"][2 * p + side]
+            if w is not None:
+                assert sorted(orc.map_end(arr[p].tobytes().decode())) == sorted(w), (p, side)

@@ -77,6 +77,7 @@ struct PeParams {
     uint8_t *tile_map;               // vs_pe_count_tracked: one byte per 64 x 64 tile of node_mat, then of short_mat; NULL = none
     uint32_t tile_T;                 // tiles per matrix side = ceil(N / 64)
     uint32_t phase0;                 // VS_PHASE0: probe grid 0, s, 2s, ... (generic instantiations only; see vs_seed_phase)
+    uint32_t mid_fast;               // k_pe_mid: clean ends are compared straight-line (vs_agree_fast; the block has the shape of MODE 1)
 };
 
 // A counter cell is about to be added to: its tile is marked (a plain store of 1; racing stores write the same value).
@@ -1813,10 +1814,28 @@ k_pe_mid(PeParams P, const uint32_t *__restrict__ in_list, const uint32_t *__res
                     node = po.node; pos = po.pos; opp = po.strand ^ (s_pb[pr] >> 31);
                     nm.woff = po.woff; nm.len = po.len;
                 }
-                const uint32_t *tw = opp ? P.idx.rc_words : P.idx.fwd_words;
                 const uint32_t q = opp ? nm.len - pos - w : pos;
                 uint32_t a, qa, len;
-                if (!vs_extend(P.rd.words, rbase, rlen, tw, nm.woff * 16u, nm.len, j, q, wv_seed, s, K, mk, rbase, &a, &qa, &len)) continue;
+                if (P.mid_fast && !mk) {
+                    // (r5) an end without bytes outside ACGT in a block of the straight-line shape (stride <= 32, reads <= w + 160):
+                    // the comparison of k_pe_tiles<1> -- one left window, five right ones, no data-dependent loop -- off the read's
+                    // words in global memory (the 64 lanes of the wavefront share them)
+                    uint32_t cl = s < j ? s : j;
+                    cl = cl < q ? cl : q;
+                    uint32_t rem = rlen - j - wv_seed;
+                    const uint32_t dr = nm.len - q - wv_seed;
+                    rem = rem < dr ? rem : dr;
+                    const uint32_t tb = (nm.woff + (opp ? P.idx.rc_delta : 0u)) * 16u;
+                    uint32_t left, ext;
+                    vs_agree_fast<false>(P.rd.words + (rbase >> 4), 0u, P.idx.fwd_words, tb + q, cl, tb + q + wv_seed, rem, j, wv_seed, &left, &ext);
+                    len = left + wv_seed + ext;
+                    if (left >= s || len < K) continue;
+                    a = j - left;
+                    qa = q - left;
+                } else {
+                    const uint32_t *tw = opp ? P.idx.rc_words : P.idx.fwd_words;
+                    if (!vs_extend(P.rd.words, rbase, rlen, tw, nm.woff * 16u, nm.len, j, q, wv_seed, s, K, mk, rbase, &a, &qa, &len)) continue;
+                }
                 uint32_t at = (node * 0x9E3779B1u) >> 24;  // MID_SLOTS = 256
                 bool placed = false;
                 for (uint32_t tr = 0; tr < MID_SLOTS; tr++) {
@@ -2334,6 +2353,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     // (reads with bytes outside ACGT qualify through their position lists, see k_inv4 / vs_seed_limits)
     const bool fast = (!reads->d_mask || reads->d_inv4) && idx.s <= 32u && maxlen <= 128u + idx.w + 32u &&
                       !tn.no_fast;
+    P.mid_fast = fast && VS_SEED_VERIFIED(idx.w) ? 1u : 0u;
     // compile-time-shape instantiations (see k_pe_tiles): 1 = (10, 4), 2 = (8, 3), 3 = (7, 2)
     int std_shape = 0;
     if (fast && ept == STD_EPT && P.pool_bits == STD_POOL_BITS && maxlen <= 159u && idx.K == STD_K && idx.w == STD_W &&
