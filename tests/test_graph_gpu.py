@@ -423,13 +423,14 @@ def test_chain_ranking_of_a_large_graph_on_the_device(backend, tmp_path):
     st.close()
 
 
-@pytest.mark.parametrize("config", [0, 1, 2])
+@pytest.mark.parametrize("config", [0, 1, 2, 3])
 def test_extraction_on_the_device_equals_the_checker_at_bench_size(backend, config, tmp_path):
-    """The strain-extract leg of bench configs[0] / configs[1] / configs[2] (216 / 853 / 5 039 nodes, the reference cannot run
-    the latter): every file the device run writes -- 116 stage GFAs at configs[2], contig files,
-    strain.paths, strain.fasta (the native stage handle with the HIP kernels underneath) -- against the Python
-    restatement of the stages over the numpy checker (oracle/graph_stages: Python rebuild, numpy flows / scans, link
-    sums off the host copy of the counters)."""
+    """The strain-extract leg of bench configs[0..3] (216 / 853 / 5 039 / 10 084 nodes, the reference cannot run the
+    larger ones) on the link table of the config's WHOLE per-GPU block -- the 10 M pairs (12.5 M at configs[3]) the bench
+    extracts from, not a prefix: every file the device run writes -- 116 stage GFAs at configs[2], about a thousand at
+    configs[3], contig files, strain.paths, strain.fasta (the native stage handle with the HIP kernels underneath) --
+    against the Python restatement of the stages over the numpy checker (oracle/graph_stages: Python rebuild, numpy
+    flows / scans, link sums off the host copy of the counters)."""
     import copy
     import hashlib
 
@@ -443,7 +444,7 @@ def test_extraction_on_the_device_equals_the_checker_at_bench_size(backend, conf
     st, pre, names, seqs, cum, logger, _ = workload_for(config, str(tmp_path / "work"))
     ctx = backend.ctx
     ctx.build_index(seqs, cfg["k"])
-    reads = ctx.synth_pairs(st.genomes, cum, 20250000 + config, 0, min(1_000_000, cfg["total_pairs"]), cfg["read_len"], int(0.005 * 2 ** 32), int(0.001 * 2 ** 32))
+    reads = ctx.synth_pairs(st.genomes, cum, 20250000 + config, 0, cfg["total_pairs"] // cfg["gpus"], cfg["read_len"], int(0.005 * 2 ** 32), int(0.001 * 2 ** 32))
     counter = host.PeCounter(ctx)
     counter.add(reads)
     node_mat, short_mat, _ = counter.result()
