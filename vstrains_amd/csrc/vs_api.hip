@@ -48,6 +48,7 @@ void vs_tuning_load(VsTuning &t, int level) {
     t.no_agg = env_on("VS_NO_AGG");
     t.no_mid = env_on("VS_NO_MID");
     if (const char *v = getenv("VS_ACC_QUEUE")) t.acc_queue = atoi(v) != 0;
+    if (const char *v = getenv("VS_ACC_WGS")) t.acc_wgs = atoi(v) > 0 ? (uint32_t)atoi(v) : 0u;
     t.debug_postings = getenv("VS_DEBUG_POSTINGS") != nullptr;
     t.debug_occ = getenv("VS_DEBUG_OCC") != nullptr;
     t.debug_acc = getenv("VS_DEBUG_ACC") != nullptr;

@@ -117,6 +117,7 @@ struct VsTuning {
     uint32_t rows_per_strip = 0;    // VS_ROWS_PER_STRIP (0 = automatic): matrix rows one workgroup of k_rows_sum owns at a time
     bool no_sort = false, locus_global = false, no_xcd_map = false, no_fast = false, no_std = false, no_agg = false;
     bool acc_queue = true;
+    uint32_t acc_wgs = 0;           // VS_ACC_WGS: workgroups of k_pe_accumulate's chunk queue (0 = two per CU)
     bool no_mid = false;            // VS_NO_MID: overflow pairs straight to k_pe_slow
     bool phase0 = false;            // VS_PHASE0: probe grid 0, s, 2s, ... as before round 5 (vs_seed_phase); the generic kernels only (implies VS_NO_STD)
     bool debug_postings = false, debug_occ = false, debug_acc = false;

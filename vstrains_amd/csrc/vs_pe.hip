@@ -2486,7 +2486,8 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
             uint32_t *acc_queue = nullptr;
             if (tn.acc_queue) {
                 acc_queue = (uint32_t *)ctx->d_slow_count + 1;
-                const uint32_t wgs = (uint32_t)ctx->n_cu * 2u;
+                uint32_t wgs = (uint32_t)ctx->n_cu * 2u;
+                if (tn.acc_wgs) wgs = tn.acc_wgs;  // VS_ACC_WGS: fewer workgroups than CUs = the kernel on a part of the chip (r5 gate)
                 if (acc_grid > wgs) acc_grid = wgs;
             }
             // the table is written out once this many of its slots are taken: probing stays short at a low

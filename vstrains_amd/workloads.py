@@ -22,6 +22,12 @@ CONFIGS = {
             snp_rate=0.04, abundance_ratio=0.9, read_len=250, k=127, total_pairs=50_000_000, gpus=4, seed=1004, extract=False),
     4: dict(tag="configs[4]: 100-strain 30 kb synthetic, 50k-node GFA, shard 1 of 8", n_strains=100, genome_len=30000,
             snp_rate=0.076, abundance_ratio=0.97, read_len=150, k=55, total_pairs=200_000_000, gpus=8, seed=1005, extract=False),
+    # not a BASELINE config: a bench-sized graph on which the reference's algorithm can follow strains for tens of kilobases
+    # (three well-separated abundances, SNP sites mostly more than k apart), so that the extract leg's greedy walk
+    # (contig_extension) is timed doing work -- at configs[2..4] the longest strain is 3 % .. 30 % of a genome
+    5: dict(tag="extra (not in BASELINE.json): 3-strain 150 kb synthetic, 5.6k-node GFA, walk-heavy extraction", n_strains=3,
+            genome_len=150000, snp_rate=0.02, abundance_ratio=0.45, read_len=150, k=55, total_pairs=10_000_000, gpus=1, seed=1010,
+            extract=True),
 }
 
 
