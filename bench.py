@@ -359,6 +359,13 @@ def main():
                          "slow_pairs_per_step": ctx.last_timing()["slow_pairs"]},
         }
         out["config"]["input_gfa_nodes"] = n_input_nodes
+        if use_dist and os.environ.get("VS_DIST_TIMING"):
+            # measurement runs (tools/scaling_model.py): seconds per phase of dist.sum_counts_compact, mean over the steps'
+            # exchanges of this rank; every phase is followed by a device synchronisation there, so the run is NOT a bench line
+            tims = [t for c in counters for t in getattr(c, "exchange_timing", [])]
+            keys = sorted({k for t in tims for k in t})
+            out["exchange_timing"] = {k: float(np.mean([t[k] for t in tims if k in t])) for k in keys}
+            out["exchange_timing"]["exchanges"] = len(tims)
         out["roofline"].update(pmc_traffic(args.config, R, kernel_name) if not args.dirty else {"traffic": None})
         out["roofline"].update(stream_copy(dev, achieved))
         want_extract = (cfg["extract"] or args.extract) and not args.no_extract

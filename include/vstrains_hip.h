@@ -184,6 +184,12 @@ int vs_counts_zero_tracked(vs_ctx *ctx, uint32_t *d_node_mat, uint32_t *d_short_
  * that counts more pairs than a uint32 cell can hold folds into int64 totals in between. */
 int vs_counts_fold(vs_ctx *ctx, uint32_t *d_counts, int64_t *d_wide, uint64_t n);
 
+/* (ABI 8) d_occ[j] = 1 where the j-th stretch of 64 consecutive cells (cell_bytes = 4: uint32 counters, 8: int64 totals)
+ * holds a non-zero cell, else 0, for j < n_stretches.  DEVICE pointers.  No counterpart in the reference (single
+ * process): the ranks of a multi-GPU run exchange only the occupied stretches of their counters (the non-zero cells of
+ * node_mat / short_mat, PE_Inference.py:174-188, lie in a band), and this is the one pass over the buffer that finds them. */
+int vs_counts_occupied(vs_ctx *ctx, const void *d_cells, uint32_t cell_bytes, uint64_t n_stretches, uint8_t *d_occ);
+
 /* ---- C1: sum of the counters over ranks (RCCL over xGMI) ---------------------------------------
  * No counterpart in the reference (single process); read pairs are independent and the counters
  * add (PE_Inference.py:174-188), so ranks count disjoint read blocks and sum.  One process per

@@ -297,6 +297,75 @@ def test_counter_range_across_two_ranks_gloo(exchange, monkeypatch):
     assert how == [exchange, exchange]
 
 
+def _rank_exchange_shapes(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    from vstrains_amd import dist as vdist
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    gen = torch.Generator().manual_seed(500 + rank)
+    res = []
+    # (1) occupancy from the dirty-tile map instead of a scan, staged in slabs much smaller than the union
+    vdist.SLAB_STRETCHES = 7
+    vdist._staging.clear()
+    for n in (333, 600, 1000):
+        T = (n + 63) // 64
+        k = 5
+        mi, ri, ci = torch.randint(0, 2, (k,), generator=gen), torch.randint(0, n, (k,), generator=gen), torch.randint(0, n, (k,), generator=gen)
+        m = torch.zeros((2, n, n), dtype=torch.int32)
+        m[mi, ri, ci] = torch.randint(1, 2 ** 31 - 1, (k,), generator=gen, dtype=torch.int64).to(torch.int32)
+        tiles = torch.zeros(2 * T * T, dtype=torch.uint8)
+        tiles[(mi * T + (ri >> 6)) * T + (ci >> 6)] = 1
+        dense, compact = m.clone(), m.clone()
+        dist.all_reduce(dense, op=dist.ReduceOp.SUM)
+        timing = {}
+        how = vdist.sum_counts_compact(compact, tile_map=tiles, timing=timing)
+        assert torch.equal(dense, compact), n
+        res.append((n, how, timing["occupied_stretches_of_the_union"] > vdist.SLAB_STRETCHES, sorted(k for k in timing if isinstance(timing[k], float))))
+    # (2) one rank cannot get its staging buffer: every rank takes the dense ring, nobody is left in a collective
+    vdist._staging.clear()
+    plain = vdist._staging_buffer
+    if rank == 1:
+        vdist._staging_buffer = lambda head, rows: None
+    m = torch.zeros((2, 100, 100), dtype=torch.int32)
+    m[0, rank, 3] = 5 + rank
+    dense = m.clone()
+    dist.all_reduce(dense, op=dist.ReduceOp.SUM)
+    how = vdist.sum_counts_compact(m)
+    assert torch.equal(dense, m)
+    res.append(("no staging buffer on rank 1", how))
+    vdist._staging_buffer = plain
+    assert vdist.sum_counts_compact(m.clone()) == "compact"  # (and the next call is compact again)
+    if rank == 0:
+        q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_compact_exchange_from_the_tile_map_in_slabs_and_without_a_staging_buffer():
+    """Round 5: the occupancy of a large counter comes from its dirty-tile map (no scan of the
+    buffer), the occupied stretches go through the ring in bounded slabs (256 MB of staging whatever the union's size), and
+    a rank that cannot allocate its staging buffer tells its peers before any of them enters the collective -- all take
+    the dense ring.  Two gloo ranks; every sum equals the dense all-reduce cell for cell."""
+    import torch.multiprocessing as mp
+
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29500 + ((os.getpid() + 211) % 500)
+    procs = [ctxm.Process(target=_rank_exchange_shapes, args=(rk, 2, port, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for n, how, many_slabs, phases in res[:3]:
+        assert how == "compact" and many_slabs, (n, how)
+        assert phases == ["gather", "nonzero", "occupancy", "occupancy_allreduce", "ring", "scatter"], phases
+    assert res[3] == ("no staging buffer on rank 1", "dense")
+
+
 def test_async_allreduce_without_process_group_is_a_no_op():
     import torch
 

@@ -946,3 +946,24 @@ def test_randomized_campaign_short(mode):
     import warnings
 
     warnings.warn(UserWarning("fuzz_pe %s: %s" % (mode, [l for l in proc.stdout.splitlines() if l.startswith("draws ")][-1])))
+
+
+def test_occupied_stretches_kernel_equals_the_torch_expression(host, ctx):
+    """vs_counts_occupied (round 5: the one pass over a counter buffer that finds its non-zero 64-cell stretches for the
+    multi-GPU exchange, dist.sum_counts_compact) against the torch expression it replaces, on uint32 counters and int64
+    totals, banded, dense, empty, and sizes that are no multiple of anything."""
+    import torch
+
+    from vstrains_amd import dist as vdist
+
+    c = host.PeCounter.__new__(host.PeCounter)
+    c.torch, c.ctx, c.device = torch, ctx, torch.device("cuda:%d" % ctx.device)
+    gen = torch.Generator().manual_seed(9)
+    for dtype in (torch.int32, torch.int64):
+        for m, fill in ((1, 0.5), (7, 0.0), (1000, 0.001), (4097, 0.3), (100003, 0.00002)):
+            cells = (torch.rand((m, 64), generator=gen) < fill).to(dtype) * (-5 if dtype == torch.int32 else 2 ** 40)
+            if m > 6:
+                cells[5, 63] = 1
+                cells[m - 1, 0] = -1
+            head = cells.to(c.device)
+            assert torch.equal(c._occupied(head), vdist._occupancy(head)), (dtype, m, fill)

@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""GPU box (one MI355X): the single-GPU measurements that bound the multi-GPU answer (VERDICT r4 "Next" 5).
+
+north_star asks for ">= 6x at 8 GPUs" on configs[2] (strong scaling of the 10 M-pair block); this pool has one GPU per box,
+so what can be MEASURED is (a) the whole counting step at the per-rank share of 1 / 2 / 4 / 8 ranks (10 M, 5 M, 2.5 M,
+1.25 M pairs) and (b) the local phases of the counter exchange (occupancy map, union size, gather, scatter) of such a share, alone on
+the device (a one-rank gloo group).  The ring itself is MODELLED: U x 256 B through a ring all-reduce, 2 (N-1)/N of it per
+GPU, at one xGMI link's 153 GB/s derated to 70 %.  Output: profiles/r5/scaling_model.json -- labelled a model.
+
+    python tools/scaling_model.py [--config 2] [--out gpurun_out/scaling_model.json]
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LINK_GBS = 153.0 * 0.7
+
+
+def bench(extra, env=None, timeout=1500):
+    e = dict(os.environ)
+    e.update(env or {})
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra + ["--cpu-seconds", "0", "--ingest-pairs", "0", "--no-extract"],
+                          cwd=ROOT, capture_output=True, text=True, env=e, timeout=timeout)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        raise SystemExit("bench failed: %s" % proc.stderr[-2000:])
+    return json.loads(lines[-1])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "scaling_model.json"))
+    args = ap.parse_args()
+    sys.path.insert(0, ROOT)
+    from vstrains_amd.workloads import CONFIGS
+
+    block = CONFIGS[args.config]["total_pairs"] // CONFIGS[args.config]["gpus"]
+    res = {"config": args.config, "block_pairs": block, "label": "MODEL from single-GPU measurements; no run on more than one GPU exists",
+           "ring_model": "U x 256 B x 2 (N-1)/N per GPU at %.0f GB/s (one xGMI link of 153 GB/s, 70 %%)" % LINK_GBS, "share": {}}
+    for n in (1, 2, 4, 8):
+        d = bench(["--config", str(args.config), "--pairs", str(block // n), "--steps", "20", "--warmup", "3"])
+        r = d["roofline"]
+        res["share"][str(n)] = {"pairs": block // n, "ms_per_step": d["ms_per_step"], "k_pe_tiles_ms": r["kernel_ms_avg"], "counters_ms": r["accumulate_ms_avg"],
+                                "sort_ms": r["locus_sort_ms_avg"], "overflow_ms": r["slow_kernel_ms_avg"],
+                                "host_and_launch_ms": d["ms_per_step"] - r["kernel_ms_avg"] - r["accumulate_ms_avg"] - r["locus_sort_ms_avg"] - r["slow_kernel_ms_avg"]}
+        print(n, res["share"][str(n)], flush=True)
+    # the exchange's local phases, alone on the device: this process as a one-rank gloo group, the config's counters of a
+    # per-rank share in HBM, dist.sum_counts_compact with its phase timer (a device synchronisation after every phase --
+    # nothing else runs, so the waits are the phases').  The all-reduce of a one-rank group is free: the ring is modelled.
+    ex = {}
+    code = r"""
+import json, os, sys, tempfile
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from vstrains_amd import dist as vdist, pe as host
+from vstrains_amd.workloads import CONFIGS, workload_for
+config, pairs = int(sys.argv[1]), int(sys.argv[2])
+cfg = CONFIGS[config]
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%d" %% (29500 + os.getpid() %% 400), rank=0, world_size=1)
+st, pre, names, seqs, cum, logger, _ = workload_for(config, tempfile.mkdtemp())
+ctx = host.Context(0)
+ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+ctx.build_index(seqs, cfg["k"])
+reads = ctx.synth_pairs(st.genomes, cum, 20250000 + config, 0, pairs, cfg["read_len"], int(0.005 * 2 ** 32), int(0.001 * 2 ** 32))
+c = host.PeCounter(ctx)
+c.add(reads)
+torch.cuda.synchronize()
+want = c.mats.clone()
+tims = []
+for rep in range(8):
+    t = {}
+    how = vdist.sum_counts_compact(c.mats, tile_map=c.tile_map, timing=t, occupancy_fn=c._occupied if os.environ.get("VS_TORCH_OCCUPANCY") != "1" else None)
+    tims.append(t)
+assert torch.equal(want, c.mats) and how == "compact"
+keys = sorted({k for t in tims[2:] for k in t})
+print(json.dumps({k: float(np.mean([t[k] for t in tims[2:] if k in t])) for k in keys}))
+""" % ROOT
+    for n in (1, 2, 4, 8):
+        proc = subprocess.run([sys.executable, "-c", code, str(args.config), str(block // n)], cwd=ROOT, capture_output=True, text=True, timeout=900)
+        lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+        if proc.returncode != 0 or not lines:
+            raise SystemExit("exchange microbenchmark failed: %s" % proc.stderr[-2000:])
+        ex[str(n)] = {"pairs_per_rank": block // n, "phases_s": json.loads(lines[-1])}
+        print("exchange phases at share 1/%d:" % n, ex[str(n)], flush=True)
+    res["exchange_phases_alone_on_the_device"] = ex
+    t1 = res["share"]["1"]["ms_per_step"]
+    model = {}
+    for n in (2, 4, 8):
+        ph = ex[str(n)]["phases_s"] or {}
+        u = ph.get("occupied_stretches_of_the_union", 0)
+        local_ms = 1e3 * sum(ph.get(k, 0.0) for k in ("occupancy", "nonzero", "gather", "scatter"))
+        ring_ms = u * 256.0 * 2.0 * (n - 1) / n / (LINK_GBS * 1e9) * 1e3
+        count_ms = res["share"][str(n)]["ms_per_step"]
+        serial = count_ms + local_ms + ring_ms
+        overlapped = max(count_ms, local_ms + ring_ms)
+        model[str(n)] = {"count_ms": count_ms, "exchange_local_ms": local_ms, "ring_ms_modelled": ring_ms, "occupied_stretches": u,
+                         "speedup_if_nothing_overlaps": t1 / serial, "speedup_if_the_exchange_hides_behind_the_next_block": t1 / overlapped}
+    res["strong_scaling_model"] = model
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, "w") as fh:
+        json.dump(res, fh, indent=1)
+        fh.write("\n")
+    print(json.dumps(model, indent=1))
+
+
+if __name__ == "__main__":
+    main()

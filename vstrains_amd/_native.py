@@ -49,6 +49,7 @@ SYMBOLS = {
     "vs_pe_count_tracked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vs_counts_zero_tracked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "vs_counts_fold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "vs_counts_occupied": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]),
     "vs_comm_unique_id": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vs_comm_init_rank": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "vs_comm_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -78,9 +78,36 @@ __global__ void __launch_bounds__(256) k_counts_fold(uint32_t *__restrict__ coun
     }
 }
 
+// occ[j] = 1 where the j-th stretch of 64 consecutive 32-bit words holds a non-zero word (int64 totals: a stretch of 64
+// cells is two of these, OR-ed by the caller's stride).  One wavefront per stretch and turn, a lane per word, the verdict
+// by ballot: the buffer is read once, coalesced, at the rate the chip streams.
+__global__ void __launch_bounds__(256) k_counts_occupied(const uint32_t *__restrict__ words, uint64_t n_stretches, uint32_t words_per_stretch,
+                                                         uint8_t *__restrict__ occ) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * 4u;
+    for (uint64_t j = wave; j < n_stretches; j += n_waves) {
+        uint32_t any = 0u;
+        for (uint32_t k = lane; k < words_per_stretch; k += 64u) any |= words[j * words_per_stretch + k];
+        const unsigned long long hit = __ballot(any != 0u);
+        if (lane == 0u) occ[j] = hit ? 1u : 0u;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int vs_counts_occupied(vs_ctx *ctx, const void *d_cells, uint32_t cell_bytes, uint64_t n_stretches, uint8_t *d_occ) {
+    if (!ctx || (n_stretches && (!d_cells || !d_occ)) || (cell_bytes != 4u && cell_bytes != 8u)) return vs_fail(ctx, VS_E_ARG, "vs_counts_occupied: bad argument");
+    if (!n_stretches) return VS_OK;
+    VS_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t grid = (n_stretches + 3u) / 4u;
+    const uint64_t cap = (uint64_t)ctx->n_cu * 64u;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(k_counts_occupied, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const uint32_t *)d_cells, n_stretches, 16u * cell_bytes, d_occ);
+    VS_HIP(ctx, hipGetLastError());
+    return VS_OK;
+}
 
 int vs_counts_fold(vs_ctx *ctx, uint32_t *d_counts, int64_t *d_wide, uint64_t n) {
     if (!ctx || !d_counts || !d_wide) return VS_E_ARG;

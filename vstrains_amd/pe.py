@@ -495,6 +495,17 @@ class PeCounter:
             self.ctx.pe_count(reads, self.mats[0].data_ptr(), self.mats[1].data_ptr(), self.stats.data_ptr(),
                               tile_map_ptr=self.tile_map.data_ptr() if self.tile_map is not None else None)
 
+    def _occupied(self, head):
+        """uint8 [m]: which 64-cell stretches of ``head`` ([m, 64] view of a counter buffer on this device) hold a non-zero
+        cell -- one pass of the library's kernel over the buffer, on torch's current stream."""
+        torch = self.torch
+        occ = torch.empty(head.shape[0], dtype=torch.uint8, device=head.device)
+        with torch.cuda.device(self.device):
+            self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            nat.check(self.ctx._h, nat.lib().vs_counts_occupied(self.ctx._h, C.c_void_p(head.data_ptr()), head.element_size(),
+                                                                head.shape[0], C.c_void_p(occ.data_ptr())))
+        return occ
+
     def all_reduce(self):
         """Sum over the ranks of the process group, in place.  The ranks first agree (one small
         all-reduce) on whether the uint32 buffers can hold the sum; if not, or if some rank already
@@ -519,7 +530,14 @@ class PeCounter:
         target = self.wide if fold else self.mats
         # (occupied 64-cell stretches of the union of the ranks' counters through the ring, or the whole buffer when the
         # counters are dense: dist.sum_counts_compact decides from the union, which every rank sees alike)
-        self.last_all_reduce = vdist.sum_counts_compact(target, allow_compact=compact_votes == world)
+        # (the dirty-tile map of a large uint32 buffer says where its cells can be non-zero: no scan of the buffer)
+        timing = {} if os.environ.get("VS_DIST_TIMING") else None
+        self.last_all_reduce = vdist.sum_counts_compact(target, allow_compact=compact_votes == world,
+                                                        tile_map=None if fold else self.tile_map, timing=timing,
+                                                        occupancy_fn=self._occupied if target.is_cuda else None)
+        if timing is not None:
+            self.exchange_timing = getattr(self, "exchange_timing", [])
+            self.exchange_timing.append(timing)
         all_reduce_counts(None, self.stats)
         if self.tile_map is not None:
             vdist.all_reduce_max(self.tile_map)  # (the sum brought the other ranks' cells: their tiles are dirty here too)
