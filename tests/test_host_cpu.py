@@ -614,6 +614,46 @@ def _open_all_shards(host, fwd, rve, world):
             for rk in range(world)]
 
 
+def test_a_rank_that_fails_in_the_whole_file_open_fails_every_rank(tmp_path, monkeypatch):
+    """ Files with carriage returns (or gzip) are opened whole by every rank; a rank that fails alone there
+    reports it through the one-integer status exchange, so that its peers raise too instead of entering the next
+    collective without it."""
+    from vstrains_amd import pe as host
+
+    fwd, rve = str(tmp_path / "f.fq"), str(tmp_path / "r.fq")
+    for path in (fwd, rve):
+        with open(path, "wb") as fh:
+            fh.write(b"@a\r\nACGT\r\n+\r\nIIII\r\n" * 40)
+    calls = {0: [], 1: []}
+
+    def gather_for(rank, peer_status):
+        def all_gather(mine):
+            calls[rank].append(list(mine))
+            if len(mine) > 1:
+                return [mine, mine]  # (both ranks count the same small files: any flags agree)
+            return [mine, [peer_status]] if rank == 0 else [[peer_status], mine]
+        return all_gather
+
+    # rank 0 opens fine, its peer reports a failure: rank 0 raises and says who
+    with pytest.raises(RuntimeError, match=r"rank\(s\) \[1\]"):
+        host.FastqPair.open_shard(fwd, rve, None, 0, 2, all_gather=gather_for(0, 1))
+    assert [len(c) for c in calls[0]] == [7, 1] and calls[0][1] == [0]
+    # rank 1 fails in the open itself: it still takes part in the status exchange, then raises its own error
+    real_init = host.FastqPair.__init__
+
+    def failing_init(self, *a, **kw):
+        raise MemoryError("inflating the file")
+
+    monkeypatch.setattr(host.FastqPair, "__init__", failing_init)
+    with pytest.raises(MemoryError):
+        host.FastqPair.open_shard(fwd, rve, None, 1, 2, all_gather=gather_for(1, 0))
+    assert [len(c) for c in calls[1]] == [7, 1] and calls[1][1] == [1]
+    monkeypatch.setattr(host.FastqPair, "__init__", real_init)
+    # and with nobody failing the block comes back
+    fq = host.FastqPair.open_shard(fwd, rve, None, 0, 2, all_gather=gather_for(0, 0))
+    assert fq.whole and fq.total_pairs == 40 and fq.n_pairs == 20
+
+
 def test_a_rank_that_cannot_open_its_files_fails_every_rank(tmp_path):
     """FastqPair.open_shard: the failure of one rank (a file it cannot open) travels with the exchanged counts, so its
     peers raise instead of waiting in the next collective."""

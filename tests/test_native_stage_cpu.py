@@ -260,3 +260,49 @@ def test_fork_chain_limit_is_the_one_measured_on_the_real_reference_function():
         else:
             with pytest.raises(RecursionError):
                 contig_ops.remap_contigs(None, {}, {}, {}, id_mapping, [ids[0]], lg)
+
+
+def test_import_refuses_sections_that_do_not_fit_and_keeps_one_copy_of_a_sequence():
+    """ vs_stage_import is public C ABI: a scan of another snapshot, an edge whose end is no vertex, a free-list
+    entry that is no slot are ValueErrors, not out-of-bounds reads later; and a handle that is loaded again and again (as
+    reference_api does for every call) holds every distinct sequence once."""
+    import copy
+    import resource
+
+    from vstrains_amd.graph import native_stage as ns
+
+    g, nodes, edges = scrambled_state(3)
+    st = native_check.stage_over_checker(["x"], np.zeros((1, 1), dtype=np.int64))
+    st.load_graph(g, nodes, edges)
+
+    class Scan:
+        pass
+
+    sc = Scan()
+    nv = len(g.vid) + 1  # (a scan of a graph with one vertex more)
+    sc.nontrivial, sc.fork_kind = [0] * nv, [0] * nv
+    sc.chain_next, sc.chain_top, sc.chain_rank = [-1] * nv, [0] * nv, [0] * nv
+    with pytest.raises(ValueError, match="scan section"):
+        st._import(ns.pack_scan(sc))
+    live = [e for e in range(len(g.esrc)) if e not in set(g._free)]
+    bad = copy.deepcopy(g)
+    bad.esrc[live[0]] = len(g.vid) + 7
+    with pytest.raises(ValueError, match="edge end out of range"):
+        st.load_graph(bad, nodes, edges)
+    bad = copy.deepcopy(g)
+    bad._free.append(len(g.esrc) + 3)
+    with pytest.raises(ValueError, match="free edge slot out of range"):
+        st.load_graph(bad, nodes, edges)
+    # thirty loads of 20 MB of sequences: one copy stays
+    big = copy.deepcopy(g)
+    rng = random.Random(1)
+    big.vseq = ["".join(rng.choice("ACGT") for _ in range(200)) * 500 + str(i) for i in range(len(g.vid))]
+    st.load_graph(big, nodes, edges)
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    for _ in range(30):
+        st.load_graph(big, nodes, edges)
+    h, _, _ = st.graph()
+    assert list(h.vseq) == list(big.vseq)
+    grown_mb = (resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before) / 1024.0
+    assert grown_mb < 0.3 * 30 * sum(map(len, big.vseq)) / 1e6, grown_mb
+    st.close()

@@ -256,6 +256,7 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
             // (the cap, or a table the device has no room for: fewer slots per seed -- longer probe chains, the same
             // answers -- down to three quarters full; beyond that the build fails and says why)
             const uint64_t distinct = h_flags[3];
+            uint32_t gave_up_bits = 0;
             if (bits_final > bits) {
                 (void)hipFree(d_keys);
                 d_keys = nullptr;
@@ -266,12 +267,19 @@ extern "C" int vs_index_build(vs_ctx *ctx, const uint8_t *node_ascii, const uint
                     bits_final--;
                 }
                 if (!d_keys) {
+                    gave_up_bits = bits_final;  // (the smallest table that was asked for and refused)
                     bits_final = bits;
                     TRY(hipMalloc((void **)&d_keys, sizeof(unsigned long long) << bits_final));
                 }
             }
             if ((3ull << bits_final) / 4u < distinct) {
-                rc = vs_fail(ctx, VS_E_RANGE, "vs_index_build: %llu distinct seeds do not fit a seed table of 2^%u slots", (unsigned long long)distinct, bits_final);
+                //  two ways to get here: the 2^30-slot cap (a graph beyond what this build supports), or a device
+                // without room for the table the graph needs -- the caller must be able to tell them apart
+                if (gave_up_bits)
+                    rc = vs_fail(ctx, VS_E_OOM, "vs_index_build: no device memory for a seed table of 2^%u slots (%llu bytes of keys) and the %llu distinct seeds do not fit 2^%u",
+                                 gave_up_bits, (unsigned long long)(sizeof(unsigned long long) << gave_up_bits), (unsigned long long)distinct, bits_final);
+                else
+                    rc = vs_fail(ctx, VS_E_RANGE, "vs_index_build: %llu distinct seeds do not fit a seed table of 2^%u slots", (unsigned long long)distinct, bits_final);
                 goto done;
             }
             n_slots_final = 1ull << bits_final;

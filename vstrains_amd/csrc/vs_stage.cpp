@@ -61,6 +61,16 @@ struct LineArena {
         used += n;
         return p;
     }
+    // every line handed out so far is dead (the caller knows: no graph, no cached text, no queued file refers to one):
+    // keep one chunk for the next lines, give the others back
+    void recycle() {
+        if (chunks.size() > 1) {
+            std::unique_ptr<char[]> last = std::move(chunks.back());
+            chunks.clear();
+            chunks.push_back(std::move(last));
+        }
+        used = 0;
+    }
 };
 
 struct WriteJob {
@@ -383,6 +393,7 @@ struct vs_stage {
     std::unique_ptr<VsStageOps> ops;
     Names names;
     std::vector<std::string> seqs;
+    std::unordered_multimap<size_t, uint32_t> seq_by_hash;  // imported sequences by content hash (vs_stage_import reuses what the handle holds)
     Graph g;
     NameMap<uint32_t> nodes;   // simp_node_dict: id -> vertex
     PairMap<uint32_t> edges;   // simp_edge_dict: (id, id) -> edge
@@ -2685,8 +2696,22 @@ int vs_stage_import(vs_stage *st, const uint8_t *blob, uint64_t len) {
                 const uint32_t n_seq = r.get<uint32_t>();
                 auto sq = r.strings(n_seq);
                 auto seq_of = r.arr<uint32_t>(nv);
-                const uint32_t seq_base = (uint32_t)st->seqs.size();
-                for (auto &s : sq) st->seqs.push_back(std::move(s));
+                //  a handle that is loaded again and again (reference_api loads the caller's graph for every call)
+                // must not keep a copy of every sequence per load: a sequence the handle already holds is found by content
+                std::vector<uint32_t> seq_at(n_seq);
+                for (uint32_t i = 0; i < n_seq; i++) {
+                    const size_t h = std::hash<std::string>()(sq[i]);
+                    uint32_t found = 0xFFFFFFFFu;
+                    auto range = st->seq_by_hash.equal_range(h);
+                    for (auto it = range.first; it != range.second && found == 0xFFFFFFFFu; ++it)
+                        if (st->seqs[it->second] == sq[i]) found = it->second;
+                    if (found == 0xFFFFFFFFu) {
+                        found = (uint32_t)st->seqs.size();
+                        st->seqs.push_back(std::move(sq[i]));
+                        st->seq_by_hash.emplace(h, found);
+                    }
+                    seq_at[i] = found;
+                }
                 ng.vdp = r.arr<double>(nv);
                 ng.vblack = r.arr<uint8_t>(nv);
                 ng.len = r.arr<uint32_t>(nv);
@@ -2704,14 +2729,21 @@ int vs_stage_import(vs_stage *st, const uint8_t *blob, uint64_t len) {
                 ng.eflow = r.arr<double>(n_slots);
                 ng.eblack = r.arr<uint8_t>(n_slots);
                 const uint32_t n_free = r.get<uint32_t>();
-                for (uint32_t e : r.arr<uint32_t>(n_free)) ng.free_.push_back(e);
+                std::vector<uint8_t> is_free(n_slots, 0);
+                for (uint32_t e : r.arr<uint32_t>(n_free)) {
+                    if (e >= n_slots) throw StageError{VS_E_ARG, "ValueError", "free edge slot out of range"};
+                    is_free[e] = 1;
+                    ng.free_.push_back(e);
+                }
+                for (uint32_t e = 0; e < n_slots; e++)  // (a slot on the free list is nobody's edge; every other names two vertices)
+                    if (!is_free[e] && (ng.esrc[e] >= nv || ng.etgt[e] >= nv)) throw StageError{VS_E_ARG, "ValueError", "edge end out of range"};
                 ng.n_edges = r.get<uint32_t>();
                 ng.vid.resize(nv);
                 ng.vseq.resize(nv);
                 for (uint32_t v = 0; v < nv; v++) {
                     ng.vid[v] = st->names.intern(ids[v]);
                     if (seq_of[v] >= n_seq) throw StageError{VS_E_ARG, "ValueError", "sequence index out of range"};
-                    ng.vseq[v] = seq_base + seq_of[v];
+                    ng.vseq[v] = seq_at[seq_of[v]];
                     if (ng.nout[v] > ng.len[v]) throw StageError{VS_E_ARG, "ValueError", "malformed adjacency row"};
                 }
                 for (uint64_t i = 0; i < tot; i++)
@@ -2739,8 +2771,16 @@ int vs_stage_import(vs_stage *st, const uint8_t *blob, uint64_t len) {
                 st->dirty = true;
                 st->scan.valid = false;
                 st->last_text.reset();
+                //  the graph that was replaced owned the cached GFA lines: once the writers are idle and no kept
+                // graph (vs_stage_keep_graph) still points at them, their arena chunks go back
+                if (!st->have_ref) {
+                    st->writer->drain();
+                    st->arena.recycle();
+                }
             } else if (tag == VS_STAGE_SCAN) {
                 const uint32_t nv = r.get<uint32_t>();
+                //  a scan of another snapshot would index the stages' arrays out of bounds
+                if (nv != st->g.num_vertices()) throw StageError{VS_E_ARG, "ValueError", "the scan section is not of the loaded graph (vertex count differs)"};
                 st->scan.nontrivial = r.arr<uint8_t>(nv);
                 st->scan.fork_kind = r.arr<uint8_t>(nv);
                 st->scan.chain_next = r.arr<int32_t>(nv);

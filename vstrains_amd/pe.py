@@ -69,7 +69,12 @@ class FastqPair:
         that takes this rank's list of integers and returns every rank's, default ``torch.distributed``), the total
         ``min(lines_f // 4, lines_r // 4)`` (PE_Inference.py:154) and this rank's record range follow, and only the
         bytes of those records are indexed (``vs_fastq_open_records``).  ``first`` / ``total_pairs`` say where the block
-        lies.  gzip files and files with carriage returns are opened whole by every rank (``whole = True``)."""
+        lies.  gzip files and files with carriage returns are opened whole by every rank (``whole = True``).
+
+        ``all_gather`` is called TWICE per open, on every rank alike and in this order: once with seven integers (the six
+        counts and a failure flag) and once with one (the status of the open itself, whole-file or by records).  A caller
+        that brings its own must accept lists of either length (it is handed this rank's list and returns the list of
+        every rank's lists, rank order)."""
         from .dist import shard_range
 
         L = nat.lib()
@@ -107,7 +112,20 @@ class FastqPair:
         for vals in everyone:
             flags |= vals[2] | vals[5]
         if flags & 3:  # carriage returns or gzip somewhere: every rank opens the files whole and takes its block of them
-            fq = cls(fwd, rve, ctx)
+            # (a rank that fails alone here -- out of memory while inflating, a transient read error -- tells its peers
+            # through the same one-integer exchange as below, so that every rank raises instead of one)
+            fq, err = None, None
+            try:
+                fq = cls(fwd, rve, ctx)
+            except Exception as e:  # noqa: BLE001 (whatever it is, the peers must hear of it)
+                err = e
+            status = all_gather([0 if err is None else 1])
+            if err is not None:
+                raise err
+            failed = [r for r, vals in enumerate(status) if vals[0]]
+            if failed:
+                fq.close()
+                raise RuntimeError("FASTQ open failed on rank(s) %s" % failed)
             fq.total_pairs = fq.n_pairs
             fq.first, last = shard_range(fq.n_pairs, rank, world)
             fq.block_offset = fq.first
