@@ -51,7 +51,10 @@
 #ifndef TILES_WAVES_LONG
 #define TILES_WAVES_LONG 5   // the long-window instantiation (k = 127) too: 21.9 ms at configs[3] against 23.3 at 4 waves (118 VGPRs)
 #endif
-#define CHUNK (TTPB * PPT)
+#ifndef PPT_LONG
+#define PPT_LONG 1u          // the same for the long-window instantiations (MODE 2, k = 127)
+#endif
+#define CHUNK (TTPB * PPT)   // (the owner array of a tile is sized for the larger of the two)
 
 struct PeParams {
     VsIndexDev idx;
@@ -461,6 +464,9 @@ k_pe_tiles(PeParams P) {
     constexpr bool FAST = MODE != 0;
     constexpr uint32_t AB = MODE == 2 ? 9u : 8u;  // bits of the read offset packed under the node length (credit / P4)
     constexpr bool STD = SW != 0u;
+    // postings per thread and expansion chunk: two for the k = 55 shapes; ONE for the long-window comparison (MODE 2), whose
+    // second posting's state went to scratch (72 B per lane at 96 VGPRs): 8.72 -> 7.29 ms at configs[3] (r5)
+    constexpr uint32_t KPPT = MODE == 2 ? PPT_LONG : PPT, KCHUNK = TTPB * KPPT;
     constexpr uint32_t STD_WPE = SW, STD_PMAX = SP;
     const uint32_t tid = threadIdx.x;
     // (the compile-time-shape instantiation is also the one without diagnostics: the host only picks
@@ -706,29 +712,29 @@ k_pe_tiles(PeParams P) {
         __syncthreads();
         if (debug_stop == 3u) continue;
         // ---- P3: one thread per posting.  Expansion of the per-probe posting counts (CSR-style
-        // frontier expansion) in chunks of CHUNK postings: every probe marks the first position it
+        // frontier expansion) in chunks of KCHUNK postings: every probe marks the first position it
         // owns in the chunk, a workgroup-wide running maximum fills the gaps, and each thread ends
-        // up with the owners of its PPT consecutive postings in registers.
+        // up with the owners of its KPPT consecutive postings in registers.
         {
         const uint32_t total = s_pcnt[NI - 1u];
         if (count_postings && tid == 0) atomicAdd((unsigned long long *)(P.slow_count + 2), (unsigned long long)total);
-        for (uint32_t c0 = 0; c0 < total; c0 += CHUNK) {
-            for (uint32_t i = tid; i < CHUNK; i += TTPB) s_owner[i] = 0;
+        for (uint32_t c0 = 0; c0 < total; c0 += KCHUNK) {
+            for (uint32_t i = tid; i < KCHUNK; i += TTPB) s_owner[i] = 0;
             __syncthreads();
             for (uint32_t it = tid; it < NI; it += TTPB) {
                 const uint32_t incl = s_pcnt[it], excl = s_pcnt[(int)it - 1];
                 if (incl > excl) {
                     const uint32_t lo = excl > c0 ? excl : c0;
-                    const uint32_t hi = incl < c0 + CHUNK ? incl : c0 + CHUNK;
+                    const uint32_t hi = incl < c0 + KCHUNK ? incl : c0 + KCHUNK;
                     if (lo < hi) s_owner[lo - c0] = it + 1u;
                 }
             }
             __syncthreads();
-            uint32_t own[PPT];
+            uint32_t own[KPPT];
             uint32_t run = 0;
 #pragma unroll
-            for (uint32_t k2 = 0; k2 < PPT; k2++) {
-                const uint32_t v = s_owner[tid * PPT + k2];
+            for (uint32_t k2 = 0; k2 < KPPT; k2++) {
+                const uint32_t v = s_owner[tid * KPPT + k2];
                 run = v > run ? v : run;
                 own[k2] = run;
             }
@@ -751,15 +757,15 @@ k_pe_tiles(PeParams P) {
                     if (wv > pw) carry = mw > carry ? mw : carry;
                 }
             }
-            // The thread's PPT postings go through stages with every stage done for all of them before
+            // The thread's KPPT postings go through stages with every stage done for all of them before
             // the next one starts: A) which posting (LDS) and its record (one global load for
             // multi-posting seeds; the node header for single ones), B) text windows + decision.
-            bool live[PPT];
-            uint32_t p_e[PPT], p_j[PPT], p_node[PPT], p_pos[PPT], p_opp[PPT];
-            VsNodeMeta p_nm[PPT];
+            bool live[KPPT];
+            uint32_t p_e[KPPT], p_j[KPPT], p_node[KPPT], p_pos[KPPT], p_opp[KPPT];
+            VsNodeMeta p_nm[KPPT];
 #pragma unroll
-            for (uint32_t k2 = 0; k2 < PPT; k2++) {
-                const uint32_t t = c0 + tid * PPT + k2;
+            for (uint32_t k2 = 0; k2 < KPPT; k2++) {
+                const uint32_t t = c0 + tid * KPPT + k2;
                 live[k2] = t < total;
                 const uint32_t it = live[k2] ? (own[k2] > carry ? own[k2] : carry) - 1u : 0u;
                 const uint32_t excl = s_pcnt[(int)it - 1];
@@ -791,7 +797,7 @@ k_pe_tiles(PeParams P) {
                 p_node[k2] = node; p_pos[k2] = pos; p_opp[k2] = opp;
             }
 #pragma unroll
-            for (uint32_t k2 = 0; k2 < PPT; k2++) {
+            for (uint32_t k2 = 0; k2 < KPPT; k2++) {
                 if (!live[k2]) continue;
                 const uint32_t e = p_e[k2], j = p_j[k2], node = p_node[k2], opp = p_opp[k2];
                 VsNodeMeta nm = p_nm[k2];
