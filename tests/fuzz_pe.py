@@ -107,6 +107,15 @@ def main():
                     env[key] = str(choices[int(rng.integers(0, len(choices)))])
         if rng.random() < 0.15:
             env["VS_NO_MID"] = "1"  # overflow pairs straight to the general kernel
+        # (r5) the probe grid: the adaptive step grid of the compile-time-shape kernels forced on / off (it is otherwise chosen by
+        # the index's postings per seed), and now and then the grid from offset 0 of the rounds before
+        u = rng.random()
+        if u < 0.4:
+            env["VS_ADAPT_GRID"] = "1"
+        elif u < 0.55:
+            env["VS_ADAPT_GRID"] = "0"
+        elif u < 0.62 and "VS_NO_STD" not in env:
+            env["VS_PHASE0"] = "1"
         os.environ.update(env)
         try:
             ctx.build_index(g.seqs, p["k"])

@@ -42,11 +42,30 @@ def valid(ch: str) -> bool:
     return ch in _C
 
 
-def map_end(read: str, seqs: Sequence[str], rcs: Sequence[str], table, w: int, s: int, K: int, first=None, probes=None) -> List[int]:
+def step_grid(rlen: int, w: int, s: int, t: int) -> List[int]:
+    """The adaptive grid of the compile-time-shape kernels (round 5): grid positions s-1, 2s-1, ... with the positions from
+    the t-th on moved D = s - 2 - (rlen - w) mod s bases towards the read's start (t = 0: all of them, the lowest exact phase;
+    t = n: none, the highest).  Every such grid starts within the first s offsets, ends within the last s, and has no gap
+    wider than s -- so every match of K bases holds one of its points; which t an end gets (the one with the fewest
+    postings) changes the work, not the result."""
+    m = rlen - w
+    n = max(1, (m + 1) // s)
+    D = max(0, s - 2 - m % s)
+    return [s - 1 + i * s - (D if i >= t else 0) for i in range(n)]
+
+
+def map_end(read: str, seqs: Sequence[str], rcs: Sequence[str], table, w: int, s: int, K: int, first=None, probes=None, grid=None) -> List[int]:
     rlen = len(read)
     agg: Dict[int, List[int]] = {}
-    j = phase(rlen, w, s) if first is None else first
-    while j + w <= rlen:
+    if grid is not None:  # explicit probe offsets: a match is credited by the first of them inside it (left extension < gap)
+        todo = [(j, (j - grid[i - 1]) if i else s) for i, j in enumerate(grid) if j + w <= rlen]
+    else:
+        j = phase(rlen, w, s) if first is None else first
+        todo = []
+        while j + w <= rlen:
+            todo.append((j, s))
+            j += s
+    for j, gap in todo:
         if probes is not None:
             probes.append(j)
         f = read[j : j + w]
@@ -58,11 +77,11 @@ def map_end(read: str, seqs: Sequence[str], rcs: Sequence[str], table, w: int, s
                 text = rcs[node] if opp else seqs[node]
                 tlen = len(text)
                 q = tlen - p - w if opp else p
-                c = min(s, j, q)
+                c = min(gap, j, q)
                 left = 0
                 while left < c and read[j - 1 - left] == text[q - 1 - left]:
                     left += 1
-                if left >= s:
+                if left >= gap:
                     continue
                 ext = 0
                 while j + w + ext < rlen and q + w + ext < tlen and read[j + w + ext] == text[q + w + ext]:
@@ -77,7 +96,6 @@ def map_end(read: str, seqs: Sequence[str], rcs: Sequence[str], table, w: int, s
                 rec[0] += ln - K + 1
                 rec[1] = min(rec[1], minp)
                 rec[2] = min(rec[2], a)
-        j += s
     keep = []
     for node in sorted(agg):
         v, c, ki = agg[node]

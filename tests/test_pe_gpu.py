@@ -575,6 +575,7 @@ def test_device_read_generator_equals_cpu_twin(host, ctx):
     {"VS_EPT": "6", "VS_GRID_PER_CU": "1"}, {"VS_ACC_FILL": "1"}, {"VS_ACC_FILL": "100"}, {"VS_NO_FAST": "1"},
     {"VS_ACC_QUEUE": "0"}, {"VS_ACC_GRID_PER_CU": "1", "VS_ACC_QUEUE": "0"}, {"VS_NO_XCD_MAP": "1"}, {"VS_GRID_PER_CU": "8"}, {"VS_NO_STD": "1"}, {"VS_SHORTCUT": "1"}, {"VS_SHORTCUT": "0"},
     {"VS_PHASE0": "1"}, {"VS_PHASE0": "1", "VS_NO_FAST": "1"}, {"VS_PHASE0": "1", "VS_SHORTCUT": "1"},  # (r5) the probe grid from offset 0, as before vs_seed_phase
+    {"VS_ADAPT_GRID": "1"}, {"VS_ADAPT_GRID": "0"}, {"VS_ADAPT_GRID": "1", "VS_SHORTCUT": "1"}, {"VS_ADAPT_GRID": "1", "VS_NO_SORT": "1"},  # (r5) the adaptive step grid forced on / off
     {"VS_ACC_ROUND": "128"},
     {"VS_EPT": "32", "VS_ACC_ROWS": "1"}, {"VS_NO_MID": "1"},
     {"VS_ACC_ROWS": "1"}, {"VS_ACC_ROWS": "1", "VS_ROWS_PER_STRIP": "1"}, {"VS_ACC_ROWS": "1", "VS_ROWS_PER_STRIP": "64", "VS_ACC_FILL": "1"},
@@ -603,6 +604,8 @@ def test_every_kernel_variant_gives_the_same_counters(host, xctx, env, monkeypat
     assert stats == tuple(int(x) for x in want[2])
     assert ctx.last_kernel.startswith("k_pe_tiles"), ctx.last_kernel
     assert bool(ctx.last_launched & ctx.RAN_ROW_OWNERS) == (env.get("VS_ACC_ROWS") == "1")
+    if "VS_ADAPT_GRID" in env and "VS_NO_STD" not in env:
+        assert ctx.last_kernel.endswith(", true>") == (env["VS_ADAPT_GRID"] == "1"), ctx.last_kernel
 
 
 def test_switches_do_not_exist_outside_experiment_mode(tmp_path):

@@ -64,3 +64,9 @@ def test_every_probe_phase_is_exact_and_the_end_phase_is_the_shortest_grid():
                 assert probes[0] < s and probes[-1] + w + s > rlen  # (no stride of the read without a probe)
                 for first in range(s):
                     assert model.map_end(read, seqs, rcs, mtab, w, s, K, first=first) == want, (K, rlen, first, read)
+                # the adaptive grids of the compile-time-shape kernels: every step point t
+                n = max(1, (rlen - w + 1) // s)
+                for t in range(n + 1):
+                    grid = model.step_grid(rlen, w, s, t)
+                    assert len(grid) == n and grid[0] < s and grid[-1] + w + s > rlen and all(b - a <= s for a, b in zip(grid, grid[1:]))
+                    assert model.map_end(read, seqs, rcs, mtab, w, s, K, grid=grid) == want, (K, rlen, t, read)

@@ -32,6 +32,7 @@ void vs_tuning_load(VsTuning &t, int level) {
     if (const char *v = getenv("VS_ACC_FILL")) t.acc_fill_pct = atoi(v);
     if (const char *v = getenv("VS_ACC_ROUND")) { const int r = atoi(v); t.acc_round = (r == 64 || r == 128 || r == 256 || r == 512 || r == 1024) ? (uint32_t)r : 0u; }
     if (const char *v = getenv("VS_SHORTCUT")) t.shortcut = atoi(v) != 0 ? 1 : 0;
+    if (const char *v = getenv("VS_ADAPT_GRID")) t.adapt_grid = atoi(v) != 0 ? 1 : 0;
     if (const char *v = getenv("VS_TABLE_SHIFT")) t.table_shift = atoi(v) < 1 ? 1u : atoi(v) > 8 ? 8u : (uint32_t)atoi(v);
     if (const char *v = getenv("VS_ACC_ROWS")) t.acc_rows = atoi(v) != 0 ? 1 : 0;
     if (const char *v = getenv("VS_LTAB_BITS")) t.ltab_bits = atoi(v) >= 0 && atoi(v) <= 31 ? atoi(v) : -1;

@@ -109,6 +109,7 @@ struct VsTuning {
     int acc_fill_pct = -1;          // VS_ACC_FILL (-1 = 1/16 of the slots)
     uint32_t acc_round = 0;         // VS_ACC_ROUND: pairs per round of the counter kernel (0 = automatic; 64 .. 1024, power of two)
     int shortcut = -1;              // VS_SHORTCUT (-1 = by index statistics)
+    int adapt_grid = -1;            // VS_ADAPT_GRID (-1 = by index statistics): the adaptive step grid of the compile-time-shape kernels
     uint32_t table_shift = 3;       // VS_TABLE_SHIFT: seed table of >= (distinct seeds << shift) slots (3: at most an eighth full)
     int acc_rows = -1;              // VS_ACC_ROWS (-1 = by graph size): counters summed by row owners (k_rows_sum) instead of pair-major (k_pe_accumulate)
     int ltab_bits = -1;             // VS_LTAB_BITS: log2 slots of the block's list table (-1 = by block size, 0 = no table: every end stands for itself)

@@ -51,6 +51,9 @@
 #ifndef TILES_WAVES_LONG
 #define TILES_WAVES_LONG 5   // the long-window instantiation (k = 127) too: 21.9 ms at configs[3] against 23.3 at 4 waves (118 VGPRs)
 #endif
+#ifndef VS_ADAPT
+#define VS_ADAPT 1           // compile-time-shape instantiations pick, per end, the cheaper of two candidate offsets per grid position (step grid)
+#endif
 #ifndef PPT_LONG
 #define PPT_LONG 1u          // the same for the long-window instantiations (MODE 2, k = 127)
 #endif
@@ -395,6 +398,28 @@ __device__ __forceinline__ uint32_t vs_probe(const VsIndexDev &idx, uint64_t key
     }
 }
 
+// The same with the first slot of the chain already loaded (`raw`, from slot `sl`): two probes of one thread have their
+// first -- nearly always only -- slot loads in flight together before either is looked at.
+__device__ __forceinline__ uint32_t vs_probe_from(const VsIndexDev &idx, uint64_t key, uint32_t sr, uint32_t sl, uint4 raw, uint32_t *pa, uint32_t *pb) {
+    const uint32_t mask = (1u << idx.table_bits) - 1u;
+    const uint4 *tab = (const uint4 *)idx.table;
+    for (;;) {
+        const uint64_t k = (uint64_t)raw.x | ((uint64_t)raw.y << 32);
+        if (k == VS_EMPTY_KEY) return 0u;
+        if ((k & ~VS_MULTI_BIT) == key) {
+            *pa = raw.z;
+            if (k & VS_MULTI_BIT) {
+                *pb = raw.w | (sr << 31);
+                return raw.w;
+            }
+            *pb = raw.w ^ (sr << 31);
+            return 1u;
+        }
+        sl = (sl + 1u) & mask;
+        raw = tab[sl];
+    }
+}
+
 extern __shared__ __attribute__((aligned(16))) uint32_t vs_lds[];
 
 // LDS carve shared by the kernel and the host-side size computation
@@ -457,7 +482,7 @@ typedef uint32_t tidx_t;
 #else
 typedef uint64_t tidx_t;
 #endif
-template <int MODE, uint32_t SW, uint32_t SP>
+template <int MODE, uint32_t SW, uint32_t SP, bool AD = false>
 __global__ void __launch_bounds__(TTPB)
 __attribute__((amdgpu_waves_per_eu(MODE == 2 ? TILES_WAVES_LONG : TILES_WAVES, MODE == 2 ? TILES_WAVES_LONG : TILES_WAVES)))
 k_pe_tiles(PeParams P) {
@@ -467,6 +492,13 @@ k_pe_tiles(PeParams P) {
     // postings per thread and expansion chunk: two for the k = 55 shapes; ONE for the long-window comparison (MODE 2), whose
     // second posting's state went to scratch (72 B per lane at 96 VGPRs): 8.72 -> 7.29 ms at configs[3] (r5)
     constexpr uint32_t KPPT = MODE == 2 ? PPT_LONG : PPT, KCHUNK = TTPB * KPPT;
+    // (r5) ADAPT: the probe grid of an end is chosen among the exact "step grids" (tests/seed_extend_model.step_grid): grid
+    // positions s-1, 2s-1, ... of which those from the t-th on are moved D = s - 2 - (len - w) mod s bases towards the
+    // read's start.  P1 probes both candidates of every position (8 slot loads per 150-base end instead of 4), picks the t
+    // with the fewest postings, and only that grid is expanded: 57 -> 43 postings per end at configs[4], 21.9 -> 17.1
+    // at configs[2] (tools/phase_gate.py).  Any grid of the family gives the same lists; the choice only changes the work.
+    constexpr bool ADAPT = STD && AD && VS_ADAPT != 0;
+    static_assert(!ADAPT || (MODE == 2 ? STD2_EPT : STD_EPT) * SP <= TTPB, "the adaptive probe phase takes one probe position per thread");
     constexpr uint32_t STD_WPE = SW, STD_PMAX = SP;
     const uint32_t tid = threadIdx.x;
     // (the compile-time-shape instantiation is also the one without diagnostics: the host only picks
@@ -648,14 +680,75 @@ k_pe_tiles(PeParams P) {
             uint32_t st = (cls == 2) ? 1u : 0u;
             // (an end with more bytes outside ACGT than vs_seed_limits can hold: the pair takes the overflow path)
             if (FAST && st && (((mf | mr) >> 24) & VS_FLAG_MANY)) st = 3u;
-            // the probe grid of either end: phi, phi + s, ... (vs_seed_phase: the shortest exact grid for the end's length)
-            s_state[2 * tid] = st | (vs_seed_phase(mf & VS_LEN_MASK, w, s, phase0) << 8);
-            s_state[2 * tid + 1] = st | (vs_seed_phase(mr & VS_LEN_MASK, w, s, phase0) << 8);
+            // the probe grid of either end.  Plain: phi, phi + s, ... (vs_seed_phase: the shortest exact grid for the end's
+            // length), phi in bits 8..31.  ADAPT: base s - 1 in bits 8..15, the step point t in bits 16..19 (set by P1), the
+            // shift D in bits 20..27 (0: the length leaves one phase only)
+            auto grid_bits = [&](uint32_t len) {
+                if (!ADAPT || !(st & 1u)) return vs_seed_phase(len, w, s, phase0) << 8;
+                const uint32_t r = (len - w) % s;
+                return ((s - 1u) << 8) | ((r + 2u <= s ? s - 2u - r : 0u) << 20);
+            };
+            s_state[2 * tid] = st | grid_bits(mf & VS_LEN_MASK);
+            s_state[2 * tid + 1] = st | grid_bits(mr & VS_LEN_MASK);
             s_ns[2 * tid] = s_ns[2 * tid + 1] = 0;
         }
         __syncthreads();
         if (debug_stop == 1u) continue;
         // ---- P1: probes
+        if (ADAPT) {
+            // one grid position per thread; both candidate offsets probed with their slot loads in flight together
+            const uint32_t it = tid;
+            const uint32_t e = it / (STD ? STD_PMAX : 1u), pi = it - e * pmax;
+            uint32_t c0 = 0, pa0 = 0, pb0 = 0, c1 = 0, pa1 = 0, pb1 = 0, D = 0;
+            const uint32_t est = (it < NI && e < ne) ? s_state[e] : 0u;
+            const bool used = (est & 3u) == 1u;
+            if (used) {
+                const uint32_t meta = s_meta[e], rlen = meta & VS_LEN_MASK;
+                D = est >> 20;
+                const uint32_t j0 = ((est >> 8) & 0xFFu) + pi * s, j1 = j0 - D;
+                if (j0 + w <= rlen) {
+                    bool ok0 = true, ok1 = D != 0u;
+                    if ((meta >> 24) & VS_FLAG_INVALID) {
+                        uint32_t lo, hi;
+                        ok0 = vs_seed_limits(s_inv[e], j0, w, rlen, &lo, &hi);
+                        if (D) ok1 = vs_seed_limits(s_inv[e], j1, w, rlen, &lo, &hi);
+                    }
+                    uint32_t sr0, sr1;
+                    const uint64_t key0 = vs_seed_key(s_words, e * wpe * 16u + j0, w, &sr0);
+                    const uint64_t key1 = vs_seed_key(s_words, e * wpe * 16u + j1, w, &sr1);
+                    const uint4 *tab = (const uint4 *)P.idx.table;
+                    const uint32_t sl0 = vs_slot_of(key0, P.idx.table_bits), sl1 = vs_slot_of(key1, P.idx.table_bits);
+                    uint4 r0 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u), r1 = r0;  // (VS_EMPTY_KEY: a seed that is not probed misses)
+                    if (ok0) r0 = tab[sl0];
+                    if (ok1) r1 = tab[sl1];
+                    c0 = vs_probe_from(P.idx, key0, sr0, sl0, r0, &pa0, &pb0);
+                    c1 = vs_probe_from(P.idx, key1, sr1, sl1, r1, &pa1, &pb1);
+                    if (!D) { c1 = c0; pa1 = pa0; pb1 = pb0; }
+                }
+            }
+            if (it < NI) { s_pa[it] = c0; s_pb[it] = c1; }  // (staged: every thread of an end needs the end's counts)
+            __syncthreads();
+            uint32_t cnt = c0, pa = pa0, pb = pb0;
+            if (used && D) {
+                // postings of the grid with step point t: positions below t unmoved, the others moved; the first minimum
+                const uint32_t b = e * pmax;
+                uint32_t cur = 0;
+                for (uint32_t i = 0; i < pmax; i++) cur += s_pb[b + i];
+                uint32_t best = cur, bt = 0;
+                for (uint32_t t = 1; t <= pmax; t++) {
+                    cur += s_pa[b + t - 1u] - s_pb[b + t - 1u];
+                    if (cur < best) { best = cur; bt = t; }
+                }
+                if (pi >= bt) { cnt = c1; pa = pa1; pb = pb1; }
+                if (pi == 0u) s_state[e] = est | (bt << 16);
+            }
+            __syncthreads();
+            if (it < NI) {
+                s_pcnt[it] = cnt;
+                s_pa[it] = pa;
+                s_pb[it] = pb;
+            }
+        } else
         for (uint32_t it = tid; it < NI; it += TTPB) {
             uint32_t e = STD ? it / STD_PMAX : vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
             uint32_t cnt = 0, pa = 0, pb = 0;
@@ -773,7 +866,19 @@ k_pe_tiles(PeParams P) {
                 const uint32_t pa = s_pa[it], pb = s_pb[it];
                 const uint32_t e = STD ? it / STD_PMAX : vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
                 p_e[k2] = e;
-                p_j[k2] = (s_state[e] >> 8) + pi * s;
+                // the probe's read offset, and above it (bits 16..) its distance from the probe before it: a match that reaches
+                // that far down holds the earlier probe, which credits it
+                uint32_t gap = s;
+                {
+                    const uint32_t est = s_state[e];
+                    if (ADAPT) {
+                        const uint32_t D = est >> 20, t = (est >> 16) & 15u;
+                        p_j[k2] = ((est >> 8) & 0xFFu) + pi * s - (pi >= t ? D : 0u);
+                        if (pi && pi == t) gap = s - D;
+                    } else {
+                        p_j[k2] = (est >> 8) + pi * s;
+                    }
+                }
                 uint32_t node = pa, pos = pb & 0x7FFFFFFFu, opp = pb >> 31;
                 p_nm[k2].woff = 0; p_nm[k2].len = 0;
                 if (live[k2] && cnt != 1u) {  // (the record carries the node header: no second round trip)
@@ -788,18 +893,20 @@ k_pe_tiles(PeParams P) {
                         const uint32_t excl2 = s_pcnt[(int)it - 2];  // (pi != 0, so it >= 1)
                         if (excl - excl2 == 1u && s_pa[it - 1u] == node) {
                             const uint32_t pbp = s_pb[it - 1u];
-                            const uint32_t want = opp ? pos + s : pos - s;
-                            if ((pbp >> 31) == opp && (pbp & 0x7FFFFFFFu) == want && (opp || pos >= s)) live[k2] = false;
+                            const uint32_t want = opp ? pos + gap : pos - gap;
+                            if ((pbp >> 31) == opp && (pbp & 0x7FFFFFFFu) == want && (opp || pos >= gap)) live[k2] = false;
                         }
                     }
                     if (live[k2]) p_nm[k2] = P.idx.meta[node];
                 }
                 p_node[k2] = node; p_pos[k2] = pos; p_opp[k2] = opp;
+                if (ADAPT) p_j[k2] |= gap << 16;
             }
 #pragma unroll
             for (uint32_t k2 = 0; k2 < KPPT; k2++) {
                 if (!live[k2]) continue;
-                const uint32_t e = p_e[k2], j = p_j[k2], node = p_node[k2], opp = p_opp[k2];
+                const uint32_t e = p_e[k2], j = ADAPT ? p_j[k2] & 0xFFFFu : p_j[k2], node = p_node[k2], opp = p_opp[k2];
+                const uint32_t gap = ADAPT ? p_j[k2] >> 16 : s;
                 VsNodeMeta nm = p_nm[k2];
                 const uint32_t meta = s_meta[e];
                 const uint32_t rlen = meta & VS_LEN_MASK;
@@ -811,7 +918,7 @@ k_pe_tiles(PeParams P) {
                     // the clean stretch [lo, hi) of the read around the seed bounds the match
                     uint32_t lo = 0u, hi = rlen;
                     if ((meta >> 24) & VS_FLAG_INVALID) vs_seed_limits(s_inv[e], j, w, rlen, &lo, &hi);
-                    uint32_t cl = s < j - lo ? s : j - lo;
+                    uint32_t cl = gap < j - lo ? gap : j - lo;
                     cl = cl < q ? cl : q;
                     uint32_t rem = hi - j - wv;
                     const uint32_t dr = nm.len - q - wv;
@@ -821,7 +928,7 @@ k_pe_tiles(PeParams P) {
                     if (MODE == 2) vs_agree_long(s_words, e * wpe * 16u, tw, tb + q, cl, tb + q + wv, rem, j, wv, &left, &ext);
                     else vs_agree_fast<STD>(s_words, e * wpe * 16u, tw, tb + q, cl, tb + q + wv, rem, j, wv, &left, &ext);
                     len = left + wv + ext;
-                    if (left >= s || len < K) continue;  // an earlier probe lies inside this match and owns it / too short
+                    if (left >= gap || len < K) continue;  // an earlier probe lies inside this match and owns it / too short
                     a = j - left;
                     qa = q - left;
                 } else {
@@ -2375,13 +2482,24 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     if (fast_long && ept == STD2_EPT && P.pool_bits == STD2_POOL_BITS && idx.K == STD2_K && idx.w == STD2_W && idx.s == STD2_S &&
         wpe == 16u && pmax == 2u && P.accumulate && !P.debug_stop && !P.count_postings && !P.dbg_counts && !tn.no_std && !tn.phase0)
         std_shape = 4;
-    const void *tiles_fn = std_shape == 1 ? (const void *)k_pe_tiles<1, 10u, 4u>
-                           : std_shape == 2 ? (const void *)k_pe_tiles<1, 8u, 3u>
-                           : std_shape == 3 ? (const void *)k_pe_tiles<1, 7u, 2u>
-                           : fast           ? (const void *)k_pe_tiles<1, 0u, 0u>
-                           : std_shape == 4 ? (const void *)k_pe_tiles<2, 16u, 2u>
-                           : fast_long      ? (const void *)k_pe_tiles<2, 0u, 0u>
-                                            : (const void *)k_pe_tiles<0, 0u, 0u>;
+    // (r5) the adaptive step grid (k_pe_tiles, ADAPT) probes twice as many seeds to expand fewer postings: it pays where a
+    // seed has many postings -- 8.9 seed positions per distinct seed at configs[4]: 24.8 -> 22.5 ms -- and costs a little
+    // where it has few (3.6 at configs[2]: 4.80 -> 4.87 ms).  VS_ADAPT_GRID=0 / 1 overrides.
+    bool adapt = std_shape != 0 && ctx->n_distinct && ctx->n_seed_pos >= 6u * ctx->n_distinct;
+    if (tn.adapt_grid >= 0) adapt = std_shape != 0 && tn.adapt_grid != 0;
+    struct TilesFn { const void *fn; const char *name; };
+    const TilesFn tf = std_shape == 1   ? (adapt ? TilesFn{(const void *)k_pe_tiles<1, 10u, 4u, true>, "k_pe_tiles<1, 10u, 4u, true>"}
+                                                 : TilesFn{(const void *)k_pe_tiles<1, 10u, 4u>, "k_pe_tiles<1, 10u, 4u>"})
+                       : std_shape == 2 ? (adapt ? TilesFn{(const void *)k_pe_tiles<1, 8u, 3u, true>, "k_pe_tiles<1, 8u, 3u, true>"}
+                                                 : TilesFn{(const void *)k_pe_tiles<1, 8u, 3u>, "k_pe_tiles<1, 8u, 3u>"})
+                       : std_shape == 3 ? (adapt ? TilesFn{(const void *)k_pe_tiles<1, 7u, 2u, true>, "k_pe_tiles<1, 7u, 2u, true>"}
+                                                 : TilesFn{(const void *)k_pe_tiles<1, 7u, 2u>, "k_pe_tiles<1, 7u, 2u>"})
+                       : fast           ? TilesFn{(const void *)k_pe_tiles<1, 0u, 0u>, "k_pe_tiles<1, 0u, 0u>"}
+                       : std_shape == 4 ? (adapt ? TilesFn{(const void *)k_pe_tiles<2, 16u, 2u, true>, "k_pe_tiles<2, 16u, 2u, true>"}
+                                                 : TilesFn{(const void *)k_pe_tiles<2, 16u, 2u>, "k_pe_tiles<2, 16u, 2u>"})
+                       : fast_long      ? TilesFn{(const void *)k_pe_tiles<2, 0u, 0u>, "k_pe_tiles<2, 0u, 0u>"}
+                                        : TilesFn{(const void *)k_pe_tiles<0, 0u, 0u>, "k_pe_tiles<0, 0u, 0u>"};
+    const void *tiles_fn = tf.fn;
     if (lds > 64u * 1024u)
         VS_HIP(ctx, hipFuncSetAttribute(tiles_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (tn.debug_occ) {
@@ -2438,27 +2556,11 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     }
     VS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     if (!d_node_mat) VS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
-    ctx->last_kernel = std_shape == 1 ? "k_pe_tiles<1, 10u, 4u>"
-                       : std_shape == 2 ? "k_pe_tiles<1, 8u, 3u>"
-                       : std_shape == 3 ? "k_pe_tiles<1, 7u, 2u>"
-                       : fast           ? "k_pe_tiles<1, 0u, 0u>"
-                       : std_shape == 4 ? "k_pe_tiles<2, 16u, 2u>"
-                       : fast_long      ? "k_pe_tiles<2, 0u, 0u>"
-                                        : "k_pe_tiles<0, 0u, 0u>";
-    if (std_shape == 1)
-        hipLaunchKernelGGL((k_pe_tiles<1, 10u, 4u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
-    else if (std_shape == 2)
-        hipLaunchKernelGGL((k_pe_tiles<1, 8u, 3u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
-    else if (std_shape == 3)
-        hipLaunchKernelGGL((k_pe_tiles<1, 7u, 2u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
-    else if (fast)
-        hipLaunchKernelGGL((k_pe_tiles<1, 0u, 0u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
-    else if (std_shape == 4)
-        hipLaunchKernelGGL((k_pe_tiles<2, 16u, 2u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
-    else if (fast_long)
-        hipLaunchKernelGGL((k_pe_tiles<2, 0u, 0u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
-    else
-        hipLaunchKernelGGL((k_pe_tiles<0, 0u, 0u>), dim3((unsigned)grid), dim3(TTPB), lds, st, P);
+    ctx->last_kernel = tf.name;
+    {
+        void *kargs[] = {(void *)&P};
+        VS_HIP(ctx, hipLaunchKernel(tiles_fn, dim3((unsigned)grid), dim3(TTPB), kargs, lds, st));
+    }
     if (d_node_mat) {
         // the last tile may be partly empty: its unused rows must read as length 0
         const uint64_t used_ends = 2ull * n_pairs;
