@@ -27,7 +27,7 @@ case "$cmd" in
       done
     done 2>&1 | tee -a gpurun_out/sweep.log ;;
   profiles)
-    configs="${1:-2 1 3 4 0}"; tag="${2:-r4}"
+    configs="${1:-2 1 3 4 0}"; tag="${2:-r5}"
     for c in $configs; do
       bash tools/profile.sh ${tag}_c$c $c --no-extract > gpurun_out/prof_${tag}_c$c.log 2>&1; tail -2 gpurun_out/prof_${tag}_c$c.log
     done
@@ -42,14 +42,14 @@ case "$cmd" in
     for c in 2 3; do [ -d pmc_${tag}_c$c ] && { mkdir -p keep_pmc; cp pmc_${tag}_c$c/summary.json keep_pmc/ 2>/dev/null; rm -rf pmc_${tag}_c$c; mv keep_pmc pmc_${tag}_c$c; }; done
     cd "$R" ;;
   bench)
-    configs="${1:-2 1 0 3 4}"; tag="${2:-r4}"; shift; shift
+    configs="${1:-2 1 0 3 4}"; tag="${2:-r5}"; shift; shift
     for c in $configs; do
       steps=20; [ $c -ge 3 ] && steps=10
       timeout 1500 python bench.py --config $c --steps $steps --warmup 2 "$@" > gpurun_out/${tag}_bench_config${c}.json 2> gpurun_out/${tag}_bench_config${c}.err
       tail -c 300 gpurun_out/${tag}_bench_config${c}.err; python -c "$LINE" < gpurun_out/${tag}_bench_config${c}.json
     done ;;
   extract)
-    configs="${1:-2 3 4}"; tag="${2:-r4}"
+    configs="${1:-2 3 4}"; tag="${2:-r5}"
     for c in $configs; do
       timeout 1500 python bench.py --config $c --steps 3 --warmup 1 --extract --cpu-seconds 0 --ingest-pairs 0 > gpurun_out/${tag}_bench_config${c}_with_extract.json 2> gpurun_out/${tag}_bench_config${c}_with_extract.err
       python -c "$LINE" < gpurun_out/${tag}_bench_config${c}_with_extract.json
@@ -59,10 +59,10 @@ case "$cmd" in
     FUZZ_STD=1 python tests/fuzz_pe.py ${2:-200} 42 2>&1 | tail -3 | tee gpurun_out/fuzz_pe_std.log
     python tests/fuzz_graph.py ${3:-400} 44 2>&1 | tail -3 | tee gpurun_out/fuzz_graph.log ;;
   suite)
-    tag="${1:-r4}"
-    python -m pytest tests -m gpu -q 2>&1 | tail -30 > gpurun_out/${tag}_gpu_tests.log; tail -3 gpurun_out/${tag}_gpu_tests.log ;;
+    tag="${1:-r5}"
+    python -m pytest tests -m gpu -q 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Host\|^Librccl" | tail -30 > gpurun_out/${tag}_gpu_tests.log; tail -3 gpurun_out/${tag}_gpu_tests.log ;;
   final)
-    tag="${1:-r4}"
+    tag="${1:-r5}"
     bash "$0" suite $tag; bash "$0" fuzz 420 200 300; bash "$0" profiles "2 1 3 4 0" $tag; bash "$0" bench "2 1 0 3 4" $tag; bash "$0" extract "2 3 4" $tag ;;
   *) echo "unknown subcommand $cmd"; exit 2 ;;
 esac
