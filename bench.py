@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[i]")
     ap.add_argument("--pairs", type=int, default=0, help="read pairs per GPU (default: the config's total / its GPU count)")
+    ap.add_argument("--read-len", type=int, default=0, help="read length instead of the config's (kernel corner measurements; not a bench line)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: every rank counts the config's per-GPU block (the driver's contract); strong: the ranks split ONE block "
                          "(the N = 1 workload of the config) between them -- the question north_star asks at configs[2]")
@@ -178,7 +179,7 @@ def main():
 
     from vstrains_amd import pe as host
 
-    L, k = cfg["read_len"], cfg["k"]
+    L, k = (args.read_len or cfg["read_len"]), cfg["k"]
     block = args.pairs if args.pairs > 0 else cfg["total_pairs"] // cfg["gpus"]  # what one GPU counts per step at N = 1
     from vstrains_amd import dist as vdist
 

@@ -394,7 +394,7 @@ def test_ragged_block_through_sort_and_double_buffered_tiles(host, ctx, dirty):
     assert int(ref_node.sum()) > 0
 
 
-@pytest.mark.parametrize("k,max_len", [(127, 256), (99, 250), (95, 256), (94, 287), (86, 200), (127, 300), (140, 330)])
+@pytest.mark.parametrize("k,max_len", [(127, 256), (99, 250), (95, 256), (94, 287), (86, 200), (127, 300), (127, 317), (127, 318), (140, 330)])
 def test_long_stride_kernel_with_ragged_dirty_reads(host, xctx, k, max_len, monkeypatch):
     """k > 85 (probe stride > 32) / reads beyond 191 bases take the long-window straight-line kernel
     (k_pe_tiles<2>): reads of every length up to its limit, some with N or other bytes outside
@@ -420,8 +420,12 @@ def test_long_stride_kernel_with_ragged_dirty_reads(host, xctx, k, max_len, monk
     for no_fast in ("0", "1"):
         monkeypatch.setenv("VS_NO_FAST", no_fast)
         (node_mat, short_mat, stats), _ = _gpu_matrices(host, ctx, g.seqs, f, r, k)
-        # (reads beyond the long-window kernel's reach -- 256 bases with 63-base seeds -- take the generic loops either way)
-        in_reach = max_len <= (256 if k >= 95 else 287)
+        # (reads beyond the long-window kernel's reach take the generic loops either way: its eight right windows compare 256
+        # bases from where the comparison starts -- behind a verified 31-base seed, at the first base of a 63-base one -- and
+        # what has to fit is the read's part behind its first probe, vs_seed_phase: up to 317 bases at k = 127)
+        K, w = k + 1, (63 if k >= 95 else 31)
+        s_ = K - w + 1
+        in_reach = all(n - ((n - w) % s_ + s_) // 2 - (w if w <= 31 else 0) <= 256 for n in range(K, max_len + 1))
         assert ctx.last_kernel.startswith("k_pe_tiles<2" if no_fast == "0" and in_reach else "k_pe_tiles<0")
         assert np.array_equal(node_mat, ref_node) and np.array_equal(short_mat, ref_short)
         assert stats == tuple(int(x) for x in ref_stats)

@@ -2477,7 +2477,15 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         else if (wpe == 7u && pmax == 2u) std_shape = 3;   // 2 x 97..107
     }
     // longer strides and reads (k = 127 with 2 x 250 bases): the straight-line kernel with more windows
-    const bool fast_long = !fast && (!reads->d_mask || reads->d_inv4) && idx.s <= 128u && maxlen <= VS_SEED_VERIFIED(idx.w) + 256u &&
+    // Its eight right windows compare 256 bases from where the comparison starts (behind a verified seed, at the first base
+    // of a 63-base one); what has to fit is the read's part behind its FIRST probe, and the grid does not start at offset 0
+    // (vs_seed_phase): reads of up to 317 bases qualify at k = 127 (r5; 256 with the grid of rounds 1-4)
+    uint32_t long_reach = 0;
+    for (uint32_t len = idx.K; len <= maxlen; len++) {
+        const uint32_t behind = len - vs_seed_phase(len, idx.w, idx.s, tn.phase0) - VS_SEED_VERIFIED(idx.w);
+        long_reach = behind > long_reach ? behind : long_reach;
+    }
+    const bool fast_long = !fast && (!reads->d_mask || reads->d_inv4) && idx.s <= 128u && long_reach <= 256u && maxlen < 512u &&
                            ctx->max_node_len < (1u << 23) && !tn.no_fast;
     if (fast_long && ept == STD2_EPT && P.pool_bits == STD2_POOL_BITS && idx.K == STD2_K && idx.w == STD2_W && idx.s == STD2_S &&
         wpe == 16u && pmax == 2u && P.accumulate && !P.debug_stop && !P.count_postings && !P.dbg_counts && !tn.no_std && !tn.phase0)
