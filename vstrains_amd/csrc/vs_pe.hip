@@ -93,6 +93,12 @@ __device__ __forceinline__ void vs_mark_tile(uint8_t *map, uint32_t T, uint32_t 
     if (!map[t]) map[t] = 1;
 }
 
+// The same without looking first: a plain store that nothing waits for (k_pe_mid marks from inside loops of fire-and-forget
+// atomics; the load of the test above was a round trip per loop turn -- r5).
+__device__ __forceinline__ void vs_mark_tile_store(uint8_t *map, uint32_t T, uint32_t mat, uint32_t x, uint32_t y) {
+    if (map) map[((uint64_t)mat * T + (x >> 6)) * T + (y >> 6)] = 1;
+}
+
 struct Mem {  // one credited maximal exact match
     uint32_t cnt, minp, minj;
 };
@@ -1956,7 +1962,9 @@ k_pe_mid(PeParams P, const uint32_t *__restrict__ in_list, const uint32_t *__res
                     if (old == EMPTY_NODE || old == node) {
                         atomicAdd(&s_cnt[at], len - K + 1u);
                         atomicMin(&s_minp[at], opp ? nm.len - qa - len : qa);
-                        atomicMin(&s_minj[at], a);
+                        // (mid_fast: reads of at most 191 bases and nodes below 2^23 bases -- the node's length rides above the
+                        // read offset, equal for every update of the slot, and the acceptance sweep needs no header load)
+                        atomicMin(&s_minj[at], P.mid_fast ? (nm.len << 8) | a : a);
                         placed = true;
                         break;
                     }
@@ -1971,7 +1979,9 @@ k_pe_mid(PeParams P, const uint32_t *__restrict__ in_list, const uint32_t *__res
                 const uint32_t i = i0 + lane;
                 const uint32_t node = s_key[i];
                 bool acc = false;
-                if (node != EMPTY_NODE) acc = vs_accept(s_cnt[i], s_minp[i], s_minj[i], P.idx.meta[node].len, rlen, K);
+                if (node != EMPTY_NODE)
+                    acc = P.mid_fast ? vs_accept32(s_cnt[i], s_minp[i], s_minj[i] & 0xFFu, s_minj[i] >> 8, rlen, K)
+                                     : vs_accept(s_cnt[i], s_minp[i], s_minj[i], P.idx.meta[node].len, rlen, K);
                 const unsigned long long mask = __ballot(acc);
                 const uint32_t at = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
                 if (acc) {
@@ -2009,7 +2019,7 @@ k_pe_mid(PeParams P, const uint32_t *__restrict__ in_list, const uint32_t *__res
             }
             vs_wave_sync();
             for (uint32_t i = lane; i < nl * nr; i += 64u) {
-                vs_mark_tile(P.tile_map, P.tile_T, 0u, L[i / nr], R[i % nr]);
+                vs_mark_tile_store(P.tile_map, P.tile_T, 0u, L[i / nr], R[i % nr]);
                 atomicAdd(&P.node_mat[(uint64_t)L[i / nr] * N + R[i % nr]], 1u);
             }
             for (uint32_t side = 0; side < 2u; side++) {
@@ -2018,7 +2028,7 @@ k_pe_mid(PeParams P, const uint32_t *__restrict__ in_list, const uint32_t *__res
                 for (uint32_t i = lane; i < n * n; i += 64u) {
                     const uint32_t a = i / n, b = i % n, x = sv[a], y = sv[b];
                     if (x < y || a == b) {
-                        vs_mark_tile(P.tile_map, P.tile_T, 1u, x, y);
+                        vs_mark_tile_store(P.tile_map, P.tile_T, 1u, x, y);
                         atomicAdd(&P.short_mat[(uint64_t)x * N + y], 1u);
                     }
                 }
@@ -2466,7 +2476,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     // (reads with bytes outside ACGT qualify through their position lists, see k_inv4 / vs_seed_limits)
     const bool fast = (!reads->d_mask || reads->d_inv4) && idx.s <= 32u && maxlen <= 128u + idx.w + 32u &&
                       !tn.no_fast;
-    P.mid_fast = fast && VS_SEED_VERIFIED(idx.w) ? 1u : 0u;
+    P.mid_fast = fast && VS_SEED_VERIFIED(idx.w) && ctx->max_node_len < (1u << 23) ? 1u : 0u;
     // compile-time-shape instantiations (see k_pe_tiles): 1 = (10, 4), 2 = (8, 3), 3 = (7, 2)
     int std_shape = 0;
     if (fast && ept == STD_EPT && P.pool_bits == STD_POOL_BITS && maxlen <= 159u && idx.K == STD_K && idx.w == STD_W &&
