@@ -423,14 +423,15 @@ def test_chain_ranking_of_a_large_graph_on_the_device(backend, tmp_path):
     st.close()
 
 
-@pytest.mark.parametrize("config", [0, 1, 2, 3])
+@pytest.mark.parametrize("config", [0, 1, 2, 3, 5])
 def test_extraction_on_the_device_equals_the_checker_at_bench_size(backend, config, tmp_path):
     """The strain-extract leg of bench configs[0..3] (216 / 853 / 5 039 / 10 084 nodes, the reference cannot run the
     larger ones) on the link table of the config's WHOLE per-GPU block -- the 10 M pairs (12.5 M at configs[3]) the bench
     extracts from, not a prefix: every file the device run writes -- 116 stage GFAs at configs[2], about a thousand at
     configs[3], contig files, strain.paths, strain.fasta (the native stage handle with the HIP kernels underneath) --
     against the Python restatement of the stages over the numpy checker (oracle/graph_stages: Python rebuild, numpy
-    flows / scans, link sums off the host copy of the counters)."""
+    flows / scans, link sums off the host copy of the counters).  [5] is the walk-heavy extra workload (3 strains of 150 kb,
+    5 578 nodes: the greedy walk follows a strain for 86 kb), 2 M of its pairs."""
     import copy
     import hashlib
 
@@ -444,7 +445,8 @@ def test_extraction_on_the_device_equals_the_checker_at_bench_size(backend, conf
     st, pre, names, seqs, cum, logger, _ = workload_for(config, str(tmp_path / "work"))
     ctx = backend.ctx
     ctx.build_index(seqs, cfg["k"])
-    reads = ctx.synth_pairs(st.genomes, cum, 20250000 + config, 0, cfg["total_pairs"] // cfg["gpus"], cfg["read_len"], int(0.005 * 2 ** 32), int(0.001 * 2 ** 32))
+    n_pairs = cfg["total_pairs"] // cfg["gpus"] if config != 5 else 2_000_000
+    reads = ctx.synth_pairs(st.genomes, cum, 20250000 + config, 0, n_pairs, cfg["read_len"], int(0.005 * 2 ** 32), int(0.001 * 2 ** 32))
     counter = host.PeCounter(ctx)
     counter.add(reads)
     node_mat, short_mat, _ = counter.result()
