@@ -897,6 +897,20 @@ def test_bench_step_with_two_ranks_on_one_gpu(tmp_path):
     assert st["n_reads"] + st["short_reads"] + st["used_reads"] == 400000
     assert (st["node_mat_sum"], st["short_mat_sum"]) == weak_sums
     assert "compact" in out["config"]["parallelism"] or "dense" in out["config"]["parallelism"]
+    # (r5) the same with counters that keep a dirty-tile map (VS_TRACK_TILES=1: what counters of 2 GiB and more do by
+    # themselves): resets zero the marked tiles only, the exchange takes its occupancy from the map, the ranks OR their maps
+    env_t = dict(env, VS_TRACK_TILES="1", VS_DIST_TIMING="1")
+    proc = subprocess.run(
+        [sys.executable, "bench.py", "--gpus", "2", "--config", "1", "--pairs", "200000", "--steps", "3", "--warmup", "1",
+         "--cpu-seconds", "0", "--no-extract"],
+        cwd=ROOT, capture_output=True, text=True, env=env_t, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    out = json.loads([l for l in proc.stdout.splitlines() if l.startswith("{")][0])
+    st = out["pe_stats"]
+    assert (st["node_mat_sum"], st["short_mat_sum"]) == weak_sums
+    assert "compact" in out["config"]["parallelism"]
+    # (tile granularity: more stretches than the scan would find, still a fraction of the buffer)
+    assert 0 < out["exchange_timing"]["occupied_stretches_of_the_union"] < 0.5 * out["exchange_timing"]["stretches"]
 
 
 def test_two_gpu_rccl_step_and_sharded_drop_in(tmp_path):
