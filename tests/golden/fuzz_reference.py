@@ -122,12 +122,14 @@ def main():
     workers = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     scratch = tempfile.mkdtemp(prefix="vstrains_fuzz_ref_")
     jobs = []
+    big = os.environ.get("FUZZ_BIG") == "1"  # (round 5: larger cases -- up to 10 strains of up to 13 kb, a thousand nodes and more)
     for i in range(draws):
         k = int(rng.choice([21, 21, 31, 55]))
         L = int(rng.choice([100, 120, 150])) if k < 55 else 150
-        kwargs = dict(n_strains=int(rng.integers(2, 7)), genome_len=int(rng.integers(1400, 4500)) if k < 55 else int(rng.integers(3000, 6500)),
+        kwargs = dict(n_strains=int(rng.integers(2, 7)) if not big else int(rng.integers(5, 11)),
+                      genome_len=(int(rng.integers(1400, 4500)) if k < 55 else int(rng.integers(3000, 6500))) * (2 if big else 1),
                       snp_rate=float(rng.choice([0.004, 0.008, 0.01, 0.012, 0.015, 0.02])), k=k,
-                      n_pairs=int(rng.integers(1500, 9000)), read_len=L, seed=int(rng.integers(1000, 10 ** 6)),
+                      n_pairs=int(rng.integers(1500, 9000)) * (3 if big else 1), read_len=L, seed=int(rng.integers(1000, 10 ** 6)),
                       abundance_ratio=float(rng.choice([0.45, 0.55, 0.6, 0.7, 0.8, 0.95])))
         if rng.random() < 0.5:
             kwargs["scramble"] = True
