@@ -206,8 +206,7 @@ __host__ __device__ inline uint32_t vs_seed_phase(uint32_t len, uint32_t w, uint
 __host__ __device__ inline uint32_t vs_seed_probes(uint32_t len, uint32_t w, uint32_t s, bool phase0 = false) {
     if (len < w) return 0u;
     if (phase0) return (len - w) / s + 1u;
-    const uint32_t n = (len - w + 1u) / s;
-    return n ? n : 1u;  // (len < K: one probe at (len - w + s) / 2 >= len - w ... such ends are dropped before any probe)
+    return (len - w + 1u) / s;  // (0 for an end shorter than K = w + s - 1: it has no (k+1)-window, PE_Inference.py:23, and is never probed)
 }
 
 int vs_fail(vs_ctx *ctx, int code, const char *fmt, ...);
