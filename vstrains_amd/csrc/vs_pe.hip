@@ -1026,8 +1026,10 @@ k_pe_tiles(PeParams P) {
 //   node_mat : left node a against right positions [4c, 4c+4)           -> nl * ceil(nr/4) runs
 //   short_mat: list position a against positions [a+4c, a+4c+4) (b >= a) -> g(n) runs per list,
 //              g(n) = sum_{m=1..n} ceil(m/4)
-#define ACC_RUN 4u
-#define ACC_GMAX 40u  // g(16)
+#ifndef ACC_RUN
+#define ACC_RUN 4u   // 4 or 8 (8: two 16-byte partner loads per run; measured r5, see profiles/EXPERIMENTS.md)
+#endif
+#define ACC_GMAX 40u  // g(16) for runs of 4 (runs of 8 need 24)
 // The cell table: 16 k slots, 32-bit keys (k_pe_accumulate: mat * N*N + x * N + y, while 2*N*N fits 32 bits, N <= 46340;
 // the row owners: cell index relative to the strip's first row).  The 16 cells of one 64-byte stretch of a matrix row
 // sit in 16 NEIGHBOURING slots (the hash picks a group of 16 slots from the key >> 4, the low four bits pick the slot
@@ -1148,6 +1150,9 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
         struct Run {
             uint32_t x, mat, bi, be;
             VsQuad yq;
+#if ACC_RUN == 8u
+            VsQuad yq2;
+#endif
             bool ok;
         };
         auto fetch = [&](uint32_t t0) {
@@ -1183,6 +1188,9 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
             // up to ACC_RUN partners, loaded together (the row holds LC entries; reading a few words
             // past `be` stays inside the lists buffer, which carries padding, and is ignored)
             R.yq = *(const VsQuad *)(wlists + off + R.bi);  // one 16-byte load
+#if ACC_RUN == 8u
+            R.yq2 = *(const VsQuad *)(wlists + off + R.bi + 4u);
+#endif
             return R;
         };
         Run nxt;
@@ -1193,15 +1201,19 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
             if (t0 + 64u < U) nxt = fetch(t0 + 64u);
             if (!c.ok) continue;
             const uint32_t x = c.x, mat = c.mat, bi = c.bi, be = c.be;
-            const uint32_t ys[4] = {c.yq.x, c.yq.y, c.yq.z, c.yq.w};
+#if ACC_RUN == 8u
+            const uint32_t ys[ACC_RUN] = {c.yq.x, c.yq.y, c.yq.z, c.yq.w, c.yq2.x, c.yq2.y, c.yq2.z, c.yq2.w};
+#else
+            const uint32_t ys[ACC_RUN] = {c.yq.x, c.yq.y, c.yq.z, c.yq.w};
+#endif
             if (use_table == 2u) {
                 if ((ys[0] ^ ys[1] ^ ys[2] ^ ys[3] ^ x) == 0xDEADBEEFu) atomicAdd(&s_lost, 1u);  // (timing experiment: decode only)
             } else if (use_table) {
                 // the four cells' slots are read together (independent LDS loads), then counted; a
                 // slot that does not hold the cell yet goes the slow way (claim / probe / global)
-                uint32_t key[4], seen[4], at[4];
+                uint32_t key[ACC_RUN], seen[ACC_RUN], at[ACC_RUN];
 #pragma unroll
-                for (uint32_t j = 0; j < 4u; j++) {
+                for (uint32_t j = 0; j < ACC_RUN; j++) {
                     const uint32_t yv = ys[j];
                     const uint32_t cx = (mat && yv < x) ? yv : x, cy = (mat && yv < x) ? x : yv;
                     key[j] = Acc32::key(mat, cx, cy, N);
@@ -1209,7 +1221,7 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
                     seen[j] = s_key[at[j]];
                 }
 #pragma unroll
-                for (uint32_t j = 0; j < 4u; j++) {
+                for (uint32_t j = 0; j < ACC_RUN; j++) {
                     if (bi + j >= be) continue;  // (j = 0 always counts)
                     if (seen[j] == key[j]) {
                         atomicAdd(&s_cnt[at[j]], 1u);
@@ -1221,7 +1233,7 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
             } else {
                 // (VS_NO_AGG=1: every increment a global atomic)
 #pragma unroll
-                for (uint32_t j = 0; j < 4u; j++) {
+                for (uint32_t j = 0; j < ACC_RUN; j++) {
                     if (bi + j >= be) continue;
                     const uint32_t yv = ys[j];
                     const uint32_t cx = (mat && yv < x) ? yv : x, cy = (mat && yv < x) ? x : yv;
