@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """CPU: what the postings a read end expands ARE (profiles/EXPERIMENTS.md, round 5) -- credited, owned by an earlier probe,
-or too short, and whether the short ones stop at a node boundary -- counted with the string-level model of the device
+or too short, whether the short ones stop at a node boundary, and how many a two-base junction pretest would reject
+(never a credited one: asserted) -- counted with the string-level model of the device
 algorithm (tests/seed_extend_model.py) on a prefix of a bench stream.
 
     python tools/posting_classes.py <config> <pairs>
@@ -33,6 +34,18 @@ for arr in (fw,rv):
             ext=0
             while j+w+ext<rlen and q+w+ext<tlen and read[j+w+ext]==text[q+w+ext]: ext+=1
             ln=left+w+ext
+            # the junction-base pretest (EXPERIMENTS r5): a seed inside the first k bases of the strand can reach K bases
+            # only through the strand's base at position k; one inside the last k only through the base at tlen-k-1
+            rej=False
+            if q+w<=k:
+                rp=j+(k-q)
+                if rp>=rlen or read[rp]!=text[k]: rej=True
+            if q>=tlen-k:
+                rp=j-(q-(tlen-k-1))
+                if rp<0 or read[rp]!=text[tlen-k-1]: rej=True
+            if rej:
+                cnt['pretest_rejects']+=1
+                assert left>=s or ln<K, 'the pretest rejected a posting that is credited'
             if left>=s: cnt['owned_by_earlier']+=1
             elif ln<K:
                 cnt['too_short']+=1
