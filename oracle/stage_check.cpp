@@ -47,8 +47,20 @@ double pairwise(const std::vector<double> &a, size_t lo, size_t n) {
 double numpy_sum(const std::vector<double> &a) { return 0.0 + pairwise(a, 0, a.size()); }
 
 struct CheckOps : VsStageOps {
-    std::vector<int64_t> p0;  // symmetric [n, n]
+    std::vector<int64_t> p0;  // symmetric [n, n] -- or, for graphs whose dense table would not fit a host (54 k nodes: 23.7 GB),
+    std::vector<uint64_t> rp;  // its non-zero cells as CSR rows (columns ascending): vs_stage_check_create_sparse
+    std::vector<uint32_t> ci;
+    std::vector<int64_t> cv;
     uint32_t n = 0;
+    int64_t cell(uint32_t i, uint32_t j) const {
+        if (rp.empty()) return p0[(uint64_t)i * n + j];
+        uint64_t lo = rp[i], hi = rp[i + 1];
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) / 2;
+            if (ci[mid] < j) lo = mid + 1; else hi = mid;
+        }
+        return lo < rp[i + 1] && ci[lo] == j ? cv[lo] : 0;
+    }
 
     int refresh(uint32_t nv, uint32_t ne, const uint64_t *row_ptr, const uint32_t *n_out, const uint32_t *nbr, const uint32_t *eidx,
                 const double *dp, double *flow, uint8_t *nontrivial, uint8_t *fork_kind, int32_t *chain_next, int32_t *chain_top,
@@ -122,7 +134,7 @@ struct CheckOps : VsStageOps {
             for (uint64_t i = list_off[qa[q]]; i < list_off[qa[q] + 1]; i++)
                 for (uint64_t j = list_off[qb[q]]; j < list_off[qb[q] + 1]; j++) {
                     if (list_idx[i] >= n || list_idx[j] >= n) { err = "list index out of range"; return VS_E_RANGE; }
-                    s += p0[(uint64_t)list_idx[i] * n + list_idx[j]];
+                    s += cell(list_idx[i], list_idx[j]);
                 }
             out[q] = s;
         }
@@ -133,7 +145,11 @@ struct CheckOps : VsStageOps {
         for (uint32_t g = 0; g < n_groups; g++)
             for (uint64_t i = list_off[g]; i < list_off[g + 1]; i++) {
                 if (list_idx[i] >= n) { err = "list index out of range"; return VS_E_RANGE; }
-                for (uint32_t c = 0; c < n; c++) t[(size_t)g * n + c] += p0[(uint64_t)list_idx[i] * n + c];
+                if (rp.empty()) {
+                    for (uint32_t c = 0; c < n; c++) t[(size_t)g * n + c] += p0[(uint64_t)list_idx[i] * n + c];
+                } else {
+                    for (uint64_t x = rp[list_idx[i]]; x < rp[list_idx[i] + 1]; x++) t[(size_t)g * n + ci[x]] += cv[x];
+                }
             }
         for (uint32_t g = 0; g < n_groups; g++)
             for (uint32_t h = 0; h < n_groups; h++) {
@@ -148,6 +164,18 @@ struct CheckOps : VsStageOps {
 }  // namespace
 
 // p0: the symmetrised PE-link table of process_pe_info as a dense [n, n] int64 matrix (host)
+// the same table as CSR rows of its non-zero cells (row_ptr[n + 1], columns ascending within a row)
+extern "C" int vs_stage_check_create_sparse(const uint64_t *row_ptr, const uint32_t *col, const int64_t *val, uint32_t n, vs_stage **out) {
+    if (!out || !row_ptr || (row_ptr[n] && (!col || !val))) return VS_E_ARG;
+    CheckOps *ops = new CheckOps();
+    ops->n = n;
+    ops->rp.assign(row_ptr, row_ptr + n + 1);
+    ops->ci.assign(col, col + row_ptr[n]);
+    ops->cv.assign(val, val + row_ptr[n]);
+    *out = vs_stage_make(ops);
+    return VS_OK;
+}
+
 extern "C" int vs_stage_check_create(const int64_t *p0, uint32_t n, vs_stage **out) {
     if (!out || (n && !p0)) return VS_E_ARG;
     CheckOps *ops = new CheckOps();

@@ -25,6 +25,8 @@ def check_lib():
         ns.bind(L)
         L.vs_stage_check_create.restype = C.c_int
         L.vs_stage_check_create.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.vs_stage_check_create_sparse.restype = C.c_int
+        L.vs_stage_check_create_sparse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
         _lib = L
     return _lib
 
@@ -48,6 +50,22 @@ def stage_over_checker(names, p0: np.ndarray) -> ns.NativeStage:
     p0 = np.ascontiguousarray(p0, dtype=np.int64)
     h = C.c_void_p()
     rc = L.vs_stage_check_create(p0.ctypes.data, len(names), C.byref(h))
+    assert rc == 0, rc
+    st = ns.NativeStage(L, h)
+    st.set_link_names(list(names))
+    return st
+
+
+def stage_over_checker_sparse(names, row_ptr, col, val) -> ns.NativeStage:
+    """The same with the symmetrised table as CSR rows of its non-zero cells (graphs whose dense table would not fit:
+    54 k nodes are 23.7 GB)."""
+    L = check_lib()
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+    col = np.ascontiguousarray(col, dtype=np.uint32)
+    val = np.ascontiguousarray(val, dtype=np.int64)
+    assert row_ptr.shape[0] == len(names) + 1 and col.shape == val.shape and int(row_ptr[-1]) == col.shape[0]
+    h = C.c_void_p()
+    rc = L.vs_stage_check_create_sparse(row_ptr.ctypes.data, col.ctypes.data, val.ctypes.data, len(names), C.byref(h))
     assert rc == 0, rc
     st = ns.NativeStage(L, h)
     st.set_link_names(list(names))

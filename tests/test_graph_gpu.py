@@ -466,6 +466,82 @@ def test_extraction_on_the_device_equals_the_checker_at_bench_size(backend, conf
     assert [f for f in dev if dev[f] != ref[f]] == []
 
 
+def test_extraction_at_config4_size_device_operations_equal_the_cpu_checker(backend, tmp_path):
+    """configs[4] (54 465 nodes, the whole 25 M-pair block of one of its eight GPUs): the strain-extract leg with the HIP
+    kernels underneath -- flows, scans, chain ranking beyond one workgroup's 8 192 vertices, link sums over the device's
+    23.7 GB table -- against the SAME engine over the CPU checker of those operations (oracle/stage_check.cpp, the link table
+    as CSR rows of its non-zero cells): all 540 files byte for byte, the same strains.  (The Python statement of the stages,
+    which the smaller configs are held to above, would take minutes at this size; the engine's decisions are pinned by the
+    goldens and the campaigns, this test pins what the DEVICE computes at the largest BASELINE graph.)"""
+    import copy
+
+    import torch
+
+    import native_check
+    import profile_extract_cpu as pec
+    from vstrains_amd import pe as host
+    from vstrains_amd.graph import pipeline
+    from vstrains_amd.graph.hip_ops import HipPeLinks
+    from vstrains_amd.workloads import CONFIGS, workload_for
+
+    cfg = CONFIGS[4]
+    st, pre, names, seqs, cum, logger, _ = workload_for(4, str(tmp_path / "work"))
+    ctx = backend.ctx
+    ctx.build_index(seqs, cfg["k"])
+    reads = ctx.synth_pairs(st.genomes, cum, 20250004, 0, cfg["total_pairs"] // cfg["gpus"], cfg["read_len"], int(0.005 * 2 ** 32), int(0.001 * 2 ** 32))
+    counter = host.PeCounter(ctx)
+    counter.add(reads)
+    del reads
+    # the symmetrised table (IO.py:598-627: both orders of both matrices summed, the diagonal once) of the non-zero cells, in
+    # the numbering the counters are in (the index's), as CSR
+    n = counter.n
+    order = counter.node_order
+    names_int = [names[i] for i in order.tolist()] if order is not None else list(names)
+    parts_ij, parts_v = [], []
+    for lo in range(0, n, 4096):  # (row slabs: torch.nonzero does not take a tensor of 3e9 cells)
+        blk = counter.mats[0, lo:lo + 4096].to(torch.int64) + counter.mats[1, lo:lo + 4096]
+        nz = torch.nonzero(blk)
+        parts_v.append(blk[nz[:, 0], nz[:, 1]])
+        nz[:, 0] += lo
+        parts_ij.append(nz)
+    ij, v = torch.cat(parts_ij), torch.cat(parts_v)
+    del parts_ij, parts_v, blk, nz
+    off = ij[:, 0] != ij[:, 1]
+    keys = torch.cat([ij[:, 0] * n + ij[:, 1], ij[off, 1] * n + ij[off, 0]])
+    vals = torch.cat([v, v[off]])
+    uk, inv = torch.unique(keys, return_inverse=True)
+    uv = torch.zeros(uk.shape[0], dtype=torch.int64, device=uk.device).scatter_add_(0, inv, vals)
+    rows = (uk // n).cpu().numpy()
+    col = (uk % n).cpu().numpy().astype(np.uint32)
+    val = uv.cpu().numpy()
+    row_ptr = np.zeros(n + 1, dtype=np.uint64)
+    row_ptr[1:] = np.cumsum(np.bincount(rows, minlength=n))
+    del ij, v, keys, vals, uk, inv, uv
+    torch.cuda.empty_cache()
+
+    class CheckerOps:
+        def native_stage(self, table):
+            return native_check.stage_over_checker_sparse(names_int, row_ptr, col, val)
+
+    outs = []
+    for which in ("device", "checker"):
+        out = str(tmp_path / which)
+        for sub in ("gfa", "tmp"):
+            os.makedirs(os.path.join(out, sub), exist_ok=True)
+        if which == "device":
+            strains = pipeline.extract_strains(copy.deepcopy(pre), HipPeLinks.from_counter(ctx, counter, names), backend, logger, out)
+        else:
+            strains = pipeline.extract_strains(copy.deepcopy(pre), None, CheckerOps(), logger, out)
+        outs.append((pec.digests(out), {k: (list(rec[0]), rec[1], rec[2]) for k, rec in strains.items()}))
+        import shutil
+
+        shutil.rmtree(out)  # (2.7 GB of stage graphs per run)
+    (dev, s_dev), (ref, s_ref) = outs
+    assert s_dev == s_ref and len(s_dev) > 100
+    assert sorted(dev) == sorted(ref) and len(dev) > 500
+    assert [f for f in dev if dev[f] != ref[f]] == []
+
+
 def test_randomized_extraction_campaign_short():
     """tests/fuzz_graph.py for fifteen seconds: random strain sets through the workload generator, the
     extraction leg on the device against the same host logic over the numpy checker, every written
