@@ -235,3 +235,17 @@ def test_runaway_trivial_split_ends_like_the_reference_and_quickly(name, tmp_pat
     with open(os.path.join(out, "vstrains.log")) as fh:
         assert "Strange topology detected, exit trivial split immediately" in fh.read()
     assert took < 30.0, took
+
+
+def test_a_runaway_that_outgrows_memory_ends_with_memoryerror(tmp_path, monkeypatch):
+    """Fuzz draw 997 of campaign 782 (round 5): after a stage that already ran away the N^2 bound of ``global_trivial_split``
+    is millions of forks with ids that grow by two characters each -- the reference was still inside that loop after a
+    quarter of an hour (its campaign run: reference_timeout), the engine had filled 40 GB after seven minutes.  Past 2 GiB of
+    id text the engine now ends the call with MemoryError (draw 997: after 34 s, 55 911 forks).  Here the limit is set to
+    1 MB on the k = 55 runaway golden, whose ids reach 73 MB: the MemoryError comes before the reference's RecursionError."""
+    monkeypatch.setenv("VS_STAGE_NAME_LIMIT_MB", "1")
+    case = Case("circular_runaway_k55")
+    inp = case.inputs(str(tmp_path))
+    out = str(tmp_path / "out")
+    with pytest.raises(MemoryError, match="ran away"):
+        pipeline.run(case.args(inp, out), file_logger(out, "valve"), NativeBackend(case))

@@ -51,10 +51,12 @@ struct LineRef {
 struct LineArena {
     std::vector<std::unique_ptr<char[]>> chunks;
     size_t used = 0, cap = 0;
+    size_t total = 0;  // bytes of all chunks
     char *alloc(size_t n) {
         if (used + n > cap) {
             cap = std::max<size_t>(n, (size_t)1 << 22);
             chunks.emplace_back(new char[cap]);
+            total += cap;
             used = 0;
         }
         char *p = chunks.back().get() + used;
@@ -70,6 +72,7 @@ struct LineArena {
             chunks.push_back(std::move(last));
         }
         used = 0;
+        total = chunks.empty() ? 0 : cap;
     }
 };
 
@@ -430,6 +433,12 @@ struct vs_stage {
         return p;
     }
     LineArena arena;
+    static constexpr size_t ARENA_LIMIT = (size_t)1 << 30;  // cached GFA lines beyond this many bytes are dropped at the next re-initialisation
+    static size_t name_bytes_limit() {  // 2 GiB of id text (held twice); VS_STAGE_NAME_LIMIT_MB: tests
+        const char *v = getenv("VS_STAGE_NAME_LIMIT_MB");
+        return v && atoi(v) > 0 ? (size_t)atoi(v) << 20 : (size_t)2 << 30;
+    }
+    uint64_t n_arena_recycled = 0;
     std::unique_ptr<FileWriter> writer;
     std::vector<LogLine> log;
     bool debug_log = false;
@@ -791,6 +800,20 @@ void vs_stage::reinit(const std::string &filename) {
         return;
     }
     SectionTimer rebuild_timer(sections, "reinit.rebuild");
+    // (r5) The cached GFA lines live in an arena that only grows, and a line dies with its vertex or edge.  A runaway trivial
+    // split on a circular graph (ids of tens of kilobytes, thousands of new vertices per stage: fuzz draw 997 of campaign 782,
+    // on which the reference itself runs for a quarter of an hour) filled 40 GB that way.  Past ARENA_LIMIT the cache is
+    // dropped as a whole once the writers are idle: every line is then formatted again when it is next written.
+    if (arena.total > ARENA_LIMIT) {
+        writer->drain();
+        for (auto &l : g.vline) l = LineRef();
+        for (auto &l : g.eline) l = LineRef();
+        for (auto &l : ref_g.vline) l = LineRef();
+        for (auto &l : ref_g.eline) l = LineRef();
+        last_text.reset();
+        arena.recycle();
+        n_arena_recycled++;
+    }
     Graph &ng = spare_g;
     ng.reset();
     const size_t nv_est = nodes.size();
@@ -1355,10 +1378,19 @@ int64_t vs_stage::global_trivial_split(NameMap<std::vector<Nid>> &id_mapping) {
             return 0;
         }
     }
+    // (r5) A runaway (a fork of "X*B" leaves an "X*B*B" that forks again) after a stage that already ran away has a bound of
+    // millions of forks and ids that grow by two characters each: the reference then spends hours inside this loop with a
+    // dictionary of ever longer strings (fuzz draw 997 of campaign 782: still running after a quarter of an hour), and this
+    // engine, fifty times faster, filled 40 GB in seven minutes.  Neither terminates in practice.  Past NAME_BYTES_LIMIT of
+    // id text the call fails with MemoryError -- what the reference's interpreter ends with too, on a machine-dependent day.
+    const size_t name_limit = name_bytes_limit();
     bool progressed = true;
     while (progressed && forks < bound) {
         progressed = false;
         std::vector<Nid> sweep = nodes.keys();
+        if (names.bytes > name_limit)
+            throw StageError{VS_E_OOM, "MemoryError", "graph trivial split ran away: " + std::to_string(forks) + " forks, " + std::to_string(names.bytes >> 20) +
+                                                         " MB of vertex ids (the reference does not terminate on this input either)"};
         for (Nid name : sweep) {
             const uint32_t v = node(name);
             if (!g.vblack[v]) continue;

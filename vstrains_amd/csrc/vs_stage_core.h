@@ -30,12 +30,14 @@ struct StageError {
 struct Names {
     std::vector<std::string> str;
     std::unordered_map<std::string, Nid> idx;
+    size_t bytes = 0;  // characters of all names (each is held twice: here and as the map's key)
     Nid intern(const std::string &s) {
         auto it = idx.find(s);
         if (it != idx.end()) return it->second;
         Nid n = (Nid)str.size();
         str.push_back(s);
         idx.emplace(s, n);
+        bytes += s.size();
         return n;
     }
     Nid find(const std::string &s) const {
