@@ -419,18 +419,16 @@ struct vs_stage {
     std::shared_ptr<std::vector<LineRef>> fresh_lines(size_t n) {
         for (auto &p : line_pool)
             if (p.use_count() == 1) {  // (only the pool holds it: no writer, not the last stage's text)
-                p->clear();
-                p->reserve(n);
+                if (p->size() < n) p->resize(n);  // (the caller overwrites every entry it keeps and cuts the rest)
                 return p;
             }
-        if (line_pool.size() < 16) {
-            line_pool.push_back(std::make_shared<std::vector<LineRef>>());
-            line_pool.back()->reserve(n);
+        // (writers that fall behind keep their vectors: the pool grows to 16 vectors or 64 MB of them, past that a vector is
+        // made per stage and freed by its writer, with the page faults that costs)
+        if (line_pool.size() < 16 || line_pool.size() * n * sizeof(LineRef) < ((size_t)64 << 20)) {
+            line_pool.push_back(std::make_shared<std::vector<LineRef>>(n));
             return line_pool.back();
         }
-        auto p = std::make_shared<std::vector<LineRef>>();
-        p->reserve(n);
-        return p;
+        return std::make_shared<std::vector<LineRef>>(n);
     }
     LineArena arena;
     static constexpr size_t ARENA_LIMIT = (size_t)1 << 30;  // cached GFA lines beyond this many bytes are dropped at the next re-initialisation
@@ -814,54 +812,89 @@ void vs_stage::reinit(const std::string &filename) {
         arena.recycle();
         n_arena_recycled++;
     }
+    std::shared_ptr<std::vector<LineRef>> lines;
     Graph &ng = spare_g;
     ng.reset();
-    const size_t nv_est = nodes.size();
-    ng.vid.reserve(nv_est); ng.vseq.reserve(nv_est); ng.vdp.reserve(nv_est); ng.vline.reserve(nv_est);
-    auto lines = fresh_lines(nodes.size() + edges.size());
+    // Both passes write into arrays sized for every live entry and cut them to what survived: a stage graph of a few
+    // thousand vertices is rebuilt several hundred times per run, and the growth checks of push_back were a third of it.
+    const size_t nv_max = nodes.size(), ne_max = edges.size();
+    ng.vid.resize(nv_max); ng.vseq.resize(nv_max); ng.vdp.resize(nv_max); ng.vline.resize(nv_max);
+    lines = fresh_lines(nv_max + ne_max);
+    LineRef *line_out = lines->data();
     // surviving vertices, map order
     NameMap<uint32_t> &nn = spare_nodes;
     nn.clear();
     if (nn.slot.size() < names.size()) nn.slot.resize(names.size() + names.size() / 4, -1);
-    nn.ents.reserve(nv_est);
-    for (auto &ent : nodes.ents) {
-        if (!ent.live || !g.vblack[ent.v]) continue;
-        const uint32_t v = ent.v;
-        lines->push_back(seg_line(v));
-        const uint32_t nvx = (uint32_t)ng.vid.size();
-        ng.vid.push_back(g.vid[v]);
-        ng.vseq.push_back(g.vseq[v]);
-        ng.vdp.push_back(g.vdp[v]);
-        ng.vline.push_back(g.vline[v]);
-        nn.set(g.vid[v], nvx);
+    nn.ents.resize(nv_max);
+    uint32_t nv = 0;
+    {
+        const uint8_t *vblack = g.vblack.data();
+        const Nid *vid = g.vid.data();
+        const uint32_t *vseq = g.vseq.data();
+        const double *vdp = g.vdp.data();
+        int32_t *slot = nn.slot.data();
+        NameMap<uint32_t>::Ent *out = nn.ents.data();
+        for (const auto &ent : nodes.ents) {
+            if (!ent.live) continue;
+            const uint32_t v = ent.v;
+            if (!vblack[v]) continue;
+            LineRef l = g.vline[v];
+            if (!l.p) l = seg_line(v);
+            const Nid name = vid[v];
+            line_out[nv] = l;
+            ng.vid[nv] = name;
+            ng.vseq[nv] = vseq[v];
+            ng.vdp[nv] = vdp[v];
+            ng.vline[nv] = l;
+            out[nv].k = name; out[nv].v = nv; out[nv].live = true;  // (the names of a map are distinct: what NameMap::set would do)
+            slot[name] = (int32_t)nv;
+            nv++;
+        }
     }
-    const uint32_t nv = (uint32_t)ng.vid.size();
+    ng.vid.resize(nv); ng.vseq.resize(nv); ng.vdp.resize(nv); ng.vline.resize(nv);
+    nn.ents.resize(nv);
+    nn.n_live = nv;
     ng.vblack.assign(nv, 1);
     // surviving edges, map order (both ends looked up BY NAME among the surviving vertices, as graph_to_gfa does)
     PairMap<uint32_t> &ne_map = spare_edges;
     ne_map.clear();
-    ne_map.reserve(edges.size());
+    ne_map.ents.resize(ne_max);
     std::vector<uint32_t> &deg = spare_deg;
     deg.assign(nv, 0);
     // (nn was filled front to back without a pop: its slot of a name IS the new vertex index)
     const int32_t *new_of_name = nn.slot.data();
     const size_t n_names = nn.slot.size();
-    ng.esrc.reserve(edges.size()); ng.etgt.reserve(edges.size()); ng.eovl.reserve(edges.size()); ng.eline.reserve(edges.size());
-    for (auto &ent : edges.ents) {
-        if (!ent.live || !g.eblack[ent.v]) continue;
-        const Nid nu = key_first(ent.k), nw = key_second(ent.k);
-        const int32_t s = nu < n_names ? new_of_name[nu] : -1, t = nw < n_names ? new_of_name[nw] : -1;
-        if (s < 0 || t < 0) continue;
-        lines->push_back(link_line(ent.v, nu, nw));
-        const uint32_t ei = (uint32_t)ng.esrc.size();
-        ng.esrc.push_back((uint32_t)s);
-        ng.etgt.push_back((uint32_t)t);
-        ng.eovl.push_back(g.eovl[ent.v]);
-        ng.eline.push_back(g.eline[ent.v]);
-        ne_map.append_new(ent.k, ei);  // (the keys of a map are distinct)
-        deg[s]++;
-        deg[t]++;
+    ng.esrc.resize(ne_max); ng.etgt.resize(ne_max); ng.eovl.resize(ne_max); ng.eline.resize(ne_max);
+    uint32_t n_kept = 0;
+    {
+        const uint8_t *eblack = g.eblack.data();
+        const int64_t *eovl = g.eovl.data();
+        PairMap<uint32_t>::Ent *out = ne_map.ents.data();
+        uint32_t *dg = deg.data();
+        LineRef *eline_out = line_out + nv;
+        for (const auto &ent : edges.ents) {
+            if (!ent.live || !eblack[ent.v]) continue;
+            const Nid nu = key_first(ent.k), nw = key_second(ent.k);
+            const int32_t s = nu < n_names ? new_of_name[nu] : -1, t = nw < n_names ? new_of_name[nw] : -1;
+            if (s < 0 || t < 0) continue;
+            LineRef l = g.eline[ent.v];
+            if (!l.p) l = link_line(ent.v, nu, nw);
+            eline_out[n_kept] = l;
+            ng.esrc[n_kept] = (uint32_t)s;
+            ng.etgt[n_kept] = (uint32_t)t;
+            ng.eovl[n_kept] = eovl[ent.v];
+            ng.eline[n_kept] = l;
+            out[n_kept].k = ent.k; out[n_kept].v = n_kept; out[n_kept].live = true;  // (PairMap::append_new: the keys of a map are distinct)
+            dg[s]++;
+            dg[t]++;
+            n_kept++;
+        }
     }
+    ng.esrc.resize(n_kept); ng.etgt.resize(n_kept); ng.eovl.resize(n_kept); ng.eline.resize(n_kept);
+    ne_map.ents.resize(n_kept);
+    ne_map.n_live = n_kept;
+    ne_map.tab_valid = false;
+    lines->resize((size_t)nv + n_kept);
     const uint32_t n_e = (uint32_t)ng.esrc.size();
     writer->submit(WriteJob{filename, lines});
     info(filename + " is stored..");
