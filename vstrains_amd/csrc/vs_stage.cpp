@@ -402,6 +402,27 @@ struct vs_stage {
     PairMap<uint32_t> edges;   // simp_edge_dict: (id, id) -> edge
     NameMap<Contig> contigs;   // contig_dict
     LinkTable full_link;       // best_matching's table, consumed by path_extension
+    // path_extension filters the table against every re-initialised graph (Extension.py:527-560).  Once a pass has run,
+    // every kept link (a, b) of an entry `no` has a among the in- and b among the out-neighbours of `no`; the next pass can
+    // only drop something from an entry whose vertex lost an edge (or vanished) since.  The re-initialisation notes the ends
+    // of every edge and every vertex it drops while this flag is set, and the pass looks at those entries only.
+    bool table_filtered = false;
+    std::vector<Nid> filter_affected;
+    std::vector<uint8_t> affected_mark;  // by name
+    void mark_affected(Nid n) {
+        if (n >= affected_mark.size()) affected_mark.resize((size_t)n + 1 + affected_mark.size() / 2, 0);
+        if (affected_mark[n]) return;
+        affected_mark[n] = 1;
+        filter_affected.push_back(n);
+    }
+    static bool check_hints() {  // VS_CHECK_UNTOUCHED=1 (the test suites set it): every shortcut of this kind is verified in full
+        static const bool on = getenv("VS_CHECK_UNTOUCHED") && atoi(getenv("VS_CHECK_UNTOUCHED")) != 0;
+        return on;
+    }
+    void forget_affected() {
+        for (Nid n : filter_affected) affected_mark[n] = 0;
+        filter_affected.clear();
+    }
     NameMap<Contig> strains;   // path_extension's result
     NameMap<int64_t> usages;
     PairMap<uint8_t> assigned;  // edge_cleaning's result: (source id, target id) -> the edge is accounted for
@@ -834,10 +855,17 @@ void vs_stage::reinit(const std::string &filename) {
         const double *vdp = g.vdp.data();
         int32_t *slot = nn.slot.data();
         NameMap<uint32_t>::Ent *out = nn.ents.data();
+        const bool note = table_filtered;
         for (const auto &ent : nodes.ents) {
-            if (!ent.live) continue;
+            if (!ent.live) {
+                if (note) mark_affected(ent.k);
+                continue;
+            }
             const uint32_t v = ent.v;
-            if (!vblack[v]) continue;
+            if (!vblack[v]) {
+                if (note) mark_affected(ent.k);
+                continue;
+            }
             LineRef l = g.vline[v];
             if (!l.p) l = seg_line(v);
             const Nid name = vid[v];
@@ -872,11 +900,18 @@ void vs_stage::reinit(const std::string &filename) {
         PairMap<uint32_t>::Ent *out = ne_map.ents.data();
         uint32_t *dg = deg.data();
         LineRef *eline_out = line_out + nv;
+        const bool note = table_filtered;
         for (const auto &ent : edges.ents) {
-            if (!ent.live || !eblack[ent.v]) continue;
             const Nid nu = key_first(ent.k), nw = key_second(ent.k);
+            if (!ent.live || !eblack[ent.v]) {
+                if (note) { mark_affected(nu); mark_affected(nw); }
+                continue;
+            }
             const int32_t s = nu < n_names ? new_of_name[nu] : -1, t = nw < n_names ? new_of_name[nw] : -1;
-            if (s < 0 || t < 0) continue;
+            if (s < 0 || t < 0) {
+                if (note) { mark_affected(nu); mark_affected(nw); }
+                continue;
+            }
             LineRef l = g.eline[ent.v];
             if (!l.p) l = link_line(ent.v, nu, nw);
             eline_out[n_kept] = l;
@@ -1919,6 +1954,7 @@ void vs_stage::best_matching() {
     }
     links_prefetch(pairs);
     full_link.clear();
+    table_filtered = false;
     for (size_t i = 0; i < branches.size(); i++) {
         const Nid no = branches[i].first;
         const auto &us = shape[i].first, &ws = shape[i].second;
@@ -2078,12 +2114,41 @@ void vs_stage::consume(const std::vector<uint32_t> &path, double pcov, double th
         }
     }
     if (!grayed) return;  // (every linked vertex was black when the pass filtered the table against the re-initialised graph)
-    for (auto &t : full_link.ents) {
-        if (!t.live) continue;
-        for (uint64_t k : t.v.keys()) {
-            if (!g.vblack[node(key_first(k))] || !g.vblack[node(key_second(k))]) t.v.pop(k);
+    auto drop_gray_links = [&](PairMap<int64_t> &kept) {
+        for (size_t li = 0; li < kept.ents.size(); li++) {
+            if (!kept.ents[li].live) continue;
+            const uint64_t k = kept.ents[li].k;
+            if (!g.vblack[node(key_first(k))] || !g.vblack[node(key_second(k))]) kept.pop(k);
         }
+    };
+    if (table_filtered) {
+        // (a filtered table links in- and out-neighbours of the entry's vertex only, and nothing was written to the graph since
+        // the pass: a link with a gray end sits in the entry of one of that vertex's neighbours)
+        std::vector<uint32_t> todo;
+        auto want = [&](Nid n) {
+            if (full_link.has(n)) todo.push_back((uint32_t)full_link.slot[n]);
+        };
+        for (uint32_t v : path) {
+            if (g.vblack[v]) continue;
+            want(g.vid[v]);
+            const uint32_t *row = g.a_nbr.data() + g.off[v];
+            for (uint32_t i = 0; i < g.len[v]; i++) want(g.vid[row[i]]);
+        }
+        std::sort(todo.begin(), todo.end());
+        todo.erase(std::unique(todo.begin(), todo.end()), todo.end());
+        for (uint32_t ti : todo)
+            if (full_link.ents[ti].live) drop_gray_links(full_link.ents[ti].v);
+        if (check_hints())  // (tests: no link with a gray end anywhere else)
+            for (auto &t : full_link.ents) {
+                if (!t.live) continue;
+                for (auto &l : t.v.ents)
+                    if (l.live && (!g.vblack[node(key_first(l.k))] || !g.vblack[node(key_second(l.k))]))
+                        state_error("consume: a link with a gray end outside the entries looked at");
+            }
+        return;
     }
+    for (auto &t : full_link.ents)
+        if (t.live) drop_gray_links(t.v);
 }
 
 // reduce_Anode: replace extracted-path ids (A<n>, possibly with a split suffix) by their member ids until none is left
@@ -2135,6 +2200,8 @@ void vs_stage::path_extension(double threshold, const std::string &temp_dir) {
     strains.clear();
     NameMap<std::vector<Nid>> members;
     LinkTable &table = full_link;
+    table_filtered = false;
+    forget_affected();
     int64_t rid = 1;
     auto bubble_vertices = [&](const std::vector<Nid> &ids) {
         std::vector<double> dps;
@@ -2160,12 +2227,12 @@ void vs_stage::path_extension(double threshold, const std::string &temp_dir) {
         if (n_forks == 0) {
             // nothing forked: every id stands for itself; the rewrite only drops what no longer is a link between an
             // in- and an out-neighbour, the survivors keep their order
-            for (size_t ti = 0; ti < table.ents.size(); ti++) {
-                if (!table.ents[ti].live) continue;
+            auto filter_entry = [&](size_t ti) {
+                if (!table.ents[ti].live) return;
                 const Nid no = table.ents[ti].k;
-                if (!nodes.has(no)) { table.pop(no); continue; }
+                if (!nodes.has(no)) { table.pop(no); return; }
                 PairMap<int64_t> &kept = table.ents[ti].v;
-                if (kept.size() == 0) continue;
+                if (kept.size() == 0) return;
                 const uint32_t v = node(no);
                 const uint32_t *row = g.a_nbr.data() + g.off[v];
                 const uint32_t n_o = g.nout[v], n_all = g.len[v];
@@ -2178,17 +2245,72 @@ void vs_stage::path_extension(double threshold, const std::string &temp_dir) {
                     for (uint32_t i = 0; i < n_o && !out_ok; i++) out_ok = row[i] == b;
                     if (!(in_ok && out_ok)) kept.pop(link);
                 }
+            };
+            if (table_filtered) {
+                // (the entries of the ids the re-initialisations since the last pass noted, in table order: no other
+                // entry can lose a link or name an id that is no node any more)
+                std::vector<uint32_t> todo;
+                for (Nid n : filter_affected)
+                    if (table.has(n)) todo.push_back((uint32_t)table.slot[n]);
+                std::sort(todo.begin(), todo.end());
+                for (uint32_t ti : todo) filter_entry(ti);
+                if (check_hints()) {  // (tests: a whole pass must find nothing left to do)
+                    for (auto &t : table.ents) {
+                        if (!t.live) continue;
+                        if (!nodes.has(t.k)) state_error("table filter: the entry of a vanished id was not looked at");
+                        const uint32_t v = node(t.k);
+                        const uint32_t *row = g.a_nbr.data() + g.off[v];
+                        for (auto &l : t.v.ents) {
+                            if (!l.live) continue;
+                            const uint32_t *a = nodes.get(key_first(l.k)), *b = nodes.get(key_second(l.k));
+                            if (!a || !b) state_error("table filter: a link to an id that is no node was not looked at");
+                            bool in_ok = false, out_ok = false;
+                            for (uint32_t i = g.nout[v]; i < g.len[v]; i++) in_ok |= row[i] == *a;
+                            for (uint32_t i = 0; i < g.nout[v]; i++) out_ok |= row[i] == *b;
+                            if (!(in_ok && out_ok)) state_error("table filter: a link that has to go was not looked at");
+                        }
+                    }
+                }
+            } else {
+                for (size_t ti = 0; ti < table.ents.size(); ti++) filter_entry(ti);
             }
+            forget_affected();
+            table_filtered = true;
             sections.slot("px.table_filter") += now_s() - t_filter;
             for (auto &u : usages.ents)
                 if (u.live && !closure.is_known(u.k)) key_error(names[u.k]);
         } else {
             std::vector<Nid> scratch_u, scratch_w;
+            const bool shortcut = table_filtered;
             for (Nid no : table.keys()) {
                 if (!nodes.has(no)) { table.pop(no); continue; }
                 PairMap<int64_t> kept;
                 table.pop(no, &kept);
                 const uint32_t v = node(no);
+                if (shortcut && !(no < affected_mark.size() && affected_mark[no])) {
+                    // (filtered table, and this vertex lost no edge since: each link's two ids still are an in- and an out-
+                    // neighbour, so neither was forked -- a forked neighbour takes its edge with it -- and the rewrite below
+                    // would put every link back where it was)
+                    if (check_hints()) {
+                        const uint32_t *row = g.a_nbr.data() + g.off[v];
+                        for (auto &l : kept.ents) {
+                            if (!l.live) continue;
+                            const Nid u = key_first(l.k), w = key_second(l.k);
+                            const std::vector<Nid> *ku = id_mapping.get(u), *kw = id_mapping.get(w);
+                            if ((ku && !ku->empty()) || (kw && !kw->empty()) || !closure.is_known(u) || !closure.is_known(w))
+                                state_error("table rewrite: a forked or unknown id in an entry that was passed over");
+                            const uint32_t *a = nodes.get(u), *b = nodes.get(w);
+                            if (!a || !b) state_error("table rewrite: a link to an id that is no node in an entry that was passed over");
+                            bool in_ok = false, out_ok = false;
+                            for (uint32_t i = g.nout[v]; i < g.len[v]; i++) in_ok |= row[i] == *a;
+                            for (uint32_t i = 0; i < g.nout[v]; i++) out_ok |= row[i] == *b;
+                            if (!(in_ok && out_ok)) state_error("table rewrite: a link that has to go in an entry that was passed over");
+                        }
+                    }
+                    kept.compact();
+                    table.set(no, std::move(kept));
+                    continue;
+                }
                 auto ins = g.in_neighbors(v), outs = g.out_neighbors(v);
                 std::vector<std::pair<uint64_t, int64_t>> items;
                 for (auto &l : kept.ents)
@@ -2218,6 +2340,8 @@ void vs_stage::path_extension(double threshold, const std::string &temp_dir) {
                 for (Nid new_no : closure.get(o.first, scratch_u)) usages.set(new_no, o.second);
             }
             usages.compact();
+            forget_affected();
+            table_filtered = true;  // (every entry was written anew, from links between its in- and its out-neighbours)
         }
 
         sections.slot("px.table_and_usages") += now_s() - t_filter;
@@ -2315,6 +2439,8 @@ void vs_stage::path_extension(double threshold, const std::string &temp_dir) {
         rid++;
     }
 
+    table_filtered = false;
+    forget_affected();
     VS_SECTION("px.final");
     // vertices that carry the same sequence (fork copies): keep the deepest one
     {
@@ -2856,6 +2982,7 @@ int vs_stage_import(vs_stage *st, const uint8_t *blob, uint64_t len) {
                 read_contigs(st, r, st->contigs);
             } else if (tag == VS_STAGE_LINKS) {
                 read_link_table(st, r, st->full_link);
+                st->table_filtered = false;
             } else {
                 throw StageError{VS_E_ARG, "ValueError", "unknown section in the import blob"};
             }
