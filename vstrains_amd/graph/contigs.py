@@ -91,14 +91,21 @@ def restore_repeats(g: AsmGraph, nodes: NodeMap, strains: ContigDict, contig_inf
                     original_contigs: ContigDict, logger) -> None:
     """Put back repeat multiplicities recorded when the SPAdes paths were parsed."""
     logger.info("resolving repeat nodes..")
+    # The reference tests every original contig against every strain; a contig can only be a subset of a strain that holds
+    # its first id, and the maxima below do not depend on the order the contigs are met in.
+    by_first: Dict[str, list] = {}
+    for cno, (cids, _, _) in original_contigs.items():
+        cset = frozenset(cids)
+        by_first.setdefault(cids[0] if cids else None, []).append((cno, cset))
     for sno, (ids, _, cov) in list(strains.items()):
         sub = origin_ids(ids)
         subset = set(sub)
         times = dict.fromkeys(sub, 1)
-        for cno, (cids, _, _) in original_contigs.items():
-            if set(cids).issubset(subset):
-                for name, count in contig_info[cno][1].items():
-                    times[name] = max(times[name], count)
+        for first in [None] + list(subset):
+            for cno, cset in by_first.get(first, ()):
+                if cset.issubset(subset):
+                    for name, count in contig_info[cno][1].items():
+                        times[name] = max(times[name], count)
         expanded: List[str] = []
         for name in sub:
             expanded.extend([name] * times[name])
