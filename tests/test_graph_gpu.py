@@ -376,6 +376,46 @@ def test_native_reinit_equals_the_python_rebuild(backend, tmp_path):
     st.close()
 
 
+@pytest.mark.parametrize("hub_degrees", [(), (7, 128), (129,), (8, 129, 300, 1000)])
+def test_stage_graph_with_and_without_rows_of_more_than_128_neighbours(backend, tmp_path, hub_degrees):
+    """The stage handle's flow / scan operation launches the kernel for neighbour sums of more than 128 addends (numpy's
+    recursive pairwise split) only when the graph has such a row: graphs without one, with one at the boundary and with
+    several, flows and scan against the checker."""
+    import random
+
+    from vstrains_amd.graph.formats import stage_graph_from_state
+    from vstrains_amd.graph.hip_ops import HipPeLinks
+    from vstrains_amd.graph.native_stage import NativeStage
+
+    rng = random.Random(len(hub_degrees) + sum(hub_degrees))
+    g = AsmGraph()
+    for i in range(1300):
+        g.add_vertex(str(i), rng.uniform(0.001, 5000.0), "ACGT", True)
+    v = 10
+    for hub, deg in enumerate(hub_degrees):
+        for k in range(deg):
+            g.add_edge(hub, 10 + (v % 1200), 21, 0.0, True)
+            g.add_edge(10 + ((v * 7) % 1200), hub, 21, 0.0, True)
+            v += 1
+    for i in range(20, 1290, 3):  # a sparse remainder: chains and small forks
+        if g.edge(i, i + 1) is None:
+            g.add_edge(i, i + 1, 21, 0.0, True)
+    nodes = {g.vid[u]: u for u in range(g.num_vertices())}
+    edges = {(g.vid[g.esrc[e]], g.vid[g.etgt[e]]): e for e in g.edges()}
+    a = stage_graph_from_state(g, nodes, edges)
+    want = chk.NumpyGraphOps().refresh(a[0])
+    table = HipPeLinks.from_matrices(backend.ctx, ["x"], np.zeros((1, 1), dtype=np.int64), np.zeros((1, 1), dtype=np.int64))
+    for _ in range(2):  # (twice: the second handle call finds the device buffers of the first)
+        st = NativeStage.on_device(backend.ctx, table, table.names)
+        st.load_graph(g, nodes, edges)
+        st.reinit(str(tmp_path / "hubs.gfa"))
+        got = st.scan()
+        gb, _, _ = st.graph()
+        assert gb.eflow == a[0].eflow
+        assert (want.nontrivial, want.fork_kind, want.chain_next, want.chain_rank) == (got.nontrivial, got.fork_kind, got.chain_next, got.chain_rank)
+        st.close()
+
+
 def test_chain_ranking_of_a_large_graph_on_the_device(backend, tmp_path):
     """More than 8 192 vertices take the multi-workgroup pointer jumping (rounds that find nothing left return at once):
     long simple paths, short ones, a ring of simple edges and a branching remainder, scan and flows against the checker."""

@@ -207,9 +207,11 @@ __global__ void __launch_bounds__(256) k_vertex_scan(uint32_t nv, const uint64_t
                                                     double *__restrict__ out_sum, double *__restrict__ in_sum,
                                                     uint8_t *__restrict__ nontrivial, uint8_t *__restrict__ fork_kind,
                                                     int32_t *__restrict__ chain_next, int32_t *__restrict__ chain_pred,
-                                                    uint32_t *__restrict__ big_list, uint32_t *__restrict__ big_count) {
+                                                    uint32_t *__restrict__ big_list, uint32_t *__restrict__ big_count,
+                                                    uint32_t *__restrict__ bad_init) {
     uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nv) return;
+    if (bad_init && v == 0) *bad_init = 0xFFFFFFFFu;  // (k_edge_flow's "no zero sum" word: set here instead of by a fill of its own)
     uint64_t lo = row_ptr[v], hi = row_ptr[v + 1];
     uint32_t no = n_out[v];
     uint32_t ni = (uint32_t)(hi - lo) - no;
@@ -637,7 +639,7 @@ int vs_graph_refresh(vs_ctx *ctx, uint32_t n_vertices, uint32_t n_edge_slots, co
     hipLaunchKernelGGL(k_vertex_scan, grid, block, 0, ctx->stream, n_vertices, d_row.as<uint64_t>(), d_no.as<uint32_t>(),
                        d_nbr.as<uint32_t>(), d_eidx.as<uint32_t>(), d_dp.as<double>(), d_vb.as<uint8_t>(), d_eb.as<uint8_t>(),
                        d_os.as<double>(), d_is.as<double>(), d_nt.as<uint8_t>(), d_fk.as<uint8_t>(), d_nx.as<int32_t>(),
-                       d_pd.as<int32_t>(), d_big.as<uint32_t>() + 1, d_big.as<uint32_t>());
+                       d_pd.as<int32_t>(), d_big.as<uint32_t>() + 1, d_big.as<uint32_t>(), (uint32_t *)nullptr);
     hipLaunchKernelGGL(k_vertex_sums_big, dim3(64), dim3(64), 0, ctx->stream, d_big.as<uint32_t>() + 1, d_big.as<uint32_t>(), d_row.as<uint64_t>(),
                        d_no.as<uint32_t>(), d_nbr.as<uint32_t>(), d_dp.as<double>(), d_os.as<double>(), d_is.as<double>());
     hipLaunchKernelGGL(k_edge_flow, grid, block, 0, ctx->stream, n_vertices, d_row.as<uint64_t>(), d_no.as<uint32_t>(),
@@ -739,14 +741,20 @@ struct HipStageOps : VsStageOps {
         memcpy(hu + o_row, row_ptr, (size_t)(nv + 1) * 8);
         memcpy(hu + o_dp, dp, (size_t)nv * 8);
         memcpy(hu + o_no, n_out, (size_t)nv * 4);
+        bool any_big = false;
+        for (uint32_t v = 0; v < nv; v++) {
+            const uint64_t no = n_out[v], ni = row_ptr[v + 1] - row_ptr[v] - no;
+            any_big |= (no > 128u) | (ni > 128u);
+        }
         if (n_adj) {
             memcpy(hu + o_nbr, nbr, (size_t)n_adj * 4);
             memcpy(hu + o_eidx, eidx, (size_t)n_adj * 4);
         }
         const double t1 = now();
         VS_HIP(ctx, hipMemcpyAsync(d_up, h_up, up_bytes, hipMemcpyHostToDevice, ctx->stream));
-        VS_HIP(ctx, hipMemsetAsync(dd + q_bad, 0xFF, 8, ctx->stream));
-        VS_HIP(ctx, hipMemsetAsync(dt + t_big, 0, 4, ctx->stream));
+        // rows of more than 128 neighbours on a side are rare: without one, neither their list's counter nor the kernel that
+        // sums them is needed (the "no zero sum" word is set by the scan kernel) -- three device operations less per stage graph
+        if (any_big) VS_HIP(ctx, hipMemsetAsync(dt + t_big, 0, 4, ctx->stream));
         const uint64_t *d_row = (const uint64_t *)(du + o_row);
         const double *d_dp = (const double *)(du + o_dp);
         const uint32_t *d_no = (const uint32_t *)(du + o_no), *d_nbr = (const uint32_t *)(du + o_nbr), *d_eidx = (const uint32_t *)(du + o_eidx);
@@ -755,9 +763,10 @@ struct HipStageOps : VsStageOps {
         dim3 grid((nv + 255) / 256), block(256);
         hipLaunchKernelGGL(k_vertex_scan, grid, block, 0, ctx->stream, nv, d_row, d_no, d_nbr, d_eidx, d_dp, (const uint8_t *)d_ones,
                            (const uint8_t *)d_ones, d_os, d_is, (uint8_t *)(dd + q_nt), (uint8_t *)(dd + q_fk), (int32_t *)(dd + q_next), d_pd,
-                           (uint32_t *)(dt + t_big) + 1, (uint32_t *)(dt + t_big));
-        hipLaunchKernelGGL(k_vertex_sums_big, dim3(64), dim3(64), 0, ctx->stream, (const uint32_t *)(dt + t_big) + 1, (const uint32_t *)(dt + t_big),
-                           d_row, d_no, d_nbr, d_dp, d_os, d_is);
+                           (uint32_t *)(dt + t_big) + 1, (uint32_t *)(dt + t_big), (uint32_t *)(dd + q_bad));
+        if (any_big)
+            hipLaunchKernelGGL(k_vertex_sums_big, dim3(64), dim3(64), 0, ctx->stream, (const uint32_t *)(dt + t_big) + 1,
+                               (const uint32_t *)(dt + t_big), d_row, d_no, d_nbr, d_dp, d_os, d_is);
         hipLaunchKernelGGL(k_edge_flow, grid, block, 0, ctx->stream, nv, d_row, d_no, d_nbr, d_eidx, d_dp, d_os, d_is, (double *)(dd + q_flow),
                            (uint32_t *)(dd + q_bad));
         if (nv <= 8192u) {
