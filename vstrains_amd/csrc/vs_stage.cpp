@@ -1013,7 +1013,7 @@ void vs_stage::edge_cleaning() {
         if (!edges.pop(a.k, &e)) key_error("(" + names[key_first(a.k)] + ", " + names[key_second(a.k)] + ")");
         g.remove_edge(e);
         dirty = true;
-        debug("intersect unsupported edge: " + names[key_first(a.k)] + " -> " + names[key_second(a.k)] + ", removed");
+        if (debug_log) debug("intersect unsupported edge: " + names[key_first(a.k)] + " -> " + names[key_second(a.k)] + ", removed");
     }
 }
 
@@ -1150,7 +1150,7 @@ int64_t vs_stage::balance_split(double threshold, bool is_prim) {
         const Nid no = br.first;
         const uint32_t v = br.second;
         auto us = black_us(v), ws = black_ws(v);
-        debug("current non trivial branch: " + names[no] + ", in-degree: " + std::to_string(us.size()) + ", out-degree: " + std::to_string(ws.size()));
+        if (debug_log) debug("current non trivial branch: " + names[no] + ", in-degree: " + std::to_string(us.size()) + ", out-degree: " + std::to_string(ws.size()));
         mark_size(fresh);
         bool any_fresh = false;
         for (Nid x : us) any_fresh = any_fresh || fresh[x];
@@ -1252,7 +1252,7 @@ int64_t vs_stage::balance_split(double threshold, bool is_prim) {
         for (auto &p : in_use.e) one_each = one_each && p.second == 1;
         for (auto &p : out_use.e) one_each = one_each && p.second == 1;
         if (!one_each) {
-            debug("->Not satisfy N-N split, skip: " + names[no]);
+            if (debug_log) debug("->Not satisfy N-N split, skip: " + names[no]);
             continue;
         }
         double worst = -1;
@@ -1265,7 +1265,7 @@ int64_t vs_stage::balance_split(double threshold, bool is_prim) {
         }
         if (first) throw StageError{VS_E_KEY, "ValueError", "max() arg is an empty sequence"};
         if (worst > 4 * threshold) continue;
-        debug("->perform split: " + names[no]);
+        if (debug_log) debug("->perform split: " + names[no]);
 
         done.push_back(no);
         PairMap<Nid> sub_of;
@@ -2001,7 +2001,7 @@ void vs_stage::increment_nt_branch_coverage() {
         if (a > best) best = a;
         if (b > best) best = b;
         if (best != g.vdp[v] || std::signbit(best) != std::signbit(g.vdp[v])) set_dp(v, best);
-        debug("NT Branch:" + names[br.first] + ", cov: " + py_repr(before) + " -> " + py_repr(g.vdp[v]));
+        if (debug_log) debug("NT Branch:" + names[br.first] + ", cov: " + py_repr(before) + " -> " + py_repr(g.vdp[v]));
     }
 }
 
@@ -2396,7 +2396,7 @@ void vs_stage::path_extension(double threshold, const std::string &temp_dir) {
         bool pcov_np = false;
         if (bbl_pcov < pcov) { pcov = bbl_pcov; pcov_np = pb_np; }
         if (bbl_cov < pcov) { pcov = bbl_cov; pcov_np = cb_np; }
-        debug("name: " + names[pno] + ", plen: " + std::to_string(plen) + ", pcov: " + py_repr(pcov) + ", bubble cov: " + py_repr(bbl_pcov));
+        if (debug_log) debug("name: " + names[pno] + ", plen: " + std::to_string(plen) + ", pcov: " + py_repr(pcov) + ", bubble cov: " + py_repr(bbl_pcov));
         {
             Contig st;
             st.ids = mem;
