@@ -82,6 +82,44 @@ def test_sparse_link_table_of_the_checker_gives_the_same_files(name, tmp_path):
     assert not case.binding(problems), problems
 
 
+def test_the_engines_check_of_its_restricted_table_passes_is_live(tmp_path):
+    """path_extension looks only at the link-table entries a re-initialisation noted (csrc/vs_stage.cpp: table_filtered).
+    Under VS_CHECK_UNTOUCHED=1 (tests/conftest.py) the engine runs the whole pass afterwards and raises if anything was left.
+    That the check would catch a pass that skipped too much is shown by taking the notes away (VS_STAGE_DROP_NOTES=1, read
+    when the library loads, hence the child process): the same golden case that passes above must then end with the
+    engine's state error."""
+    import subprocess
+    import sys
+
+    script = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from graph_case import Case, file_logger\n"
+        "from vstrains_amd.graph import pipeline\n"
+        "import test_graph_golden as T\n"
+        "case = Case('three_strain_k21'); inp = case.inputs(%r); out = %r\n"
+        "try:\n"
+        "    pipeline.run(case.args(inp, out), file_logger(out), T.make_backend(case, 'native_engine'))\n"
+        "except RuntimeError as e:\n"
+        "    print('RAISED', e)\n"
+        "else:\n"
+        "    print('PASSED')\n"
+    )
+    for drop, want in (("1", "RAISED"), (None, "PASSED")):
+        work = tmp_path / ("notes_dropped" if drop else "as_shipped")
+        work.mkdir()
+        child = script % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
+                          str(work), str(work / "out"))
+        env = dict(os.environ, VS_CHECK_UNTOUCHED="1")
+        env.pop("VS_STAGE_DROP_NOTES", None)
+        if drop:
+            env["VS_STAGE_DROP_NOTES"] = drop
+        proc = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, env=env, timeout=600)
+        last = [l for l in proc.stdout.splitlines() if l.startswith(("RAISED", "PASSED"))]
+        assert last and last[-1].startswith(want), (proc.stdout[-2000:], proc.stderr[-2000:])
+        if drop:
+            assert "passed over" in last[-1] or "not looked at" in last[-1], last[-1]
+
+
 @pytest.mark.parametrize("engine", ["native_engine", "closed_form_links", "literal_dict_links"])
 @pytest.mark.parametrize("name", case_names())
 def test_pipeline_matches_reference_outputs(name, engine, tmp_path):
