@@ -420,7 +420,7 @@ struct vs_stage {
         return on;
     }
     static bool drop_notes() {  // VS_STAGE_DROP_NOTES=1: a test's way of showing that the check above finds a pass that skipped too much
-        static const bool on = getenv("VS_STAGE_DROP_NOTES") != nullptr;
+        static const bool on = getenv("VS_STAGE_DROP_NOTES") != nullptr && check_hints();  // (only together with the check: never a silent wrong result)
         return on;
     }
     void forget_affected() {
