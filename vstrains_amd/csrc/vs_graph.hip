@@ -288,6 +288,7 @@ __global__ void __launch_bounds__(64) k_vertex_sums_big(const uint32_t *__restri
 // Vertices on a ring of simple edges never reach -1 and are reported with rank = -1 (the reference finds no head there
 // either and leaves rings alone).  buf: 6 * stride int32 of scratch (anc / rank / top, two copies each).
 #define CHAIN_TPB 1024
+#define CHAIN_FIRST_ROUNDS 4u  // rounds of the multi-launch ranking that are launched before anyone looks whether more are needed
 __global__ void __launch_bounds__(CHAIN_TPB) k_chain_rank(uint32_t nv, const int32_t *__restrict__ pred, int32_t *__restrict__ buf,
                                                           uint32_t stride, int32_t *__restrict__ top_out, int32_t *__restrict__ rank_out) {
     __shared__ int s_live;
@@ -370,8 +371,10 @@ __global__ void __launch_bounds__(256) k_chain_jump_wide(uint32_t nv, uint32_t r
 }
 __global__ void __launch_bounds__(256) k_chain_finish_wide(uint32_t nv, const int32_t *__restrict__ buf, uint32_t stride,
                                                           const int32_t *__restrict__ ctl, int32_t *__restrict__ top_out,
-                                                          int32_t *__restrict__ rank_out) {
+                                                          int32_t *__restrict__ rank_out, uint32_t next_round, uint32_t *__restrict__ live_out) {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    // (live_out: did the last round launched still find an ancestor to jump over -- the caller then launches the rest)
+    if (live_out && v == 0) *live_out = ctl[1 + next_round] ? 1u : 0u;
     if (v >= nv) return;
     const uint32_t cur = (uint32_t)ctl[0] & 1u;
     top_out[v] = buf[(4 + cur) * stride + v];
@@ -677,7 +680,7 @@ struct HipStageOps : VsStageOps {
     void *h_up = nullptr, *h_down = nullptr, *d_up = nullptr, *d_down = nullptr, *d_tmp = nullptr, *d_ones = nullptr;
     size_t cap_up = 0, cap_down = 0, cap_tmp = 0, cap_ones = 0;
     double t_pack = 0, t_enqueue = 0, t_wait = 0, t_unpack = 0;  // where a call's host time goes (VS_STAGE_OP_TIMING=1 prints the sums)
-    uint64_t n_calls = 0;
+    uint64_t n_calls = 0, n_second_waits = 0;
     static double now() {
         timespec ts;
         clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -686,8 +689,8 @@ struct HipStageOps : VsStageOps {
     HipStageOps(vs_ctx *c, const vs_links *l) : ctx(c), links(l) {}
     ~HipStageOps() override {
         if (getenv("VS_STAGE_OP_TIMING"))
-            fprintf(stderr, "[vs] stage flow/scan operation: %llu calls, pack %.4f s, enqueue %.4f s, wait %.4f s, unpack %.4f s\n",
-                    (unsigned long long)n_calls, t_pack, t_enqueue, t_wait, t_unpack);
+            fprintf(stderr, "[vs] stage flow/scan operation: %llu calls (%llu with a second wait for long chains), pack %.4f s, enqueue %.4f s, wait %.4f s, unpack %.4f s\n",
+                    (unsigned long long)n_calls, (unsigned long long)n_second_waits, t_pack, t_enqueue, t_wait, t_unpack);
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
         if (h_up) (void)hipHostFree(h_up);
@@ -769,24 +772,44 @@ struct HipStageOps : VsStageOps {
                                (const uint32_t *)(dt + t_big), d_row, d_no, d_nbr, d_dp, d_os, d_is);
         hipLaunchKernelGGL(k_edge_flow, grid, block, 0, ctx->stream, nv, d_row, d_no, d_nbr, d_eidx, d_dp, d_os, d_is, (double *)(dd + q_flow),
                            (uint32_t *)(dd + q_bad));
+        uint32_t rounds_total = 0, rounds_done = 0;
+        int32_t *buf = (int32_t *)(dt + t_pj), *ctl = (int32_t *)(dt + t_ctl);
         if (nv <= 8192u) {
             hipLaunchKernelGGL(k_chain_rank, dim3(1), dim3(CHAIN_TPB), 0, ctx->stream, nv, d_pd, (int32_t *)(dt + t_pj), chain_stride,
                                (int32_t *)(dd + q_top), (int32_t *)(dd + q_rank));
         } else {
-            int32_t *buf = (int32_t *)(dt + t_pj), *ctl = (int32_t *)(dt + t_ctl);
             hipLaunchKernelGGL(k_chain_init_wide, grid, block, 0, ctx->stream, nv, d_pd, buf, chain_stride, ctl);
+            // ceil(log2(V)) rounds rank any chain, but a stage graph's chains are short (they were contracted the pass before):
+            // four rounds (chains of up to 16) are launched, the finish kernel reports whether the fourth still found work, and
+            // only then are the others launched (a second wait; the long paths of tests and of uncontracted input graphs)
+            for (uint64_t span = 1; span < nv && rounds_total < 36u; span <<= 1) rounds_total++;
             uint32_t round = 0;
-            for (uint64_t span = 1; span < nv && round < 36u; span <<= 1, round++)
+            for (; round < rounds_total && round < CHAIN_FIRST_ROUNDS; round++)
                 hipLaunchKernelGGL(k_chain_jump_wide, grid, block, 0, ctx->stream, nv, round, buf, chain_stride, ctl);
+            rounds_done = round;
             hipLaunchKernelGGL(k_chain_finish_wide, grid, block, 0, ctx->stream, nv, buf, chain_stride, ctl, (int32_t *)(dd + q_top),
-                               (int32_t *)(dd + q_rank));
+                               (int32_t *)(dd + q_rank), round, (uint32_t *)(dd + q_bad) + 1);
         }
         VS_HIP(ctx, hipGetLastError());
         VS_HIP(ctx, hipMemcpyAsync(h_down, d_down, down_bytes, hipMemcpyDeviceToHost, ctx->stream));
         const double t2 = now();
         VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        const double t3 = now();
         const char *hd = (const char *)h_down;
+        if (rounds_done < rounds_total) {
+            uint32_t live = 0;
+            memcpy(&live, hd + q_bad + 4, 4);
+            if (live) {  // a chain of more than 2^CHAIN_FIRST_ROUNDS vertices: the other rounds, ranks and heads again
+                n_second_waits++;
+                for (uint32_t round = rounds_done; round < rounds_total; round++)
+                    hipLaunchKernelGGL(k_chain_jump_wide, grid, block, 0, ctx->stream, nv, round, buf, chain_stride, ctl);
+                hipLaunchKernelGGL(k_chain_finish_wide, grid, block, 0, ctx->stream, nv, buf, chain_stride, ctl, (int32_t *)(dd + q_top),
+                                   (int32_t *)(dd + q_rank), rounds_total, (uint32_t *)nullptr);
+                VS_HIP(ctx, hipGetLastError());
+                VS_HIP(ctx, hipMemcpyAsync((char *)h_down + q_top, dd + q_top, (q_bad - q_top), hipMemcpyDeviceToHost, ctx->stream));
+                VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            }
+        }
+        const double t3 = now();
         if (ne) memcpy(flow, hd + q_flow, (size_t)ne * 8);
         memcpy(chain_next, hd + q_next, (size_t)nv * 4);
         memcpy(chain_top, hd + q_top, (size_t)nv * 4);
