@@ -333,10 +333,11 @@ __global__ void __launch_bounds__(CHAIN_TPB) k_chain_rank(uint32_t nv, const int
 }
 
 // The same ranking for graphs too large for one workgroup to be quick about (tens of thousands of vertices): one launch
-// per round over all vertices, ceil(log2(V)) launches enqueued back to back -- but a round first looks at what the round
-// before it reported (ctl[1 + r]: some vertex still had an ancestor to jump over) and returns at once when there was
-// nothing left, so the launches behind the last productive round cost a few microseconds each and no host round trip
-// decides anything.  ctl[0] = rounds that did work (its parity names the buffer that holds the result).
+// per round over all vertices, up to ceil(log2(V)) of them -- a round first looks at what the round before it reported
+// (ctl[1 + r]: some vertex still had an ancestor to jump over) and returns at once when there was nothing left, so a launch
+// behind the last productive round costs a few microseconds.  The stage handle enqueues CHAIN_FIRST_ROUNDS of them with the
+// rest of its operation and the others only when k_chain_finish_wide reports that the last of those still found work
+// (HipStageOps::run).  ctl[0] = rounds that did work (its parity names the buffer that holds the result).
 __global__ void __launch_bounds__(256) k_chain_init_wide(uint32_t nv, const int32_t *__restrict__ pred, int32_t *__restrict__ buf, uint32_t stride,
                                                         int32_t *__restrict__ ctl) {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
