@@ -223,6 +223,8 @@ def main():
     n_nodes = len(g.seqs)
     dense_bytes = 2 * n_nodes * n_nodes * 4
     counters = [host.PeCounter(ctx) for _ in range(2 if use_dist else 1)]
+    if rank == 0 and (cfg["extract"] or args.extract) and not args.no_extract:
+        counters[0].reserve_link_table()  # (as the pipeline does where it makes its counters: pe_inference.count_links)
     main_stream = torch.cuda.current_stream()
     side_stream = torch.cuda.Stream() if use_dist else None
     counted = [None for _ in counters]

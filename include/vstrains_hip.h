@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VS_ABI_VERSION 8
+#define VS_ABI_VERSION 9
 
 enum {
     VS_OK = 0,
@@ -251,6 +251,12 @@ int vs_links_from_wide(vs_ctx *ctx, const int64_t *d_node_mat, const int64_t *d_
 /* Same from HOST int64 matrices (e.g. parsed back from pe_info / st_info text). */
 int vs_links_from_host(vs_ctx *ctx, const int64_t *node_mat, const int64_t *short_mat, uint32_t n,
                        vs_links **out);
+/* Optional, ABI 9: set aside the device buffer of the next table of n nodes (n*n int64) now -- typically when the counters
+ * are allocated, before any read is counted -- so that vs_links_from_counts / _from_wide / _from_host does not have to ask the
+ * driver for it later (a hipMalloc of tens of gigabytes takes 0.3 ms or half a second depending on what the process freed
+ * before: 23.7 GB at 54 465 nodes).  The buffer belongs to the context until a table of that size takes it; a second call
+ * replaces it, n = 0 gives it back.  The reference has no counterpart: its table is a Python dict. */
+int vs_links_reserve(vs_ctx *ctx, uint32_t n);
 void vs_links_free(vs_ctx *ctx, vs_links *links);
 int vs_links_size(const vs_links *links, uint32_t *n);
 int vs_links_to_host(vs_ctx *ctx, const vs_links *links, int64_t *out /* n*n */);

@@ -133,6 +133,38 @@ def test_link_table_matches_process_pe_info(backend, n):
     assert np.array_equal(dev.group_matrix(groups), ref.group_matrix(groups))
 
 
+def test_link_table_takes_a_reserved_buffer_of_its_size_and_only_that(backend):
+    """vs_links_reserve (ABI 9) sets the table's buffer aside ahead of time: a table of that size takes it, another size is
+    allocated as before, a second reservation replaces the first, n = 0 gives it back -- the table is the same either way."""
+    import ctypes as C
+
+    from vstrains_amd import _native as nat
+    from vstrains_amd.graph.hip_ops import HipPeLinks
+
+    ctx = backend.ctx
+    rng = np.random.default_rng(11)
+
+    def table(n):
+        names = [str(i) for i in range(n)]
+        node = rng.integers(0, 50, size=(n, n)) * (rng.random((n, n)) < 0.3)
+        short = np.triu(rng.integers(0, 90, size=(n, n)) * (rng.random((n, n)) < 0.4))
+        want = node + node.T + short + short.T
+        want[np.arange(n), np.arange(n)] = node.diagonal() + short.diagonal()
+        dev = HipPeLinks.from_matrices(ctx, names, node, short)
+        assert np.array_equal(dev.to_numpy(), want)
+        return dev
+
+    for reserve, build in ((45, 45), (7, 45), (45, 7), (0, 33)):
+        nat.check(ctx._h, nat.lib().vs_links_reserve(ctx._h, C.c_uint32(reserve)))
+        a = table(build)
+        b = table(build)  # (the reservation is gone after one table of its size: this one allocates)
+        del a, b
+    nat.check(ctx._h, nat.lib().vs_links_reserve(ctx._h, C.c_uint32(300)))
+    nat.check(ctx._h, nat.lib().vs_links_reserve(ctx._h, C.c_uint32(20)))  # replaces
+    table(20)
+    nat.check(ctx._h, nat.lib().vs_links_reserve(ctx._h, C.c_uint32(0)))
+
+
 def test_link_table_from_device_counters(backend):
     """vs_links_from_counts reads the uint32 counters vs_pe_count filled, in place."""
     import torch

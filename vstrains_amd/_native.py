@@ -61,6 +61,7 @@ SYMBOLS = {
     "vs_links_from_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "vs_links_from_wide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "vs_links_from_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "vs_links_reserve": (C.c_int, [C.c_void_p, C.c_uint32]),
     "vs_links_free": (None, [C.c_void_p, C.c_void_p]),
     "vs_links_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "vs_links_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -149,6 +149,7 @@ void vs_ctx_destroy(vs_ctx *ctx) {
     free_index(ctx);
     if (ctx->d_slow_list) (void)hipFree(ctx->d_slow_list);
     if (ctx->d_slow_count) (void)hipFree(ctx->d_slow_count);
+    if (ctx->links_spare) (void)hipFree(ctx->links_spare);
     if (ctx->d_slow_list2) (void)hipFree(ctx->d_slow_list2);
     if (ctx->d_dense) (void)hipFree(ctx->d_dense);
     for (void *q : {ctx->d_locus_keys, ctx->d_perm, ctx->d_locus_hist, ctx->d_scan_tmp, ctx->d_lists, ctx->d_list_counts, ctx->d_rows, ctx->d_row_entries, ctx->d_mult, ctx->d_ltab})

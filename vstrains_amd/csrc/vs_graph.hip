@@ -460,7 +460,24 @@ template <typename TIn>
 int links_build(vs_ctx *ctx, const TIn *d_node, const TIn *d_short, uint32_t n, vs_links **out) {
     vs_links *L = new vs_links();
     L->n = n;
-    hipError_t e = hipMalloc((void **)&L->d_p0, (size_t)(n ? (uint64_t)n * n : 1) * sizeof(int64_t));
+    const bool timing = getenv("VS_LINKS_TIMING") != nullptr;  // where the call's host time goes, on stderr
+    auto now = [] {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+    };
+    if (timing) (void)hipStreamSynchronize(ctx->stream);
+    const double t0 = now();
+    hipError_t e = hipSuccess;
+    const bool reserved = ctx->links_spare && ctx->links_spare_n == n && n;
+    if (reserved) {  // vs_links_reserve set it aside
+        L->d_p0 = (int64_t *)ctx->links_spare;
+        ctx->links_spare = nullptr;
+        ctx->links_spare_n = 0;
+    } else {
+        e = hipMalloc((void **)&L->d_p0, (size_t)(n ? (uint64_t)n * n : 1) * sizeof(int64_t));
+    }
+    const double t1 = now();
     if (e != hipSuccess) {
         delete L;
         return vs_fail(ctx, VS_E_OOM, "vs_links: %s", hipGetErrorString(e));
@@ -477,12 +494,37 @@ int links_build(vs_ctx *ctx, const TIn *d_node, const TIn *d_short, uint32_t n, 
             return vs_fail(ctx, VS_E_HIP, "k_links_symmetrize: %s", hipGetErrorString(e));
         }
     }
+    if (timing) {
+        (void)hipStreamSynchronize(ctx->stream);
+        fprintf(stderr, "[vs] link table of %u nodes: %.2f GB %s %.4f s, k_links_symmetrize %.4f s\n", n, (double)n * n * 8 / 1e9,
+                reserved ? "taken from vs_links_reserve" : "hipMalloc", t1 - t0, now() - t1);
+    }
     *out = L;
     return VS_OK;
 }
 }  // namespace
 
 extern "C" {
+
+int vs_links_reserve(vs_ctx *ctx, uint32_t n) {
+    if (!ctx) return VS_E_ARG;
+    VS_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->links_spare && ctx->links_spare_n == n) return VS_OK;
+    if (ctx->links_spare) {
+        VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->links_spare);
+        ctx->links_spare = nullptr;
+        ctx->links_spare_n = 0;
+    }
+    if (!n) return VS_OK;
+    const hipError_t e = hipMalloc(&ctx->links_spare, (size_t)n * n * sizeof(int64_t));
+    if (e != hipSuccess) {
+        ctx->links_spare = nullptr;
+        return vs_fail(ctx, VS_E_OOM, "vs_links_reserve: %.2f GB: %s", (double)n * n * 8 / 1e9, hipGetErrorString(e));
+    }
+    ctx->links_spare_n = n;
+    return VS_OK;
+}
 
 int vs_links_from_counts(vs_ctx *ctx, const uint32_t *d_node_mat, const uint32_t *d_short_mat, uint32_t n, vs_links **out) {
     if (!ctx || !out || (n && (!d_node_mat || !d_short_mat))) return vs_fail(ctx, VS_E_ARG, "vs_links_from_counts: bad argument");

@@ -146,6 +146,8 @@ struct vs_ctx {
     void *d_slow_list = nullptr;   // pair indices sent to the slow path
     uint64_t slow_cap = 0;
     void *d_slow_count = nullptr;  // uint32 counters (see pe_launch)
+    void *links_spare = nullptr;   // vs_links_reserve: the buffer of the next link table (links_spare_n nodes)
+    uint32_t links_spare_n = 0;
     void *d_slow_list2 = nullptr;  // pairs k_pe_mid hands on to k_pe_slow
     uint64_t slow2_cap = 0;
     void *d_dense = nullptr;       // dense per-workgroup state for the slow path

@@ -37,6 +37,8 @@ def count_links(ctx, gfa: str, fwd: str, rve: str, kmer_size: int):
     # one process per GPU (torchrun): this rank counts its contiguous block of the pairs and the
     # counters are summed over ranks afterwards (RCCL all-reduce); a single process takes everything
     rank, world = _rank_world()
+    if rank == 0:
+        counter.reserve_link_table()  # (the graph stages follow on this rank: their table's buffer is taken now)
     if world > 1:
         # nobody reads a whole file: every rank counts the lines of its byte range, the ranks exchange the counts and
         # each indexes only the bytes of its own records (:154's total follows from the counts)
