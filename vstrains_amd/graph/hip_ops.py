@@ -235,11 +235,11 @@ class HipBackend:
 
         print("----------------------Paired-End Information Alignment----------------------")
         if self.write_info_text:
-            self.pe_stats = pe_inference.run(gfa, aln_dir, fwd, rve, ksize, ctx=self.ctx)
+            self.pe_stats = pe_inference.run(gfa, aln_dir, fwd, rve, ksize, ctx=self.ctx, stages_follow=True)
             ids, counter = pe_inference.run.last
         else:
             os.makedirs(aln_dir, exist_ok=True)
-            ids, counter = pe_inference.count_links(self.ctx, gfa, fwd, rve, ksize)
+            ids, counter = pe_inference.count_links(self.ctx, gfa, fwd, rve, ksize, stages_follow=True)
         if list(ids) != list(names):
             raise RuntimeError("node order of %s differs from the stage graph" % gfa)
         return HipPeLinks.from_counter(self.ctx, counter, names)

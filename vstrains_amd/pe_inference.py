@@ -26,9 +26,11 @@ def _rank_world():
     return 0, 1
 
 
-def count_links(ctx, gfa: str, fwd: str, rve: str, kmer_size: int):
+def count_links(ctx, gfa: str, fwd: str, rve: str, kmer_size: int, stages_follow: bool = False):
     """Index the nodes of ``gfa`` and count every pair of the two FASTQ files; the counters stay
-    on the device.  Returns ``(node ids in file order, PeCounter)``."""
+    on the device.  Returns ``(node ids in file order, PeCounter)``.  ``stages_follow``: the graph stages will build their
+    PE-link table from these counters in this process (the pipeline; not the stand-alone script, which writes the two text
+    files) -- the table's device buffer is then set aside together with the counters."""
     ids, seqs = host.read_gfa_segments(gfa)  # :100-112
     ctx.build_index(seqs, kmer_size)  # :114-135  (KeyError on a bad node base, as :13)
     counter = host.PeCounter(ctx)
@@ -37,8 +39,8 @@ def count_links(ctx, gfa: str, fwd: str, rve: str, kmer_size: int):
     # one process per GPU (torchrun): this rank counts its contiguous block of the pairs and the
     # counters are summed over ranks afterwards (RCCL all-reduce); a single process takes everything
     rank, world = _rank_world()
-    if rank == 0:
-        counter.reserve_link_table()  # (the graph stages follow on this rank: their table's buffer is taken now)
+    if rank == 0 and stages_follow:
+        counter.reserve_link_table()  # (the graph stages run on this rank: their table's buffer is taken now)
     if world > 1:
         # nobody reads a whole file: every rank counts the lines of its byte range, the ranks exchange the counts and
         # each indexes only the bytes of its own records (:154's total follows from the counts)
@@ -86,7 +88,7 @@ def write_info_files(out_dir: str, ids, counter):
     return out_file, stats
 
 
-def run(gfa: str, out_dir: str, fwd: str, rve: str, kmer_size: int, device: int = 0, ctx=None):
+def run(gfa: str, out_dir: str, fwd: str, rve: str, kmer_size: int, device: int = 0, ctx=None, stages_follow: bool = False):
     # PE_Inference.py:93-96: the output directory is wiped and recreated
     if out_dir[-1] == "/":
         out_dir = out_dir[:-1]
@@ -102,7 +104,7 @@ def run(gfa: str, out_dir: str, fwd: str, rve: str, kmer_size: int, device: int 
     glb_start = time.time()
     if ctx is None:
         ctx = host.Context(device)
-    ids, counter = count_links(ctx, gfa, fwd, rve, kmer_size)
+    ids, counter = count_links(ctx, gfa, fwd, rve, kmer_size, stages_follow=stages_follow)
     run.last = (ids, counter)
     if rank != 0:
         return None  # every rank holds the summed counters; rank 0 writes the files
