@@ -163,19 +163,21 @@ def compare(case, out_dir, skip=()):
     return problems, got
 
 
-def reference_command_inputs(work):
-    """The inputs tools/time_reference.py gave the REAL reference command at BASELINE configs[0] (and the digests it
-    committed, tests/golden/reference_digests.json "configs[0]_whole_command"): the config's assembler-style GFA + contig
-    paths and its 100 000 read pairs as FASTQ text (the CPU twin of the device generator, the same stream the bench counts)."""
+def reference_command_inputs(work, config=0):
+    """The inputs the REAL reference command was given at BASELINE configs[config] (and the digests committed for it,
+    tests/golden/reference_digests.json "configs[i]_whole_command"; tools/time_reference.py for configs[0],
+    tools/time_reference_stages.py for configs[1] and configs[2]): the config's assembler-style GFA + contig paths and the
+    first ``pairs`` read pairs of its bench stream as FASTQ text (the CPU twin of the device generator, the same stream
+    the bench counts)."""
     import json
 
     from oracle import pe_oracle_c
     from vstrains_amd.workloads import CONFIGS, workload_for
 
     with open(os.path.join(HERE, "golden", "reference_digests.json")) as fh:
-        want = json.load(fh)["configs[0]_whole_command"]
-    cfg = CONFIGS[0]
-    st, pre, names, seqs, cum, logger, _ = workload_for(0, work)
+        want = json.load(fh)["configs[%d]_whole_command" % config]
+    cfg = CONFIGS[config]
+    st, pre, names, seqs, cum, logger, _ = workload_for(config, work)
     L = cfg["read_len"]
     fw, rv = pe_oracle_c.synth_pairs(st.genomes, cum, want["stream_seed"], 0, want["pairs"], L, int(0.005 * 2 ** 32), int(0.001 * 2 ** 32))
     paths = {"gfa": os.path.join(work, "input.gfa"), "paths": os.path.join(work, "input.paths")}
@@ -183,7 +185,8 @@ def reference_command_inputs(work):
     for key, arr, tag in (("fwd", fw, b"f"), ("rve", rv, b"r")):
         paths[key] = os.path.join(work, key + ".fq")
         with open(paths[key], "wb") as fh:
-            fh.write(b"".join(b"@%s%d\n%s\n+\n%s\n" % (tag, i, arr[i].tobytes(), qual) for i in range(arr.shape[0])))
+            for lo in range(0, arr.shape[0], 100000):
+                fh.write(b"".join(b"@%s%d\n%s\n+\n%s\n" % (tag, i, arr[i].tobytes(), qual) for i in range(lo, min(arr.shape[0], lo + 100000))))
     return paths, want
 
 

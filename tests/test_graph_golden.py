@@ -174,17 +174,19 @@ def test_every_file_equals_the_committed_rotate_model_run(name, tmp_path):
         assert all(p.split(" ", 1)[1] in seed_dependent for p in problems), problems
 
 
-def test_native_engine_reproduces_the_real_reference_command_at_configs0(tmp_path):
-    """The same pin as tests/test_configs_gpu.py::test_cli_reproduces_the_real_reference_command_at_configs0 on a box
-    without a GPU: the C oracle counts the 100 000 pairs, the native stage engine runs over the CPU checker of its device
-    operations, and the 29 files every run of the REAL reference command agrees on must come out the same."""
+@pytest.mark.parametrize("config", [0, 1])
+def test_native_engine_reproduces_the_real_reference_command(config, tmp_path):
+    """The same pin as tests/test_configs_gpu.py::test_cli_reproduces_the_real_reference_command* on a box without a GPU: the
+    C oracle counts the pairs (100 000 at configs[0], 1 M at configs[1]), the native stage engine runs over the CPU checker
+    of its device operations, and the files every run of the REAL reference command agrees on (29 at configs[0], 83 at
+    configs[1]: 853 nodes, 20 strains) must come out the same."""
     import numpy as np
 
     from graph_case import reference_command_inputs, reference_command_problems
     from oracle import pe_oracle_c
     from vstrains_amd.graph.hip_ops import HipPeLinks  # noqa: F401  (only to show what the product would use)
 
-    inp, want = reference_command_inputs(str(tmp_path / "work"))
+    inp, want = reference_command_inputs(str(tmp_path / "work"), config)
 
     class OracleCountsNativeStages:
         def pe_links(self, gfa, aln_dir, fwd, rve, ksize, names):
