@@ -37,7 +37,7 @@ class NumpyGraphOps:
                 g.eflow[e] = float(numpy.mean([(g.vdp[v] / u_out) * g.vdp[u], (g.vdp[u] / v_in) * g.vdp[v]]))
 
     def scan(self, g):
-        from vstrains_amd.graph.ops import GraphScan
+        from .graph_stages.model import GraphScan
 
         nv = g.num_vertices()
         nontrivial = [False] * nv

@@ -10,9 +10,7 @@ from __future__ import annotations
 from functools import reduce
 from typing import Dict, List, Tuple
 
-from vstrains_amd.graph.asm_graph import AsmGraph, EdgeMap, NodeMap
-from vstrains_amd.graph.contigs import contig_steps, contigs_by_node  # noqa: F401  (re-exported for the stage modules)
-from vstrains_amd.graph.formats import ContigDict, path_length
+from .model import OGraph as AsmGraph, ContigDict, EdgeMap, NodeMap, contig_steps, contigs_by_node, path_length  # noqa: F401  (re-exported for the stage modules)
 
 
 PY_MERGE_ID_FRAMES = 993  # nested merge_id frames CPython 3.10 allows the reference's CLI (limit 1000, six frames above, len() on top)

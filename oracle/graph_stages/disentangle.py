@@ -23,12 +23,12 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy
 
-from vstrains_amd.graph.asm_graph import BLACK, GRAY, AsmGraph, EdgeMap, NodeMap
-from vstrains_amd.graph.contigs import drop_duplicate_contigs, trim_contigs
+from .model import BLACK, GRAY, EdgeMap, NodeMap, OGraph as AsmGraph
+from .model import drop_duplicate_contigs, trim_contigs
 from .contig_ops import contig_steps, contigs_by_node, remap_contigs
-from vstrains_amd.graph.formats import (ContigDict, path_length, path_sequence, read_stage_gfa, stage_graph_from_state,
+from .model import (ContigDict, path_length, path_sequence, read_stage_gfa, stage_graph_from_state,
                       write_stage_gfa)
-from vstrains_amd.graph.ops import GraphOps, GraphScan
+from .model import GraphOps, GraphScan
 from .links import LiveLinks, nontrivial_ids
 
 
@@ -106,13 +106,9 @@ def reinit(stage: Stage, ops: GraphOps, logger, filename: str, untouched: bool =
         return Stage(stage.g, stage.nodes, stage.edges, stage.scan, snap)
     # one pass: the file write_stage_gfa would write, and the graph read_stage_gfa(filename) would
     # give back (float(repr(dp)) == dp), without the parse
-    if hasattr(ops, "reinit"):  # the device backend does rebuild + flows + scan in one library call
-        g, nodes, edges, text, scan = ops.reinit(stage.g, stage.nodes, stage.edges, filename)
-        logger.info(filename + " is stored..")
-    else:
-        g, nodes, edges, text = stage_graph_from_state(stage.g, stage.nodes, stage.edges, gfa_path=filename, want_text=True)
-        logger.info(filename + " is stored..")
-        scan = ops.refresh(g)
+    g, nodes, edges, text = stage_graph_from_state(stage.g, stage.nodes, stage.edges, gfa_path=filename, want_text=True)
+    logger.info(filename + " is stored..")
+    scan = ops.refresh(g)
     return Stage(g, nodes, edges, scan, _Snapshot(g, nodes, edges, text))
 
 
@@ -415,13 +411,13 @@ def global_trivial_split(stage: Stage, logger):
     forks = 0
     # (one shared empty dict stands for "not forked" until a vertex really is: remap_contigs only reads)
     id_mapping: Dict[str, Dict[str, None]] = dict.fromkeys(nodes.keys(), _NO_KIDS)
-    vblack, adj, nout = g.vblack, g.adj, g.nout
+    vblack, outs, ins = g.vblack, g.outs, g.ins
     # A stage that is still the graph its scan looked at (path_extension calls this right after a re-initialisation) and
     # in which no vertex has one black edge on one side and several on the other -- ``fork_kind``, worked out for every
     # vertex by the scan -- has nothing to fork: the sweep below would look at every vertex to find that out (twice a
     # strain, tens of thousands of vertices).  VS_CHECK_UNTOUCHED=1 sweeps anyway and insists on the outcome.
     scan, snap = stage.scan, stage.snap
-    nothing_to_fork = (scan is not None and snap is not None and len(scan.fork_kind) == len(adj) and not any(scan.fork_kind)
+    nothing_to_fork = (scan is not None and snap is not None and len(scan.fork_kind) == len(outs) and not any(scan.fork_kind)
                        and snap.matches(g, nodes, edges))
     if nothing_to_fork and not _CHECK_UNTOUCHED:
         logger.debug("No of trivial branch be removed: 0")
@@ -438,8 +434,8 @@ def global_trivial_split(stage: Stage, logger):
                 id_mapping[name] = _NO_KIDS
             # a fork needs one black edge on one side and several on the other: the stored degrees
             # (gray edges included) rule most vertices out before any list is built
-            n_o = nout[v]
-            n_i = len(adj[v]) - n_o
+            n_o = len(outs[v])
+            n_i = len(ins[v])
             if n_o == 0 or n_i == 0 or n_o + n_i < 3:
                 continue
             ines = g.black_in_edges(v)

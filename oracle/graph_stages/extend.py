@@ -17,12 +17,10 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy
 
-from vstrains_amd.graph.asm_graph import GRAY, AsmGraph, NodeMap
-from vstrains_amd.graph.contigs import origin_ids
+from .model import GRAY, NodeMap, OGraph as AsmGraph, origin_ids
 from .contig_ops import contigs_by_node, remap_contigs
 from .disentangle import _CHECK_UNTOUCHED, Stage, _add_edge, _add_vertex, _retire_vertex, global_trivial_split, reinit
-from vstrains_amd.graph.formats import ContigDict, path_length, path_sequence
-from vstrains_amd.graph.ops import GraphOps, PeLinks
+from .model import ContigDict, GraphOps, PeLinks, path_length, path_sequence
 from .links import LiveLinks, nontrivial_ids
 
 LinkTable = Dict[str, Dict[Tuple[str, str], int]]

@@ -19,8 +19,7 @@ from __future__ import annotations
 
 from typing import Dict, Iterable, List, Tuple
 
-from vstrains_amd.graph.asm_graph import NodeMap
-from vstrains_amd.graph.ops import GraphScan, PeLinks
+from .model import GraphScan, NodeMap, PeLinks
 
 
 class LiveLinks:

@@ -6,8 +6,8 @@ from __future__ import annotations
 
 import numpy
 
-from vstrains_amd.graph.contigs import drop_duplicate_contigs, resolve_contigs, trim_contigs
-from vstrains_amd.graph.formats import read_stage_gfa, write_contig_fasta, write_contig_paths, write_stage_gfa
+from .model import (adopt, drop_duplicate_contigs, read_stage_gfa, resolve_contigs, trim_contigs, write_contig_fasta, write_contig_paths,
+                    write_stage_gfa)
 
 from . import disentangle as dis
 from . import extend as ext
@@ -16,8 +16,11 @@ from . import extend as ext
 def extract_stages(pre, table, ops, links, logger, out: str):
     """-> strain_dict as of VStrains_SPAdes.py:262 (resolved, trimmed on es_graph_L2, duplicates dropped).  ``links``: a ``LiveLinks`` / ``DictLiveLinks`` over ``table``."""
     contigs = pre.contigs
-    stage1 = dis.Stage(pre.g1, pre.nodes1, pre.edges1)
-    dis.edge_cleaning(pre.g1, pre.edges1, contigs, links, logger)
+    # the prepared graph is taken over as DATA into the checker's own container (model.adopt): adjacency order, GFA text and
+    # contig bookkeeping from here on are this package's statement of the reference, not the product's
+    g1, nodes1, edges1 = adopt(pre.g1, pre.nodes1, pre.edges1)
+    stage1 = dis.Stage(g1, nodes1, edges1)
+    dis.edge_cleaning(g1, edges1, contigs, links, logger)
     stage2 = dis.reinit(stage1, ops, logger, "{0}/gfa/es_graph_L2.gfa".format(out))
     write_contig_paths(contigs, "{0}/tmp/pre_contigs.paths".format(out))
     write_contig_fasta(stage2.g, stage2.nodes, contigs, "{0}/tmp/pre_contigs.fasta".format(out))
