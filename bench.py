@@ -85,6 +85,32 @@ def strain_recovery(genomes, fasta_path):
             "true_strains_recovered_whole": whole, "longest_extracted_bp": longest, "longest_over_genome": round(longest / glen, 4)}
 
 
+def reference_stage_time(config):
+    """The REAL reference's time for the same leg (VStrains_SPAdes.py:133-272: pe_info on disk -> strain_dict returned),
+    measured in the build container as ONE interval by tools/time_reference_stages.py (the reference cannot travel to the
+    GPU box): /root/reference/vstrains behind the graph-tool stand-in on this config's graph, 1 thread.  A committed
+    record, not a measurement of this run."""
+    path = os.path.join(ROOT, "profiles", "r6", "reference_stages_config%d.json" % config)
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)
+    except OSError:
+        return None
+    done = {k: v for k, v in rec["runs"].items() if v.get("returncode") == 0 and v.get("after_pe_to_run_return_s")}
+    out = {"kind": "reference", "nodes": rec["nodes"], "pairs": rec["pairs"], "cores": 1, "where": "build container (8 vCPU), "
+           "graph-tool / gfapy replaced by tests/golden/gt_standin (pure Python: slower than the C++ library)",
+           "source": "profiles/r6/reference_stages_config%d.json" % config}
+    if done:
+        base = done.get("rotate/0") or done[sorted(done)[0]]
+        out["reference_s"] = base["after_pe_to_run_return_s"]
+        out["strains"] = base.get("strains")
+        out["all_runs_s"] = {k: round(v["after_pe_to_run_return_s"], 2) for k, v in sorted(done.items())}
+    else:
+        out["reference_s"] = None
+        out["progress"] = rec.get("progress")  # how far the reference got, and at which rate
+    return out
+
+
 def strain_extract(ctx, counter, pre, names, logger, out_dir, genomes=None):
     """The second half of the metric: pe counters (resident in HBM) -> strain.paths, i.e.
     VStrains_SPAdes.py:134-272 with the graph kernels on the device."""
@@ -233,17 +259,33 @@ def main():
     step_no = [0]
     exchanges = []
 
+    collectives = []
+
     def exchange(b):
+        # (r6) two collectives, no host wait: the first exchange of the run learns the size of the ranks' union, the later
+        # ones are staged for 1.25 times that (PeCounter.all_reduce(predict=True)); the flags and the real size are looked at
+        # when the buffer comes up again (settle: one read of numbers the side stream finished long before)
         with torch.cuda.stream(side_stream):
             side_stream.wait_event(counted[b])
-            counters[b].all_reduce()
+            for other in counters:  # (the two buffers share what is known about the union)
+                if counters[b]._xstate_cap() is None and other._xstate_cap() is not None:
+                    counters[b]._xstate_cap(other._xstate_cap())
+            counters[b].all_reduce(predict=True)
             exchanges.append(counters[b].last_all_reduce)
+            collectives.append(counters[b].last_collectives)
             summed[b] = side_stream.record_event()
+
+    def settle(b):
+        if use_dist and summed[b] is not None:
+            with torch.cuda.stream(side_stream):
+                counters[b].settle()
+                summed[b] = side_stream.record_event()
 
     def step():
         b = step_no[0] % len(counters)
         step_no[0] += 1
         c = counters[b]
+        settle(b)
         if summed[b] is not None:
             main_stream.wait_event(summed[b])
         c.reset()
@@ -258,6 +300,8 @@ def main():
         if use_dist and waiting[0] is not None:
             exchange(waiting[0])
             waiting[0] = None
+        for b in range(len(counters)):
+            settle(b)
         for ev in summed:
             if ev is not None:
                 main_stream.wait_event(ev)
@@ -339,8 +383,9 @@ def main():
                 "node_bases": int(sum(len(s) for s in g.seqs)),
                 "parallelism": ("read-block sharding x%d (%s: %d pairs per rank per step) + per-step sum of the [2,N,N] counters over the ranks, "
                                 "overlapped with the next block: occupied 64-cell stretches of the union through the ring or the whole %.2f GB "
-                                "buffer when it is dense (steps of this run: %s)"
-                                % (world, args.scaling, R, dense_bytes / 1e9, ", ".join("%s x%d" % (m, exchanges.count(m)) for m in sorted(set(exchanges))) or "none"))
+                                "buffer when it is dense (steps of this run: %s; collectives per exchange: %s)"
+                                % (world, args.scaling, R, dense_bytes / 1e9, ", ".join("%s x%d" % (m, exchanges.count(m)) for m in sorted(set(exchanges))) or "none",
+                                   ", ".join("%d x%d" % (m, collectives.count(m)) for m in sorted(set(collectives))) or "none"))
                                if use_dist else "one GPU, no exchange",
                 "rccl_ranks": rccl_ranks, "collective_backend": coll_backend,
                 "index": ctx.index_info, "index_build_s": index_s, "workload_build_s": workload_s,
@@ -380,6 +425,7 @@ def main():
                 ex = strain_extract(ctx, counter, pre, names, logger, work_dir, genomes=st.genomes)
                 out["strain_extract_s"] = ex.pop("seconds")
                 out["strain_extract"] = ex
+                ex["cpu_baseline"] = reference_stage_time(args.config)
             except Exception as err:  # the PE line is still printed, but the run FAILS (exit status 1)
                 import traceback
 

@@ -366,6 +366,129 @@ def test_compact_exchange_from_the_tile_map_in_slabs_and_without_a_staging_buffe
     assert res[3] == ("no staging buffer on rank 1", "dense")
 
 
+def _rank_packed_eight(rank, world, port, q):
+    """Eight gloo ranks through PeCounter.all_reduce / dist.sum_counts_packed (r6: two collectives per sum)."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from vstrains_amd import dist as vdist
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    res = {}
+    n = 96
+
+    def banded(seed, cells):
+        gen = torch.Generator().manual_seed(seed)
+        m = torch.zeros((2, n, n), dtype=torch.int32)
+        if cells:
+            i = torch.randint(0, n, (cells,), generator=gen)
+            j = (i + torch.randint(0, 6, (cells,), generator=gen)).clamp(max=n - 1)
+            m[torch.randint(0, 2, (cells,), generator=gen), i, j] = torch.randint(1, 1000, (cells,), generator=gen).to(torch.int32)
+        return m
+
+    def dense_sum(t):
+        d = t.clone()
+        dist.all_reduce(d, op=dist.ReduceOp.SUM)
+        return d
+
+    # (1) uneven shards, one rank with no pairs at all: compact, TWO collectives, stats and pairs ride in the second
+    c = _cpu_counter(n, 0 if rank == 5 else 1000 * (rank + 1))
+    c.mats.copy_(banded(100 + rank, 0 if rank == 5 else 4 * (rank + 1)))
+    c.stats += torch.tensor([rank + 1, 2 * rank, 3], dtype=torch.int64)
+    want = dense_sum(c.mats)
+    c.all_reduce()
+    res["uneven"] = (c.last_all_reduce, c.last_collectives, bool(torch.equal(c.mats, want)), c.stats.tolist(), c.pairs_in_buffer, c.wide is None)
+    # (2) one rank vetoes the compact form: every rank takes the dense ring, same sums
+    c = _cpu_counter(n, 10)
+    c.mats.copy_(banded(200 + rank, 5))
+    want = dense_sum(c.mats)
+    if rank == 3:
+        os.environ["VS_COMPACT_ALLREDUCE"] = "0"
+    c.all_reduce()
+    os.environ.pop("VS_COMPACT_ALLREDUCE", None)
+    res["veto"] = (c.last_all_reduce, bool(torch.equal(c.mats, want)), c.pairs_in_buffer)
+    # (3) the uint32 buffers cannot hold the sum of eight ranks (cells above 2^31 among them): all fold, int64 totals summed
+    c = _cpu_counter(n, 2 ** 28 + rank)
+    _set_cell(c, 1, 7, 7, 2 ** 32 - 1 - rank)
+    _set_cell(c, 0, 2, 9, 2 ** 31 + rank)
+    c.all_reduce()
+    node, short, _ = c.result()
+    res["fold"] = (c.wide is not None, c.pairs_in_buffer, int(short[7, 7]), int(node[2, 9]), c.last_all_reduce)
+    # (3b) ... and they can when the bound says so: 2^25 pairs on the largest of eight ranks
+    c = _cpu_counter(n, 2 ** 25 if rank == 2 else 17)
+    _set_cell(c, 0, 1, 1, 2 ** 28 + rank)
+    c.all_reduce()
+    res["nofold"] = (c.wide is None, c.pairs_in_buffer, int(c.result()[0][1, 1]))
+    # (4) only rank 0 needs the sums (the drop-in's writer): reduce instead of all-reduce
+    c = _cpu_counter(n, 5)
+    c.mats.copy_(banded(300 + rank, 6))
+    mine = c.mats.clone()
+    want = dense_sum(c.mats)
+    c.all_reduce(dst=0)
+    res["dst"] = bool(torch.equal(c.mats, want)) if rank == 0 else bool(torch.equal(c.mats, mine))
+    # (5) the steady state of fixed-size steps: the first exchange learns the union's size, the following ones are PREDICTED
+    # (no host wait, two collectives); a step whose union outgrows the prediction is completed by settle()
+    c = _cpu_counter(n, 0)
+    steps = []
+    for step in range(5):
+        c.settle()
+        c.mats.zero_()
+        c.stats.zero_()
+        c.pairs_in_buffer = 100
+        cells = 3 if step < 3 else 60 if step == 3 else 3  # (step 3: twenty times the cells)
+        c.mats.copy_(banded(1000 * step + rank, cells))
+        c.stats += 1
+        want = dense_sum(c.mats)
+        c.all_reduce(predict=True)
+        waits_before = c._xstate.host_waits
+        coll = c.last_collectives
+        c.settle()
+        steps.append((coll, waits_before, bool(torch.equal(c.mats, want)), c.stats.tolist(), c._xstate.collectives))
+    res["steady"] = steps
+    if rank in (0, 5):
+        q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_packed_exchange_eight_ranks_gloo():
+    """Round 6: PeCounter.all_reduce is TWO collectives -- MAX over [occupancy | flag bytes],
+    SUM over [occupied stretches | stats row] -- on eight ranks with uneven shards, a rank without pairs, a rank that vetoes
+    the compact form, counters beyond 2^31 that force the fold, a reduce to the writer only, and the predicted steady state
+    (no host wait; a union that outgrows the prediction is repaired by settle())."""
+    import torch.multiprocessing as mp
+
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29500 + ((os.getpid() + 333) % 500)
+    world = 8
+    procs = [ctxm.Process(target=_rank_packed_eight, args=(rk, world, port, q)) for rk in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank in (0, 5):
+        r = got[rank]
+        how, coll, same, stats, pairs, narrow = r["uneven"]
+        assert how == "compact" and coll == 2 and same and narrow
+        assert stats == [sum(range(1, 9)), 2 * sum(range(8)), 24] and pairs == sum(1000 * (k + 1) for k in range(8) if k != 5)
+        assert r["veto"] == ("dense", True, 80)
+        wide, pairs, s77, n29, _ = r["fold"]
+        assert wide and pairs == 0 and s77 == sum(2 ** 32 - 1 - k for k in range(8)) and n29 == sum(2 ** 31 + k for k in range(8))
+        assert r["nofold"] == (True, 2 ** 25 + 7 * 17, 8 * 2 ** 28 + 28)
+        assert r["dst"]
+        st = r["steady"]
+        assert st[0][0] == 2 and st[0][1] == 1                    # the first exchange asks the device once
+        for coll, waits, same, stats, coll_after in st[1:]:
+            assert coll == 2 and waits == 0 and same and stats == [8, 8, 8]
+        assert st[0][2] and st[3][4] > 2                          # step 3 outgrew the prediction: settle() summed the rest
+        assert st[4][4] == 2
+
+
 def test_async_allreduce_without_process_group_is_a_no_op():
     import torch
 

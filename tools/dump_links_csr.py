@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""GPU box: the symmetrised PE-link table (IO.py:598-627) of a BASELINE config's whole per-GPU read block as CSR rows of
+its non-zero cells, in the GFA's node order, written under gpurun_out/ in parts of at most --part-mb megabytes (gpurun
+brings back 64 MiB per call: name the parts a call should write with --parts a,b,...).  The build container then runs the
+checker's Python statement of the stages (oracle/graph_stages) on it -- tools/extract_digests_from_csr.py -- and commits the
+digests the `-m gpu` suite holds the device run to (tests/golden/extract_digests_config4.json).
+
+    python tools/dump_links_csr.py --config 4 [--parts 0,1] [--part-mb 28]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=4)
+    ap.add_argument("--parts", default=None)
+    ap.add_argument("--part-mb", type=float, default=28.0)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out"))
+    args = ap.parse_args()
+    import tempfile
+
+    import torch
+
+    from vstrains_amd import pe as host
+    from vstrains_amd.workloads import CONFIGS, workload_for
+
+    cfg = CONFIGS[args.config]
+    work = tempfile.mkdtemp(prefix="vs_dump_")
+    st, pre, names, seqs, cum, logger, _ = workload_for(args.config, work)
+    ctx = host.Context(0)
+    ctx.build_index(seqs, cfg["k"])
+    n_pairs = cfg["total_pairs"] // cfg["gpus"]
+    reads = ctx.synth_pairs(st.genomes, cum, 20250000 + args.config, 0, n_pairs, cfg["read_len"], int(0.005 * 2 ** 32), int(0.001 * 2 ** 32))
+    counter = host.PeCounter(ctx)
+    counter.add(reads)
+    del reads
+    n = counter.n
+    order = counter.node_order  # index numbering -> GFA position
+    parts_ij, parts_v = [], []
+    for lo in range(0, n, 4096):
+        blk = counter.mats[0, lo:lo + 4096].to(torch.int64) + counter.mats[1, lo:lo + 4096]
+        nz = torch.nonzero(blk)
+        parts_v.append(blk[nz[:, 0], nz[:, 1]])
+        nz[:, 0] += lo
+        parts_ij.append(nz)
+    ij, v = torch.cat(parts_ij), torch.cat(parts_v)
+    if order is not None:  # to the GFA's numbering: the file is independent of how the device numbers its index
+        o = torch.as_tensor(np.asarray(order, dtype=np.int64), device=ij.device)
+        ij = torch.stack([o[ij[:, 0]], o[ij[:, 1]]], dim=1)
+    off = ij[:, 0] != ij[:, 1]
+    keys = torch.cat([ij[:, 0] * n + ij[:, 1], ij[off, 1] * n + ij[off, 0]])
+    vals = torch.cat([v, v[off]])
+    uk, inv = torch.unique(keys, return_inverse=True)
+    uv = torch.zeros(uk.shape[0], dtype=torch.int64, device=uk.device).scatter_add_(0, inv, vals)
+    rows = (uk // n).cpu().numpy()
+    col = (uk % n).cpu().numpy().astype(np.uint32)
+    val = uv.cpu().numpy()
+    assert val.max() < 2 ** 32
+    row_ptr = np.zeros(n + 1, dtype=np.uint64)
+    row_ptr[1:] = np.cumsum(np.bincount(rows, minlength=n))
+    nnz = int(col.shape[0])
+    # parts: whole rows, about part_mb of raw (col u32 + val u32) each
+    per = int(args.part_mb * 1e6 / 8)
+    cuts = [0]
+    while cuts[-1] < n:
+        target = int(row_ptr[cuts[-1]]) + per
+        nxt = int(np.searchsorted(row_ptr, target, side="right")) - 1
+        cuts.append(min(n, max(nxt, cuts[-1] + 1)))
+    n_parts = len(cuts) - 1
+    want = range(n_parts) if args.parts is None else [int(x) for x in args.parts.split(",") if int(x) < n_parts]
+    os.makedirs(args.out, exist_ok=True)
+    import hashlib
+
+    meta = {"config": args.config, "nodes": int(n), "pairs": int(n_pairs), "nnz": nnz, "parts": n_parts, "row_cuts": cuts,
+            "names_sha256": hashlib.sha256("\n".join(names).encode()).hexdigest(),
+            "csr_sha256": hashlib.sha256(row_ptr.tobytes() + col.tobytes() + val.astype(np.uint32).tobytes()).hexdigest(),
+            "stats": [int(x) for x in counter.stats] if hasattr(counter, "stats") else None}
+    with open(os.path.join(args.out, "links_c%d_meta.json" % args.config), "w") as fh:
+        json.dump(meta, fh)
+    for p in want:
+        lo, hi = cuts[p], cuts[p + 1]
+        a, b = int(row_ptr[lo]), int(row_ptr[hi])
+        path = os.path.join(args.out, "links_c%d_part%d.npz" % (args.config, p))
+        np.savez_compressed(path, row_lo=lo, row_hi=hi, row_ptr=(row_ptr[lo:hi + 1] - row_ptr[lo]).astype(np.uint32), col=col[a:b], val=val[a:b].astype(np.uint32))
+        print("part", p, "rows", lo, hi, "cells", b - a, "bytes", os.path.getsize(path), flush=True)
+    print(json.dumps({k: meta[k] for k in ("nodes", "pairs", "nnz", "parts", "csr_sha256")}))
+
+
+if __name__ == "__main__":
+    main()

@@ -10,8 +10,9 @@ tools/time_reference_stages.py, which sets PYTHONPATH (stand-in first), PYTHONHA
 
 --pe-cache DIR: DIR/pe_info, DIR/st_info and DIR/s_graph_L1.sha256 were written by the real
 VStrains_PE_Inference.py on a byte-identical s_graph_L1.gfa (the harness checks the SHA-256 of the file the
-reference has just written and refuses otherwise); the PE subprocess -- whose output depends on neither the in-edge
-model nor the hash seed -- is then replaced by a copy of those files, so that eight runs need one PE run.
+reference has just written; another s_graph_L1.gfa -- the stand-in's other in-edge model numbers the segments differently
+-- gets a cache of its own, made by the real script on first use); the PE subprocess -- whose output depends on the graph
+file and the reads only -- is then replaced by a copy of those files, so that eight runs need two PE runs.
 
 Every INFO line the reference logs is appended to <timing>.progress with the seconds since start, as it happens:
 a run that is killed leaves how far it got and at which rate.

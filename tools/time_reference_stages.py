@@ -144,13 +144,21 @@ def collect(work, meta, models, seeds, out_path, digests_path):
     base_key = ("rotate", 0) if ("rotate", 0) in runs else sorted(runs)[0]
     base = runs[base_key]
     names_all = sorted(set().union(*[set(r) for r in runs.values()]))
-    stable = [f for f in names_all if all(r.get(f) == base.get(f) for r in runs.values())]
+    # what the tests bind: the files every run under the BASE run's in-edge model agrees on (the product follows that model,
+    # DESIGN.md 8); what is independent of the model is listed beside it -- at configs[1] the other model already writes another
+    # graph_L0.gfa (the flip walk of IO.py:191-229 follows the adjacency order) and ends with 21 strains instead of 20
+    same_model = {k: r for k, r in runs.items() if k[0] == base_key[0]}
+    stable = [f for f in names_all if all(r.get(f) == base.get(f) for r in same_model.values())]
+    stable_all = [f for f in names_all if all(r.get(f) == base.get(f) for r in runs.values())]
     ran_models = sorted({m for m, _ in runs})
     ran_seeds = sorted({h for _, h in runs})
     entry = {
         "workload": meta["workload"], "pairs": meta["pairs"], "stream_seed": meta["stream_seed"], "nodes": meta["nodes"],
         "s_graph_L1_gfa_sha256": meta["s_graph_L1_gfa_sha256"],
         "files_sha256": {f: base[f] for f in stable},
+        "files_sha256_scope": "files every run under the in-edge model of base_run agrees on (all hash seeds run)",
+        "files_identical_under_both_in_edge_models": stable_all,
+        "strains_per_run": {"%s/%d" % k: timings["%s/%d" % k].get("strains") for k in sorted(runs)},
         "base_run_files_sha256": dict(base), "base_run": "%s/%d" % base_key,
         "runs": sorted("%s/%d" % k for k in runs),
         "digest_form": "tests/golden/make_graph_golden.collect (GFA / FASTA sequences as digests), then SHA-256 of that text",
@@ -169,7 +177,7 @@ def collect(work, meta, models, seeds, out_path, digests_path):
     with open(digests_path, "w") as fh:
         json.dump(old, fh, indent=1, sort_keys=True)
         fh.write("\n")
-    print("written", digests_path, "stable", len(stable), "of", len(names_all))
+    print("written", digests_path, "stable under the base model", len(stable), "under both", len(stable_all), "of", len(names_all))
 
 
 def main():

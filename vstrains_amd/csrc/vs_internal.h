@@ -159,7 +159,7 @@ struct vs_ctx {
     double last_sort_ms = 0;
     // per-end accepted lists between k_pe_tiles and k_pe_accumulate
     void *d_lists = nullptr, *d_list_counts = nullptr;
-    uint64_t lists_cap = 0;
+    uint64_t lists_cap = 0, lists_words = 0;
     // row-owner counting (k_list_owners / k_rows_count / k_rows_fill / k_rows_sum): per matrix and row the counts, cursors
     // and offsets (6 x (N + 2) words), the items of every row (one word per listed node), the multiplicity of every end's list
     void *d_rows = nullptr, *d_row_entries = nullptr, *d_mult = nullptr, *d_ltab = nullptr;

@@ -37,7 +37,19 @@
 #include "vs_internal.h"
 
 #define TPB 256
-#define LC 16u  // accepted nodes kept per read end in LDS (more -> slow path)
+// The hand-off between the mapping kernel and the counter kernels (r6): the accepted nodes of a tile's ends are PACKED --
+// end after end, every list padded to whole quads (16 bytes), no fixed row per end.  Found by a wavefront prefix sum over
+// the ends' list lengths (k_pe_tiles P4), in LDS first, then written out as one coalesced stretch.
+//   LC    list words a tile's region of the hand-off buffer holds per end ON AVERAGE (region = ept * LC words)
+//   LCAP  accepted nodes an end may have on the main path (more -> the overflow kernels); rows of 16 sent 2.3 % of the
+//         pairs of configs[4] (ends of 17 .. 19 nodes) through k_pe_mid a second time
+//   pair-major counters (k_pe_accumulate): counts[end] = n | quad offset inside the tile's region << 8
+//   row owners (graphs beyond 46 340 nodes): their entries name lists by END INDEX, so the lists keep a fixed stride
+//         there -- rows LROW words apart, of which only the quads that hold nodes are written; counts[end] = n
+#define LC 16u
+#define LCAP 20u
+#define LROW 32u  // words from one end's row to the next in the row owners' layout: 128 bytes, so that a list of up to 16 nodes lies in ONE
+                  // 64-byte stretch (rows of LCAP words, 80 bytes apart, straddle one every other time: 10.9 -> 13.0 ms at configs[4])
 #define EMPTY_NODE 0xFFFFFFFFu
 #ifndef PPT
 #define PPT 2u               // postings per thread and expansion chunk
@@ -75,8 +87,9 @@ struct PeParams {
     uint32_t tiles_per_wg; // contiguous run of tiles per workgroup
     uint32_t magic_pmax, magic_wpe;  // vs_fastdiv constants
     uint32_t count_postings;         // VS_DEBUG_POSTINGS: sum the postings expanded (diagnostics)
-    uint32_t *out_lists;             // [n_tiles * ept * LC] accepted node ids per end, tile order
-    uint32_t *out_counts;            // [n_tiles * ept] list lengths (0 for ends that add nothing)
+    uint32_t *out_lists;             // accepted node ids, tile order: packed regions of ept * LC words / rows of LCAP words (out_rows)
+    uint32_t *out_counts;            // [n_tiles * ept] list lengths (0 for ends that add nothing), packed form: | quad offset << 8
+    uint32_t out_rows;               // 1: fixed rows of LCAP words per end (the row owners follow), 0: packed
     uint64_t n_pairs;
     uint32_t no_xcd_map;             // VS_NO_XCD_MAP=1: workgroup b takes run b (experiments)
     uint32_t shortcut;               // overlapping-seed ownership shortcut for single postings (P3 stage A)
@@ -97,6 +110,43 @@ __device__ __forceinline__ void vs_mark_tile(uint8_t *map, uint32_t T, uint32_t 
 // atomics; the load of the test above was a round trip per loop turn -- r5).
 __device__ __forceinline__ void vs_mark_tile_store(uint8_t *map, uint32_t T, uint32_t mat, uint32_t x, uint32_t y) {
     if (map) map[((uint64_t)mat * T + (x >> 6)) * T + (y >> 6)] = 1;
+}
+
+// Inclusive scans over the 64 lanes of a wavefront by DPP moves -- row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then the
+// last lane of a row broadcast to the rows after it (row_bcast 15 / 31) -- six VALU instructions where the __shfl_up form
+// takes six ds_bpermute round trips through the LDS crossbar (r6; -DVS_DPP_SCAN=0: the __shfl_up form).  A lane whose source
+// lies outside its row keeps the `old` operand: the identity of the operation.
+#ifndef VS_DPP_SCAN
+#define VS_DPP_SCAN 1
+#endif
+#define VS_DPP_STEP(op, ctrl, rowmask) { const uint32_t t_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rowmask, 0xf, false); v = op; }
+__device__ __forceinline__ uint32_t vs_wave_scan_add(uint32_t v) {
+#if VS_DPP_SCAN
+    VS_DPP_STEP(v + t_, 0x111, 0xf) VS_DPP_STEP(v + t_, 0x112, 0xf) VS_DPP_STEP(v + t_, 0x114, 0xf) VS_DPP_STEP(v + t_, 0x118, 0xf)
+    VS_DPP_STEP(v + t_, 0x142, 0xa) VS_DPP_STEP(v + t_, 0x143, 0xc)
+#else
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t2 = __shfl_up(v, d, 64);
+        if (lane >= (uint32_t)d) v += t2;
+    }
+#endif
+    return v;
+}
+__device__ __forceinline__ uint32_t vs_wave_scan_max(uint32_t v) {
+#if VS_DPP_SCAN
+    VS_DPP_STEP(v > t_ ? v : t_, 0x111, 0xf) VS_DPP_STEP(v > t_ ? v : t_, 0x112, 0xf) VS_DPP_STEP(v > t_ ? v : t_, 0x114, 0xf)
+    VS_DPP_STEP(v > t_ ? v : t_, 0x118, 0xf) VS_DPP_STEP(v > t_ ? v : t_, 0x142, 0xa) VS_DPP_STEP(v > t_ ? v : t_, 0x143, 0xc)
+#else
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t2 = __shfl_up(v, d, 64);
+        if (lane >= (uint32_t)d && t2 > v) v = t2;
+    }
+#endif
+    return v;
 }
 
 struct Mem {  // one credited maximal exact match
@@ -791,13 +841,8 @@ k_pe_tiles(PeParams P) {
             uint32_t local = 0;
             for (uint32_t i = 0; i < chunk; i++)
                 if (b + i < NI) local += s_pcnt[b + i];
-            uint32_t incl = local;
+            const uint32_t incl = vs_wave_scan_add(local);
             const uint32_t lane = tid & 63u;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                uint32_t t = __shfl_up(incl, d, 64);
-                if (lane >= (uint32_t)d) incl += t;
-            }
             if (lane == 63u) s_misc[tid >> 6] = incl;
             __syncthreads();
             uint32_t off = incl - local;
@@ -837,13 +882,8 @@ k_pe_tiles(PeParams P) {
                 run = v > run ? v : run;
                 own[k2] = run;
             }
-            uint32_t incl = run;
+            const uint32_t incl = vs_wave_scan_max(run);
             const uint32_t lane = tid & 63u;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t t2 = __shfl_up(incl, d, 64);
-                if (lane >= (uint32_t)d && t2 > incl) incl = t2;
-            }
             if (lane == 63u) s_misc[4u + (tid >> 6)] = incl;
             uint32_t carry = __shfl_up(incl, 1, 64);
             if (lane == 0u) carry = 0;
@@ -951,41 +991,114 @@ k_pe_tiles(PeParams P) {
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wavefront's LDS-direct loads of the next tile's words are in
         __syncthreads();
         if (debug_stop == 4u) continue;
-        // ---- P4: acceptance test per table slot; accepted nodes go to the end's list
-        for (uint32_t i = tid; i < pool; i += TTPB) {
-            uint32_t key = s_hkey[i];
-            if (key != EMPTY_NODE) {
-                uint32_t e = key >> 25, node = key & 0x01FFFFFFu;
-                uint32_t rlen = s_meta[e] & VS_LEN_MASK;
-                const uint32_t hj = s_hminj[i];
-                const uint32_t nlen = FAST ? hj >> AB : P.idx.meta[node].len;
-                const uint32_t minj = FAST ? hj & ((1u << AB) - 1u) : hj;
-                if (FAST ? vs_accept32(s_hcnt[i], s_hminp[i], minj, nlen, rlen, K) : vs_accept(s_hcnt[i], s_hminp[i], minj, nlen, rlen, K)) {
-                    uint32_t k2 = atomicAdd(&s_ns[e], 1u);
-                    if (k2 < LC) s_list[e * LC + k2] = node; else atomicOr(&s_state[e], 2u);
+        // ---- P4: acceptance test per table slot; an accepted node takes the next position of its end's list
+        // (r6) The lists are PACKED: first every slot is judged and the ends' list lengths counted (the slot keeps its
+        // position, its count is not needed any more), then ONE wavefront turns the lengths -- rounded up to whole quads -- into
+        // offsets by a prefix sum over the ends, then the nodes go to their places.  An end with more than LCAP nodes, or one
+        // that does not fit what is left of the tile's region (ept * LC words), is an overflow end.
+        // (the thread index is laundered through an empty asm: what this phase derives from it -- slot and end indices,
+        // LDS and global addresses -- then cannot be hoisted out of the tile loop, where it would sit in vector registers
+        // across P3, the phase the kernel's 96-register budget is made for)
+        uint32_t lt = tid;
+        asm volatile("" : "+v"(lt));
+        // (compile-time shapes: a thread's four slots -- key and position -- stay in registers across the prefix sum)
+        constexpr uint32_t SPT = STD ? (1u << C_POOL_BITS) / TTPB : 1u;
+        uint32_t r_key[SPT], r_at[SPT];
+        auto judge = [&](uint32_t i, uint32_t key) -> uint32_t {  // the position of slot i's node in its end's list, or none
+            const uint32_t e = key >> 25, node = key & 0x01FFFFFFu;
+            const uint32_t rlen = s_meta[e] & VS_LEN_MASK;
+            const uint32_t hj = s_hminj[i];
+            const uint32_t nlen = FAST ? hj >> AB : P.idx.meta[node].len;
+            const uint32_t minj = FAST ? hj & ((1u << AB) - 1u) : hj;
+            if (FAST ? vs_accept32(s_hcnt[i], s_hminp[i], minj, nlen, rlen, K) : vs_accept(s_hcnt[i], s_hminp[i], minj, nlen, rlen, K))
+                return atomicAdd(&s_ns[e], 1u);
+            return 0xFFFFFFFFu;
+        };
+        if (STD) {
+#pragma unroll
+            for (uint32_t j = 0; j < SPT; j++) {
+                const uint32_t i = lt + j * TTPB;
+                r_key[j] = s_hkey[i];
+                r_at[j] = r_key[j] != EMPTY_NODE ? judge(i, r_key[j]) : 0xFFFFFFFFu;
+            }
+        } else {
+            for (uint32_t i = lt; i < pool; i += TTPB) {
+                const uint32_t key = s_hkey[i];
+                if (key != EMPTY_NODE) s_hcnt[i] = judge(i, key);
+            }
+        }
+        __syncthreads();
+        if (lt < 64u) {  // two ends per lane (ept <= TTPB / 2 = 128)
+            const uint32_t e0 = 2u * lt, e1 = e0 + 1u;
+            const uint32_t st0 = e0 < ne ? s_state[e0] : 0u, st1 = e1 < ne ? s_state[e1] : 0u;
+            const uint32_t n0 = (st0 & 3u) == 1u ? s_ns[e0] : 0u, n1 = (st1 & 3u) == 1u ? s_ns[e1] : 0u;
+            bool over0 = n0 > LCAP, over1 = n1 > LCAP;
+            const uint32_t q0 = over0 ? 0u : (n0 + 3u) >> 2, q1 = over1 ? 0u : (n1 + 3u) >> 2;
+            const uint32_t incl = vs_wave_scan_add(q0 + q1);
+            const uint32_t capq = (ept * LC) >> 2;
+            const uint32_t o0 = incl - q0 - q1, o1 = o0 + q0;
+            over0 |= o0 + q0 > capq;
+            over1 |= o1 + q1 > capq;
+            // (an end whose nodes are not placed -- overflow, or not an end of a used pair -- says so in its offset)
+            if (e0 < ne) { s_pcnt[e0] = over0 || (st0 & 3u) != 1u ? 0xFFFFFFFFu : 4u * o0; if (over0) s_state[e0] = st0 | 2u; }
+            if (e1 < ne) { s_pcnt[e1] = over1 || (st1 & 3u) != 1u ? 0xFFFFFFFFu : 4u * o1; if (over1) s_state[e1] = st1 | 2u; }
+            if (lt == 63u) s_misc[8] = 4u * (incl < capq ? incl : capq);  // words of the tile's packed lists
+        }
+        __syncthreads();
+        uint32_t *s_off = s_pcnt;  // (the scan of P2 is done with)
+        if (STD) {
+#pragma unroll
+            for (uint32_t j = 0; j < SPT; j++)
+                if (r_at[j] != 0xFFFFFFFFu) {
+                    const uint32_t o = s_off[r_key[j] >> 25];
+                    if (o != 0xFFFFFFFFu) s_list[o + r_at[j]] = r_key[j] & 0x01FFFFFFu;
+                }
+        } else {
+            for (uint32_t i = lt; i < pool; i += TTPB) {
+                const uint32_t key = s_hkey[i];
+                if (key != EMPTY_NODE) {
+                    const uint32_t at = s_hcnt[i], o = s_off[key >> 25];
+                    if (at != 0xFFFFFFFFu && o != 0xFFFFFFFFu) s_list[o + at] = key & 0x01FFFFFFu;
                 }
             }
         }
         __syncthreads();
         // pairs with an overflowed end go to the slow list
-        if (tid < npair) {
-            uint32_t st = s_state[2 * tid] | s_state[2 * tid + 1];
+        if (lt < npair) {
+            uint32_t st = s_state[2 * lt] | s_state[2 * lt + 1];
             if ((st & 1u) && (st & 2u)) {
                 uint32_t at = atomicAdd(P.slow_count, 1u);
-                P.slow_list[at] = s_gend[2 * tid] >> 1;
-                s_state[2 * tid] |= 2u;
-                s_state[2 * tid + 1] |= 2u;
+                P.slow_list[at] = s_gend[2 * lt] >> 1;
+                s_state[2 * lt] |= 2u;
+                s_state[2 * lt + 1] |= 2u;
             }
         }
         __syncthreads();
         if (debug_stop == 5u) continue;
-        // ---- P5: hand the accepted lists to k_pe_accumulate (one LC-word row per end, tile order;
-        // length 0 for ends of dropped pairs and of pairs the slow path takes)
+        // ---- P5: hand the accepted lists to the counter kernels, tile order; length 0 for ends of dropped pairs and of
+        // pairs the slow path takes
         if (accumulate) {
-            uint32_t *ol = P.out_lists + (uint64_t)tile * ept * LC;
-            for (uint32_t i = tid; i < ne * LC; i += TTPB) ol[i] = s_list[i];
-            for (uint32_t i = tid; i < ne; i += TTPB)
-                P.out_counts[(uint64_t)tile * ept + i] = (s_state[i] & 3u) == 1u ? s_ns[i] : 0u;
+            if (!P.out_rows) {  // the tile's packed lists as they lie in LDS: one coalesced stretch
+                uint32_t *ol = P.out_lists + (uint64_t)tile * ept * LC;
+                const uint32_t total = s_misc[8];
+                for (uint32_t i = lt; i < total; i += TTPB) ol[i] = s_list[i];
+                for (uint32_t i = lt; i < ne; i += TTPB) {
+                    const uint32_t n = (s_state[i] & 3u) == 1u ? s_ns[i] : 0u;
+                    P.out_counts[(uint64_t)tile * ept + i] = n ? n | (s_off[i] >> 2) << 8 : 0u;
+                }
+            } else {  // a row per end, LROW words apart; a lane per (end, quad), only the quads that hold nodes
+                uint32_t *ol = P.out_lists + (uint64_t)tile * ept * LROW;
+                for (uint32_t i = lt; i < ne * (LCAP / 4u); i += TTPB) {
+                    const uint32_t e = i / (LCAP / 4u), q4 = 4u * (i - e * (LCAP / 4u));
+                    const uint32_t n = (s_state[e] & 3u) == 1u ? s_ns[e] : 0u;
+                    if (q4 < n) {
+                        const uint32_t *src = s_list + s_off[e] + q4;
+                        *(VsQuad *)(ol + e * LROW + q4) = VsQuad{src[0], src[1], src[2], src[3]};
+                    }
+                }
+                for (uint32_t i = lt; i < ne; i += TTPB)
+                    P.out_counts[(uint64_t)tile * ept + i] = (s_state[i] & 3u) == 1u ? s_ns[i] : 0u;
+            }
         }
         if (want_dbg) {
             for (uint32_t i = tid; i < ne; i += TTPB) {
@@ -993,7 +1106,7 @@ k_pe_tiles(PeParams P) {
                 uint32_t n = s_ns[i];
                 const uint64_t ge = s_gend[i];
                 P.dbg_counts[ge] = n;
-                for (uint32_t k2 = 0; k2 < n && k2 < P.dbg_cap; k2++) P.dbg_lists[ge * P.dbg_cap + k2] = s_list[i * LC + k2];
+                for (uint32_t k2 = 0; k2 < n && k2 < P.dbg_cap; k2++) P.dbg_lists[ge * P.dbg_cap + k2] = s_list[s_off[i] + k2];
             }
         }
     }
@@ -1020,7 +1133,7 @@ k_pe_tiles(PeParams P) {
 #define ACC_BITS 14
 #endif
 #define ACC_SLOTS (1u << ACC_BITS)
-#define ACC_LDS_BYTES ((2u * ACC_SLOTS + (ACC_TPB / 64) * 66u + (LC + 1u) + (LC + 1u) * 40u + 4u) * 4u)
+#define ACC_LDS_BYTES ((2u * ACC_SLOTS + (ACC_TPB / 64) * 66u + (LCAP + 1u) + (LCAP + 1u) * ACC_GMAX + 4u) * 4u)
 // Work units: a list row is cut into runs of at most ACC_RUN partners, one lane per run, so that
 // every lane of a wavefront has about the same (small, fully unrolled) amount of work:
 //   node_mat : left node a against right positions [4c, 4c+4)           -> nl * ceil(nr/4) runs
@@ -1029,7 +1142,7 @@ k_pe_tiles(PeParams P) {
 #ifndef ACC_RUN
 #define ACC_RUN 4u   // 4 or 8 (8: two 16-byte partner loads per run; measured r5, see profiles/EXPERIMENTS.md)
 #endif
-#define ACC_GMAX 40u  // g(16) for runs of 4 (runs of 8 need 24)
+#define ACC_GMAX 60u  // g(LCAP = 20) for runs of 4 (runs of 8 need 36)
 // The cell table: 16 k slots, 32-bit keys (k_pe_accumulate: mat * N*N + x * N + y, while 2*N*N fits 32 bits, N <= 46340;
 // the row owners: cell index relative to the strip's first row).  The 16 cells of one 64-byte stretch of a matrix row
 // sit in 16 NEIGHBOURING slots (the hash picks a group of 16 slots from the key >> 4, the low four bits pick the slot
@@ -1069,18 +1182,18 @@ __global__ void __launch_bounds__(ACC_TPB)
 k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_slots_pairs,
                 uint32_t pairs_per_wg, uint32_t N, uint32_t use_table, uint32_t fill_limit,
                 uint32_t *__restrict__ node_mat, uint32_t *__restrict__ short_mat, uint32_t *__restrict__ queue,
-                uint32_t *__restrict__ dbg, uint32_t ppw) {  // VS_DEBUG_ACC: [0] increments past the table, [1] write-outs, [2] cells written, [3] rounds
+                uint32_t *__restrict__ dbg, uint32_t ppw, uint32_t ept) {  // VS_DEBUG_ACC: [0] increments past the table, [1] write-outs, [2] cells written, [3] rounds
     uint32_t *s_key = vs_lds;                      // [ACC_SLOTS]
     uint32_t *s_cnt = vs_lds + ACC_SLOTS;          // [ACC_SLOTS]
     uint32_t(*s_pref)[66] = (uint32_t(*)[66])(vs_lds + 2u * ACC_SLOTS);  // [ACC_TPB / 64][66]
-    uint32_t *s_g = vs_lds + 2u * ACC_SLOTS + (ACC_TPB / 64) * 66u;      // [LC + 1]: g(n)
-    uint32_t *s_ua = s_g + (LC + 1u);                                     // [LC + 1][ACC_GMAX]: run -> position a
-    uint32_t &s_used = s_ua[(LC + 1u) * ACC_GMAX];
-    uint32_t &s_lost = s_ua[(LC + 1u) * ACC_GMAX + 1u];
+    uint32_t *s_g = vs_lds + 2u * ACC_SLOTS + (ACC_TPB / 64) * 66u;      // [LCAP + 1]: g(n)
+    uint32_t *s_ua = s_g + (LCAP + 1u);                                   // [LCAP + 1][ACC_GMAX]: run -> position a
+    uint32_t &s_used = s_ua[(LCAP + 1u) * ACC_GMAX];
+    uint32_t &s_lost = s_ua[(LCAP + 1u) * ACC_GMAX + 1u];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t NN = N * N;  // (use_table: 2 * N * N fits 32 bits)
     for (uint32_t i = tid; i < ACC_SLOTS; i += ACC_TPB) { s_key[i] = Acc32::EMPTY; s_cnt[i] = 0; }
-    if (tid <= LC) {
+    if (tid <= LCAP) {
         uint32_t gsum = 0;
         for (uint32_t m = 1; m <= tid; m++) gsum += (m + ACC_RUN - 1u) / ACC_RUN;
         s_g[tid] = gsum;
@@ -1093,7 +1206,8 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
     __syncthreads();
     // chunks of pairs_per_wg pairs: chunk blockIdx.x, or (queue) whichever chunk is next when this
     // workgroup is free -- the table then lives across chunks and is written out on fill only
-    uint32_t &s_chunk = s_ua[(LC + 1u) * ACC_GMAX + 2u];
+    uint32_t &s_chunk = s_ua[(LCAP + 1u) * ACC_GMAX + 2u];
+    const uint32_t ppt = ept >> 1, region_q = (ept * LC) >> 2;  // pairs per tile of the mapping kernel; quads of a tile's region
     // every cell of the table to its counter (one global atomic per cell), the table emptied
     auto write_out = [&]() {
         for (uint32_t i = tid; i < ACC_SLOTS; i += ACC_TPB) {
@@ -1123,19 +1237,20 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
     for (uint64_t base = lo; base < hi; base += (ACC_TPB / 64u) * ppw) {
         const uint64_t wbase = base + wv * ppw;             // wave-uniform
         const uint32_t *wcounts = counts + 2u * wbase;
-        const uint32_t *wlists = lists + 2u * wbase * LC;
-        uint32_t nl = 0, nr = 0;
+        // the lists are packed per tile of the mapping kernel (k_pe_tiles P4 / P5): where a pair's two lists start, in quads
+        // from the region of the wavefront's first tile -- at most 64 pairs further on, so 11 bits each, next to the lengths
+        const uint64_t tile0 = wbase / ppt;                 // wave-uniform
+        const uint32_t rem0 = (uint32_t)(wbase - tile0 * ppt);
+        const uint32_t *wlists = lists + tile0 * ept * LC;
+        uint32_t nl = 0, nr = 0, packed = 0;
         if (lane < ppw && wbase + lane < hi) {
             const uint2 c = *(const uint2 *)(wcounts + 2u * lane);
-            nl = c.x; nr = c.y;
+            nl = c.x & 0xFFu; nr = c.y & 0xFFu;
+            const uint32_t tq = (rem0 + lane) / ppt * region_q;
+            packed = nl | nr << 5 | (tq + (c.x >> 8)) << 10 | (tq + (c.y >> 8)) << 21;
         }
         const uint32_t u = nl * ((nr + ACC_RUN - 1u) / ACC_RUN) + s_g[nl] + s_g[nr];
-        uint32_t incl = u;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t2 = __shfl_up(incl, d, 64);
-            if (lane >= (uint32_t)d) incl += t2;
-        }
+        const uint32_t incl = vs_wave_scan_add(u);
         s_pref[wv][lane + 1u] = incl;
         if (lane == 0) s_pref[wv][0] = 0;
         if (lane == 63u) s_pref[wv][65] = 0xFFFFFFFFu;  // sentinel: the look-ahead below never runs off
@@ -1166,27 +1281,27 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
             a0 += s_pref[wv][a0 + 1u] <= t ? 1u : 0u;
             while (s_pref[wv][a0 + 1u] <= t) a0++;
             uint32_t r = t - s_pref[wv][a0];
-            // list lengths of pair a0: lane a0 holds them (cross-lane read, no memory round trip)
-            const uint32_t ql = __shfl(nl, (int)a0, 64), qr = __shfl(nr, (int)a0, 64);
+            // list lengths and places of pair a0: lane a0 holds them (ONE cross-lane read, no memory round trip)
+            const uint32_t pk = __shfl(packed, (int)a0, 64);
+            const uint32_t ql = pk & 31u, qr = (pk >> 5) & 31u, rowl = ((pk >> 10) & 0x7FFu) << 2, rowr = (pk >> 21) << 2;
             R.ok = t_raw < U;
-            const uint32_t row = 2u * a0 * LC;
             const uint32_t cq = (qr + ACC_RUN - 1u) / ACC_RUN;
             uint32_t off;
             if (r < ql * cq) {  // node_mat: left node a, right positions of run c
-                const uint32_t a = cq == 1u ? r : cq == 2u ? r >> 1 : cq == 4u ? r >> 2 : (r * 43691u) >> 17;
-                R.x = wlists[row + a]; R.mat = 0u; off = row + LC; R.bi = ACC_RUN * (r - a * cq); R.be = qr;
+                const uint32_t a = cq == 1u ? r : cq == 2u ? r >> 1 : cq == 4u ? r >> 2 : cq == 3u ? (r * 43691u) >> 17 : (r * 52429u) >> 18;
+                R.x = wlists[rowl + a]; R.mat = 0u; off = rowr; R.bi = ACC_RUN * (r - a * cq); R.be = qr;
             } else {
                 r -= ql * cq;
                 uint32_t n = ql;
-                off = row;
+                off = rowl;
                 const uint32_t gl = s_g[ql];
-                if (r >= gl) { r -= gl; n = qr; off = row + LC; }
+                if (r >= gl) { r -= gl; n = qr; off = rowr; }
                 const uint32_t a = s_ua[n * ACC_GMAX + r];
                 const uint32_t crun = r - (s_g[n] - s_g[n - a]);  // runs of positions before a: g(n) - g(n-a)
                 R.x = wlists[off + a]; R.mat = 1u; R.bi = a + ACC_RUN * crun; R.be = n;
             }
-            // up to ACC_RUN partners, loaded together (the row holds LC entries; reading a few words
-            // past `be` stays inside the lists buffer, which carries padding, and is ignored)
+            // up to ACC_RUN partners, loaded together (reading a few words past `be` -- the list's padding, the next
+            // list -- stays inside the lists buffer, which carries padding at its end, and is ignored)
             R.yq = *(const VsQuad *)(wlists + off + R.bi);  // one 16-byte load
 #if ACC_RUN == 8u
             R.yq2 = *(const VsQuad *)(wlists + off + R.bi + 4u);
@@ -1266,12 +1381,13 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
 // same list rows k_pe_accumulate counts (the overflow kernels and the row owners mark theirs where they add).  A caller that zeroes its
 // counters before every block then zeroes these tiles only (k_zero_tiles) -- a few per cent of a 50 k-node matrix.
 __global__ void __launch_bounds__(256) k_mark_tiles(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts,
-                                                   uint64_t n_slots_pairs, uint8_t *__restrict__ map, uint32_t T) {
+                                                   uint64_t n_slots_pairs, uint8_t *__restrict__ map, uint32_t T, uint32_t ept) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_slots_pairs) return;
-    const uint32_t nl = counts[2u * p], nr = counts[2u * p + 1u];
+    const uint32_t cl = counts[2u * p], cr = counts[2u * p + 1u], nl = cl & 0xFFu, nr = cr & 0xFFu;
     if (!nl && !nr) return;
-    const uint32_t *rl = lists + 2u * p * LC, *rr = rl + LC;
+    // (packed lists: the region of the pair's tile, the quad offsets of its two ends)
+    const uint32_t *region = lists + 2u * p / ept * ept * LC, *rl = region + 4u * (cl >> 8), *rr = region + 4u * (cr >> 8);
     uint8_t *smap = map + (uint64_t)T * T;
     // The distinct tile coordinates (node >> 6) of a list, up to eight of them, in registers (every index below is a
     // compile-time constant: no scratch memory).  The rows come as 16-byte loads, only as many as the list is long.  A list
@@ -1292,7 +1408,7 @@ __global__ void __launch_bounds__(256) k_mark_tiles(const uint32_t *__restrict__
 #pragma unroll
     for (uint32_t j = 0; j < 8u; j++) { tl[j] = 0u; tr[j] = 0u; }
 #pragma unroll
-    for (uint32_t q = 0; q < LC / 4u; q++) {
+    for (uint32_t q = 0; q < LCAP / 4u; q++) {
         if (4u * q < nl) {
             const VsQuad v = *(const VsQuad *)(rl + 4u * q);
             const uint32_t e[4] = {v.x, v.y, v.z, v.w};
@@ -1384,7 +1500,7 @@ __global__ void __launch_bounds__(64) k_zero_tiles(uint32_t *__restrict__ node_m
 #define ROWS_TPB 1024u
 #define ROWS_CAP 4096u     // distinct rows of a chunk that get an LDS cursor (the rest: a global atomic per entry)
 #define ROWS_KEYS 65536u   // rows per histogram pass (larger graphs take several passes over the lists)
-#define ROWS_SUB ((1u << 27) - 1024u)  // pairs per transposition (an entry names a read end in 28 bits; row offsets are 32-bit)
+#define ROWS_SUB ((1u << 26) - 1024u)  // pairs per transposition (an entry names a read end in 27 bits, its list's length in five; row offsets are 32-bit)
 static inline size_t rows_lds_bytes(uint32_t n_keys) { return sizeof(uint32_t) * (((size_t)n_keys + 2u) / 2u + ROWS_CAP + ROWS_CAP / 2u + 4u); }
 
 // Which read ends stand for a list of their own, and for how many ends: short_mat takes one weighted pass per DISTINCT
@@ -1399,21 +1515,22 @@ static inline size_t rows_lds_bytes(uint32_t n_keys) { return sizeof(uint32_t) *
 // reads of one locus repeat each other nine times in ten, their mates rarely; with it the kernel took 5.6 ms at
 // configs[4], without 4.1.)
 #define LTAB_PROBES 16u
-__device__ __forceinline__ void vs_load_list(const uint32_t *__restrict__ row, uint32_t n, uint32_t (&v)[LC]) {
-    const VsQuad a = *(const VsQuad *)row, b = n > 4u ? *(const VsQuad *)(row + 4) : VsQuad{0, 0, 0, 0};
-    const VsQuad c = n > 8u ? *(const VsQuad *)(row + 8) : VsQuad{0, 0, 0, 0}, d = n > 12u ? *(const VsQuad *)(row + 12) : VsQuad{0, 0, 0, 0};
-    const uint32_t w[LC] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+__device__ __forceinline__ void vs_load_list(const uint32_t *__restrict__ row, uint32_t n, uint32_t (&v)[LCAP]) {
+    const VsQuad z{0, 0, 0, 0};
+    const VsQuad a = *(const VsQuad *)row, b = n > 4u ? *(const VsQuad *)(row + 4) : z, c = n > 8u ? *(const VsQuad *)(row + 8) : z;
+    const VsQuad d = n > 12u ? *(const VsQuad *)(row + 12) : z, f = n > 16u ? *(const VsQuad *)(row + 16) : z;
+    const uint32_t w[LCAP] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w, f.x, f.y, f.z, f.w};
 #pragma unroll
-    for (uint32_t i = 0; i < LC; i++) v[i] = i < n ? w[i] : 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < LCAP; i++) v[i] = i < n ? w[i] : 0xFFFFFFFFu;
 }
 // the same set of n nodes?  (both padded with 0xFFFFFFFF)
-__device__ __forceinline__ bool vs_same_list(const uint32_t (&mine)[LC], const uint32_t (&other)[LC], uint32_t n) {
+__device__ __forceinline__ bool vs_same_list(const uint32_t (&mine)[LCAP], const uint32_t (&other)[LCAP], uint32_t n) {
     bool same = true;
 #pragma unroll
-    for (uint32_t k2 = 0; k2 < LC; k2++) {
+    for (uint32_t k2 = 0; k2 < LCAP; k2++) {
         bool found = false;
 #pragma unroll
-        for (uint32_t i = 0; i < LC; i++) found |= mine[i] == other[k2];
+        for (uint32_t i = 0; i < LCAP; i++) found |= mine[i] == other[k2];
         same &= found || k2 >= n;
     }
     return same;
@@ -1427,17 +1544,17 @@ k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ c
     const uint32_t e = (uint32_t)e64, n = counts[e];
     uint32_t m = n ? 1u : 0u, own = e;
     if (n && ltab) {
-        uint32_t mine[LC];
-        vs_load_list(lists + e64 * LC, n, mine);
+        uint32_t mine[LCAP];
+        vs_load_list(lists + e64 * LROW, n, mine);
         unsigned long long f2 = n;
 #pragma unroll
-        for (uint32_t i = 0; i < LC; i++)
+        for (uint32_t i = 0; i < LCAP; i++)
             if (i < n) {
                 unsigned long long g = (mine[i] + 1ull) * 0x9E3779B97F4A7C15ull;
                 g ^= g >> 29;
                 f2 += g * 0xBF58476D1CE4E5B9ull;  // (a sum: the order of the nodes does not matter)
             }
-        const uint32_t tag = ((uint32_t)(f2 >> 32) & ~15u) | (n - 1u);  // (the list length rides in the tag: no load for the owner's)
+        const uint32_t tag = ((uint32_t)(f2 >> 32) & ~31u) | (n - 1u);  // (the list length rides in the tag: no load for the owner's)
         const unsigned long long word = ((unsigned long long)tag << 32) | (e + 1u);
         uint32_t h = (uint32_t)((f2 * 0xD6E8FEB86659FD93ull) >> (64u - ltab_bits));
         for (uint32_t pr = 0; pr < LTAB_PROBES; pr++) {
@@ -1451,8 +1568,8 @@ k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ c
                 }
             }
             if ((uint32_t)(cur >> 32) == tag) {
-                uint32_t other[LC];
-                vs_load_list(lists + (uint64_t)((uint32_t)cur - 1u) * LC, n, other);
+                uint32_t other[LCAP];
+                vs_load_list(lists + (uint64_t)((uint32_t)cur - 1u) * LROW, n, other);
                 if (vs_same_list(mine, other, n)) {
                     atomicAdd(&lmult[h], 1u);
                     m = 0u;
@@ -1529,14 +1646,15 @@ __device__ __forceinline__ void vs_rows_histogram(uint32_t *h32, const uint32_t 
                                                   const uint32_t *__restrict__ owners, uint64_t lo, uint64_t hi, uint32_t key_lo, uint32_t n_keys) {
     for (uint64_t i = lo * 4u + threadIdx.x; i < hi * 4u; i += ROWS_TPB) {
         uint64_t row;
-        const uint32_t q = (uint32_t)i & 3u, n = vs_rows_item<MODE>(counts, owners, i >> 2, row);
-        if (4u * q >= n) continue;
-        const VsQuad v = *(const VsQuad *)(lists + row * LC + 4u * q);
-        const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t q0 = (uint32_t)i & 3u, n = vs_rows_item<MODE>(counts, owners, i >> 2, row);
+        for (uint32_t q = q0; 4u * q < n; q += 4u) {  // (a list of 17 .. LCAP nodes: its fifth quad is the first lane's too)
+            const VsQuad v = *(const VsQuad *)(lists + row * LROW + 4u * q);
+            const uint32_t e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (uint32_t j = 0; j < 4u; j++) {
-            const uint32_t x = e[j] - key_lo;
-            if (4u * q + j < n && x < n_keys) atomicAdd(&h32[x >> 1], 1u << ((x & 1u) * 16u));
+            for (uint32_t j = 0; j < 4u; j++) {
+                const uint32_t x = e[j] - key_lo;
+                if (4u * q + j < n && x < n_keys) atomicAdd(&h32[x >> 1], 1u << ((x & 1u) * 16u));
+            }
         }
     }
 }
@@ -1605,33 +1723,35 @@ k_rows_fill(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ cou
     __syncthreads();
     for (uint64_t i = lo * 4u + tid; i < hi * 4u; i += ROWS_TPB) {
         uint64_t row;
-        const uint32_t q = (uint32_t)i & 3u, n = vs_rows_item<MODE>(counts, owners, i >> 2, row);
-        if (4u * q >= n) continue;
-        const VsQuad v = *(const VsQuad *)(lists + row * LC + 4u * q);
-        const uint32_t e[4] = {v.x, v.y, v.z, v.w};
-        // what an entry says: whose list row k_rows_sum reads, and that list's length - 1 in the top four bits -- the block's
+        const uint32_t q0 = (uint32_t)i & 3u, n = vs_rows_item<MODE>(counts, owners, i >> 2, row);
+        if (4u * q0 >= n) continue;
+        // what an entry says: whose list row k_rows_sum reads, and that list's length - 1 in the top five bits -- the block's
         // owner of the pair's RIGHT list (a few hundred distinct rows per matrix row, cached, instead of one row per pair) /
         // the owning end itself
         uint32_t payload;
-        if (MODE) payload = (uint32_t)row | ((n - 1u) << 28);
+        if (MODE) payload = (uint32_t)row | ((n - 1u) << 27);
         else {
             const uint64_t re = 2u * (i >> 2) + 1u;
-            payload = gown[re] | ((counts[re] - 1u) << 28);
+            payload = gown[re] | ((counts[re] - 1u) << 27);
         }
+        for (uint32_t q = q0; 4u * q < n; q += 4u) {
+            const VsQuad v = *(const VsQuad *)(lists + row * LROW + 4u * q);
+            const uint32_t e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (uint32_t j = 0; j < 4u; j++) {
-            const uint32_t x = e[j] - key_lo;
-            if (4u * q + j >= n || x >= n_keys) continue;
-            const uint32_t code = (h32[x >> 1] >> ((x & 1u) * 16u)) & 0xFFFFu;
-            uint32_t pos;
-            if (code != 0xFFFFu) {
-                const uint32_t sh = (code & 1u) * 16u;
-                const uint32_t old = atomicAdd(&s_fill[code >> 1], 1u << sh);
-                pos = s_base[code] + ((old >> sh) & 0xFFFFu);
-            } else {
-                pos = row_ptr[e[j]] + atomicAdd(&row_cursor[e[j]], 1u);
+            for (uint32_t j = 0; j < 4u; j++) {
+                const uint32_t x = e[j] - key_lo;
+                if (4u * q + j >= n || x >= n_keys) continue;
+                const uint32_t code = (h32[x >> 1] >> ((x & 1u) * 16u)) & 0xFFFFu;
+                uint32_t pos;
+                if (code != 0xFFFFu) {
+                    const uint32_t sh = (code & 1u) * 16u;
+                    const uint32_t old = atomicAdd(&s_fill[code >> 1], 1u << sh);
+                    pos = s_base[code] + ((old >> sh) & 0xFFFFu);
+                } else {
+                    pos = row_ptr[e[j]] + atomicAdd(&row_cursor[e[j]], 1u);
+                }
+                entries[pos] = payload;
             }
-            entries[pos] = payload;
         }
     }
 }
@@ -1703,10 +1823,10 @@ k_rows_sum(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ coun
             wgt = 1u;
             yq = VsQuad{0u, 0u, 0u, 0u};
             if (it != 0xFFFFFFFFu) {
-                const uint64_t row = it & 0x0FFFFFFFu;  // (a read end of the transposition)
-                n = (it >> 28) + 1u;
+                const uint64_t row = it & 0x07FFFFFFu;  // (a read end of the transposition)
+                n = (it >> 27) + 1u;
                 if (MODE) wgt = mult[row];
-                yq = *(const VsQuad *)(lists + row * LC + 4u * q);
+                yq = *(const VsQuad *)(lists + row * LROW + 4u * q);
             }
         };
         uint32_t p1 = e0 < e1 ? load_item(e0) : 0xFFFFFFFFu;
@@ -1716,7 +1836,7 @@ k_rows_sum(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ coun
         load_list(p1, n1, w1, y1);
         uint32_t pass = 0;
         for (uint32_t base = e0; base < e1; base += STEP, pass++) {
-            const uint32_t n = n1, wgt = w1;
+            const uint32_t n = n1, wgt = w1, p0 = p1;
             const VsQuad yq = y1;
             p1 = p2;
             load_list(p1, n1, w1, y1);
@@ -1730,25 +1850,30 @@ k_rows_sum(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ coun
                     if (t < nrows && s_rowend[t - 1u] <= i) xl = t;
                 }
                 const uint32_t kbase = xl * N + align, x = first + xl;
-                const uint32_t ys[4] = {yq.x, yq.y, yq.z, yq.w};
-                uint32_t key[4], seen[4], at[4];
+                auto add_quad = [&](const VsQuad &yv, uint32_t q4) {
+                    const uint32_t ys[4] = {yv.x, yv.y, yv.z, yv.w};
+                    uint32_t key[4], seen[4], at[4];
 #pragma unroll
-                for (uint32_t j = 0; j < 4u; j++) {
-                    key[j] = kbase + ys[j];
-                    at[j] = RsTable::slot(key[j]);
-                    seen[j] = s_key[at[j]];
-                }
-#pragma unroll
-                for (uint32_t j = 0; j < 4u; j++) {
-                    if (4u * q + j >= n || (MODE && ys[j] < x)) continue;  // (short_mat: the cell (x, y) belongs to the smaller node's row)
-                    if (seen[j] == key[j]) {
-                        atomicAdd(&s_cnt[at[j]], wgt);
-                    } else if (!vs_cell_claim<RsTable>(s_key, s_cnt, &s_used, key[j], at[j], wgt)) {
-                        atomicAdd(&s_lost, 1u);
-                        vs_mark_tile(tile_map, T, (uint32_t)MODE, x, ys[j]);
-                        atomicAdd(mat + cell0 + (key[j] - align), wgt);
+                    for (uint32_t j = 0; j < 4u; j++) {
+                        key[j] = kbase + ys[j];
+                        at[j] = RsTable::slot(key[j]);
+                        seen[j] = s_key[at[j]];
                     }
-                }
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; j++) {
+                        if (q4 + j >= n || (MODE && ys[j] < x)) continue;  // (short_mat: the cell (x, y) belongs to the smaller node's row)
+                        if (seen[j] == key[j]) {
+                            atomicAdd(&s_cnt[at[j]], wgt);
+                        } else if (!vs_cell_claim<RsTable>(s_key, s_cnt, &s_used, key[j], at[j], wgt)) {
+                            atomicAdd(&s_lost, 1u);
+                            vs_mark_tile(tile_map, T, (uint32_t)MODE, x, ys[j]);
+                            atomicAdd(mat + cell0 + (key[j] - align), wgt);
+                        }
+                    }
+                };
+                add_quad(yq, 4u * q);
+                // (a list of 17 .. LCAP nodes: its fifth quad is the first lane's too -- one entry in forty at configs[4])
+                if (n > 16u && q == 0u) add_quad(*(const VsQuad *)(lists + (uint64_t)(p0 & 0x07FFFFFFu) * LROW + 16u), 16u);
             }
             if ((pass & 3u) == 3u) {  // (a strip that outruns the limit between two looks finds the table crowded and adds the rest to memory itself: slower, the same sums)
                 __syncthreads();
@@ -2255,7 +2380,7 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
         for (void **q : {&ctx->d_row_entries, &ctx->d_mult, &ctx->d_ltab})
             if (*q) { VS_HIP(ctx, hipFree(*q)); *q = nullptr; }
         ctx->row_entries_cap = ctx->ltab_cap = 0;
-        VS_HIP(ctx, hipMalloc(&ctx->d_row_entries, sizeof(uint32_t) * (3u * sub_pairs * LC + 16u)));
+        VS_HIP(ctx, hipMalloc(&ctx->d_row_entries, sizeof(uint32_t) * (3u * sub_pairs * LCAP + 16u)));
         VS_HIP(ctx, hipMalloc(&ctx->d_mult, sizeof(uint32_t) * (6u * sub_pairs + 4u)));  // mult[2 np], owners[2 np], gown[2 np]
         VS_HIP(ctx, hipMalloc(&ctx->d_ltab, (sizeof(uint64_t) + sizeof(uint32_t)) * ltab_slots + 16u));
         ctx->row_entries_cap = sub_pairs;
@@ -2285,7 +2410,7 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
     uint32_t *lmult = use_ltab ? (uint32_t *)((unsigned long long *)ctx->d_ltab + ltab_slots) : nullptr;
     for (uint64_t p0 = 0; p0 < slots_pairs; p0 += sub_pairs) {
         const uint64_t np = slots_pairs - p0 < sub_pairs ? slots_pairs - p0 : sub_pairs;
-        const uint32_t *sl = (const uint32_t *)ctx->d_lists + 2u * p0 * LC, *sc = (const uint32_t *)ctx->d_list_counts + 2u * p0;
+        const uint32_t *sl = (const uint32_t *)ctx->d_lists + 2u * p0 * LROW, *sc = (const uint32_t *)ctx->d_list_counts + 2u * p0;
         uint32_t *mult = (uint32_t *)ctx->d_mult, *owners = mult + 2u * sub_pairs, *gown = owners + 2u * sub_pairs;
         const unsigned n_chunks = (unsigned)((np + ROWS_CHUNK - 1u) / ROWS_CHUNK);
         const unsigned n_chunks1 = (unsigned)((2u * np + ROWS_CHUNK1 - 1u) / ROWS_CHUNK1);  // (every end could be an owner; a chunk past the last owner returns at once)
@@ -2303,7 +2428,7 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
         }
         for (int mode = 0; mode < 2; mode++) {
             uint32_t *row_count = rows + 3u * mode * cap, *row_cursor = row_count + cap, *row_ptr = row_cursor + cap;
-            uint32_t *entries = (uint32_t *)ctx->d_row_entries + (mode ? np * LC : 0u);
+            uint32_t *entries = (uint32_t *)ctx->d_row_entries + (mode ? np * LCAP : 0u);
             for (uint32_t key_lo = 0; key_lo < N; key_lo += n_keys) {
                 const uint32_t nk = N - key_lo < n_keys ? N - key_lo : n_keys;
                 if (mode) hipLaunchKernelGGL(k_rows_count<1>, dim3(n_chunks1), dim3(ROWS_TPB), rl, st, sl, sc, (const uint32_t *)owners, 0ull, (const uint32_t *)n_owners, key_lo, nk, row_count);
@@ -2319,7 +2444,7 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
         }
         for (int mode = 0; mode < 2; mode++) {
             const uint32_t *row_ptr = rows + 3u * mode * cap + 2u * cap;
-            const uint32_t *entries = (const uint32_t *)ctx->d_row_entries + (mode ? np * LC : 0u);
+            const uint32_t *entries = (const uint32_t *)ctx->d_row_entries + (mode ? np * LCAP : 0u);
             const uint32_t n_strips = (N + R[mode] - 1u) / R[mode];
             uint32_t grid = (uint32_t)ctx->n_cu * (RSUM_LDS_BYTES <= 40000u ? 4u : 2u) * (1024u / RS_TPB);
             if (grid > n_strips) grid = n_strips;
@@ -2430,17 +2555,28 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         }
     }
 
+    // which counter kernels follow decides the layout of the hand-off: pair-major with one cell table while 2*N*N fits its
+    // 32-bit keys (packed lists), by row owners above (rows of LCAP words); VS_ACC_ROWS=0 / 1 overrides (0 beyond 46 340
+    // nodes: no table, every increment a global atomic).  VS_NO_AGG=1 turns the summing in LDS off
+    uint32_t use_table = tn.no_agg ? 0u : 1u;
+    if (tn.acc_ablate >= 0) use_table = (uint32_t)tn.acc_ablate;  // 2: decode only, 3: no write-outs (VS_EXPERIMENT=timing only)
+    const bool fits32 = 2ull * idx.n_nodes * idx.n_nodes < 0xFFFFFFFFull;
+    bool use_rows = tn.acc_rows >= 0 ? tn.acc_rows != 0 : !fits32;
+    if (idx.n_nodes == 0 || use_table != 1u) use_rows = false;
+    if (!use_rows && !fits32 && use_table == 1u) use_table = 0u;
     // per-end lists handed from k_pe_tiles to k_pe_accumulate
     const uint64_t n_tiles_all = (n_pairs + ept / 2 - 1) / (ept / 2);
     const uint64_t list_ends = n_tiles_all * ept;
-    if (d_node_mat && ctx->lists_cap < list_ends) {
+    const uint64_t list_words = list_ends * (use_rows ? LROW : LC) + 16u;  // (either layout of the hand-off)
+    if (d_node_mat && (ctx->lists_cap < list_ends || ctx->lists_words < list_words)) {
         if (ctx->d_lists) VS_HIP(ctx, hipFree(ctx->d_lists));
         if (ctx->d_list_counts) VS_HIP(ctx, hipFree(ctx->d_list_counts));
         ctx->d_lists = ctx->d_list_counts = nullptr;
-        ctx->lists_cap = 0;
-        VS_HIP(ctx, hipMalloc(&ctx->d_lists, sizeof(uint32_t) * (list_ends * LC + 16)));
+        ctx->lists_cap = ctx->lists_words = 0;
+        VS_HIP(ctx, hipMalloc(&ctx->d_lists, sizeof(uint32_t) * list_words));
         VS_HIP(ctx, hipMalloc(&ctx->d_list_counts, sizeof(uint32_t) * (list_ends + 2)));
         ctx->lists_cap = list_ends;
+        ctx->lists_words = list_words;
     }
 
     PeParams P;
@@ -2469,6 +2605,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     P.dbg_counts = d_dbg_counts;
     P.dbg_cap = dbg_cap;
     P.accumulate = d_node_mat ? 1u : 0u;
+    P.out_rows = use_rows ? 1u : 0u;
     P.tile_map = d_node_mat ? d_tile_map : nullptr;
     P.tile_T = (idx.n_nodes + 63u) >> 6;
     P.no_xcd_map = tn.no_xcd_map ? 1u : 0u;
@@ -2597,15 +2734,6 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         if (list_ends > used_ends)
             VS_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->d_list_counts + used_ends, 0, sizeof(uint32_t) * (list_ends - used_ends), st));
         const uint64_t slots_pairs = list_ends / 2;
-        // VS_NO_AGG=1 turns the summing in LDS off (every increment a global atomic)
-        uint32_t use_table = tn.no_agg ? 0u : 1u;
-        if (tn.acc_ablate >= 0) use_table = (uint32_t)tn.acc_ablate;  // 2: decode only, 3: no write-outs (VS_EXPERIMENT=timing only)
-        // pair-major with one cell table while 2*N*N fits its 32-bit keys, by row owners above; VS_ACC_ROWS=0 / 1
-        // overrides (0 beyond 46 340 nodes: no table, every increment a global atomic)
-        const bool fits32 = 2ull * idx.n_nodes * idx.n_nodes < 0xFFFFFFFFull;
-        bool use_rows = tn.acc_rows >= 0 ? tn.acc_rows != 0 : !fits32;
-        if (idx.n_nodes == 0 || use_table != 1u) use_rows = false;
-        if (!use_rows && !fits32 && use_table == 1u) use_table = 0u;
         VS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
         if (use_rows) {
             const int rc = pe_count_by_rows(ctx, slots_pairs, d_node_mat, d_short_mat, d_tile_map, P.tile_T);
@@ -2636,11 +2764,11 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
             const uint32_t acc_ppw = tn.acc_round ? tn.acc_round / (ACC_TPB / 64u) : 64u;  // VS_ACC_ROUND: pairs per round
             if (d_tile_map && slots_pairs)  // (timed with the counter kernel: it is part of the counting)
                 hipLaunchKernelGGL(k_mark_tiles, dim3((unsigned)((slots_pairs + 255u) / 256u)), dim3(256), 0, st, (const uint32_t *)ctx->d_lists,
-                                   (const uint32_t *)ctx->d_list_counts, slots_pairs, d_tile_map, P.tile_T);
+                                   (const uint32_t *)ctx->d_list_counts, slots_pairs, d_tile_map, P.tile_T, ept);
             VS_HIP(ctx, hipFuncSetAttribute((const void *)k_pe_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES));
             hipLaunchKernelGGL(k_pe_accumulate, dim3(acc_grid), dim3(ACC_TPB), ACC_LDS_BYTES, st, (const uint32_t *)ctx->d_lists,
                                (const uint32_t *)ctx->d_list_counts, slots_pairs, per_wg, idx.n_nodes, use_table, fill_limit, d_node_mat,
-                               d_short_mat, acc_queue, acc_dbg, acc_ppw);
+                               d_short_mat, acc_queue, acc_dbg, acc_ppw, ept);
         }
     }
     VS_HIP(ctx, hipEventRecord(ctx->ev[1], st));

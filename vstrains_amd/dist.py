@@ -112,18 +112,18 @@ def _occupancy_from_tiles(tile_map, n: int, m: int):
 
 
 # One bounded staging buffer per (device, dtype) for the gathered stretches: the exchange walks the occupied stretches in
-# slabs of at most SLAB_STRETCHES, so its transient is 256 MB (int32) whatever the union's size -- a counter of 23.7 GB half
-# occupied used to ask for 12 GB on top of the counters.  (ADVICE r4.)
-SLAB_STRETCHES = 1 << 20
+# slabs of at most SLAB_STRETCHES, so its transient is bounded (1 GB of int32 cells) whatever the union's size -- a counter
+# of 23.7 GB half occupied used to ask for 12 GB on top of the counters.  (ADVICE r4.)
+SLAB_STRETCHES = 1 << 22
 _staging = {}
 
 
 def _staging_buffer(head, want_rows: int):
-    """[rows, 64] buffer of ``head``'s dtype on its device, rows = min(want_rows, SLAB_STRETCHES), grown only; None when the
-    allocation fails (the caller tells its peers before any of them enters the collective)."""
+    """[rows, 64] buffer of ``head``'s dtype on its device, rows = min(want_rows, SLAB_STRETCHES + 1), grown only; None when
+    the allocation fails (the caller says so in the flag bytes of the first collective: no rank is left waiting)."""
     import torch
 
-    rows = max(1, min(int(want_rows), SLAB_STRETCHES))
+    rows = max(2, min(int(want_rows), SLAB_STRETCHES + 1))
     key = (str(head.device), head.dtype)
     buf = _staging.get(key)
     if buf is not None and buf.shape[0] >= rows:
@@ -136,17 +136,71 @@ def _staging_buffer(head, want_rows: int):
     return buf
 
 
-def sum_counts_compact(mats, allow_compact: bool = True, tile_map=None, timing=None, occupancy_fn=None) -> str:
-    """In-place sum over the ranks of a counter tensor (int32 storage of uint32 cells, or int64 totals) by way of its
-    occupied 64-cell stretches.  Returns "compact" or "dense" (what was done; the same on every rank).  Same integers as
-    ``all_reduce(SUM)`` on the whole tensor: the stretches that are left out are zero on every rank.
+# ---- the packed exchange (r6): two collectives per sum ----------------------------------------------------------------
+# a step's exchange was an agreement all-reduce, the occupancy MAX, a host wait on torch.nonzero, a status
+# MAX, the slab SUMs, the stats SUM and the tile-map MAX -- six or seven collectives whose latency on eight ranks nobody has
+# measured.  Now:
+#   C1  MAX over ONE uint8 tensor: [occupancy map of the 64-cell stretches (or the counter's dirty-tile map, from which
+#       every rank derives the same occupancy) | FLAG_BYTES flag bytes].  MAX over bytes is OR for 0 / 1 flags.
+#   C2  SUM over ONE staging tensor: [the occupied stretches of the union | one more row that carries the caller's small
+#       int64 sums -- the three stats, the pairs in the buffers -- as 16-bit limbs in the cells' dtype].
+# (a union of more than SLAB_STRETCHES stretches takes one SUM per slab; a dense union, a veto or a rank without staging
+# memory send the whole tensor through the ring, and the tail row after it.)
+FLAG_BYTES = 8
+FLAG_NO_COMPACT, FLAG_WIDE, FLAG_NO_STAGING, FLAG_PAIRS_LOG2 = 0, 1, 2, 3
+LIMBS = 4  # 16-bit limbs per int64 of the tail: exact while every addend is below 2^63 and there are fewer than 2^15 ranks
 
-    ``occupancy_fn``: head ([m, 64] view) -> uint8 [m] on the same device (default: a torch expression).
-    ``tile_map``: the counter's dirty-tile bytes (uint32 buffers of 2 GiB and more keep them); the occupancy then comes
-    from that map instead of a scan of the buffer.  ``timing``: a dict that receives the seconds of every phase
-    (measurement runs: each phase is followed by a device synchronisation).
-    Collectives of one call, in order, on every rank alike: the occupancy map (MAX), one status word (MAX), then the
-    staged slabs (SUM) -- or the whole tensor (SUM) when the union is dense or some rank could not get its staging buffer."""
+
+def _tail_encode(tail, row):
+    """``tail`` (int64 [k], k <= 16, non-negative) into ``row`` ([64] of the cells' dtype): int64 cells take the values as
+    they are, int32 cells four 16-bit limbs each (a sum over ranks of limbs stays far below 2^31)."""
+    import torch
+
+    row.zero_()
+    k = tail.numel()
+    if row.dtype == torch.int64:
+        row[:k] = tail
+    else:
+        t = tail.to(torch.int64)
+        for i in range(LIMBS):
+            row[i * 16:i * 16 + k] = ((t >> (16 * i)) & 0xFFFF).to(row.dtype)
+
+
+def _tail_decode(row, k):
+    import torch
+
+    if row.dtype == torch.int64:
+        return row[:k].clone()
+    out = torch.zeros(k, dtype=torch.int64, device=row.device)
+    for i in range(LIMBS):
+        out += row[i * 16:i * 16 + k].to(torch.int64) << (16 * i)
+    return out
+
+
+class ExchangeState:
+    """What a counter keeps between its exchanges: the union size of the last one (the next is staged for 1.25 times that
+    without asking the device), and the unsettled predicted exchange."""
+
+    def __init__(self):
+        self.cap = None
+        self.pending = None
+        self.collectives = 0   # of the most recent call
+        self.host_waits = 0
+
+
+def sum_counts_packed(mats, tail=None, flags=None, tile_map=None, timing=None, occupancy_fn=None, state=None, predict=False, dst=None,
+                      on_flags=None):
+    """In-place sum over the ranks of a counter tensor (int32 storage of uint32 cells, or int64 totals), of ``tail`` (small
+    int64 tensor, summed) and OR of ``flags`` (uint8 [FLAG_BYTES]; byte FLAG_PAIRS_LOG2 is MAXed as a number), in TWO
+    collectives (see above).  -> (how, flags_of_all_ranks, summed_tail): how is "compact" or "dense", the same on every rank.
+
+    ``predict`` (needs ``state`` with a union size from an earlier call): no host wait at all -- the gather is sized from
+    the previous union (``torch.nonzero_static``), the device keeps the real size, and ``settle_exchange(state)`` -- called
+    when the sums are consumed, steps later -- looks at it and at the flags and sums the stretches that did not fit then.
+    ``dst``: the SUM collectives reduce to that rank only (the drop-in's writer); the other ranks' tensors keep their own
+    counts.  ``on_flags``: called with the flag bytes of all ranks (a list) once the host has them; if it returns a tensor,
+    THAT is what has to be summed instead (PeCounter folds into int64 totals when the uint32 buffers cannot hold the sum):
+    the exchange starts over on it -- the rare path, two more collectives."""
     import time
 
     import torch
@@ -159,51 +213,189 @@ def sum_counts_compact(mats, allow_compact: bool = True, tile_map=None, timing=N
             timing[name] = timing.get(name, 0.0) + time.perf_counter() - t0
         return time.perf_counter()
 
+    if state is None:
+        state = ExchangeState()
+    state.collectives = state.host_waits = 0
+
+    def c_sum(t):
+        state.collectives += 1
+        if dst is None:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        else:
+            dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM)
+
+    mine = dst is None or dist.get_rank() == dst
+    dev = mats.device
     flat = mats.view(-1)
     m = flat.numel() // STRETCH
-    if not allow_compact or m == 0:
-        t = time.perf_counter()
-        dist.all_reduce(mats, op=dist.ReduceOp.SUM)
-        mark("ring", t)
-        return "dense"
     head = flat[: m * STRETCH].view(m, STRETCH)
+    k_tail = 0 if tail is None else int(tail.numel())
+    assert k_tail <= 16
+    my_flags = torch.zeros(FLAG_BYTES, dtype=torch.uint8, device=dev) if flags is None else flags.to(device=dev, dtype=torch.uint8).clone()
     t = time.perf_counter()
     n = mats.shape[-1]
     use_tiles = tile_map is not None and mats.dim() == 3 and mats.shape[0] == 2 and mats.shape[1] == n and n >= STRETCH
-    # (occupancy_fn: the library's one-pass kernel over the buffer, vs_counts_occupied -- PeCounter hands it in for device
-    # tensors; the torch expression below makes three passes and a [m, 64] temporary)
-    occ = _occupancy_from_tiles(tile_map, n, m) if use_tiles else occupancy_fn(head) if occupancy_fn is not None else _occupancy(head)
+    # the staging buffer BEFORE the first collective: a rank that cannot have it says so in its flag bytes
+    want = (state.cap + 1) if (predict and state.cap is not None) else min(m // 2 + 2, 1 << 20)
+    buf = _staging_buffer(head, want) if m else None
+    if m and buf is None:
+        my_flags[FLAG_NO_STAGING] = 1
+    # C1 = [occupancy map (unless the tile map stands for it) | the counter's dirty-tile map, if it keeps one | flag bytes]
+    occ_local = None if use_tiles else ((occupancy_fn(head) if occupancy_fn is not None else _occupancy(head)) if m
+                                        else torch.zeros(0, dtype=torch.uint8, device=dev))
+    n_occ = 0 if occ_local is None else occ_local.numel()
+    n_tiles = 0 if tile_map is None else tile_map.numel()
+    nb = n_occ + n_tiles
+    c1 = torch.empty(nb + FLAG_BYTES, dtype=torch.uint8, device=dev)
+    if n_occ:
+        c1[:n_occ] = occ_local
+    if n_tiles:
+        c1[n_occ:nb] = tile_map
+    c1[nb:] = my_flags
     t = mark("occupancy", t)
-    dist.all_reduce(occ, op=dist.ReduceOp.MAX)  # union of the ranks' occupancy maps
+    state.collectives += 1
+    dist.all_reduce(c1, op=dist.ReduceOp.MAX)
     t = mark("occupancy_allreduce", t)
-    idx = torch.nonzero(occ).view(-1)  # (the one host wait of the exchange: the union's size decides the branch)
-    u = int(idx.numel())
+    all_flags = c1[nb:]
+    if n_tiles:
+        tile_map.copy_(c1[n_occ:nb])  # (the sum brings the other ranks' cells: their tiles are dirty here too)
+    occ = _occupancy_from_tiles(tile_map, n, m) if use_tiles else c1[:n_occ]
+
+    def tail_only():  # (dense branch: the tail goes through on its own)
+        if not k_tail:
+            return None
+        row = torch.empty(STRETCH, dtype=mats.dtype, device=dev)
+        _tail_encode(tail, row)
+        c_sum(row)
+        return _tail_decode(row, k_tail)
+
+    if predict and state.cap is not None and m and buf is not None:
+        cap = min(state.cap, buf.shape[0] - 1)
+        idx = torch.nonzero_static(occ, size=cap, fill_value=0).view(-1)
+        stage = buf[: cap + 1]
+        torch.index_select(head, 0, idx, out=stage[:cap])
+        if k_tail:
+            _tail_encode(tail, stage[cap])
+        else:
+            stage[cap].zero_()
+        t = mark("gather", t)
+        c_sum(stage)
+        t = mark("ring", t)
+        if mine:
+            head.index_copy_(0, idx, stage[:cap])
+        tail_flat = flat[m * STRETCH:]
+        if tail_flat.numel():
+            c_sum(tail_flat)
+        mark("scatter", t)
+        state.pending = {"u": occ.sum(dtype=torch.int64), "cap": cap, "flags": all_flags, "occ": occ, "head": head, "dst": dst}
+        return "compact", all_flags, (_tail_decode(stage[cap], k_tail) if k_tail else None)
+
+    # one host wait: the flags and the union's size together
+    if m:
+        word = torch.cat([all_flags.to(torch.int64), occ.sum(dtype=torch.int64).view(1)]).cpu()
+        state.host_waits += 1
+        fl, u = word[:FLAG_BYTES].tolist(), int(word[FLAG_BYTES])
+    else:
+        fl, u = all_flags.cpu().tolist(), 0
+        state.host_waits += 1
     t = mark("nonzero", t)
     if timing is not None:
         timing["stretches"] = m
         timing["occupied_stretches_of_the_union"] = u
-    # the staging buffer BEFORE any rank commits to the compact branch: a rank that cannot have it says so, and all take
-    # the dense ring together (a lone rank raising here would leave its peers waiting in the collective)
-    buf = _staging_buffer(head, u) if 0 < u <= COMPACT_MAX_FILL * m else None
-    status = torch.tensor([1 if (0 < u <= COMPACT_MAX_FILL * m and buf is None) else 0], dtype=torch.int32, device=mats.device)
-    if 0 < u <= COMPACT_MAX_FILL * m:
-        dist.all_reduce(status, op=dist.ReduceOp.MAX)
-    if u > COMPACT_MAX_FILL * m or int(status.item()):
+    if on_flags is not None:
+        other = on_flags(fl)
+        if other is not None:
+            done = state.collectives
+            clean = torch.zeros(FLAG_BYTES, dtype=torch.uint8)
+            clean[FLAG_NO_COMPACT] = 1 if fl[FLAG_NO_COMPACT] else 0
+            res = sum_counts_packed(other, tail, clean, tile_map=None, timing=timing, occupancy_fn=occupancy_fn, state=state, dst=dst)
+            state.collectives += done
+            return res
+    state.cap = max(64, int(1.25 * u) + 16)
+    if m == 0 or fl[FLAG_NO_COMPACT] or fl[FLAG_NO_STAGING] or u > COMPACT_MAX_FILL * m:
         t = time.perf_counter()
-        dist.all_reduce(mats, op=dist.ReduceOp.SUM)
+        c_sum(mats)
+        out_tail = tail_only()
         mark("ring", t)
-        return "dense"
-    for lo in range(0, u, SLAB_STRETCHES):
-        part = idx[lo:lo + SLAB_STRETCHES]
-        stage = buf[: part.numel()]
+        return "dense", all_flags, out_tail
+    idx = torch.nonzero_static(occ, size=u, fill_value=0).view(-1)
+    bigger = _staging_buffer(head, u + 1)  # (grown when it can be: fewer slabs; the old one serves otherwise)
+    if bigger is not None:
+        buf = bigger
+    rows = buf.shape[0] - 1
+    out_tail = None
+    lo = 0
+    while True:
+        part = idx[lo:lo + rows]
+        k = int(part.numel())
+        last = lo + k >= u
+        stage = buf[: k + (1 if last else 0)]
         t = time.perf_counter()
-        torch.index_select(head, 0, part, out=stage)
+        if k:
+            torch.index_select(head, 0, part, out=stage[:k])
+        if last:
+            if k_tail:
+                _tail_encode(tail, stage[k])
+            else:
+                stage[k].zero_()
         t = mark("gather", t)
-        dist.all_reduce(stage, op=dist.ReduceOp.SUM)
+        c_sum(stage)
         t = mark("ring", t)
-        head.index_copy_(0, part, stage)
+        if mine and k:
+            head.index_copy_(0, part, stage[:k])
+        if last and k_tail:
+            out_tail = _tail_decode(stage[k], k_tail)
         mark("scatter", t)
-    tail = flat[m * STRETCH:]
-    if tail.numel():
-        dist.all_reduce(tail, op=dist.ReduceOp.SUM)
-    return "compact"
+        lo += k
+        if last:
+            break
+    tail_flat = flat[m * STRETCH:]
+    if tail_flat.numel():
+        c_sum(tail_flat)
+    return "compact", all_flags, out_tail
+
+
+def settle_exchange(state) -> None:
+    """The deferred half of a predicted exchange: ONE host read (the union's real size and the flag bytes, both long since
+    computed), then -- every rank alike, they all hold the same numbers -- the stretches beyond the predicted size summed
+    now, and the prediction raised.  Raises if a flag says the predicted exchange was not allowed (a rank vetoed the compact
+    form, held int64 totals or had no staging memory): the bench's steady state checks those statically."""
+    import torch
+    import torch.distributed as dist
+
+    p = state.pending
+    if p is None:
+        return
+    state.pending = None
+    word = torch.cat([p["flags"].to(torch.int64), p["u"].view(1)]).cpu()
+    state.host_waits += 1
+    fl, u, cap = word[:FLAG_BYTES].tolist(), int(word[FLAG_BYTES]), p["cap"]
+    if fl[FLAG_NO_COMPACT] or fl[FLAG_WIDE] or fl[FLAG_NO_STAGING]:
+        raise RuntimeError("a predicted exchange ran although a rank's flags forbid it: %r" % (fl,))
+    if u > cap:
+        head, dst = p["head"], p["dst"]
+        rest = torch.nonzero_static(p["occ"], size=u, fill_value=0).view(-1)[cap:]
+        mine = dst is None or dist.get_rank() == dst
+        for lo in range(0, int(rest.numel()), SLAB_STRETCHES):
+            part = rest[lo:lo + SLAB_STRETCHES]
+            stage = head.index_select(0, part)
+            state.collectives += 1
+            if dst is None:
+                dist.all_reduce(stage, op=dist.ReduceOp.SUM)
+            else:
+                dist.reduce(stage, dst=dst, op=dist.ReduceOp.SUM)
+            if mine:
+                head.index_copy_(0, part, stage)
+    state.cap = max(state.cap or 0, int(1.25 * u) + 16, 64)
+
+
+def sum_counts_compact(mats, allow_compact: bool = True, tile_map=None, timing=None, occupancy_fn=None) -> str:
+    """In-place sum over the ranks of a counter tensor by way of its occupied 64-cell stretches: ``sum_counts_packed``
+    without a tail.  Returns "compact" or "dense" (what was done; the same on every rank).  Same integers as
+    ``all_reduce(SUM)`` on the whole tensor: the stretches that are left out are zero on every rank."""
+    import torch
+
+    flags = torch.zeros(FLAG_BYTES, dtype=torch.uint8)
+    if not allow_compact:
+        flags[FLAG_NO_COMPACT] = 1
+    return sum_counts_packed(mats, flags=flags, tile_map=tile_map, timing=timing, occupancy_fn=occupancy_fn)[0]

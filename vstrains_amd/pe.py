@@ -530,43 +530,89 @@ class PeCounter:
                                                                 head.shape[0], C.c_void_p(occ.data_ptr())))
         return occ
 
-    def all_reduce(self):
-        """Sum over the ranks of the process group, in place.  The ranks first agree (one small
-        all-reduce) on whether the uint32 buffers can hold the sum; if not, or if some rank already
-        holds int64 totals, every rank folds and the int64 totals are summed instead."""
-        from .dist import all_reduce_counts, group_size
+    def all_reduce(self, dst=None, predict=False):
+        """Sum over the ranks of the process group, in place, in TWO collectives (``dist.sum_counts_packed``): a MAX over
+        [occupancy of the counters' 64-cell stretches | flag bytes], then a SUM over [the occupied stretches of the union |
+        a row with the three stats and the pairs in the buffers].  The flag bytes settle, for every rank alike, whether the
+        uint32 buffers can hold the sum (a bound on the largest rank's pairs, times the ranks): if not, or if some rank
+        already holds int64 totals, every rank folds and the int64 totals are summed (a rare second exchange); a rank
+        whose environment turns the compact exchange off vetoes it for everybody (no mismatched collectives).
+
+        ``dst``: only that rank needs the sums (the drop-in's writer): the SUM collectives reduce to it, the other ranks
+        keep their own counts.  ``predict``: the steady state of fixed-size steps (bench.py) -- no host wait at all; the
+        preconditions (no int64 totals, the bound, the veto) are checked statically here and again from the flag bytes when
+        ``settle()`` is called before the buffer is reused."""
+        from .dist import group_size
 
         if group_size() <= 1:
             return
         from . import dist as vdist
 
         torch = self.torch
-        # one agreement round: sums of (pairs in the buffers, "holds int64 totals", "may exchange occupied stretches only");
-        # a rank whose environment turns the compact exchange off vetoes it for everybody (no mismatched collectives)
-        may_compact = os.environ.get("VS_COMPACT_ALLREDUCE", "1") not in ("0", "")
-        flags = torch.tensor([self.pairs_in_buffer, 1 if self.wide is not None else 0, 1 if may_compact else 0], dtype=torch.int64, device=self.device)
-        all_reduce_counts(None, flags)
-        total_in_buffers, any_wide, compact_votes = int(flags[0].item()), int(flags[1].item()), int(flags[2].item())
         world = group_size()
-        fold = bool(any_wide or 2 * total_in_buffers >= U32_LIMIT)
-        if fold:
-            self.fold()
-        target = self.wide if fold else self.mats
-        # (occupied 64-cell stretches of the union of the ranks' counters through the ring, or the whole buffer when the
-        # counters are dense: dist.sum_counts_compact decides from the union, which every rank sees alike)
-        # (the dirty-tile map of a large uint32 buffer says where its cells can be non-zero: no scan of the buffer)
+        may_compact = os.environ.get("VS_COMPACT_ALLREDUCE", "1") not in ("0", "")
+        p = int(self.pairs_in_buffer)
+        a_bits = p.bit_length()
+        flags = torch.zeros(vdist.FLAG_BYTES, dtype=torch.uint8)
+        flags[vdist.FLAG_NO_COMPACT] = 0 if may_compact else 1
+        flags[vdist.FLAG_WIDE] = 1 if self.wide is not None else 0
+        # the largest rank's pairs as (bit length, its top eight bits): MAX over the bytes bounds the maximum from above
+        flags[vdist.FLAG_PAIRS_LOG2] = a_bits
+        flags[vdist.FLAG_PAIRS_LOG2 + 1] = (p >> (a_bits - 8)) if a_bits > 8 else p
+        tail = torch.cat([self.stats.to(torch.int64), torch.tensor([p], dtype=torch.int64, device=self.stats.device)])
+        if not hasattr(self, "_xstate"):
+            self._xstate = vdist.ExchangeState()
         timing = {} if os.environ.get("VS_DIST_TIMING") else None
-        self.last_all_reduce = vdist.sum_counts_compact(target, allow_compact=compact_votes == world,
-                                                        tile_map=None if fold else self.tile_map, timing=timing,
-                                                        occupancy_fn=self._occupied if target.is_cuda else None)
+        occ_fn = self._occupied if self.mats.is_cuda else None
+        if predict and self._xstate.cap is not None:
+            if self.wide is not None or 2 * p * world >= U32_LIMIT or not may_compact:
+                raise OverflowError("a predicted exchange sums uint32 buffers through their occupied stretches: 2 * %d pairs * %d "
+                                    "ranks must fit, without int64 totals or a veto; use all_reduce()" % (p, world))
+            how, _, out_tail = vdist.sum_counts_packed(self.mats, tail, flags, tile_map=self.tile_map, timing=timing, occupancy_fn=occ_fn,
+                                                       state=self._xstate, predict=True, dst=dst)
+            self.last_all_reduce = how
+            self.stats.copy_(out_tail[:3])
+            self.pairs_in_buffer = p * world  # (a bound; the steps' blocks are of one size)
+        else:
+            how, fl, out_tail = vdist.sum_counts_packed(self.mats, tail, flags, tile_map=self.tile_map, timing=timing, occupancy_fn=occ_fn,
+                                                        state=self._xstate, dst=dst, on_flags=self._fold_if_needed)
+            self.last_all_reduce = how
+            out = out_tail.cpu()
+            self.stats.copy_(out[:3].to(self.stats.device))
+            self.pairs_in_buffer = 0 if self.wide is not None else int(out[3])
+        self.last_collectives = self._xstate.collectives
         if timing is not None:
             self.exchange_timing = getattr(self, "exchange_timing", [])
             self.exchange_timing.append(timing)
-        all_reduce_counts(None, self.stats)
-        if self.tile_map is not None:
-            vdist.all_reduce_max(self.tile_map)  # (the sum brought the other ranks' cells: their tiles are dirty here too)
-        if not fold:
-            self.pairs_in_buffer = total_in_buffers
+
+    def _fold_if_needed(self, fl):
+        """The flag bytes of all ranks are in: do the uint32 buffers hold the sum?  If not, every rank folds and the int64
+        totals are what is summed (returned to ``sum_counts_packed``, which starts over on them)."""
+        from . import dist as vdist
+
+        a_bits, top = int(fl[vdist.FLAG_PAIRS_LOG2]), int(fl[vdist.FLAG_PAIRS_LOG2 + 1])
+        bound = ((top + 1) << (a_bits - 8)) if a_bits > 8 else 255
+        if fl[vdist.FLAG_WIDE] or 2 * bound * vdist.group_size() >= U32_LIMIT:
+            self.fold()
+            return self.wide
+        return None
+
+    def _xstate_cap(self, value=None):
+        """The union size the next predicted exchange is staged for (None: not known yet); with a value: set it."""
+        from . import dist as vdist
+
+        if not hasattr(self, "_xstate"):
+            self._xstate = vdist.ExchangeState()
+        if value is not None:
+            self._xstate.cap = value
+        return self._xstate.cap
+
+    def settle(self):
+        """The deferred half of ``all_reduce(predict=True)``; call before the buffer is counted into again."""
+        from . import dist as vdist
+
+        if getattr(self, "_xstate", None) is not None:
+            vdist.settle_exchange(self._xstate)
 
     def all_reduce_async(self):
         """Overlapped form for fixed-size steps (bench.py): the caller keeps counting into a second

@@ -51,7 +51,7 @@ def count_links(ctx, gfa: str, fwd: str, rve: str, kmer_size: int, stages_follow
         count_fastq(ctx, fq, counter, 0, len(fq), progress=True)
     fq.close()
     if world > 1:
-        counter.all_reduce()
+        counter.all_reduce(dst=0)  # (only rank 0 writes the files and runs the stages: the sums are reduced to it)
     return ids, counter
 
 
@@ -107,7 +107,7 @@ def run(gfa: str, out_dir: str, fwd: str, rve: str, kmer_size: int, device: int 
     ids, counter = count_links(ctx, gfa, fwd, rve, kmer_size, stages_follow=stages_follow)
     run.last = (ids, counter)
     if rank != 0:
-        return None  # every rank holds the summed counters; rank 0 writes the files
+        return None  # the counters were reduced to rank 0, which writes the files
     out_file, stats = write_info_files(out_dir, ids, counter)
     glb_elapsed = time.time() - glb_start
     print("Global time elapsed: ", glb_elapsed)  # :209-211
