@@ -202,7 +202,7 @@ def main():
             futs = [pool.submit(one_run, args.work, m, h) for h in seeds for m in models]
             for f in cf.as_completed(futs):
                 print("finished", f.result(), flush=True)
-    collect(args.work, meta, models, seeds, out, args.digests)
+    collect(args.work, meta, ["rotate", "plain"], [0, 1, 2, 3], out, args.digests)  # (whatever runs the work directory holds)
 
 
 if __name__ == "__main__":

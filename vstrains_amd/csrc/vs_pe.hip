@@ -45,11 +45,15 @@
 //         pairs of configs[4] (ends of 17 .. 19 nodes) through k_pe_mid a second time
 //   pair-major counters (k_pe_accumulate): counts[end] = n | quad offset inside the tile's region << 8
 //   row owners (graphs beyond 46 340 nodes): their entries name lists by END INDEX, so the lists keep a fixed stride
-//         there -- rows LROW words apart, of which only the quads that hold nodes are written; counts[end] = n
+//         there -- a row of LC words per end, of which only the quads that hold nodes are written, and ONE more quad per
+//         end, in an array of its own behind the rows, for nodes 17 .. LCAP; counts[end] = n
 #define LC 16u
 #define LCAP 20u
-#define LROW 32u  // words from one end's row to the next in the row owners' layout: 128 bytes, so that a list of up to 16 nodes lies in ONE
-                  // 64-byte stretch (rows of LCAP words, 80 bytes apart, straddle one every other time: 10.9 -> 13.0 ms at configs[4])
+// (rows of LCAP words, 80 bytes apart, straddle a 64-byte stretch every other time -- the row owners took 13.0 ms instead of
+// 10.9 at configs[4] -- and rows 128 bytes apart are fetched as whole 128-byte lines: k_list_owners 2.9 -> 4.1 ms)
+__device__ __forceinline__ const uint32_t *vs_row_quad(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ hi, uint64_t row, uint32_t q) {
+    return q < LC / 4u ? lists + row * LC + 4u * q : hi + row * 4u;
+}
 #define EMPTY_NODE 0xFFFFFFFFu
 #ifndef PPT
 #define PPT 2u               // postings per thread and expansion chunk
@@ -89,7 +93,8 @@ struct PeParams {
     uint32_t count_postings;         // VS_DEBUG_POSTINGS: sum the postings expanded (diagnostics)
     uint32_t *out_lists;             // accepted node ids, tile order: packed regions of ept * LC words / rows of LCAP words (out_rows)
     uint32_t *out_counts;            // [n_tiles * ept] list lengths (0 for ends that add nothing), packed form: | quad offset << 8
-    uint32_t out_rows;               // 1: fixed rows of LCAP words per end (the row owners follow), 0: packed
+    uint32_t out_rows;               // 1: fixed rows of LC words per end + out_lists_hi (the row owners follow), 0: packed
+    uint32_t *out_lists_hi;          // [n_tiles * ept * 4] nodes 17 .. LCAP of every end (row layout)
     uint64_t n_pairs;
     uint32_t no_xcd_map;             // VS_NO_XCD_MAP=1: workgroup b takes run b (experiments)
     uint32_t shortcut;               // overlapping-seed ownership shortcut for single postings (P3 stage A)
@@ -1086,14 +1091,14 @@ k_pe_tiles(PeParams P) {
                     const uint32_t n = (s_state[i] & 3u) == 1u ? s_ns[i] : 0u;
                     P.out_counts[(uint64_t)tile * ept + i] = n ? n | (s_off[i] >> 2) << 8 : 0u;
                 }
-            } else {  // a row per end, LROW words apart; a lane per (end, quad), only the quads that hold nodes
-                uint32_t *ol = P.out_lists + (uint64_t)tile * ept * LROW;
+            } else {  // a row per end (+ its quad of the second array); a lane per (end, quad), only the quads that hold nodes
+                uint32_t *ol = P.out_lists + (uint64_t)tile * ept * LC, *oh = P.out_lists_hi + (uint64_t)tile * ept * 4u;
                 for (uint32_t i = lt; i < ne * (LCAP / 4u); i += TTPB) {
                     const uint32_t e = i / (LCAP / 4u), q4 = 4u * (i - e * (LCAP / 4u));
                     const uint32_t n = (s_state[e] & 3u) == 1u ? s_ns[e] : 0u;
                     if (q4 < n) {
                         const uint32_t *src = s_list + s_off[e] + q4;
-                        *(VsQuad *)(ol + e * LROW + q4) = VsQuad{src[0], src[1], src[2], src[3]};
+                        *(VsQuad *)(q4 < LC ? ol + e * LC + q4 : oh + e * 4u) = VsQuad{src[0], src[1], src[2], src[3]};
                     }
                 }
                 for (uint32_t i = lt; i < ne; i += TTPB)
@@ -1515,10 +1520,10 @@ static inline size_t rows_lds_bytes(uint32_t n_keys) { return sizeof(uint32_t) *
 // reads of one locus repeat each other nine times in ten, their mates rarely; with it the kernel took 5.6 ms at
 // configs[4], without 4.1.)
 #define LTAB_PROBES 16u
-__device__ __forceinline__ void vs_load_list(const uint32_t *__restrict__ row, uint32_t n, uint32_t (&v)[LCAP]) {
+__device__ __forceinline__ void vs_load_list(const uint32_t *__restrict__ row, const uint32_t *__restrict__ hi, uint32_t n, uint32_t (&v)[LCAP]) {
     const VsQuad z{0, 0, 0, 0};
     const VsQuad a = *(const VsQuad *)row, b = n > 4u ? *(const VsQuad *)(row + 4) : z, c = n > 8u ? *(const VsQuad *)(row + 8) : z;
-    const VsQuad d = n > 12u ? *(const VsQuad *)(row + 12) : z, f = n > 16u ? *(const VsQuad *)(row + 16) : z;
+    const VsQuad d = n > 12u ? *(const VsQuad *)(row + 12) : z, f = n > 16u ? *(const VsQuad *)hi : z;
     const uint32_t w[LCAP] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w, f.x, f.y, f.z, f.w};
 #pragma unroll
     for (uint32_t i = 0; i < LCAP; i++) v[i] = i < n ? w[i] : 0xFFFFFFFFu;
@@ -1526,6 +1531,16 @@ __device__ __forceinline__ void vs_load_list(const uint32_t *__restrict__ row, u
 // the same set of n nodes?  (both padded with 0xFFFFFFFF)
 __device__ __forceinline__ bool vs_same_list(const uint32_t (&mine)[LCAP], const uint32_t (&other)[LCAP], uint32_t n) {
     bool same = true;
+    if (n <= LC) {  // (nearly every list: the first LC positions of either side hold everything)
+#pragma unroll
+        for (uint32_t k2 = 0; k2 < LC; k2++) {
+            bool found = false;
+#pragma unroll
+            for (uint32_t i = 0; i < LC; i++) found |= mine[i] == other[k2];
+            same &= found || k2 >= n;
+        }
+        return same;
+    }
 #pragma unroll
     for (uint32_t k2 = 0; k2 < LCAP; k2++) {
         bool found = false;
@@ -1537,7 +1552,7 @@ __device__ __forceinline__ bool vs_same_list(const uint32_t (&mine)[LCAP], const
 }
 
 __global__ void __launch_bounds__(256)
-k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint64_t n_ends, uint32_t *__restrict__ mult,
+k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ lists_hi, const uint32_t *__restrict__ counts, uint64_t n_ends, uint32_t *__restrict__ mult,
               uint32_t *__restrict__ gown, unsigned long long *__restrict__ ltab, uint32_t *__restrict__ lmult, uint32_t ltab_bits) {
     const uint64_t e64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e64 >= n_ends) return;
@@ -1545,7 +1560,7 @@ k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ c
     uint32_t m = n ? 1u : 0u, own = e;
     if (n && ltab) {
         uint32_t mine[LCAP];
-        vs_load_list(lists + e64 * LROW, n, mine);
+        vs_load_list(lists + e64 * LC, lists_hi + e64 * 4u, n, mine);
         unsigned long long f2 = n;
 #pragma unroll
         for (uint32_t i = 0; i < LCAP; i++)
@@ -1569,7 +1584,7 @@ k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ c
             }
             if ((uint32_t)(cur >> 32) == tag) {
                 uint32_t other[LCAP];
-                vs_load_list(lists + (uint64_t)((uint32_t)cur - 1u) * LROW, n, other);
+                vs_load_list(lists + (uint64_t)((uint32_t)cur - 1u) * LC, lists_hi + (uint64_t)((uint32_t)cur - 1u) * 4u, n, other);
                 if (vs_same_list(mine, other, n)) {
                     atomicAdd(&lmult[h], 1u);
                     m = 0u;
@@ -1642,13 +1657,13 @@ __device__ __forceinline__ uint32_t vs_rows_item(const uint32_t *__restrict__ co
 
 // one lane per (item, quad of its list): the 16-bit bin of every listed node in [key_lo, key_lo + n_keys) + 1
 template <int MODE>
-__device__ __forceinline__ void vs_rows_histogram(uint32_t *h32, const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts,
+__device__ __forceinline__ void vs_rows_histogram(uint32_t *h32, const uint32_t *__restrict__ lists, const uint32_t *__restrict__ lists_hi, const uint32_t *__restrict__ counts,
                                                   const uint32_t *__restrict__ owners, uint64_t lo, uint64_t hi, uint32_t key_lo, uint32_t n_keys) {
     for (uint64_t i = lo * 4u + threadIdx.x; i < hi * 4u; i += ROWS_TPB) {
         uint64_t row;
         const uint32_t q0 = (uint32_t)i & 3u, n = vs_rows_item<MODE>(counts, owners, i >> 2, row);
         for (uint32_t q = q0; 4u * q < n; q += 4u) {  // (a list of 17 .. LCAP nodes: its fifth quad is the first lane's too)
-            const VsQuad v = *(const VsQuad *)(lists + row * LROW + 4u * q);
+            const VsQuad v = *(const VsQuad *)vs_row_quad(lists, lists_hi, row, q);
             const uint32_t e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (uint32_t j = 0; j < 4u; j++) {
@@ -1661,7 +1676,7 @@ __device__ __forceinline__ void vs_rows_histogram(uint32_t *h32, const uint32_t 
 
 template <int MODE>
 __global__ void __launch_bounds__(ROWS_TPB)
-k_rows_count(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ owners, uint64_t n_items,
+k_rows_count(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ lists_hi, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ owners, uint64_t n_items,
              const uint32_t *__restrict__ n_owners, uint32_t key_lo, uint32_t n_keys, uint32_t *__restrict__ row_count) {
     uint32_t *h32 = vs_lds;
     const uint32_t words = (n_keys + 1u) >> 1, tid = threadIdx.x;
@@ -1671,7 +1686,7 @@ k_rows_count(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ co
     if (lo >= n_items) return;
     for (uint32_t i = tid; i < words; i += ROWS_TPB) h32[i] = 0u;
     __syncthreads();
-    vs_rows_histogram<MODE>(h32, lists, counts, owners, lo, hi, key_lo, n_keys);
+    vs_rows_histogram<MODE>(h32, lists, lists_hi, counts, owners, lo, hi, key_lo, n_keys);
     __syncthreads();
     for (uint32_t i = tid; i < words; i += ROWS_TPB) {
         const uint32_t v = h32[i];
@@ -1682,7 +1697,7 @@ k_rows_count(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ co
 
 template <int MODE>
 __global__ void __launch_bounds__(ROWS_TPB)
-k_rows_fill(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ owners, uint64_t n_items,
+k_rows_fill(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ lists_hi, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ owners, uint64_t n_items,
             const uint32_t *__restrict__ n_owners, const uint32_t *__restrict__ gown, uint32_t key_lo, uint32_t n_keys,
             const uint32_t *__restrict__ row_ptr, uint32_t *__restrict__ row_cursor, uint32_t *__restrict__ entries) {
     uint32_t *h32 = vs_lds;
@@ -1698,7 +1713,7 @@ k_rows_fill(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ cou
     __syncthreads();
     const uint64_t per = MODE ? ROWS_CHUNK1 : ROWS_CHUNK;
     const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n_items ? lo + per : n_items;
-    vs_rows_histogram<MODE>(h32, lists, counts, owners, lo, hi, key_lo, n_keys);
+    vs_rows_histogram<MODE>(h32, lists, lists_hi, counts, owners, lo, hi, key_lo, n_keys);
     __syncthreads();
     // a bin that is not empty: reserve the chunk's stretch of that row, and turn the bin into the number of its cursor
     for (uint32_t i = tid; i < words; i += ROWS_TPB) {
@@ -1735,7 +1750,7 @@ k_rows_fill(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ cou
             payload = gown[re] | ((counts[re] - 1u) << 27);
         }
         for (uint32_t q = q0; 4u * q < n; q += 4u) {
-            const VsQuad v = *(const VsQuad *)(lists + row * LROW + 4u * q);
+            const VsQuad v = *(const VsQuad *)vs_row_quad(lists, lists_hi, row, q);
             const uint32_t e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (uint32_t j = 0; j < 4u; j++) {
@@ -1770,7 +1785,7 @@ typedef CellTable<RS_BITS> RsTable;
 #define RSUM_MAX_ROWS 64u
 template <int MODE>
 __global__ void __launch_bounds__(RS_TPB)
-k_rows_sum(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ mult, uint32_t N,
+k_rows_sum(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ lists_hi, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ mult, uint32_t N,
            const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ entries, uint32_t R, uint32_t n_strips, uint32_t fill_limit,
            uint32_t *__restrict__ mat, uint32_t off, uint8_t *__restrict__ tile_map, uint32_t T, uint32_t *__restrict__ queue,
            uint32_t *__restrict__ dbg) {
@@ -1826,7 +1841,7 @@ k_rows_sum(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ coun
                 const uint64_t row = it & 0x07FFFFFFu;  // (a read end of the transposition)
                 n = (it >> 27) + 1u;
                 if (MODE) wgt = mult[row];
-                yq = *(const VsQuad *)(lists + row * LROW + 4u * q);
+                yq = *(const VsQuad *)(lists + row * LC + 4u * q);
             }
         };
         uint32_t p1 = e0 < e1 ? load_item(e0) : 0xFFFFFFFFu;
@@ -1873,7 +1888,7 @@ k_rows_sum(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ coun
                 };
                 add_quad(yq, 4u * q);
                 // (a list of 17 .. LCAP nodes: its fifth quad is the first lane's too -- one entry in forty at configs[4])
-                if (n > 16u && q == 0u) add_quad(*(const VsQuad *)(lists + (uint64_t)(p0 & 0x07FFFFFFu) * LROW + 16u), 16u);
+                if (n > 16u && q == 0u) add_quad(*(const VsQuad *)(lists_hi + (uint64_t)(p0 & 0x07FFFFFFu) * 4u), 16u);
             }
             if ((pass & 3u) == 3u) {  // (a strip that outruns the limit between two looks finds the table crowded and adds the rest to memory itself: slower, the same sums)
                 __syncthreads();
@@ -2410,14 +2425,15 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
     uint32_t *lmult = use_ltab ? (uint32_t *)((unsigned long long *)ctx->d_ltab + ltab_slots) : nullptr;
     for (uint64_t p0 = 0; p0 < slots_pairs; p0 += sub_pairs) {
         const uint64_t np = slots_pairs - p0 < sub_pairs ? slots_pairs - p0 : sub_pairs;
-        const uint32_t *sl = (const uint32_t *)ctx->d_lists + 2u * p0 * LROW, *sc = (const uint32_t *)ctx->d_list_counts + 2u * p0;
+        const uint32_t *sl = (const uint32_t *)ctx->d_lists + 2u * p0 * LC, *sh = (const uint32_t *)ctx->d_lists + 2u * slots_pairs * LC + 2u * p0 * 4u;
+        const uint32_t *sc = (const uint32_t *)ctx->d_list_counts + 2u * p0;
         uint32_t *mult = (uint32_t *)ctx->d_mult, *owners = mult + 2u * sub_pairs, *gown = owners + 2u * sub_pairs;
         const unsigned n_chunks = (unsigned)((np + ROWS_CHUNK - 1u) / ROWS_CHUNK);
         const unsigned n_chunks1 = (unsigned)((2u * np + ROWS_CHUNK1 - 1u) / ROWS_CHUNK1);  // (every end could be an owner; a chunk past the last owner returns at once)
         VS_HIP(ctx, hipMemsetAsync(rows, 0, sizeof(uint32_t) * 6u * cap, st));
         VS_HIP(ctx, hipMemsetAsync(n_owners, 0, sizeof(uint32_t), st));
         if (use_ltab) VS_HIP(ctx, hipMemsetAsync(ctx->d_ltab, 0, (sizeof(uint64_t) + sizeof(uint32_t)) * ltab_slots, st));
-        hipLaunchKernelGGL(k_list_owners, dim3((unsigned)((2u * np + 255u) / 256u)), dim3(256), 0, st, sl, sc, 2u * np, mult, gown, ltab, lmult, ltab_bits);
+        hipLaunchKernelGGL(k_list_owners, dim3((unsigned)((2u * np + 255u) / 256u)), dim3(256), 0, st, sl, sh, sc, 2u * np, mult, gown, ltab, lmult, ltab_bits);
         if (use_ltab)
             hipLaunchKernelGGL(k_owners_mult, dim3((unsigned)((ltab_slots + 255u) / 256u)), dim3(256), 0, st, (const unsigned long long *)ltab,
                                (const uint32_t *)lmult, ltab_slots, mult);
@@ -2431,15 +2447,15 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
             uint32_t *entries = (uint32_t *)ctx->d_row_entries + (mode ? np * LCAP : 0u);
             for (uint32_t key_lo = 0; key_lo < N; key_lo += n_keys) {
                 const uint32_t nk = N - key_lo < n_keys ? N - key_lo : n_keys;
-                if (mode) hipLaunchKernelGGL(k_rows_count<1>, dim3(n_chunks1), dim3(ROWS_TPB), rl, st, sl, sc, (const uint32_t *)owners, 0ull, (const uint32_t *)n_owners, key_lo, nk, row_count);
-                else hipLaunchKernelGGL(k_rows_count<0>, dim3(n_chunks), dim3(ROWS_TPB), rl, st, sl, sc, (const uint32_t *)nullptr, np, (const uint32_t *)nullptr, key_lo, nk, row_count);
+                if (mode) hipLaunchKernelGGL(k_rows_count<1>, dim3(n_chunks1), dim3(ROWS_TPB), rl, st, sl, sh, sc, (const uint32_t *)owners, 0ull, (const uint32_t *)n_owners, key_lo, nk, row_count);
+                else hipLaunchKernelGGL(k_rows_count<0>, dim3(n_chunks), dim3(ROWS_TPB), rl, st, sl, sh, sc, (const uint32_t *)nullptr, np, (const uint32_t *)nullptr, key_lo, nk, row_count);
             }
             int rc = vs_scan_u32(ctx, row_count, row_ptr, (uint64_t)N + 1u, scan_tmp, nullptr);
             if (rc) return rc;
             for (uint32_t key_lo = 0; key_lo < N; key_lo += n_keys) {
                 const uint32_t nk = N - key_lo < n_keys ? N - key_lo : n_keys;
-                if (mode) hipLaunchKernelGGL(k_rows_fill<1>, dim3(n_chunks1), dim3(ROWS_TPB), rl, st, sl, sc, (const uint32_t *)owners, 0ull, (const uint32_t *)n_owners, (const uint32_t *)gown, key_lo, nk, (const uint32_t *)row_ptr, row_cursor, entries);
-                else hipLaunchKernelGGL(k_rows_fill<0>, dim3(n_chunks), dim3(ROWS_TPB), rl, st, sl, sc, (const uint32_t *)nullptr, np, (const uint32_t *)nullptr, (const uint32_t *)gown, key_lo, nk, (const uint32_t *)row_ptr, row_cursor, entries);
+                if (mode) hipLaunchKernelGGL(k_rows_fill<1>, dim3(n_chunks1), dim3(ROWS_TPB), rl, st, sl, sh, sc, (const uint32_t *)owners, 0ull, (const uint32_t *)n_owners, (const uint32_t *)gown, key_lo, nk, (const uint32_t *)row_ptr, row_cursor, entries);
+                else hipLaunchKernelGGL(k_rows_fill<0>, dim3(n_chunks), dim3(ROWS_TPB), rl, st, sl, sh, sc, (const uint32_t *)nullptr, np, (const uint32_t *)nullptr, (const uint32_t *)gown, key_lo, nk, (const uint32_t *)row_ptr, row_cursor, entries);
             }
         }
         for (int mode = 0; mode < 2; mode++) {
@@ -2452,10 +2468,10 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
             const uint32_t off = (uint32_t)(((uintptr_t)m >> 2) & 15u);
             VS_HIP(ctx, hipMemsetAsync(queue, 0, sizeof(uint32_t), st));
             if (mode)
-                hipLaunchKernelGGL(k_rows_sum<1>, dim3(grid), dim3(RS_TPB), RSUM_LDS_BYTES, st, sl, sc, (const uint32_t *)mult, N, row_ptr, entries, R[1], n_strips, fill, m,
+                hipLaunchKernelGGL(k_rows_sum<1>, dim3(grid), dim3(RS_TPB), RSUM_LDS_BYTES, st, sl, sh, sc, (const uint32_t *)mult, N, row_ptr, entries, R[1], n_strips, fill, m,
                                    off, d_tile_map, T, queue, dbg);
             else
-                hipLaunchKernelGGL(k_rows_sum<0>, dim3(grid), dim3(RS_TPB), RSUM_LDS_BYTES, st, sl, sc, (const uint32_t *)mult, N, row_ptr, entries, R[0], n_strips, fill, m,
+                hipLaunchKernelGGL(k_rows_sum<0>, dim3(grid), dim3(RS_TPB), RSUM_LDS_BYTES, st, sl, sh, sc, (const uint32_t *)mult, N, row_ptr, entries, R[0], n_strips, fill, m,
                                    off, d_tile_map, T, queue, dbg);
         }
     }
@@ -2567,7 +2583,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     // per-end lists handed from k_pe_tiles to k_pe_accumulate
     const uint64_t n_tiles_all = (n_pairs + ept / 2 - 1) / (ept / 2);
     const uint64_t list_ends = n_tiles_all * ept;
-    const uint64_t list_words = list_ends * (use_rows ? LROW : LC) + 16u;  // (either layout of the hand-off)
+    const uint64_t list_words = list_ends * (use_rows ? LC + 4u : LC) + 16u;  // (either layout of the hand-off)
     if (d_node_mat && (ctx->lists_cap < list_ends || ctx->lists_words < list_words)) {
         if (ctx->d_lists) VS_HIP(ctx, hipFree(ctx->d_lists));
         if (ctx->d_list_counts) VS_HIP(ctx, hipFree(ctx->d_list_counts));
@@ -2606,6 +2622,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
     P.dbg_cap = dbg_cap;
     P.accumulate = d_node_mat ? 1u : 0u;
     P.out_rows = use_rows ? 1u : 0u;
+    P.out_lists_hi = (uint32_t *)ctx->d_lists + list_ends * LC;
     P.tile_map = d_node_mat ? d_tile_map : nullptr;
     P.tile_T = (idx.n_nodes + 63u) >> 6;
     P.no_xcd_map = tn.no_xcd_map ? 1u : 0u;

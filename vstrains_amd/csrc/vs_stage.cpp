@@ -447,9 +447,13 @@ struct vs_stage {
                 if (p->size() < n) p->resize(n);  // (the caller overwrites every entry it keeps and cuts the rest)
                 return p;
             }
-        // (writers that fall behind keep their vectors: the pool grows to 16 vectors or 64 MB of them, past that a vector is
-        // made per stage and freed by its writer, with the page faults that costs)
-        if (line_pool.size() < 16 || line_pool.size() * n * sizeof(LineRef) < ((size_t)64 << 20)) {
+        // (writers that fall behind keep their vectors: the pool grows to 16 vectors, or to 64 of them while they hold less
+        // than 64 MB, past that a vector is made per stage and freed by its writer, with the page faults that costs.  Bounded
+        // by COUNT too -- ADVICE r5: a small graph with a lagging writer used to pool tens of thousands of vectors, every call
+        // scanning them all)
+        size_t held = 0;
+        for (auto &p : line_pool) held += p->capacity() * sizeof(LineRef);
+        if (line_pool.size() < 16 || (line_pool.size() < 64 && held + n * sizeof(LineRef) < ((size_t)64 << 20))) {
             line_pool.push_back(std::make_shared<std::vector<LineRef>>(n));
             return line_pool.back();
         }
@@ -1782,7 +1786,17 @@ struct vs_stage::Closure {
 // of global_trivial_split on some circular graphs (every fork of "X*B" leaves an "X*B*B" that forks again, up to the
 // N^2 bound: fuzz_reference draw 236 of campaign 778, tests/golden/graph/circular_runaway_k55).  Depth of an id = 1 for an
 // id that was not forked, else 1 + the deepest of its forks; worked out without recursion.
-static const uint32_t PY_MERGE_ID_FRAMES = 993;  // (CPython 3.10, sys.getrecursionlimit() == 1000, the CLI's call depth)
+// (CPython 3.10, sys.getrecursionlimit() == 1000, the CLI's call depth: the number models the reference's COMMAND.  A caller at
+// another depth or under another limit -- the in-process API from a deeper stack, a raised recursion limit -- says so with
+// VS_STAGE_MERGE_ID_FRAMES=<n>, read once per process; INTEGRATION.md "limits that model the reference's interpreter")
+static uint32_t merge_id_frames() {
+    static const uint32_t v = [] {
+        const char *e = getenv("VS_STAGE_MERGE_ID_FRAMES");
+        return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 993u;
+    }();
+    return v;
+}
+#define PY_MERGE_ID_FRAMES merge_id_frames()
 void vs_stage::check_fork_depth(const NameMap<std::vector<Nid>> &id_mapping, const Closure &closure) {
     std::vector<uint32_t> depth(names.size(), 0);  // 0 = not worked out yet
     std::vector<std::pair<Nid, size_t>> stack;     // (id, next fork to look at)

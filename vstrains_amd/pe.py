@@ -471,8 +471,16 @@ class PeCounter:
     def reserve_link_table(self) -> None:
         """Set aside the device buffer of the PE-link table the graph stages will build from these counters (N x N int64,
         ``vs_links_reserve``): called where the counters are made when the stages follow, so that the table's build does
-        not wait for a large ``hipMalloc`` (0.3 ms or half a second for 23.7 GB, depending on what was freed before)."""
-        nat.check(self.ctx._h, nat.lib().vs_links_reserve(self.ctx._h, self.n))
+        not wait for a large ``hipMalloc`` (0.3 ms or half a second for 23.7 GB, depending on what was freed before).
+        An optimisation only: when the memory is not there now, the build allocates later (or fails there, where every rank
+        can be told) -- a lone rank raising here would leave its peers waiting in the next collective."""
+        rc = nat.lib().vs_links_reserve(self.ctx._h, self.n)
+        if rc == nat.VS_E_OOM:
+            import warnings
+
+            warnings.warn("the PE-link table's buffer could not be set aside now (%d nodes); it is allocated when the table is built" % self.n)
+            return
+        nat.check(self.ctx._h, rc)
 
     def reset(self):
         if self.tile_map is not None:
