@@ -75,6 +75,59 @@ class NumpyGraphOps:
         return GraphScan(nontrivial, fork, nxt, top, rank)
 
 
+class SparsePeLinks:
+    """The same table (``process_pe_info`` IO.py:598-627: key {u, v} = both orders of both matrices summed, the diagonal
+    once) held as CSR rows of its non-zero cells -- graphs whose dict would have 1.5e9 keys (54 k nodes).  ``row_ptr``
+    [n + 1], ``col`` ascending inside a row, ``val`` int64; rows and columns in the order of ``names``."""
+
+    def __init__(self, names: Sequence[str], row_ptr, col, val):
+        self.names = list(names)
+        self._index = {n: i for i, n in enumerate(self.names)}
+        self.row_ptr = numpy.asarray(row_ptr, dtype=numpy.int64)
+        self.col = numpy.asarray(col, dtype=numpy.int64)
+        self.val = numpy.asarray(val, dtype=numpy.int64)
+        self._rows: Dict[int, Dict[int, int]] = {}
+
+    def index_of(self, name: str) -> int:
+        return self._index[name]
+
+    def _row(self, r: int) -> Dict[int, int]:
+        d = self._rows.get(r)
+        if d is None:
+            a, b = int(self.row_ptr[r]), int(self.row_ptr[r + 1])
+            d = self._rows[r] = dict(zip(self.col[a:b].tolist(), self.val[a:b].tolist()))
+        return d
+
+    def cell(self, r: int, c: int) -> int:
+        return self._row(r).get(c, 0)
+
+    def block_sums(self, queries):
+        out = []
+        for rows, cols in queries:
+            s = 0
+            for r in rows:
+                d = self._row(r)
+                if d:
+                    for c in cols:
+                        s += d.get(c, 0)
+            out.append(s)
+        return out
+
+    def group_matrix(self, groups):
+        """Entry (i, j) = block sum of groups[i] x groups[j], worked out when it is asked for (the reference fills a V x V
+        table, Extension.py:766-799, and reads the (in-neighbour, out-neighbour) entries of the remaining branches)."""
+        table = self
+
+        class _Lazy:
+            shape = (len(groups), len(groups))
+
+            def __getitem__(self, ij):
+                i, j = ij
+                return table.block_sums([(groups[i], groups[j])])[0]
+
+        return _Lazy()
+
+
 class DictPeLinks:
     """``process_pe_info``: the N(N+1)/2-key dict built from the two count matrices."""
 

@@ -70,3 +70,42 @@ def stage_over_checker_sparse(names, row_ptr, col, val) -> ns.NativeStage:
     st = ns.NativeStage(L, h)
     st.set_link_names(list(names))
     return st
+
+
+def links_csr_of_counter(counter):
+    """The symmetrised PE-link table (IO.py:598-627: both orders of both matrices summed, the diagonal once) of a device
+    counter as CSR rows of its non-zero cells, in the GFA's node order (whatever numbering the device index uses):
+    (row_ptr u64 [n + 1], col u32 ascending inside a row, val i64, sha256 of the three).  tools/dump_links_csr.py writes the
+    same arrays for the build container (tests/golden/extract_digests_config4.json names their hash)."""
+    import hashlib
+
+    import torch
+
+    n = counter.n
+    order = counter.node_order
+    parts_ij, parts_v = [], []
+    for lo in range(0, n, 4096):  # (row slabs: torch.nonzero does not take a tensor of 3e9 cells)
+        blk = counter.mats[0, lo:lo + 4096].to(torch.int64) + counter.mats[1, lo:lo + 4096]
+        nz = torch.nonzero(blk)
+        parts_v.append(blk[nz[:, 0], nz[:, 1]])
+        nz[:, 0] += lo
+        parts_ij.append(nz)
+    ij, v = torch.cat(parts_ij), torch.cat(parts_v)
+    del parts_ij, parts_v
+    if order is not None:
+        o = torch.as_tensor(np.asarray(order, dtype=np.int64), device=ij.device)
+        ij = torch.stack([o[ij[:, 0]], o[ij[:, 1]]], dim=1)
+    off = ij[:, 0] != ij[:, 1]
+    keys = torch.cat([ij[:, 0] * n + ij[:, 1], ij[off, 1] * n + ij[off, 0]])
+    vals = torch.cat([v, v[off]])
+    uk, inv = torch.unique(keys, return_inverse=True)
+    uv = torch.zeros(uk.shape[0], dtype=torch.int64, device=uk.device).scatter_add_(0, inv, vals)
+    rows = (uk // n).cpu().numpy()
+    col = (uk % n).cpu().numpy().astype(np.uint32)
+    val = uv.cpu().numpy()
+    row_ptr = np.zeros(n + 1, dtype=np.uint64)
+    row_ptr[1:] = np.cumsum(np.bincount(rows, minlength=n))
+    sha = hashlib.sha256(row_ptr.tobytes() + col.tobytes() + val.astype(np.uint32).tobytes()).hexdigest()
+    del ij, v, keys, vals, uk, inv, uv
+    torch.cuda.empty_cache()
+    return row_ptr, col, val, sha

@@ -133,6 +133,70 @@ def test_link_table_matches_process_pe_info(backend, n):
     assert np.array_equal(dev.group_matrix(groups), ref.group_matrix(groups))
 
 
+@pytest.mark.parametrize("n", [64, 65, 200, 517])
+def test_sparse_link_table_from_the_dirty_tiles_equals_the_dense_one(backend, n):
+    """(r6, ABI 10) vs_links_from_counts_tracked: counters that keep a dirty-tile map give the table as CSR rows of its
+    non-zero cells, built from the marked 64 x 64 tiles only (the form graphs of 32 768 nodes and more take: 0.4 GB instead
+    of 23.7 GB at configs[4]).  Same cells as the dense table of the same counters and as process_pe_info's dict
+    (IO.py:598-627), same block sums and group matrices; cells outside the marked tiles are never read -- a tile that is
+    NOT marked may hold anything."""
+    import torch
+
+    from vstrains_amd import pe as host
+    from vstrains_amd.graph.hip_ops import HipPeLinks
+
+    ctx = backend.ctx
+    rng = np.random.default_rng(1000 + n)
+    names = [str(i) for i in range(n)]
+
+    seqs = ["ACGT" * 20 + "".join("ACGT"[(i >> (2 * j)) & 3] for j in range(8)) for i in range(n)]
+    ctx.build_index(seqs, 21)  # (a counter takes its size from the context's index)
+    counter = host.PeCounter(ctx, track_tiles=True)
+    T = (n + 63) // 64
+    node = rng.integers(1, 2 ** 31, size=(n, n)) * (rng.random((n, n)) < 0.05)
+    short = np.triu(rng.integers(1, 2 ** 32 - 1, size=(n, n)) * (rng.random((n, n)) < 0.05))
+    # whole tiles without any cell: left unmarked, and filled with garbage the build must not look at
+    tiles = np.zeros((2, T, T), dtype=np.uint8)
+    for m, mat in enumerate((node, short)):
+        for I in range(T):
+            for J in range(T):
+                if rng.random() < 0.3:
+                    mat[I * 64:(I + 1) * 64, J * 64:(J + 1) * 64] = 0
+                tiles[m, I, J] = 1 if mat[I * 64:(I + 1) * 64, J * 64:(J + 1) * 64].any() else 0
+    dirty_node, dirty_short = node.copy(), short.copy()
+    for m, mat in enumerate((dirty_node, dirty_short)):
+        for I in range(T):
+            for J in range(T):
+                if not tiles[m, I, J]:
+                    mat[I * 64:(I + 1) * 64, J * 64:(J + 1) * 64] = 12345
+    order = counter.node_order
+    counter.node_order = None  # (this test speaks the counters' own numbering)
+    counter.node_rank = None
+    counter.mats[0].copy_(torch.from_numpy(dirty_node.astype(np.uint32).view(np.int32)))
+    counter.mats[1].copy_(torch.from_numpy(dirty_short.astype(np.uint32).view(np.int32)))
+    counter.tile_map.copy_(torch.from_numpy(tiles.reshape(-1)))
+    sparse = HipPeLinks.from_counter(ctx, counter, names, sparse_min_nodes=64)
+    ref = chk.DictPeLinks(names, node, short)
+    want = node + node.T + short + short.T
+    want[np.arange(n), np.arange(n)] = node.diagonal() + short.diagonal()
+    assert np.array_equal(sparse.to_numpy(), want)
+    py = random.Random(n)
+    queries = []
+    for _ in range(300):
+        rows = [py.randrange(n) for _ in range(py.randrange(0, 6))]
+        cols = [py.randrange(n) for _ in range(py.choice([0, 1, 2, 5, 70, 130]))]
+        queries.append((rows, cols))
+    assert sparse.block_sums(queries) == ref.block_sums(queries)
+    groups = [[py.randrange(n) for _ in range(py.randrange(0, 5))] for _ in range(20)]
+    assert np.array_equal(sparse.group_matrix(groups), ref.group_matrix(groups))
+    # ... and below the threshold the same call gives the dense table of the counters as they are (garbage and all)
+    dense = HipPeLinks.from_counter(ctx, counter, names, sparse_min_nodes=10 ** 6)
+    wd = dirty_node + dirty_node.T + dirty_short + dirty_short.T
+    wd[np.arange(n), np.arange(n)] = dirty_node.diagonal() + dirty_short.diagonal()
+    assert np.array_equal(dense.to_numpy(), wd)
+    counter.node_order = order
+
+
 def test_link_table_takes_a_reserved_buffer_of_its_size_and_only_that(backend):
     """vs_links_reserve (ABI 9) sets the table's buffer aside ahead of time: a table of that size takes it, another size is
     allocated as before, a second reservation replaces the first, n = 0 gives it back -- the table is the same either way."""
@@ -541,16 +605,20 @@ def test_extraction_on_the_device_equals_the_checker_at_bench_size(backend, conf
 def test_extraction_at_config4_size_device_operations_equal_the_cpu_checker(backend, tmp_path):
     """configs[4] (54 465 nodes, the whole 25 M-pair block of one of its eight GPUs): the strain-extract leg with the HIP
     kernels underneath -- flows, scans, chain ranking beyond one workgroup's 8 192 vertices, link sums over the device's
-    23.7 GB table -- against the SAME engine over the CPU checker of those operations (oracle/stage_check.cpp, the link table
-    as CSR rows of its non-zero cells): all 540 files byte for byte, the same strains.  (The Python statement of the stages,
-    which the smaller configs are held to above, would take minutes at this size; the engine's decisions are pinned by the
-    goldens and the campaigns, this test pins what the DEVICE computes at the largest BASELINE graph.)"""
+    link table -- against
+      (a) (r6) the digests of an INDEPENDENT run: the checker's Python statement of the stages (oracle/graph_stages: its own
+          graph container, GFA reader / writer, contig bookkeeping; numpy operations) on the same link table, run once in
+          the build container (tools/extract_digests_from_csr.py on the CSR rows tools/dump_links_csr.py wrote here;
+          tests/golden/extract_digests_config4.json) -- every decision of the engine at the largest BASELINE graph;
+      (b) the SAME engine over the CPU checker of its device operations (oracle/stage_check.cpp, the link table as CSR rows
+          of its non-zero cells): what the DEVICE computes.
+    All files byte for byte, the same strains."""
     import copy
-
-    import torch
+    import json
 
     import native_check
     import profile_extract_cpu as pec
+    from conftest import GOLDEN
     from vstrains_amd import pe as host
     from vstrains_amd.graph import pipeline
     from vstrains_amd.graph.hip_ops import HipPeLinks
@@ -564,36 +632,17 @@ def test_extraction_at_config4_size_device_operations_equal_the_cpu_checker(back
     counter = host.PeCounter(ctx)
     counter.add(reads)
     del reads
-    # the symmetrised table (IO.py:598-627: both orders of both matrices summed, the diagonal once) of the non-zero cells, in
-    # the numbering the counters are in (the index's), as CSR
-    n = counter.n
-    order = counter.node_order
-    names_int = [names[i] for i in order.tolist()] if order is not None else list(names)
-    parts_ij, parts_v = [], []
-    for lo in range(0, n, 4096):  # (row slabs: torch.nonzero does not take a tensor of 3e9 cells)
-        blk = counter.mats[0, lo:lo + 4096].to(torch.int64) + counter.mats[1, lo:lo + 4096]
-        nz = torch.nonzero(blk)
-        parts_v.append(blk[nz[:, 0], nz[:, 1]])
-        nz[:, 0] += lo
-        parts_ij.append(nz)
-    ij, v = torch.cat(parts_ij), torch.cat(parts_v)
-    del parts_ij, parts_v, blk, nz
-    off = ij[:, 0] != ij[:, 1]
-    keys = torch.cat([ij[:, 0] * n + ij[:, 1], ij[off, 1] * n + ij[off, 0]])
-    vals = torch.cat([v, v[off]])
-    uk, inv = torch.unique(keys, return_inverse=True)
-    uv = torch.zeros(uk.shape[0], dtype=torch.int64, device=uk.device).scatter_add_(0, inv, vals)
-    rows = (uk // n).cpu().numpy()
-    col = (uk % n).cpu().numpy().astype(np.uint32)
-    val = uv.cpu().numpy()
-    row_ptr = np.zeros(n + 1, dtype=np.uint64)
-    row_ptr[1:] = np.cumsum(np.bincount(rows, minlength=n))
-    del ij, v, keys, vals, uk, inv, uv
-    torch.cuda.empty_cache()
+    row_ptr, col, val, csr_sha = native_check.links_csr_of_counter(counter)
+    fixture = None
+    fpath = os.path.join(GOLDEN, "extract_digests_config4.json")
+    if os.path.exists(fpath):
+        with open(fpath) as fh:
+            fixture = json.load(fh)
+        assert fixture["csr_sha256"] == csr_sha, "the independent run worked on another link table than this device counted"
 
     class CheckerOps:
         def native_stage(self, table):
-            return native_check.stage_over_checker_sparse(names_int, row_ptr, col, val)
+            return native_check.stage_over_checker_sparse(list(names), row_ptr, col, val)
 
     outs = []
     for which in ("device", "checker"):
@@ -612,6 +661,11 @@ def test_extraction_at_config4_size_device_operations_equal_the_cpu_checker(back
     assert s_dev == s_ref and len(s_dev) > 100
     assert sorted(dev) == sorted(ref) and len(dev) > 500
     assert [f for f in dev if dev[f] != ref[f]] == []
+    assert fixture is not None, "tests/golden/extract_digests_config4.json is missing: the independent leg did not run"
+    want = fixture["files_sha256"]
+    assert sorted(dev) == sorted(want), sorted(set(dev) ^ set(want))[:10]
+    assert [f for f in sorted(dev) if dev[f] != want[f]] == []
+    assert s_dev == {k: (list(r[0]), r[1], r[2]) for k, r in fixture["strains"].items()}
 
 
 def test_randomized_extraction_campaign_short():

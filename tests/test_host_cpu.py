@@ -24,7 +24,7 @@ def test_library_exports_every_symbol_of_the_header():
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(L, name)
-    assert L.vs_abi_version() == 9
+    assert L.vs_abi_version() == 10
 
 
 def test_no_device_means_loud_failure_not_fallback():

@@ -243,7 +243,7 @@ def test_fork_chain_limit_is_the_one_measured_on_the_real_reference_function():
     assert contig_ops.PY_MERGE_ID_FRAMES == want["max_nested_merge_id_frames"]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "vstrains_amd", "csrc", "vs_stage.cpp")) as fh:
-        (n,) = re.findall(r"PY_MERGE_ID_FRAMES = (\d+);", fh.read())
+        (n,) = re.findall(r"atoi\(e\) : (\d+)u;", fh.read())  # (the default of merge_id_frames(); VS_STAGE_MERGE_ID_FRAMES overrides it)
     assert int(n) == want["max_nested_merge_id_frames"]
     # the checker on chains either side of the limit (no graph needed: nothing is a contig)
     import logging

@@ -42,30 +42,12 @@ def main():
     counter = host.PeCounter(ctx)
     counter.add(reads)
     del reads
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import native_check
+
     n = counter.n
-    order = counter.node_order  # index numbering -> GFA position
-    parts_ij, parts_v = [], []
-    for lo in range(0, n, 4096):
-        blk = counter.mats[0, lo:lo + 4096].to(torch.int64) + counter.mats[1, lo:lo + 4096]
-        nz = torch.nonzero(blk)
-        parts_v.append(blk[nz[:, 0], nz[:, 1]])
-        nz[:, 0] += lo
-        parts_ij.append(nz)
-    ij, v = torch.cat(parts_ij), torch.cat(parts_v)
-    if order is not None:  # to the GFA's numbering: the file is independent of how the device numbers its index
-        o = torch.as_tensor(np.asarray(order, dtype=np.int64), device=ij.device)
-        ij = torch.stack([o[ij[:, 0]], o[ij[:, 1]]], dim=1)
-    off = ij[:, 0] != ij[:, 1]
-    keys = torch.cat([ij[:, 0] * n + ij[:, 1], ij[off, 1] * n + ij[off, 0]])
-    vals = torch.cat([v, v[off]])
-    uk, inv = torch.unique(keys, return_inverse=True)
-    uv = torch.zeros(uk.shape[0], dtype=torch.int64, device=uk.device).scatter_add_(0, inv, vals)
-    rows = (uk // n).cpu().numpy()
-    col = (uk % n).cpu().numpy().astype(np.uint32)
-    val = uv.cpu().numpy()
+    row_ptr, col, val, csr_sha = native_check.links_csr_of_counter(counter)
     assert val.max() < 2 ** 32
-    row_ptr = np.zeros(n + 1, dtype=np.uint64)
-    row_ptr[1:] = np.cumsum(np.bincount(rows, minlength=n))
     nnz = int(col.shape[0])
     # parts: whole rows, about part_mb of raw (col u32 + val u32) each
     per = int(args.part_mb * 1e6 / 8)
@@ -81,7 +63,7 @@ def main():
 
     meta = {"config": args.config, "nodes": int(n), "pairs": int(n_pairs), "nnz": nnz, "parts": n_parts, "row_cuts": cuts,
             "names_sha256": hashlib.sha256("\n".join(names).encode()).hexdigest(),
-            "csr_sha256": hashlib.sha256(row_ptr.tobytes() + col.tobytes() + val.astype(np.uint32).tobytes()).hexdigest(),
+            "csr_sha256": csr_sha,
             "stats": [int(x) for x in counter.stats] if hasattr(counter, "stats") else None}
     with open(os.path.join(args.out, "links_c%d_meta.json" % args.config), "w") as fh:
         json.dump(meta, fh)

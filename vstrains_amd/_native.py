@@ -59,6 +59,7 @@ SYMBOLS = {
     "vs_pe_last_launched": (C.c_uint32, [C.c_void_p]),
     "vs_pe_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "vs_links_from_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "vs_links_from_counts_tracked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "vs_links_from_wide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "vs_links_from_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "vs_links_reserve": (C.c_int, [C.c_void_p, C.c_uint32]),

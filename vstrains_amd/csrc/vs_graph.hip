@@ -16,7 +16,14 @@
 
 struct vs_links {
     uint32_t n = 0;
-    int64_t *d_p0 = nullptr;  // [n*n] symmetric; diagonal = node[i][i] + short[i][i]
+    int64_t *d_p0 = nullptr;  // [n*n] symmetric; diagonal = node[i][i] + short[i][i]  (dense form)
+    // sparse form (r6, graphs of 2^15 nodes and more whose counters keep a dirty-tile map): CSR rows of the non-zero cells,
+    // columns ascending inside a row -- 0.4 GB instead of 23.7 GB at 54 465 nodes (1.2 % of the cells are non-zero)
+    uint32_t *d_row_ptr = nullptr;  // [n + 1]
+    uint32_t *d_col = nullptr;      // [nnz]
+    int64_t *d_val = nullptr;       // [nnz]
+    uint64_t nnz = 0;
+    bool sparse() const { return d_row_ptr != nullptr; }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -120,6 +127,164 @@ __global__ void __launch_bounds__(256) k_links_group_cols(const int64_t *__restr
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, VS_WAVE);
     if (lane == 0) out[pair] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5 sparse (r6): the same table as CSR rows, built from the counters' DIRTY 64 x 64 tiles only
+// (vs_pe_count_tracked marks a tile wherever a block adds to a cell; a cell outside the marked tiles
+// is zero).  process_pe_info (IO.py:598-627) as above: cell {i, j} = node[i][j] + node[j][i] +
+// short[i][j] + short[j][i], the diagonal once.  A workgroup takes the tile pair (I, J), I <= J, if any
+// of its four source tiles is marked, sums them into S = tile (I, J) of the table (LDS, int64) --
+// tile (J, I) is S transposed -- and
+//   pass 1 (k_sl_count)  counts the non-zero cells per table row and tile column -> cnt[row][tile col] (bytes)
+//   (k_sl_rows)          per row: the prefix of its tile-column counts -> where every (row, tile col) piece starts in
+//                        the row, and the row's total; a scan over the totals gives row_ptr
+//   pass 2 (k_sl_fill)   sums the same tiles again and writes every row's cells of that tile column, ascending, by a
+//                        ballot / prefix count over the 64 columns (one wavefront per row)
+// Nothing but the marked tiles is read: 2 x 0.5 GB instead of the 2 x 11.9 GB of counters + 23.7 GB of table.
+// ---------------------------------------------------------------------------------------------
+#define SL_T 64u
+template <typename TIn>
+__device__ __forceinline__ bool sl_load_pair(const TIn *__restrict__ node, const TIn *__restrict__ shrt, const uint8_t *__restrict__ map,
+                                             uint32_t n, uint32_t T, uint32_t I, uint32_t J, int64_t (*S)[SL_T + 1]) {
+    // marked source tiles: node (I,J), node (J,I), short (I,J), short (J,I)
+    const uint8_t *smap = map + (uint64_t)T * T;
+    const bool a = map[(uint64_t)I * T + J], b = map[(uint64_t)J * T + I], c = smap[(uint64_t)I * T + J], d = smap[(uint64_t)J * T + I];
+    if (!(a | b | c | d)) return false;
+    const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;  // 64 x 4
+    for (uint32_t r = ty; r < SL_T; r += 4u) S[r][tx] = 0;
+    __syncthreads();
+    for (uint32_t r = ty; r < SL_T; r += 4u) {
+        const uint32_t gi = I * SL_T + r, gj = J * SL_T + tx;
+        if (gi < n && gj < n && (a | c)) {
+            const uint64_t at = (uint64_t)gi * n + gj;
+            S[r][tx] += (a ? (int64_t)node[at] : 0) + (c ? (int64_t)shrt[at] : 0);
+        }
+    }
+    __syncthreads();
+    // row r of tile (J, I) adds to column r of S; on the diagonal tile (J == I) that is S + S^T, the diagonal cells once
+    for (uint32_t r = ty; r < SL_T; r += 4u) {
+        const uint32_t hi = J * SL_T + r, hj = I * SL_T + tx;
+        if (hi < n && hj < n && (b | d) && (I != J || r != tx)) {
+            const uint64_t at = (uint64_t)hi * n + hj;
+            S[tx][r] += (b ? (int64_t)node[at] : 0) + (d ? (int64_t)shrt[at] : 0);
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
+__device__ __forceinline__ void sl_pair_of(uint32_t p, uint32_t T, uint32_t &I, uint32_t &J) {
+    // linear pair index -> (I, J) with I <= J, row I of the upper triangle holds T - I pairs
+    const double tt = 2.0 * T + 1.0;
+    uint32_t i = (uint32_t)((tt - sqrt(tt * tt - 8.0 * (double)p)) * 0.5);
+    while (i > 0 && (uint64_t)i * T - (uint64_t)i * (i - 1u) / 2u > p) i--;
+    while ((uint64_t)(i + 1u) * T - (uint64_t)(i + 1u) * i / 2u <= p) i++;
+    I = i;
+    J = i + (uint32_t)(p - ((uint64_t)i * T - (uint64_t)i * (i - 1u) / 2u));
+}
+
+template <typename TIn>
+__global__ void __launch_bounds__(256) k_sl_count(const TIn *__restrict__ node, const TIn *__restrict__ shrt, const uint8_t *__restrict__ map,
+                                                 uint32_t n, uint32_t T, uint8_t *__restrict__ cnt) {
+    __shared__ int64_t S[SL_T][SL_T + 1];
+    uint32_t I, J;
+    sl_pair_of(blockIdx.x, T, I, J);
+    if (!sl_load_pair(node, shrt, map, n, T, I, J, S)) return;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    for (uint32_t r = wv; r < SL_T; r += 4u) {
+        const unsigned long long row_nz = __ballot(S[r][lane] != 0), col_nz = __ballot(S[lane][r] != 0);
+        if (lane == 0) {
+            const uint32_t gi = I * SL_T + r, gj = J * SL_T + r;
+            if (gi < n && row_nz) cnt[(uint64_t)gi * T + J] = (uint8_t)__popcll(row_nz);           // row r of tile (I, J)  (at most 64: fits the byte)
+            if (I != J && gj < n && col_nz) cnt[(uint64_t)gj * T + I] = (uint8_t)__popcll(col_nz);  // row r of tile (J, I) = column r of S
+        }
+    }
+}
+
+// (cnt: cells of a 64-cell piece of a row, one byte; 0 = the piece is empty and has no offset)
+__global__ void __launch_bounds__(256) k_sl_rows(const uint8_t *__restrict__ cnt, uint32_t n, uint32_t T, uint32_t *__restrict__ piece_off,
+                                                uint32_t *__restrict__ row_total) {
+    const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (row >= n) return;
+    uint32_t run = 0;
+    for (uint32_t t0 = 0; t0 < T; t0 += 64u) {
+        const uint32_t t = t0 + lane;
+        const uint32_t c = t < T ? cnt[(uint64_t)row * T + t] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= (uint32_t)d) incl += up;
+        }
+        if (c) piece_off[(uint64_t)row * T + t] = run + incl - c;
+        run += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) row_total[row] = run;
+}
+
+template <typename TIn>
+__global__ void __launch_bounds__(256) k_sl_fill(const TIn *__restrict__ node, const TIn *__restrict__ shrt, const uint8_t *__restrict__ map,
+                                                uint32_t n, uint32_t T, const uint32_t *__restrict__ piece_off, const uint32_t *__restrict__ row_ptr,
+                                                uint32_t *__restrict__ col, int64_t *__restrict__ val) {
+    __shared__ int64_t S[SL_T][SL_T + 1];
+    uint32_t I, J;
+    sl_pair_of(blockIdx.x, T, I, J);
+    if (!sl_load_pair(node, shrt, map, n, T, I, J, S)) return;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    for (uint32_t r = wv; r < SL_T; r += 4u) {
+        {   // row r of tile (I, J): columns J * 64 + lane
+            const int64_t v = S[r][lane];
+            const unsigned long long nz = __ballot(v != 0);
+            const uint32_t gi = I * SL_T + r;
+            if (v != 0 && gi < n) {
+                const uint32_t at = row_ptr[gi] + piece_off[(uint64_t)gi * T + J] + (uint32_t)__popcll(nz & ((1ull << lane) - 1ull));
+                col[at] = J * SL_T + lane;
+                val[at] = v;
+            }
+        }
+        if (I != J) {  // row r of tile (J, I): columns I * 64 + lane
+            const int64_t v = S[lane][r];
+            const unsigned long long nz = __ballot(v != 0);
+            const uint32_t gj = J * SL_T + r;
+            if (v != 0 && gj < n) {
+                const uint32_t at = row_ptr[gj] + piece_off[(uint64_t)gj * T + I] + (uint32_t)__popcll(nz & ((1ull << lane) - 1ull));
+                col[at] = I * SL_T + lane;
+                val[at] = v;
+            }
+        }
+    }
+}
+
+// block sums over the CSR rows: one wavefront per query; for every row of list a the lanes take the columns of list b and
+// look each up in the row (binary search over ascending columns)
+__global__ void __launch_bounds__(256) k_links_block_sums_csr(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col,
+                                                             const int64_t *__restrict__ val, const uint64_t *__restrict__ list_off,
+                                                             const uint32_t *__restrict__ list_idx, const uint32_t *__restrict__ qa,
+                                                             const uint32_t *__restrict__ qb, uint64_t n_queries, int64_t *__restrict__ out) {
+    uint64_t q = (uint64_t)blockIdx.x * (blockDim.x / VS_WAVE) + (threadIdx.x / VS_WAVE);
+    if (q >= n_queries) return;
+    uint32_t lane = threadIdx.x & (VS_WAVE - 1);
+    uint64_t a0 = list_off[qa[q]], a1 = list_off[qa[q] + 1];
+    uint64_t b0 = list_off[qb[q]], b1 = list_off[qb[q] + 1];
+    int64_t s = 0;
+    for (uint64_t i = a0; i < a1; i++) {
+        const uint32_t r = list_idx[i];
+        const uint32_t lo0 = row_ptr[r], hi0 = row_ptr[r + 1];
+        if (lo0 == hi0) continue;
+        for (uint64_t j = b0 + lane; j < b1; j += VS_WAVE) {
+            const uint32_t c = list_idx[j];
+            uint32_t lo = lo0, hi = hi0;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (col[mid] < c) lo = mid + 1u; else hi = mid;
+            }
+            if (lo < hi0 && col[lo] == c) s += val[lo];
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, VS_WAVE);
+    if (lane == 0) out[q] = s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -502,6 +667,56 @@ int links_build(vs_ctx *ctx, const TIn *d_node, const TIn *d_short, uint32_t n, 
     *out = L;
     return VS_OK;
 }
+#define VS_LINKS_SPARSE_MIN 32768u  // nodes from which a table with a dirty-tile map is held as CSR rows (4 GiB of counters)
+template <typename TIn>
+int links_build_sparse(vs_ctx *ctx, const TIn *d_node, const TIn *d_short, uint32_t n, const uint8_t *d_tile_map, vs_links **out) {
+    vs_links *L = new vs_links();
+    L->n = n;
+    const uint32_t T = (n + SL_T - 1u) / SL_T;
+    const uint64_t pairs = (uint64_t)T * (T + 1u) / 2u;
+    uint8_t *d_cnt = nullptr;
+    uint32_t *d_piece = nullptr, *d_total = nullptr;
+    uint64_t *d_scan_tmp = nullptr, *d_sum = nullptr;
+    auto cleanup = [&]() {
+        for (void *q : {(void *)d_cnt, (void *)d_piece, (void *)d_total, (void *)d_scan_tmp, (void *)d_sum})
+            if (q) (void)hipFree(q);
+    };
+    auto fail = [&](int code, const char *what, hipError_t e) {
+        cleanup();
+        vs_links_free(ctx, L);
+        return vs_fail(ctx, code, "vs_links (sparse): %s: %s", what, hipGetErrorString(e));
+    };
+    hipError_t e;
+    if ((e = hipMalloc((void **)&d_cnt, (size_t)n * T)) != hipSuccess) return fail(VS_E_OOM, "piece counts", e);
+    if ((e = hipMalloc((void **)&d_piece, (size_t)n * T * sizeof(uint32_t))) != hipSuccess) return fail(VS_E_OOM, "piece offsets", e);
+    if ((e = hipMalloc((void **)&d_total, ((size_t)n + 2u) * sizeof(uint32_t))) != hipSuccess) return fail(VS_E_OOM, "row totals", e);
+    if ((e = hipMalloc((void **)&L->d_row_ptr, ((size_t)n + 2u) * sizeof(uint32_t))) != hipSuccess) return fail(VS_E_OOM, "row_ptr", e);
+    if ((e = hipMalloc((void **)&d_scan_tmp, ((size_t)n / 2048u + 8u) * sizeof(uint64_t))) != hipSuccess) return fail(VS_E_OOM, "scan", e);
+    if ((e = hipMalloc((void **)&d_sum, sizeof(uint64_t))) != hipSuccess) return fail(VS_E_OOM, "sum", e);
+    if ((e = hipMemsetAsync(d_cnt, 0, (size_t)n * T, ctx->stream)) != hipSuccess) return fail(VS_E_HIP, "memset", e);
+    if ((e = hipMemsetAsync(d_total, 0, ((size_t)n + 2u) * sizeof(uint32_t), ctx->stream)) != hipSuccess) return fail(VS_E_HIP, "memset", e);
+    hipLaunchKernelGGL((k_sl_count<TIn>), dim3((unsigned)pairs), dim3(256), 0, ctx->stream, d_node, d_short, d_tile_map, n, T, d_cnt);
+    hipLaunchKernelGGL(k_sl_rows, dim3((n + 3u) / 4u), dim3(256), 0, ctx->stream, (const uint8_t *)d_cnt, n, T, d_piece, d_total);
+    int rc = vs_scan_u32(ctx, d_total, L->d_row_ptr, (uint64_t)n + 1u, d_scan_tmp, d_sum);
+    if (rc) { cleanup(); vs_links_free(ctx, L); return rc; }
+    uint64_t nnz = 0;
+    if ((e = hipMemcpyAsync(&nnz, d_sum, sizeof nnz, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return fail(VS_E_HIP, "copy", e);
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(VS_E_HIP, "count pass", e);
+    if (nnz > 0xFFFFFFF0ull) { cleanup(); vs_links_free(ctx, L); return vs_fail(ctx, VS_E_RANGE, "vs_links (sparse): %llu non-zero cells", (unsigned long long)nnz); }
+    L->nnz = nnz;
+    if ((e = hipMalloc((void **)&L->d_col, (size_t)(nnz + 1u) * sizeof(uint32_t))) != hipSuccess) return fail(VS_E_OOM, "columns", e);
+    if ((e = hipMalloc((void **)&L->d_val, (size_t)(nnz + 1u) * sizeof(int64_t))) != hipSuccess) return fail(VS_E_OOM, "values", e);
+    hipLaunchKernelGGL((k_sl_fill<TIn>), dim3((unsigned)pairs), dim3(256), 0, ctx->stream, d_node, d_short, d_tile_map, n, T, (const uint32_t *)d_piece,
+                       (const uint32_t *)L->d_row_ptr, L->d_col, L->d_val);
+    if ((e = hipGetLastError()) != hipSuccess) return fail(VS_E_HIP, "k_sl_fill", e);
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(VS_E_HIP, "fill pass", e);
+    cleanup();
+    if (getenv("VS_LINKS_TIMING"))
+        fprintf(stderr, "[vs] link table of %u nodes held as CSR rows: %llu non-zero cells, %.3f GB (dense: %.2f GB)\n", n, (unsigned long long)nnz,
+                (double)nnz * 12 / 1e9, (double)n * n * 8 / 1e9);
+    *out = L;
+    return VS_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -532,6 +747,21 @@ int vs_links_from_counts(vs_ctx *ctx, const uint32_t *d_node_mat, const uint32_t
     return links_build<uint32_t>(ctx, d_node_mat, d_short_mat, n, out);
 }
 
+int vs_links_from_counts_tracked(vs_ctx *ctx, const uint32_t *d_node_mat, const uint32_t *d_short_mat, uint32_t n, const uint8_t *d_tile_map,
+                                 uint32_t sparse_min_nodes, vs_links **out) {
+    if (!ctx || !out || (n && (!d_node_mat || !d_short_mat))) return vs_fail(ctx, VS_E_ARG, "vs_links_from_counts_tracked: bad argument");
+    VS_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t min_nodes = sparse_min_nodes ? sparse_min_nodes : VS_LINKS_SPARSE_MIN;
+    if (!d_tile_map || n < min_nodes || n < SL_T) return links_build<uint32_t>(ctx, d_node_mat, d_short_mat, n, out);
+    if (ctx->links_spare) {  // (a dense buffer set aside earlier is not needed: give it back)
+        VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->links_spare);
+        ctx->links_spare = nullptr;
+        ctx->links_spare_n = 0;
+    }
+    return links_build_sparse<uint32_t>(ctx, d_node_mat, d_short_mat, n, d_tile_map, out);
+}
+
 int vs_links_from_wide(vs_ctx *ctx, const int64_t *d_node_mat, const int64_t *d_short_mat, uint32_t n, vs_links **out) {
     if (!ctx || !out || (n && (!d_node_mat || !d_short_mat))) return vs_fail(ctx, VS_E_ARG, "vs_links_from_wide: bad argument");
     VS_HIP(ctx, hipSetDevice(ctx->device));
@@ -558,6 +788,9 @@ void vs_links_free(vs_ctx *ctx, vs_links *links) {
         (void)hipStreamSynchronize(ctx->stream);
     }
     if (links->d_p0) (void)hipFree(links->d_p0);
+    if (links->d_row_ptr) (void)hipFree(links->d_row_ptr);
+    if (links->d_col) (void)hipFree(links->d_col);
+    if (links->d_val) (void)hipFree(links->d_val);
     delete links;
 }
 
@@ -570,6 +803,21 @@ int vs_links_size(const vs_links *links, uint32_t *n) {
 int vs_links_to_host(vs_ctx *ctx, const vs_links *links, int64_t *out) {
     if (!ctx || !links || !out) return vs_fail(ctx, VS_E_ARG, "vs_links_to_host: bad argument");
     VS_HIP(ctx, hipSetDevice(ctx->device));
+    if (links->sparse()) {  // (the dense matrix the caller asked for, filled from the rows)
+        const uint32_t n = links->n;
+        std::vector<uint32_t> rp((size_t)n + 1u), col((size_t)links->nnz);
+        std::vector<int64_t> val((size_t)links->nnz);
+        VS_HIP(ctx, hipMemcpyAsync(rp.data(), links->d_row_ptr, rp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (links->nnz) {
+            VS_HIP(ctx, hipMemcpyAsync(col.data(), links->d_col, col.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            VS_HIP(ctx, hipMemcpyAsync(val.data(), links->d_val, val.size() * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memset(out, 0, (size_t)n * n * sizeof(int64_t));
+        for (uint32_t r = 0; r < n; r++)
+            for (uint32_t i = rp[r]; i < rp[r + 1]; i++) out[(size_t)r * n + col[i]] = val[i];
+        return VS_OK;
+    }
     VS_HIP(ctx, hipMemcpyAsync(out, links->d_p0, (size_t)links->n * links->n * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VS_OK;
@@ -601,6 +849,11 @@ int vs_links_block_sums(vs_ctx *ctx, const vs_links *links, const uint64_t *list
     VS_TRY(dev_upload(ctx, sc, d_qb, qb, (size_t)n_queries * sizeof(uint32_t)));
     VS_TRY(dev_alloc(ctx, sc, d_out, (size_t)n_queries * sizeof(int64_t)));
     const unsigned waves = 256 / VS_WAVE;
+    if (links->sparse())
+        hipLaunchKernelGGL(k_links_block_sums_csr, dim3((unsigned)((n_queries + waves - 1) / waves)), dim3(256), 0, ctx->stream,
+                           (const uint32_t *)links->d_row_ptr, (const uint32_t *)links->d_col, (const int64_t *)links->d_val, d_off.as<uint64_t>(),
+                           d_idx.as<uint32_t>(), d_qa.as<uint32_t>(), d_qb.as<uint32_t>(), n_queries, d_out.as<int64_t>());
+    else
     hipLaunchKernelGGL(k_links_block_sums, dim3((unsigned)((n_queries + waves - 1) / waves)), dim3(256), 0, ctx->stream,
                        links->d_p0, links->n, d_off.as<uint64_t>(), d_idx.as<uint32_t>(), d_qa.as<uint32_t>(),
                        d_qb.as<uint32_t>(), n_queries, d_out.as<int64_t>());
@@ -617,6 +870,12 @@ int vs_links_group_matrix(vs_ctx *ctx, const vs_links *links, const uint64_t *li
     if (list_off[n_groups] && !list_idx) return vs_fail(ctx, VS_E_ARG, "vs_links_group_matrix: list_idx is NULL");
     VS_TRY(check_lists(ctx, links, list_off, list_idx, n_groups));
     VS_HIP(ctx, hipSetDevice(ctx->device));
+    if (links->sparse()) {  // every (g, h) pair as a block-sum query over the rows
+        std::vector<uint32_t> qa((size_t)n_groups * n_groups), qb(qa.size());
+        for (uint32_t g = 0; g < n_groups; g++)
+            for (uint32_t h = 0; h < n_groups; h++) { qa[(size_t)g * n_groups + h] = g; qb[(size_t)g * n_groups + h] = h; }
+        return vs_links_block_sums(ctx, links, list_off, list_idx, n_groups, qa.data(), qb.data(), qa.size(), out);
+    }
     uint32_t n = links->n;
     SlotCounter sc;
     DevBuf d_off, d_idx, d_t, d_out;

@@ -96,8 +96,9 @@ class HipPeLinks(PeLinks):
         self.calls = 0
 
     @classmethod
-    def from_counter(cls, ctx, counter, names: Sequence[str]):
-        """``counter``: ``pe.PeCounter`` whose [2,N,N] int32 tensor ``vs_pe_count`` filled."""
+    def from_counter(cls, ctx, counter, names: Sequence[str], sparse_min_nodes: int = 0):
+        """``counter``: ``pe.PeCounter`` whose [2,N,N] int32 tensor ``vs_pe_count`` filled.  ``sparse_min_nodes``: from how
+        many nodes a counter with a dirty-tile map gives a CSR table (0: the library's default, 32 768; tests pass 64)."""
         n = len(names)
         assert counter.n == n
         counter.torch.cuda.synchronize(counter.device)
@@ -107,6 +108,12 @@ class HipPeLinks(PeLinks):
             counter.torch.cuda.synchronize(counter.device)
             nat.check(ctx._h, nat.lib().vs_links_from_wide(ctx._h, C.c_void_p(counter.wide[0].data_ptr()),
                                                            C.c_void_p(counter.wide[1].data_ptr()), n, C.byref(h)))
+        elif getattr(counter, "tile_map", None) is not None:
+            # (ABI 10) counters that keep a dirty-tile map: from 32 768 nodes on the table is built from the marked tiles
+            # only and held as CSR rows of its non-zero cells (0.4 GB instead of 23.7 GB at 54 465 nodes)
+            nat.check(ctx._h, nat.lib().vs_links_from_counts_tracked(ctx._h, C.c_void_p(counter.mats[0].data_ptr()),
+                                                                     C.c_void_p(counter.mats[1].data_ptr()), n,
+                                                                     C.c_void_p(counter.tile_map.data_ptr()), sparse_min_nodes, C.byref(h)))
         else:
             nat.check(ctx._h, nat.lib().vs_links_from_counts(ctx._h, C.c_void_p(counter.mats[0].data_ptr()),
                                                              C.c_void_p(counter.mats[1].data_ptr()), n, C.byref(h)))

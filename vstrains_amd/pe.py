@@ -474,6 +474,8 @@ class PeCounter:
         not wait for a large ``hipMalloc`` (0.3 ms or half a second for 23.7 GB, depending on what was freed before).
         An optimisation only: when the memory is not there now, the build allocates later (or fails there, where every rank
         can be told) -- a lone rank raising here would leave its peers waiting in the next collective."""
+        if self.tile_map is not None and self.n >= 32768:
+            return  # (the table of such counters is built from their dirty tiles as CSR rows, ABI 10: nothing to set aside)
         rc = nat.lib().vs_links_reserve(self.ctx._h, self.n)
         if rc == nat.VS_E_OOM:
             import warnings
