@@ -43,11 +43,11 @@ from vstrains_amd.workloads import CONFIGS, workload  # noqa: E402  (generator p
 
 def pmc_traffic(config, pairs, kernel_name):
     """HBM bytes of one k_pe_tiles launch from the committed rocprofv3 PMC passes of THIS round
-    (profiles/r5/pmc_summary_config<i>.json, collected with tools/profile.sh on the default workload
+    (profiles/r6/pmc_summary_config<i>.json, collected with tools/profile.sh on the default workload
     of that config; counters cannot be read inside this process).  2 x FETCH_SIZE (the guide's gfx950
     rule for wide reads) + WRITE_SIZE, both in KB.  None unless the profile is of the same workload
     size and of the kernel instantiation this run launched."""
-    path = os.path.join(ROOT, "profiles", "r5", "pmc_summary_config%d.json" % config)
+    path = os.path.join(ROOT, "profiles", "r6", "pmc_summary_config%d.json" % config)
     if not os.path.exists(path):
         return {"traffic": None}
     try:
@@ -63,7 +63,7 @@ def pmc_traffic(config, pairs, kernel_name):
         fetch = k["FETCH_SIZE"]["per_dispatch_mean"] * 1024.0
         write = k["WRITE_SIZE"]["per_dispatch_mean"] * 1024.0
         return {"traffic": 2.0 * fetch + write, "traffic_unit": "B per k_pe_tiles launch",
-                "traffic_source": "profiles/r5/pmc_summary_config%d.json (2*FETCH_SIZE + WRITE_SIZE of %s; separate rocprofv3 --pmc passes, not live)"
+                "traffic_source": "profiles/r6/pmc_summary_config%d.json (2*FETCH_SIZE + WRITE_SIZE of %s; separate rocprofv3 --pmc passes, not live)"
                                   % (config, names[0])}
     except Exception:
         return {"traffic": None}

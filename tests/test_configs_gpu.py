@@ -173,7 +173,7 @@ def test_row_owner_counting_with_more_rows_per_chunk_than_lds_cursors(host, xctx
     _assert_equals_oracle(got, orc, st, cum, seed, L, M, sub, nth)
 
 
-def test_config3_10k_nodes_k127_reads_of_250(host, ctx, tmp_path):
+def test_config3_10k_nodes_k127_reads_of_250(host, ctx, tmp_path):  # (also: k = 127 reads of 250 bases select the long-window shape)
     import torch
 
     from vstrains_amd.workloads import CONFIGS, workload_for
@@ -186,7 +186,9 @@ def test_config3_10k_nodes_k127_reads_of_250(host, ctx, tmp_path):
     sub, nth = int(0.005 * 2 ** 32), int(0.001 * 2 ** 32)
     R = 1_200_000
     whole = _count(host, ctx, st, cum, seed, L, [(0, R)], sub, nth)
-    assert ctx.last_kernel.startswith("k_pe_tiles<2")  # straight-line comparison with the long windows (stride 98, 2 x 250)
+    # straight-line comparison with the long windows, and its COMPILE-TIME shape (16 words, two probes, 60 ends per tile):
+    # the host's LDS loop has to land on exactly 60 ends for it -- a layout change must not drop the shape silently
+    assert ctx.last_kernel.startswith("k_pe_tiles<2, 16u, 2u"), ctx.last_kernel
     parts = _count(host, ctx, st, cum, seed, L, [(0, 300_001), (300_001, 7), (300_008, R - 300_008)], sub, nth)
     assert torch.equal(whole.mats, parts.mats) and torch.equal(whole.stats, parts.stats)
     stats = whole.stats.cpu().tolist()

@@ -307,6 +307,15 @@ int index_file(vs_ctx *ctx, const char *path, FqFile &f) {
             std::vector<uint64_t> &v = pos[p];
             v.clear();
             v.reserve((hi - lo) / 64 + 16);
+#ifdef MADV_POPULATE_READ
+            // (r6) a mapped file: this part's pages are brought into the page table in ONE call instead of a fault per 4 KB page
+            // as the scan reaches it -- 600 k faults for 2.5 GB of text were most of the open's time.  A kernel that does not
+            // know the advice says EINVAL and the scan faults the pages in as before.
+            if (first_visit && f.map_base && txt == f.map_base && hi > lo) {
+                const size_t pg = 4096u, a = lo & ~(pg - 1u);
+                (void)madvise((void *)(txt + a), hi - a, MADV_POPULATE_READ);
+            }
+#endif
             for (size_t c0 = lo; c0 < hi; c0 += (256u << 10)) {
                 const size_t c1 = c0 + (256u << 10) < hi ? c0 + (256u << 10) : hi;
                 if (first_visit && !cr[p] && memchr(txt + c0, '\r', c1 - c0)) cr[p] = 1;

@@ -124,6 +124,9 @@ __device__ __forceinline__ void vs_mark_tile_store(uint8_t *map, uint32_t T, uin
 #ifndef VS_DPP_SCAN
 #define VS_DPP_SCAN 1
 #endif
+#ifndef VS_LAUNDER_TOP
+#define VS_LAUNDER_TOP 0
+#endif
 #define VS_DPP_STEP(op, ctrl, rowmask) { const uint32_t t_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rowmask, 0xf, false); v = op; }
 __device__ __forceinline__ uint32_t vs_wave_scan_add(uint32_t v) {
 #if VS_DPP_SCAN
@@ -684,6 +687,12 @@ k_pe_tiles(PeParams P) {
     prefetch_headers();
     prefetch_pair(tile_lo + 2u);
     for (tidx_t tile = tile_lo; tile < tile_hi; tile++) {
+#if VS_LAUNDER_TOP
+        uint32_t ltop = tid;  // (experiment: nothing P0 .. P2 derive from the thread index is hoisted out of the tile loop)
+        asm volatile("" : "+v"(ltop));
+#else
+        const uint32_t ltop = tid;
+#endif
         const tidx_t p0 = tile * ppt;
         const uint32_t npair = (uint32_t)((n_pairs32 - p0) < ppt ? (n_pairs32 - p0) : ppt);
         const uint32_t ne = 2u * npair;
@@ -701,16 +710,16 @@ k_pe_tiles(PeParams P) {
         }
         __syncthreads();  // previous tile fully consumed; this tile's words have landed (see before P4)
         // ---- P0: the next tile's headers go to the other copy, the (end, node) table is emptied
-        if (tid < ne1) {
-            n_gend[tid] = pf_gend;
-            n_gwoff[tid] = pf_gwoff;
-            n_meta[tid] = pf_meta;
+        if (ltop < ne1) {
+            n_gend[ltop] = pf_gend;
+            n_gwoff[ltop] = pf_gwoff;
+            n_meta[ltop] = pf_meta;
         }
-        if (has_inv && tid < ept) {  // (one copy is enough: nothing reads it before the barrier below)
-            s_inv[tid] = cur_inv;
+        if (has_inv && ltop < ept) {  // (one copy is enough: nothing reads it before the barrier below)
+            s_inv[ltop] = cur_inv;
             cur_inv = pf_inv;
         }
-        for (uint32_t i = tid; i < pool; i += TTPB) {
+        for (uint32_t i = ltop; i < pool; i += TTPB) {
             s_hkey[i] = EMPTY_NODE;
             s_hcnt[i] = 0;
             s_hminp[i] = 0xFFFFFFFFu;
@@ -731,8 +740,8 @@ k_pe_tiles(PeParams P) {
             }
         }
         // pair classification (PE_Inference.py:160-165): one thread per pair
-        if (tid < npair) {
-            uint32_t mf = s_meta[2 * tid], mr = s_meta[2 * tid + 1];
+        if (ltop < npair) {
+            uint32_t mf = s_meta[2 * ltop], mr = s_meta[2 * ltop + 1];
             uint32_t cls;
             if (((mf | mr) >> 24) & VS_FLAG_N) cls = 0;
             else if ((mf & VS_LEN_MASK) < K || (mr & VS_LEN_MASK) < K) cls = 1;
@@ -749,16 +758,16 @@ k_pe_tiles(PeParams P) {
                 const uint32_t r = (len - w) % s;
                 return ((s - 1u) << 8) | ((r + 2u <= s ? s - 2u - r : 0u) << 20);
             };
-            s_state[2 * tid] = st | grid_bits(mf & VS_LEN_MASK);
-            s_state[2 * tid + 1] = st | grid_bits(mr & VS_LEN_MASK);
-            s_ns[2 * tid] = s_ns[2 * tid + 1] = 0;
+            s_state[2 * ltop] = st | grid_bits(mf & VS_LEN_MASK);
+            s_state[2 * ltop + 1] = st | grid_bits(mr & VS_LEN_MASK);
+            s_ns[2 * ltop] = s_ns[2 * ltop + 1] = 0;
         }
         __syncthreads();
         if (debug_stop == 1u) continue;
         // ---- P1: probes
         if (ADAPT) {
             // one grid position per thread; both candidate offsets probed with their slot loads in flight together
-            const uint32_t it = tid;
+            const uint32_t it = ltop;
             const uint32_t e = it / (STD ? STD_PMAX : 1u), pi = it - e * pmax;
             uint32_t c0 = 0, pa0 = 0, pb0 = 0, c1 = 0, pa1 = 0, pb1 = 0, D = 0;
             const uint32_t est = (it < NI && e < ne) ? s_state[e] : 0u;
@@ -810,7 +819,7 @@ k_pe_tiles(PeParams P) {
                 s_pb[it] = pb;
             }
         } else
-        for (uint32_t it = tid; it < NI; it += TTPB) {
+        for (uint32_t it = ltop; it < NI; it += TTPB) {
             uint32_t e = STD ? it / STD_PMAX : vs_fastdiv(it, P.magic_pmax), pi = it - e * pmax;
             uint32_t cnt = 0, pa = 0, pb = 0;
             const uint32_t est = e < ne ? s_state[e] : 0u;
@@ -842,16 +851,16 @@ k_pe_tiles(PeParams P) {
         // ---- P2: inclusive scan of the postings per probe, s_pcnt[0..NI)
         {
             const uint32_t chunk = (NI + TTPB - 1u) / TTPB;
-            const uint32_t b = tid * chunk;
+            const uint32_t b = ltop * chunk;
             uint32_t local = 0;
             for (uint32_t i = 0; i < chunk; i++)
                 if (b + i < NI) local += s_pcnt[b + i];
             const uint32_t incl = vs_wave_scan_add(local);
-            const uint32_t lane = tid & 63u;
-            if (lane == 63u) s_misc[tid >> 6] = incl;
+            const uint32_t lane = ltop & 63u;
+            if (lane == 63u) s_misc[ltop >> 6] = incl;
             __syncthreads();
             uint32_t off = incl - local;
-            for (uint32_t wv = 0; wv < (tid >> 6); wv++) off += s_misc[wv];
+            for (uint32_t wv = 0; wv < (ltop >> 6); wv++) off += s_misc[wv];
             for (uint32_t i = 0; i < chunk; i++)
                 if (b + i < NI) {
                     off += s_pcnt[b + i];
@@ -1553,7 +1562,7 @@ __device__ __forceinline__ bool vs_same_list(const uint32_t (&mine)[LCAP], const
 
 __global__ void __launch_bounds__(256)
 k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ lists_hi, const uint32_t *__restrict__ counts, uint64_t n_ends, uint32_t *__restrict__ mult,
-              uint32_t *__restrict__ gown, unsigned long long *__restrict__ ltab, uint32_t *__restrict__ lmult, uint32_t ltab_bits) {
+              uint32_t *__restrict__ gown, unsigned long long *__restrict__ ltab, uint32_t *__restrict__ lmult, uint32_t ltab_bits, uint32_t sub_bits) {
     const uint64_t e64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e64 >= n_ends) return;
     const uint32_t e = (uint32_t)e64, n = counts[e];
@@ -1571,7 +1580,12 @@ k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ l
             }
         const uint32_t tag = ((uint32_t)(f2 >> 32) & ~31u) | (n - 1u);  // (the list length rides in the tag: no load for the owner's)
         const unsigned long long word = ((unsigned long long)tag << 32) | (e + 1u);
-        uint32_t h = (uint32_t)((f2 * 0xD6E8FEB86659FD93ull) >> (64u - ltab_bits));
+        // (r6 experiment, sub_bits != 0) the table is cut into sub-tables of 2^sub_bits slots, one per 2^(sub_bits - 1) consecutive ends:
+        // ends are in locus order and an end's list is repeated by ends near it, so a sub-table's 768 KB stay in the
+        // Infinity Cache while its ends are looked up, where the one table of the block (768 MB at 25 M pairs) is HBM traffic
+        // for every probe and every multiplicity atomic.  A list that recurs in another sub-table gets another owner there.
+        const uint32_t sub_base = sub_bits ? (e >> (sub_bits - 1u)) << sub_bits : 0u, hbits = sub_bits ? sub_bits : ltab_bits;
+        uint32_t h = sub_base + (uint32_t)((f2 * 0xD6E8FEB86659FD93ull) >> (64u - hbits));
         for (uint32_t pr = 0; pr < LTAB_PROBES; pr++) {
             unsigned long long cur = ltab[h];
             if (cur == 0ull) {
@@ -1592,7 +1606,7 @@ k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ l
                     break;
                 }
             }
-            h = (h + 1u) & ((1u << ltab_bits) - 1u);
+            h = sub_base + ((h - sub_base + 1u) & ((1u << hbits) - 1u));
         }
         // (no place within LTAB_PROBES slots -- a crowded table: m = 1, the end stands for itself)
     }
@@ -2387,6 +2401,13 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
     uint32_t ltab_bits = 10;
     while ((1ull << ltab_bits) < 2u * sub_pairs && ltab_bits < 31u) ltab_bits++;
     if (tn.ltab_bits >= 0) ltab_bits = (uint32_t)tn.ltab_bits;
+#ifndef VS_LTAB_SUB_BITS
+#define VS_LTAB_SUB_BITS 0
+#endif
+    // sub-tables (see k_list_owners) when the table is much larger than one of them and nobody asked for a table size
+    const uint32_t sub_bits = (tn.ltab_bits < 0 && VS_LTAB_SUB_BITS && ltab_bits > VS_LTAB_SUB_BITS + 2u) ? (uint32_t)VS_LTAB_SUB_BITS : 0u;
+    if (sub_bits)  // (a sub-table holds two slots per end it serves: the table as a whole two per end of the block)
+        while ((1ull << ltab_bits) < 4u * sub_pairs + (1ull << sub_bits) && ltab_bits < 31u) ltab_bits++;
     const bool use_ltab = ltab_bits > 0;
     const uint64_t ltab_slots = use_ltab ? 1ull << ltab_bits : 0;
     // entries: one word per listed node -- the left lists (node_mat) and the lists of the owning ends (short_mat); the
@@ -2433,7 +2454,7 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
         VS_HIP(ctx, hipMemsetAsync(rows, 0, sizeof(uint32_t) * 6u * cap, st));
         VS_HIP(ctx, hipMemsetAsync(n_owners, 0, sizeof(uint32_t), st));
         if (use_ltab) VS_HIP(ctx, hipMemsetAsync(ctx->d_ltab, 0, (sizeof(uint64_t) + sizeof(uint32_t)) * ltab_slots, st));
-        hipLaunchKernelGGL(k_list_owners, dim3((unsigned)((2u * np + 255u) / 256u)), dim3(256), 0, st, sl, sh, sc, 2u * np, mult, gown, ltab, lmult, ltab_bits);
+        hipLaunchKernelGGL(k_list_owners, dim3((unsigned)((2u * np + 255u) / 256u)), dim3(256), 0, st, sl, sh, sc, 2u * np, mult, gown, ltab, lmult, ltab_bits, sub_bits);
         if (use_ltab)
             hipLaunchKernelGGL(k_owners_mult, dim3((unsigned)((ltab_slots + 255u) / 256u)), dim3(256), 0, st, (const unsigned long long *)ltab,
                                (const uint32_t *)lmult, ltab_slots, mult);
