@@ -129,8 +129,33 @@ def collect(work, meta, models, seeds, out_path, digests_path):
             t["strains"] = open(os.path.join(out_v, "strain.paths")).read().count("\n") // 2
             t["files_written"] = len(files)
             timings["%s/%d" % (model, hs)] = t
+    # runs that have not finished (or were stopped): how far the reference got and at which rate -- a measured "cannot"
+    progress = {}
+    for model in models:
+        for hs in seeds:
+            prog = os.path.join(work, "timing_%s_%d.json.progress" % (model, hs))
+            if os.path.exists(prog) and not os.path.exists(prog[:-len(".progress")]):
+                with open(prog) as fh:
+                    lines = [l.rstrip("\n").split("\t", 1) for l in fh if "\t" in l]
+                if not lines:
+                    continue
+                stored = [(float(t), m) for t, m in lines if m.endswith(" is stored..")]
+                after_pe = next((float(t) for t, m in lines if m == "paired end information stored"), None)
+                out_v = os.path.join(work, "out_%s_%d" % (model, hs))
+                gfa_dir = os.path.join(out_v, "gfa")
+                progress["%s/%d" % (model, hs)] = {
+                    "state": "not finished when this record was written",
+                    "seconds_since_start_at_last_log_line": float(lines[-1][0]),
+                    "pe_files_handed_over_at_s": after_pe,
+                    "stage_graphs_written": len(stored),
+                    "last_stage_graph": os.path.basename(stored[-1][1].split(" ")[0]) if stored else None,
+                    "seconds_per_stage_graph_after_pe": ((stored[-1][0] - after_pe) / max(len([1 for t, _ in stored if t > after_pe]), 1)) if (stored and after_pe) else None,
+                    "last_lines": [[float(t), m[:120]] for t, m in lines[-6:]],
+                    "gfa_files_on_disk": sorted(os.listdir(gfa_dir)) if os.path.isdir(gfa_dir) else []}
     result = dict(meta)
     result["runs"] = timings
+    if progress:
+        result["progress"] = progress
     result["host"] = {"cpus": os.cpu_count(), "python": sys.version.split()[0]}
     result["label"] = ("the real reference command behind tests/golden/gt_standin (a pure-Python model of graph-tool / gfapy: slower than the "
                        "C++ library it stands for); after_pe_to_run_return_s = VStrains_SPAdes.py:133-272 as one measured interval, 1 thread; "

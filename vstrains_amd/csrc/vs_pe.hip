@@ -518,7 +518,7 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
 }
 
 // SW, SP != 0: the tile shape is a compile-time one for k = 55 -- 64 ends per tile, 1024-slot table,
-// SW packed words and SP probes per end (vs_seed_probes): (10, 4) = 2 x 145..159 bases, (8, 3) = 2 x 113..128,
+// SW packed words and SP probes per end (vs_seed_probes): (10, 4) = 2 x 145..159 bases, (8, 3) = 2 x 113..128, (7, 3) = 2 x 108..112,
 // (7, 2) = 2 x 97..107.  Every LDS array then sits at a constant offset (folded into the LDS
 // instructions) instead of costing a scalar register and an add, the divisions by pmax / wpe and
 // k+1 / seed length / stride become constants.  The host picks one when the block has that shape.
@@ -1157,6 +1157,9 @@ k_pe_tiles(PeParams P) {
 #define ACC_RUN 4u   // 4 or 8 (8: two 16-byte partner loads per run; measured r5, see profiles/EXPERIMENTS.md)
 #endif
 #define ACC_GMAX 60u  // g(LCAP = 20) for runs of 4 (runs of 8 need 36)
+#ifndef ACC_AHEAD
+#define ACC_AHEAD 1   // windows whose list loads are in flight ahead of the one being counted (r6: 2 and 3 measured, no gain -- EXPERIMENTS)
+#endif
 // The cell table: 16 k slots, 32-bit keys (k_pe_accumulate: mat * N*N + x * N + y, while 2*N*N fits 32 bits, N <= 46340;
 // the row owners: cell index relative to the strip's first row).  The 16 cells of one 64-byte stretch of a matrix row
 // sit in 16 NEIGHBOURING slots (the hash picks a group of 16 slots from the key >> 4, the low four bits pick the slot
@@ -1322,12 +1325,25 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
 #endif
             return R;
         };
-        Run nxt;
-        nxt.ok = false;
-        if (U) nxt = fetch(0u);
+        // the list loads of ACC_AHEAD windows are in flight while one is counted (r6: two and three windows ahead were measured
+        // against one -- 2.23 / 2.25 / 2.31 ms at configs[2]: the kernel does not wait on these loads)
+        Run q1, q2, q3;
+        q1.ok = q2.ok = q3.ok = false;
+        if (U) q1 = fetch(0u);
+        if (ACC_AHEAD >= 2 && 64u < U) q2 = fetch(64u);
+        if (ACC_AHEAD >= 3 && 128u < U) q3 = fetch(128u);
         for (uint32_t t0 = 0; t0 < U; t0 += 64u) {
-            const Run c = nxt;
-            if (t0 + 64u < U) nxt = fetch(t0 + 64u);
+            const Run c = q1;
+            if (ACC_AHEAD >= 3) {
+                q1 = q2; q2 = q3; q3.ok = false;
+                if (t0 + 192u < U) q3 = fetch(t0 + 192u);
+            } else if (ACC_AHEAD == 2) {
+                q1 = q2; q2.ok = false;
+                if (t0 + 128u < U) q2 = fetch(t0 + 128u);
+            } else {
+                q1.ok = false;
+                if (t0 + 64u < U) q1 = fetch(t0 + 64u);
+            }
             if (!c.ok) continue;
             const uint32_t x = c.x, mat = c.mat, bi = c.bi, be = c.be;
 #if ACC_RUN == 8u
@@ -2672,6 +2688,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
         if (wpe == 10u && pmax == 4u) std_shape = 1;       // 2 x 145..159 bases
         else if (wpe == 8u && pmax == 3u) std_shape = 2;   // 2 x 113..128
         else if (wpe == 7u && pmax == 2u) std_shape = 3;   // 2 x 97..107
+        else if (wpe == 7u && pmax == 3u) std_shape = 5;   // 2 x 108..112 (r6, ADVICE r5: these took the generic kernel)
     }
     // longer strides and reads (k = 127 with 2 x 250 bases): the straight-line kernel with more windows
     // Its eight right windows compare 256 bases from where the comparison starts (behind a verified seed, at the first base
@@ -2699,6 +2716,8 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
                                                  : TilesFn{(const void *)k_pe_tiles<1, 8u, 3u>, "k_pe_tiles<1, 8u, 3u>"})
                        : std_shape == 3 ? (adapt ? TilesFn{(const void *)k_pe_tiles<1, 7u, 2u, true>, "k_pe_tiles<1, 7u, 2u, true>"}
                                                  : TilesFn{(const void *)k_pe_tiles<1, 7u, 2u>, "k_pe_tiles<1, 7u, 2u>"})
+                       : std_shape == 5 ? (adapt ? TilesFn{(const void *)k_pe_tiles<1, 7u, 3u, true>, "k_pe_tiles<1, 7u, 3u, true>"}
+                                                 : TilesFn{(const void *)k_pe_tiles<1, 7u, 3u>, "k_pe_tiles<1, 7u, 3u>"})
                        : fast           ? TilesFn{(const void *)k_pe_tiles<1, 0u, 0u>, "k_pe_tiles<1, 0u, 0u>"}
                        : std_shape == 4 ? (adapt ? TilesFn{(const void *)k_pe_tiles<2, 16u, 2u, true>, "k_pe_tiles<2, 16u, 2u, true>"}
                                                  : TilesFn{(const void *)k_pe_tiles<2, 16u, 2u>, "k_pe_tiles<2, 16u, 2u>"})
