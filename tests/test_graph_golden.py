@@ -174,12 +174,13 @@ def test_every_file_equals_the_committed_rotate_model_run(name, tmp_path):
         assert all(p.split(" ", 1)[1] in seed_dependent for p in problems), problems
 
 
-@pytest.mark.parametrize("config", [0, 1])
+@pytest.mark.parametrize("config", [0, 1, 2])
 def test_native_engine_reproduces_the_real_reference_command(config, tmp_path):
     """The same pin as tests/test_configs_gpu.py::test_cli_reproduces_the_real_reference_command* on a box without a GPU: the
-    C oracle counts the pairs (100 000 at configs[0], 1 M at configs[1]), the native stage engine runs over the CPU checker
-    of its device operations, and the files every run of the REAL reference command agrees on (29 at configs[0], 83 at
-    configs[1]: 853 nodes, 20 strains) must come out the same."""
+    C oracle counts the pairs (100 000 at configs[0], 1 M at configs[1], the 200 k-pair prefix at configs[2]), the native stage
+    engine runs over the CPU checker of its device operations, and the files every run of the REAL reference command agrees on
+    (58 at configs[0]; 83 at configs[1]: 853 nodes, 20 strains; 124 at configs[2]: 5 039 nodes, 30 strains -- the reference
+    took 73 minutes for that leg, profiles/r6/reference_stages_config2.json) must come out the same."""
     import numpy as np
 
     from graph_case import reference_command_inputs, reference_command_problems
@@ -195,6 +196,10 @@ def test_native_engine_reproduces_the_real_reference_command(config, tmp_path):
             f, r = pe_oracle.fastq_sequences(fwd), pe_oracle.fastq_sequences(rve)
             node_mat, short_mat, _ = pe_oracle_c.Oracle(seqs, ksize).count_pairs(f, r)
             os.makedirs(aln_dir, exist_ok=True)
+            if config >= 2:  # (25 M lines of text per file and a 12.7 M-key dict: the table as a symmetric matrix, no text)
+                import profile_extract_cpu as pec
+
+                return pec.NumpyPeLinks(names, node_mat, short_mat)
             for fname, mat in (("pe_info", node_mat), ("st_info", short_mat)):
                 with open(os.path.join(aln_dir, fname), "w") as fh:
                     fh.write(pe_oracle.matrix_text(ids, mat))
