@@ -123,7 +123,7 @@ def _staging_buffer(head, want_rows: int):
     the allocation fails (the caller says so in the flag bytes of the first collective: no rank is left waiting)."""
     import torch
 
-    rows = max(2, min(int(want_rows), SLAB_STRETCHES + 1))
+    rows = max(3, min(int(want_rows), SLAB_STRETCHES + 2))
     key = (str(head.device), head.dtype)
     buf = _staging.get(key)
     if buf is not None and buf.shape[0] >= rows:
@@ -161,9 +161,8 @@ def _tail_encode(tail, row):
     if row.dtype == torch.int64:
         row[:k] = tail
     else:
-        t = tail.to(torch.int64)
-        for i in range(LIMBS):
-            row[i * 16:i * 16 + k] = ((t >> (16 * i)) & 0xFFFF).to(row.dtype)
+        shifts = torch.arange(0, 16 * LIMBS, 16, dtype=torch.int64, device=tail.device).unsqueeze(1)
+        row.view(LIMBS, 16)[:, :k] = ((tail.to(torch.int64).unsqueeze(0) >> shifts) & 0xFFFF).to(row.dtype)
 
 
 def _tail_decode(row, k):
@@ -171,10 +170,8 @@ def _tail_decode(row, k):
 
     if row.dtype == torch.int64:
         return row[:k].clone()
-    out = torch.zeros(k, dtype=torch.int64, device=row.device)
-    for i in range(LIMBS):
-        out += row[i * 16:i * 16 + k].to(torch.int64) << (16 * i)
-    return out
+    shifts = torch.arange(0, 16 * LIMBS, 16, dtype=torch.int64, device=row.device).unsqueeze(1)
+    return (row.view(LIMBS, 16)[:, :k].to(torch.int64) << shifts).sum(dim=0)
 
 
 class ExchangeState:
@@ -236,7 +233,7 @@ def sum_counts_packed(mats, tail=None, flags=None, tile_map=None, timing=None, o
     n = mats.shape[-1]
     use_tiles = tile_map is not None and mats.dim() == 3 and mats.shape[0] == 2 and mats.shape[1] == n and n >= STRETCH
     # the staging buffer BEFORE the first collective: a rank that cannot have it says so in its flag bytes
-    want = (state.cap + 1) if (predict and state.cap is not None) else min(m // 2 + 2, 1 << 20)
+    want = (state.cap + 2) if (predict and state.cap is not None) else min(m // 2 + 3, 1 << 20)
     buf = _staging_buffer(head, want) if m else None
     if m and buf is None:
         my_flags[FLAG_NO_STAGING] = 1
@@ -269,26 +266,38 @@ def sum_counts_packed(mats, tail=None, flags=None, tile_map=None, timing=None, o
         c_sum(row)
         return _tail_decode(row, k_tail)
 
-    if predict and state.cap is not None and m and buf is not None:
-        cap = min(state.cap, buf.shape[0] - 1)
-        idx = torch.nonzero_static(occ, size=cap, fill_value=0).view(-1)
-        stage = buf[: cap + 1]
-        torch.index_select(head, 0, idx, out=stage[:cap])
+    left = flat[m * STRETCH:]  # the cells behind the last whole stretch (fewer than 64): they ride in a row of their own
+    n_left = int(left.numel())
+
+    def extra_rows(stage, at):  # stage[at] <- the tail's limbs, stage[at + 1] <- the leftover cells
         if k_tail:
-            _tail_encode(tail, stage[cap])
+            _tail_encode(tail, stage[at])
         else:
-            stage[cap].zero_()
+            stage[at].zero_()
+        stage[at + 1].zero_()
+        if n_left:
+            stage[at + 1][:n_left] = left
+
+    def extra_back(stage, at):
+        if n_left and mine:
+            left.copy_(stage[at + 1][:n_left])
+        return _tail_decode(stage[at], k_tail) if k_tail else None
+
+    if predict and state.cap is not None and m and buf is not None:
+        cap = min(state.cap, buf.shape[0] - 2)
+        idx = torch.nonzero_static(occ, size=cap, fill_value=0).view(-1)
+        stage = buf[: cap + 2]
+        torch.index_select(head, 0, idx, out=stage[:cap])
+        extra_rows(stage, cap)
         t = mark("gather", t)
         c_sum(stage)
         t = mark("ring", t)
         if mine:
             head.index_copy_(0, idx, stage[:cap])
-        tail_flat = flat[m * STRETCH:]
-        if tail_flat.numel():
-            c_sum(tail_flat)
+        out_tail = extra_back(stage, cap)
         mark("scatter", t)
         state.pending = {"u": occ.sum(dtype=torch.int64), "cap": cap, "flags": all_flags, "occ": occ, "head": head, "dst": dst}
-        return "compact", all_flags, (_tail_decode(stage[cap], k_tail) if k_tail else None)
+        return "compact", all_flags, out_tail
 
     # one host wait: the flags and the union's size together
     if m:
@@ -319,39 +328,33 @@ def sum_counts_packed(mats, tail=None, flags=None, tile_map=None, timing=None, o
         mark("ring", t)
         return "dense", all_flags, out_tail
     idx = torch.nonzero_static(occ, size=u, fill_value=0).view(-1)
-    bigger = _staging_buffer(head, u + 1)  # (grown when it can be: fewer slabs; the old one serves otherwise)
+    bigger = _staging_buffer(head, u + 2)  # (grown when it can be: fewer slabs; the old one serves otherwise)
     if bigger is not None:
         buf = bigger
-    rows = buf.shape[0] - 1
+    rows = buf.shape[0] - 2
     out_tail = None
     lo = 0
     while True:
         part = idx[lo:lo + rows]
         k = int(part.numel())
         last = lo + k >= u
-        stage = buf[: k + (1 if last else 0)]
+        stage = buf[: k + (2 if last else 0)]
         t = time.perf_counter()
         if k:
             torch.index_select(head, 0, part, out=stage[:k])
         if last:
-            if k_tail:
-                _tail_encode(tail, stage[k])
-            else:
-                stage[k].zero_()
+            extra_rows(stage, k)
         t = mark("gather", t)
         c_sum(stage)
         t = mark("ring", t)
         if mine and k:
             head.index_copy_(0, part, stage[:k])
-        if last and k_tail:
-            out_tail = _tail_decode(stage[k], k_tail)
+        if last:
+            out_tail = extra_back(stage, k)
         mark("scatter", t)
         lo += k
         if last:
             break
-    tail_flat = flat[m * STRETCH:]
-    if tail_flat.numel():
-        c_sum(tail_flat)
     return "compact", all_flags, out_tail
 
 
