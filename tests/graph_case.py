@@ -190,11 +190,30 @@ def reference_command_inputs(work, config=0):
     return paths, want
 
 
+def strain_set_sha256(fasta_path):
+    """The extracted strain sequences as a set, each on its lexicographically smaller strand (tools/time_reference_stages.py
+    writes the same digest of the REAL reference's strain.fasta per run: at configs[0] and configs[2] it is the same under
+    BOTH in-edge models of the stand-in -- the one statement about the final result that does not depend on the model)."""
+    import hashlib
+
+    comp = str.maketrans("ACGT", "TGCA")
+    seqs = []
+    with open(fasta_path) as fh:
+        for line in fh:
+            line = line.strip()
+            if line and not line.startswith(">"):
+                seqs.append(min(line, line[::-1].translate(comp)))
+    return hashlib.sha256("\n".join(sorted(seqs)).encode()).hexdigest()
+
+
 def reference_command_problems(out_dir, want):
     """Files of ``want["files_sha256"]`` (the ones all eight runs of the real command agree on: both in-edge models of the
     stand-in, hash seeds 0-3) that ``out_dir`` does not reproduce."""
     import hashlib
 
     got = gold.collect(out_dir)
-    return ["%s %s" % ("missing" if rel not in got else "differs", rel) for rel, sha in sorted(want["files_sha256"].items())
-            if rel not in got or hashlib.sha256(got[rel].encode()).hexdigest() != sha]
+    problems = ["%s %s" % ("missing" if rel not in got else "differs", rel) for rel, sha in sorted(want["files_sha256"].items())
+                if rel not in got or hashlib.sha256(got[rel].encode()).hexdigest() != sha]
+    if "strain_set_sha256" in want and strain_set_sha256(os.path.join(out_dir, "strain.fasta")) != want["strain_set_sha256"]:
+        problems.append("differs the set of strain sequences (strand-normalised)")
+    return problems

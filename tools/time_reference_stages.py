@@ -108,6 +108,19 @@ def one_run(work, model, hashseed):
     return model, hashseed, pv.returncode
 
 
+def strain_set_sha256(fasta_path):
+    """SHA-256 of the extracted strain SEQUENCES as a set, each on its lexicographically smaller strand: what is left of
+    strain.fasta when names, order and orientation -- everything that follows the stand-in's node numbering -- are dropped."""
+    comp = str.maketrans("ACGT", "TGCA")
+    seqs = []
+    with open(fasta_path) as fh:
+        for line in fh:
+            line = line.strip()
+            if line and not line.startswith(">"):
+                seqs.append(min(line, line[::-1].translate(comp)))
+    return hashlib.sha256("\n".join(sorted(seqs)).encode()).hexdigest()
+
+
 def collect(work, meta, models, seeds, out_path, digests_path):
     import make_graph_golden as gold
 
@@ -127,6 +140,7 @@ def collect(work, meta, models, seeds, out_path, digests_path):
                      if rel not in ("aln/pe_info", "aln/st_info", "vstrains.log.info")}
             runs[(model, hs)] = files
             t["strains"] = open(os.path.join(out_v, "strain.paths")).read().count("\n") // 2
+            t["strain_set_sha256"] = strain_set_sha256(os.path.join(out_v, "strain.fasta"))
             t["files_written"] = len(files)
             timings["%s/%d" % (model, hs)] = t
     # runs that have not finished (or were stopped): how far the reference got and at which rate -- a measured "cannot"
@@ -184,6 +198,10 @@ def collect(work, meta, models, seeds, out_path, digests_path):
         "files_sha256_scope": "files every run under the in-edge model of base_run agrees on (all hash seeds run)",
         "files_identical_under_both_in_edge_models": stable_all,
         "strains_per_run": {"%s/%d" % k: timings["%s/%d" % k].get("strains") for k in sorted(runs)},
+        "strain_set_sha256_per_run": {"%s/%d" % k: timings["%s/%d" % k].get("strain_set_sha256") for k in sorted(runs)},
+        "strain_set_sha256": timings["%s/%d" % base_key].get("strain_set_sha256"),
+        "strain_set_identical_in_every_run": len({timings["%s/%d" % k].get("strain_set_sha256") for k in runs}) == 1,
+        "strain_set_form": "the sequences of strain.fasta, each on its lexicographically smaller strand, sorted, joined by newlines",
         "base_run_files_sha256": dict(base), "base_run": "%s/%d" % base_key,
         "runs": sorted("%s/%d" % k for k in runs),
         "digest_form": "tests/golden/make_graph_golden.collect (GFA / FASTA sequences as digests), then SHA-256 of that text",
