@@ -124,8 +124,17 @@ __device__ __forceinline__ void vs_mark_tile_store(uint8_t *map, uint32_t T, uin
 #ifndef VS_DPP_SCAN
 #define VS_DPP_SCAN 1
 #endif
+// (r6) SIX workgroups per CU for the compile-time shapes of graphs whose ends touch few nodes (the non-adaptive instantiations):
+// a tile table of 768 slots instead of 1 024 (12 per end, placed by a multiply-high range reduction instead of a power-of-two
+// mask) and a list region of 960 words make 26.8 KB of LDS per workgroup, and with the thread index laundered at the top of the
+// tile loop as well (nothing P0 .. P2 derive from it is hoisted across P3) the kernel fits 80 vector registers without
+// scratch: six wavefronts per SIMD instead of five.  configs[2]: 4.70 -> 4.45 ms; either half alone gains nothing
+// (VS_LAUNDER_TOP alone: noise; the smaller table at five workgroups: +2 %).  -DVS_POOL12=0 -DVS_LAUNDER_TOP=0: round 5's shape.
 #ifndef VS_LAUNDER_TOP
-#define VS_LAUNDER_TOP 0
+#define VS_LAUNDER_TOP 1
+#endif
+#ifndef VS_POOL12
+#define VS_POOL12 1
 #endif
 #define VS_DPP_STEP(op, ctrl, rowmask) { const uint32_t t_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rowmask, 0xf, false); v = op; }
 __device__ __forceinline__ uint32_t vs_wave_scan_add(uint32_t v) {
@@ -490,7 +499,7 @@ extern __shared__ __attribute__((aligned(16))) uint32_t vs_lds[];
 struct TileLayout {
     uint32_t woff, gend, meta, inv, words, pcnt, pa, pb, hkey, hcnt, hminp, hminj, ns, state, list, owner, misc, total;
 };
-__host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, uint32_t words_cap, uint32_t pool) {
+__host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, uint32_t words_cap, uint32_t pool, uint32_t list_trim = 0u) {
     TileLayout t;
     uint32_t o = 0;
     const uint32_t NI = ept * pmax;
@@ -511,7 +520,7 @@ __host__ __device__ inline TileLayout tile_layout(uint32_t ept, uint32_t pmax, u
     t.state = o; o += ept;
     // the posting owners of P3 and the accepted lists of P4/P5 are never live together
     t.list = o;
-    t.owner = o; o += (ept * LC > CHUNK ? ept * LC : CHUNK);
+    t.owner = o; o += (ept * LC - list_trim > CHUNK ? ept * LC - list_trim : CHUNK);
     t.misc = o;  o += 16u;
     t.total = o;
     return t;
@@ -548,7 +557,7 @@ typedef uint64_t tidx_t;
 #endif
 template <int MODE, uint32_t SW, uint32_t SP, bool AD = false>
 __global__ void __launch_bounds__(TTPB)
-__attribute__((amdgpu_waves_per_eu(MODE == 2 ? TILES_WAVES_LONG : TILES_WAVES, MODE == 2 ? TILES_WAVES_LONG : TILES_WAVES)))
+__attribute__((amdgpu_waves_per_eu((VS_POOL12 && SW != 0u && !AD) ? 6 : MODE == 2 ? TILES_WAVES_LONG : TILES_WAVES, (VS_POOL12 && SW != 0u && !AD) ? 6 : MODE == 2 ? TILES_WAVES_LONG : TILES_WAVES)))
 k_pe_tiles(PeParams P) {
     constexpr bool FAST = MODE != 0;
     constexpr uint32_t AB = MODE == 2 ? 9u : 8u;  // bits of the read offset packed under the node length (credit / P4)
@@ -579,9 +588,13 @@ k_pe_tiles(PeParams P) {
     const uint32_t NI = ept * pmax;
     const uint32_t w = STD ? C_W : P.idx.w, s = STD ? C_S : P.idx.s, K = STD ? C_K : P.idx.K;
     const uint32_t wv = VS_SEED_VERIFIED(w);  // seed bases the comparison skips (0: seeds with mixed keys, vs_seed_key)
-    const uint32_t pool = STD ? (1u << C_POOL_BITS) : P.pool, pool_shift = 32u - (STD ? C_POOL_BITS : P.pool_bits);
+    // (the 768-slot table is for graphs whose ends touch few nodes: the adaptive instantiations -- many postings per seed, long
+    // lists -- keep 1 024 slots and five wavefronts per SIMD)
+    constexpr bool P12 = VS_POOL12 != 0 && STD && !AD;
+    constexpr uint32_t C_POOL = P12 ? 768u : (1u << C_POOL_BITS), C_TRIM = P12 ? (MODE == 2 ? 192u : 64u) : 0u;  // (k = 127: 16 words per end of read text leave less)
+    const uint32_t pool = STD ? C_POOL : P.pool, pool_shift = 32u - (STD ? C_POOL_BITS : P.pool_bits);
     const uint32_t words_cap = STD ? C_EPT * STD_WPE : P.words_cap;
-    const TileLayout T = tile_layout(ept, pmax, words_cap, pool);
+    const TileLayout T = tile_layout(ept, pmax, words_cap, pool, C_TRIM);
     // (these five point at the current tile's copy; see the top of the tile loop)
     uint32_t *s_gwoff = vs_lds + T.woff;   // global word offsets (mask reads, slow path)
     uint32_t *s_gend = vs_lds + T.gend;
@@ -642,7 +655,7 @@ k_pe_tiles(PeParams P) {
     // One credited maximal exact match into the tile's (end, node) table.
     auto credit = [&](uint32_t e, uint32_t node, uint32_t nlen, uint32_t add, uint32_t minp, uint32_t a) {
         const uint32_t key = (e << 25) | node;
-        uint32_t at = (key * 0x9E3779B1u) >> pool_shift;
+        uint32_t at = P12 ? __umulhi(key * 0x9E3779B1u, C_POOL) : (key * 0x9E3779B1u) >> pool_shift;
         bool placed = false;
         for (uint32_t pr = 0; pr < 64u; pr++) {
             const uint32_t old = atomicCAS(&s_hkey[at], EMPTY_NODE, key);
@@ -655,7 +668,7 @@ k_pe_tiles(PeParams P) {
                 placed = true;
                 break;
             }
-            at = (at + 1u) & (pool - 1u);
+            at = P12 ? (at + 1u == C_POOL ? 0u : at + 1u) : (at + 1u) & (pool - 1u);
         }
         if (!placed) atomicOr(&s_state[e], 2u);
     };
@@ -688,7 +701,7 @@ k_pe_tiles(PeParams P) {
     prefetch_pair(tile_lo + 2u);
     for (tidx_t tile = tile_lo; tile < tile_hi; tile++) {
 #if VS_LAUNDER_TOP
-        uint32_t ltop = tid;  // (experiment: nothing P0 .. P2 derive from the thread index is hoisted out of the tile loop)
+        uint32_t ltop = tid;  // (nothing P0 .. P2 derive from the thread index is hoisted out of the tile loop: see VS_POOL12)
         asm volatile("" : "+v"(ltop));
 #else
         const uint32_t ltop = tid;
@@ -1016,7 +1029,7 @@ k_pe_tiles(PeParams P) {
         uint32_t lt = tid;
         asm volatile("" : "+v"(lt));
         // (compile-time shapes: a thread's four slots -- key and position -- stay in registers across the prefix sum)
-        constexpr uint32_t SPT = STD ? (1u << C_POOL_BITS) / TTPB : 1u;
+        constexpr uint32_t SPT = STD ? C_POOL / TTPB : 1u;
         uint32_t r_key[SPT], r_at[SPT];
         auto judge = [&](uint32_t i, uint32_t key) -> uint32_t {  // the position of slot i's node in its end's list, or none
             const uint32_t e = key >> 25, node = key & 0x01FFFFFFu;
@@ -1049,7 +1062,7 @@ k_pe_tiles(PeParams P) {
             bool over0 = n0 > LCAP, over1 = n1 > LCAP;
             const uint32_t q0 = over0 ? 0u : (n0 + 3u) >> 2, q1 = over1 ? 0u : (n1 + 3u) >> 2;
             const uint32_t incl = vs_wave_scan_add(q0 + q1);
-            const uint32_t capq = (ept * LC) >> 2;
+            const uint32_t capq = (ept * LC - C_TRIM) >> 2;
             const uint32_t o0 = incl - q0 - q1, o1 = o0 + q0;
             over0 |= o0 + q0 > capq;
             over1 |= o1 + q1 > capq;
@@ -2724,6 +2737,7 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
                        : fast_long      ? TilesFn{(const void *)k_pe_tiles<2, 0u, 0u>, "k_pe_tiles<2, 0u, 0u>"}
                                         : TilesFn{(const void *)k_pe_tiles<0, 0u, 0u>, "k_pe_tiles<0, 0u, 0u>"};
     const void *tiles_fn = tf.fn;
+    if (std_shape && VS_POOL12 && !adapt) lds = (size_t)tile_layout(ept, pmax, ept * wpe, 768u, std_shape == 4 ? 192u : 64u).total * sizeof(uint32_t);
     if (lds > 64u * 1024u)
         VS_HIP(ctx, hipFuncSetAttribute(tiles_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (tn.debug_occ) {
