@@ -1170,9 +1170,6 @@ k_pe_tiles(PeParams P) {
 #define ACC_RUN 4u   // 4 or 8 (8: two 16-byte partner loads per run; measured r5, see profiles/EXPERIMENTS.md)
 #endif
 #define ACC_GMAX 60u  // g(LCAP = 20) for runs of 4 (runs of 8 need 36)
-#ifndef ACC_AHEAD
-#define ACC_AHEAD 1   // windows whose list loads are in flight ahead of the one being counted (r6: 2 and 3 measured, no gain -- EXPERIMENTS)
-#endif
 // The cell table: 16 k slots, 32-bit keys (k_pe_accumulate: mat * N*N + x * N + y, while 2*N*N fits 32 bits, N <= 46340;
 // the row owners: cell index relative to the strip's first row).  The 16 cells of one 64-byte stretch of a matrix row
 // sit in 16 NEIGHBOURING slots (the hash picks a group of 16 slots from the key >> 4, the low four bits pick the slot
@@ -1338,25 +1335,14 @@ k_pe_accumulate(const uint32_t *__restrict__ lists, const uint32_t *__restrict__
 #endif
             return R;
         };
-        // the list loads of ACC_AHEAD windows are in flight while one is counted (r6: two and three windows ahead were measured
-        // against one -- 2.23 / 2.25 / 2.31 ms at configs[2]: the kernel does not wait on these loads)
-        Run q1, q2, q3;
-        q1.ok = q2.ok = q3.ok = false;
-        if (U) q1 = fetch(0u);
-        if (ACC_AHEAD >= 2 && 64u < U) q2 = fetch(64u);
-        if (ACC_AHEAD >= 3 && 128u < U) q3 = fetch(128u);
+        // (r6: the list loads of two and three windows ahead instead of one were measured -- 2.23 / 2.25 / 2.31 ms at configs[2]: the
+        // kernel does not wait on these loads; profiles/EXPERIMENTS.md)
+        Run nxt;
+        nxt.ok = false;
+        if (U) nxt = fetch(0u);
         for (uint32_t t0 = 0; t0 < U; t0 += 64u) {
-            const Run c = q1;
-            if (ACC_AHEAD >= 3) {
-                q1 = q2; q2 = q3; q3.ok = false;
-                if (t0 + 192u < U) q3 = fetch(t0 + 192u);
-            } else if (ACC_AHEAD == 2) {
-                q1 = q2; q2.ok = false;
-                if (t0 + 128u < U) q2 = fetch(t0 + 128u);
-            } else {
-                q1.ok = false;
-                if (t0 + 64u < U) q1 = fetch(t0 + 64u);
-            }
+            const Run c = nxt;
+            if (t0 + 64u < U) nxt = fetch(t0 + 64u);
             if (!c.ok) continue;
             const uint32_t x = c.x, mat = c.mat, bi = c.bi, be = c.be;
 #if ACC_RUN == 8u
@@ -1591,7 +1577,7 @@ __device__ __forceinline__ bool vs_same_list(const uint32_t (&mine)[LCAP], const
 
 __global__ void __launch_bounds__(256)
 k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ lists_hi, const uint32_t *__restrict__ counts, uint64_t n_ends, uint32_t *__restrict__ mult,
-              uint32_t *__restrict__ gown, unsigned long long *__restrict__ ltab, uint32_t *__restrict__ lmult, uint32_t ltab_bits, uint32_t sub_bits) {
+              uint32_t *__restrict__ gown, unsigned long long *__restrict__ ltab, uint32_t *__restrict__ lmult, uint32_t ltab_bits) {
     const uint64_t e64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e64 >= n_ends) return;
     const uint32_t e = (uint32_t)e64, n = counts[e];
@@ -1609,12 +1595,9 @@ k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ l
             }
         const uint32_t tag = ((uint32_t)(f2 >> 32) & ~31u) | (n - 1u);  // (the list length rides in the tag: no load for the owner's)
         const unsigned long long word = ((unsigned long long)tag << 32) | (e + 1u);
-        // (r6 experiment, sub_bits != 0) the table is cut into sub-tables of 2^sub_bits slots, one per 2^(sub_bits - 1) consecutive ends:
-        // ends are in locus order and an end's list is repeated by ends near it, so a sub-table's 768 KB stay in the
-        // Infinity Cache while its ends are looked up, where the one table of the block (768 MB at 25 M pairs) is HBM traffic
-        // for every probe and every multiplicity atomic.  A list that recurs in another sub-table gets another owner there.
-        const uint32_t sub_base = sub_bits ? (e >> (sub_bits - 1u)) << sub_bits : 0u, hbits = sub_bits ? sub_bits : ltab_bits;
-        uint32_t h = sub_base + (uint32_t)((f2 * 0xD6E8FEB86659FD93ull) >> (64u - hbits));
+        // (r6: sub-tables per stretch of consecutive ends, so that a sub-table stays in the Infinity Cache, were measured and LOSE --
+        // lists recur across the whole block and get an owner per sub-table; profiles/EXPERIMENTS.md)
+        uint32_t h = (uint32_t)((f2 * 0xD6E8FEB86659FD93ull) >> (64u - ltab_bits));
         for (uint32_t pr = 0; pr < LTAB_PROBES; pr++) {
             unsigned long long cur = ltab[h];
             if (cur == 0ull) {
@@ -1635,7 +1618,7 @@ k_list_owners(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ l
                     break;
                 }
             }
-            h = sub_base + ((h - sub_base + 1u) & ((1u << hbits) - 1u));
+            h = (h + 1u) & ((1u << ltab_bits) - 1u);
         }
         // (no place within LTAB_PROBES slots -- a crowded table: m = 1, the end stands for itself)
     }
@@ -2430,13 +2413,6 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
     uint32_t ltab_bits = 10;
     while ((1ull << ltab_bits) < 2u * sub_pairs && ltab_bits < 31u) ltab_bits++;
     if (tn.ltab_bits >= 0) ltab_bits = (uint32_t)tn.ltab_bits;
-#ifndef VS_LTAB_SUB_BITS
-#define VS_LTAB_SUB_BITS 0
-#endif
-    // sub-tables (see k_list_owners) when the table is much larger than one of them and nobody asked for a table size
-    const uint32_t sub_bits = (tn.ltab_bits < 0 && VS_LTAB_SUB_BITS && ltab_bits > VS_LTAB_SUB_BITS + 2u) ? (uint32_t)VS_LTAB_SUB_BITS : 0u;
-    if (sub_bits)  // (a sub-table holds two slots per end it serves: the table as a whole two per end of the block)
-        while ((1ull << ltab_bits) < 4u * sub_pairs + (1ull << sub_bits) && ltab_bits < 31u) ltab_bits++;
     const bool use_ltab = ltab_bits > 0;
     const uint64_t ltab_slots = use_ltab ? 1ull << ltab_bits : 0;
     // entries: one word per listed node -- the left lists (node_mat) and the lists of the owning ends (short_mat); the
@@ -2483,7 +2459,7 @@ static int pe_count_by_rows(vs_ctx *ctx, uint64_t slots_pairs, uint32_t *d_node_
         VS_HIP(ctx, hipMemsetAsync(rows, 0, sizeof(uint32_t) * 6u * cap, st));
         VS_HIP(ctx, hipMemsetAsync(n_owners, 0, sizeof(uint32_t), st));
         if (use_ltab) VS_HIP(ctx, hipMemsetAsync(ctx->d_ltab, 0, (sizeof(uint64_t) + sizeof(uint32_t)) * ltab_slots, st));
-        hipLaunchKernelGGL(k_list_owners, dim3((unsigned)((2u * np + 255u) / 256u)), dim3(256), 0, st, sl, sh, sc, 2u * np, mult, gown, ltab, lmult, ltab_bits, sub_bits);
+        hipLaunchKernelGGL(k_list_owners, dim3((unsigned)((2u * np + 255u) / 256u)), dim3(256), 0, st, sl, sh, sc, 2u * np, mult, gown, ltab, lmult, ltab_bits);
         if (use_ltab)
             hipLaunchKernelGGL(k_owners_mult, dim3((unsigned)((ltab_slots + 255u) / 256u)), dim3(256), 0, st, (const unsigned long long *)ltab,
                                (const uint32_t *)lmult, ltab_slots, mult);
