@@ -823,13 +823,14 @@ def test_fastq_open_refuses_invalid_utf8_and_blocks_take_dirty_reads(host, ctx, 
     assert stats == tuple(int(x) for x in ref[2])
 
 
-@pytest.mark.parametrize("exchange", ["dense", "compact"])
-def test_sharded_drop_in_two_ranks_on_one_gpu(tmp_path, exchange):
+@pytest.mark.parametrize("exchange,ranks", [("dense", 2), ("compact", 2), ("compact", 8)])
+def test_sharded_drop_in_two_ranks_on_one_gpu(tmp_path, exchange, ranks):
     """The PE drop-in under torchrun with two ranks: each rank counts its contiguous block of the
     pairs with the real kernels, the counters are summed, rank 0 alone touches the output
     directory and writes the files -- byte-identical to the reference's.  One GPU here, so both
     ranks use device 0 and the sum goes through gloo (RCCL needs a device per rank; the RCCL call
-    itself is exercised by the one-rank tests and by bench.py --gpus N)."""
+    itself is exercised by the one-rank tests and by bench.py --gpus N).  (r6) Also with EIGHT ranks on the one device: eight
+    cooperative FASTQ shards, the packed two-collective sum reduced to rank 0 (the only rank that writes)."""
     import socket
 
     name, d, meta = [c for c in pe_cases() if c[0] == "errors_k21"][0]
@@ -844,7 +845,7 @@ def test_sharded_drop_in_two_ranks_on_one_gpu(tmp_path, exchange):
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
         proc = subprocess.run(
-            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
              "--master-port", str(port), "-m", "vstrains_amd.pe_inference", "-g", os.path.join(d, "graph.gfa"), "-o", str(out),
              "-f", os.path.join(d, "fwd.fq"), "-r", os.path.join(d, "rve.fq"), "-k", str(meta["k"])],
             cwd=ROOT, capture_output=True, text=True, env=env, timeout=600)
