@@ -2666,8 +2666,10 @@ static int pe_launch(vs_ctx *ctx, const vs_reads *reads, uint32_t *d_node_mat, u
 
     // straight-line extension when the whole block qualifies (see vs_extend_fast)
     // (reads with bytes outside ACGT qualify through their position lists, see k_inv4 / vs_seed_limits)
+    // (and nodes below 2^23 bases: the straight-line kernels carry a node's length above the read offset in one table word -- a
+    // longer node takes the generic kernel; r6: the guard was missing for MODE 1)
     const bool fast = (!reads->d_mask || reads->d_inv4) && idx.s <= 32u && maxlen <= 128u + idx.w + 32u &&
-                      !tn.no_fast;
+                      ctx->max_node_len < (1u << 23) && !tn.no_fast;
     P.mid_fast = fast && VS_SEED_VERIFIED(idx.w) && ctx->max_node_len < (1u << 23) ? 1u : 0u;
     // compile-time-shape instantiations (see k_pe_tiles): 1 = (10, 4), 2 = (8, 3), 3 = (7, 2)
     int std_shape = 0;
