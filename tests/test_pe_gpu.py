@@ -119,6 +119,36 @@ def test_lowercase_node_raises_keyerror(host, ctx):
     assert "KeyError: %r" % ei.value.args[0] == meta["stderr_last"]
 
 
+def test_a_node_of_more_than_two_to_the_23_bases_takes_the_generic_kernel(host, ctx):
+    """(r6) The straight-line kernels pack a node's length above the read offset in 24 bits of one table word; a graph with a
+    node of 2^23 bases or more must not take them (the guard was missing for MODE 1 until round 6).  One node of 2^23 + 500
+    bases and two ordinary ones, 400 read pairs of 2 x 150 off the long node's far end: the generic kernel runs and the
+    counters equal the C oracle's."""
+    rng = np.random.default_rng(77)
+    big = "".join("ACGT"[i] for i in rng.integers(0, 4, size=(1 << 23) + 500))
+    small = ["".join("ACGT"[i] for i in rng.integers(0, 4, size=300)) for _ in range(2)]
+    seqs = [small[0], big, small[1]]
+    comp = str.maketrans("ACGT", "TGCA")
+    fwd, rve = [], []
+    for _ in range(400):
+        a = int(rng.integers(len(big) - 3000, len(big) - 700))
+        ins = int(rng.integers(300, 600))
+        frag = big[a:a + ins]
+        f, r = frag[:150], frag[-150:][::-1].translate(comp)
+        if rng.random() < 0.5:
+            f, r = r, f
+        fwd.append(f)
+        rve.append(r)
+    ctx.build_index(seqs, 55)
+    counter = host.PeCounter(ctx)
+    counter.add(ctx.pack_pairs(fwd, rve))
+    assert ctx.last_kernel.startswith("k_pe_tiles<0"), ctx.last_kernel
+    node_mat, short_mat, stats = counter.result()
+    ref = pe_oracle_c.Oracle(seqs, 55).count_pairs(fwd, rve)
+    assert np.array_equal(node_mat, ref[0]) and np.array_equal(short_mat, ref[1])
+    assert stats == tuple(int(x) for x in ref[2]) and int(node_mat[1, 1]) > 300
+
+
 def test_cli_drop_in_writes_identical_files(tmp_path):
     name, d, meta = [c for c in pe_cases() if c[0] == "errors_k21"][0]
     out = tmp_path / "aln"
